@@ -1,0 +1,126 @@
+/* scade_hip.h -- C ABI of libscade_hip.so, the MI355X (gfx950) implementation of
+ * SCADE's per-ray rendering hot path.
+ *
+ * The reference (mikacuy/scade) has NO native/FFI layer: its boundary for this
+ * path is the Python operator API of model/run_nerf_helpers.py and
+ * run_scade_scannet.py.  Each entry point below names the reference operator
+ * (file:line, relative to the reference checkout) whose arithmetic it replaces;
+ * scade_amd/ binds them with ctypes behind those same Python names.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer to fp32 (row-major, contiguous unless a
+ *    *_stride argument says otherwise; strides are in elements); the caller
+ *    (PyTorch) owns all memory, the library never allocates or retains pointers;
+ *  - `stream` is a hipStream_t; kernels are only enqueued, never synchronised;
+ *  - return 0 on success, a negative argument-error code or a positive
+ *    hipError_t otherwise; scade_last_error() returns the thread-local message;
+ *  - optional pointers may be NULL where the comment says so.
+ */
+#ifndef SCADE_HIP_H
+#define SCADE_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int scade_version(void);
+const char* scade_last_error(void);
+
+/* ---- NeRF MLP (model/run_nerf_helpers.py:193-247 NeRF, :131-139 DenseLayer) --- */
+
+/* floats in the packed parameter blob consumed by scade_mlp_fwd */
+long scade_mlp_packed_floats(void);
+/* dynamic LDS bytes of the fused forward kernel (reported for occupancy checks) */
+int scade_mlp_lds_bytes(void);
+
+/* Re-layout the 24 parameter tensors of NeRF(D=8,W=256,input_ch=57,input_ch_views=3,
+ * skips=[4],use_viewdirs=True) into MFMA A-fragment order.  params[] is a HOST
+ * array of 24 DEVICE pointers in the order
+ *   pts_linears.{0..7}.{weight,bias}, views_linears.0.{weight,bias},
+ *   feature_linear.{weight,bias}, alpha_linear.{weight,bias}, rgb_linear.{weight,bias}
+ * (nn.Linear [out,in] layout, helpers:205-220).  Re-run after every optimizer step. */
+int scade_mlp_pack(const float* const* params, float* packed, void* stream);
+
+/* Fused embed + MLP forward:  out[P,4] = [rgb(3, pre-sigmoid), softplus(alpha, beta=10)].
+ *  mode 0: `in` is x[P,60] = [gamma(x)(57) | viewdir(3)]  == NeRF.forward(x), helpers:223-247
+ *  mode 1: `in` is pts[P,3]; viewdirs[P/S,3]; bb = {cx,cy,cz,scale}; the kernel applies
+ *          (pts-bb_center)*bb_scale, the 9-frequency positional encoding and the
+ *          per-ray view broadcast  == run_network(...), run_scade_scannet.py:48-63 with
+ *          get_embedder(9,0)/get_embedder(0,0), helpers:142-189.
+ *  acts (nullable): [10][P][256] workspace receiving the post-activation tile of every
+ *          hidden layer (training; consumed by scade_mlp_bwd). */
+int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,
+                  const float* bb, int P, int S, float* out, float* acts, void* stream);
+
+/* ---- positional encoding (Embedder.embed, helpers:142-172; get_embedder :174-189) */
+/* out[P, D*(1+2*multires)] = [x, sin(x*pi*2^0), cos(x*pi*2^0), ..., cos(x*pi*2^(L-1))] */
+int scade_embed(const float* x, int P, int D, int multires, float* out, void* stream);
+
+/* ---- ray sampling (run_scade_scannet.py:638-657, perturb_z_vals :564-579) ------ */
+/* z_vals[N,S] = near*(1-t)+far*t (or the lindisp form), optional stratified jitter with
+ * t_rand[N,S] (NULL == perturb 0), and pts[N,S,3] = o + d*z (pts nullable).
+ * rays rows: o(0..2) d(3..5) near(6) far(7); t_vals = linspace(0,1,S). */
+int scade_ray_points(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
+                     int N, int S, int lindisp, float* z_vals, float* pts, void* stream);
+
+/* stratified jitter of an existing z tensor (perturb_z_vals :564-579), t_rand[N,S] ~ U[0,1) */
+int scade_perturb_z(const float* z_vals, const float* t_rand, int N, int S, float* out,
+                    void* stream);
+
+/* ---- alpha compositing (compute_weights :511-522, raw2outputs :530-562) -------- */
+/* noise (nullable) is the pre-drawn sigma noise [N,S] (raw_noise_std * randn). */
+int scade_composite_fwd(const float* raw, const float* z_vals, const float* rays_d, int d_stride,
+                        const float* noise, int N, int S, float* rgb_map, float* disp_map,
+                        float* acc_map, float* weights, float* depth_map, void* stream);
+/* gradient w.r.t. raw[N,S,4]; each g_* may be NULL (== zero). */
+int scade_composite_bwd(const float* raw, const float* z_vals, const float* rays_d, int d_stride,
+                        const float* noise, int N, int S, const float* g_rgb, const float* g_disp,
+                        const float* g_acc, const float* g_weights, const float* g_depth,
+                        float* g_raw, void* stream);
+
+/* ---- inverse-CDF sampler (helpers:337-383 sample_pdf, :385-436 sample_pdf_return_u,
+ *      :439-538 joint variants share the kernel with u_stride = 0) ------------------ */
+/* bins: M values per ray (bins_are_mids = 0) or M+1 z values whose midpoints are the
+ * bins (bins_are_mids = 1, run_scade_scannet.py:702/:723).  weights: M-1 values per ray
+ * at weights[n*w_stride + j] (a strided view such as weights[...,1:-1] is passed as
+ * base+1 with the parent row stride).  cdf_in (nullable): use this [N,M] cdf instead of
+ * building it from weights (bit-exact index test).  u: S draws per ray, u_stride = 0
+ * broadcasts one row.  Optional outputs: inds[N,S] (int64, searchsorted right=True),
+ * cdf_out[N,M], z_std[N] (std of the samples, unbiased=False, :744). */
+int scade_sample_pdf_fwd(const float* bins, int bins_stride, int bins_are_mids,
+                         const float* weights, int w_stride, const float* cdf_in, const float* u,
+                         int u_stride, int N, int M, int S, float* samples, long long* inds,
+                         float* cdf_out, float* z_std, void* stream);
+/* gradient w.r.t. the M-1 weights (dense [N,M-1] output). */
+int scade_sample_pdf_bwd(const float* bins, int bins_stride, int bins_are_mids,
+                         const float* weights, int w_stride, const float* u, int u_stride,
+                         const float* g_samples, int N, int M, int S, float* g_weights,
+                         void* stream);
+
+/* ---- coarse+fine merge (run_scade_scannet.py:713-714) --------------------------- */
+/* z_out[N,Sa+Sb] = sort(cat(z_a, z_b)); pts (nullable) = o + d*z_out from rays rows. */
+int scade_merge_sorted(const float* z_a, int Sa, const float* z_b, int Sb, const float* rays,
+                       int ray_stride, int N, float* z_out, float* pts, void* stream);
+
+/* ---- space-carving loss (helpers:93-128) ---------------------------------------- */
+/* pred[N,P]; hyp[K,N] (the reference's [K,N,1], hypothesis-major); mask[N] nullable;
+ * threshold <= 0 disables; is_joint selects helpers:115-119.  workspace holds
+ * scade_carve_workspace_floats() floats and must be passed unchanged to the backward. */
+long scade_carve_workspace_floats(int N, int P, int K, int is_joint);
+int scade_carve_fwd(const float* pred, const float* hyp, const float* mask, float threshold,
+                    int is_joint, int N, int P, int K, float* workspace, float* loss,
+                    void* stream);
+int scade_carve_bwd(const float* pred, const float* hyp, const float* mask, float threshold,
+                    int is_joint, int N, int P, int K, const float* workspace,
+                    const float* g_loss, float* g_pred, float* g_hyp, void* stream);
+
+/* ---- photometric loss (helpers:11 img2mse; row mask = run_scade_wild.py:978-986) - */
+int scade_mse_fwd(const float* x, const float* y, const float* row_mask, int n, int c,
+                  float* loss, void* stream);
+int scade_mse_bwd(const float* x, const float* y, const float* row_mask, int n, int c,
+                  const float* g_loss, float* g_x, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCADE_HIP_H */

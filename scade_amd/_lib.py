@@ -1,0 +1,95 @@
+"""ctypes binding of libscade_hip.so (include/scade_hip.h).
+
+There is deliberately NO fallback: if the library is missing or a call fails the
+product path raises.  PyTorch only provides device memory and the stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_long, c_void_p
+from typing import Optional
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libscade_hip.so")
+
+_P = c_void_p
+_I = c_int
+
+# name -> (restype, argtypes); must list every symbol declared in include/scade_hip.h
+SIGNATURES = {
+    "scade_version": (c_int, []),
+    "scade_last_error": (c_char_p, []),
+    "scade_mlp_packed_floats": (c_long, []),
+    "scade_mlp_lds_bytes": (c_int, []),
+    "scade_mlp_pack": (c_int, [_P, _P, _P]),
+    "scade_mlp_fwd": (c_int, [_P, _I, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "scade_embed": (c_int, [_P, _I, _I, _I, _P, _P]),
+    "scade_ray_points": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "scade_perturb_z": (c_int, [_P, _P, _I, _I, _P, _P]),
+    "scade_composite_fwd": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
+    "scade_composite_bwd": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "scade_sample_pdf_fwd": (c_int, [_P, _I, _I, _P, _I, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "scade_sample_pdf_bwd": (c_int, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
+    "scade_merge_sorted": (c_int, [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "scade_carve_workspace_floats": (c_long, [_I, _I, _I, _I]),
+    "scade_carve_fwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P]),
+    "scade_carve_bwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "scade_mse_fwd": (c_int, [_P, _P, _P, _I, _I, _P, _P]),
+    "scade_mse_bwd": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
+}
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def load() -> ctypes.CDLL:
+    """dlopen the in-tree library and type every entry point.  Raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"scade_amd: {LIB_PATH} not found. Build it with `python -m scade_amd.build` "
+            "(hipcc, gfx950). There is no CPU/PyTorch fallback for this path.")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def last_error() -> str:
+    msg = load().scade_last_error()
+    return msg.decode() if msg else ""
+
+
+def ptr(t: Optional[torch.Tensor]):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def stream():
+    return c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def call(name: str, *args) -> None:
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name} failed (code {rc}): {last_error()}")
+
+
+def check(t: torch.Tensor, what: str, dtype=torch.float32) -> torch.Tensor:
+    """Product-path guard: HIP device tensor of the right dtype."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{what}: expected a torch.Tensor, got {type(t).__name__}")
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"{what}: tensor is on {t.device}; scade_amd runs on the MI355X HIP device only "
+            "(no CPU fallback)")
+    if t.dtype != dtype:
+        raise TypeError(f"{what}: expected {dtype}, got {t.dtype}")
+    return t

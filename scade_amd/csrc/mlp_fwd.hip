@@ -1,0 +1,403 @@
+// Fused positional-encoding + 8x256 NeRF MLP forward for gfx950 (CDNA4).
+//
+// Replaces, in one launch, the reference's run_network -> Embedder.embed ->
+// batchify -> NeRF.forward chain (run_scade_scannet.py:48-63,
+// model/run_nerf_helpers.py:142-172, 223-247), which the reference issues as
+// ~60 eager ATen ops materialising a [P,60] embedding in HBM.
+//
+// Design (MI355X-first):
+//  * one workgroup = 4 wavefronts (one per SIMD) owns a tile of 64 points and
+//    walks all 12 layers with the activations resident in LDS (64 KiB h-tile,
+//    XOR-swizzled, + 15 KiB embedding tile = 79 KiB  ->  2 workgroups / CU);
+//  * layers are computed TRANSPOSED, out^T[feature][point] = W[feature][k] *
+//    act^T[k][point], on v_mfma_f32_32x32x2_f32 (exact fp32): the weight is the
+//    A operand, read straight from L2 in a pre-packed fragment order (every
+//    wave owns 64 output features, so nothing about W is shared inside the
+//    workgroup and it never touches LDS); the activation is the B operand read
+//    from LDS with ds_read_b128; both operands are k-contiguous so one 16-byte
+//    read feeds 4 MFMAs; the accumulator layout then gives every lane 4
+//    consecutive features of ONE point -> ds_write_b128 epilogue, in place;
+//  * skip-concat (layer 5) and view-concat are extra k-blocks, never a concat;
+//  * the 256->1 and 128->3 heads are VALU dot products.
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace scade {
+
+constexpr int TM = 64;                         // points per workgroup
+constexpr int H_FLOATS = TM * W;               // 16384
+constexpr int EMB_STRIDE = 60;                 // floats; 240 B rows -> conflict-free b128
+constexpr int EMB_FLOATS = TM * EMB_STRIDE;    // 3840
+constexpr int MLP_LDS_BYTES = (H_FLOATS + EMB_FLOATS) * 4;  // 80896
+
+struct MlpFwdArgs {
+  const float* packed;    // PACKED_FWD_FLOATS
+  const float* in;        // mode 0: x [P,60];  mode 1: pts [P,3]
+  const float* viewdirs;  // mode 1: [P/S,3]
+  const float* bb;        // mode 1: {cx,cy,cz,scale}
+  float* out;             // [P,4]
+  float* acts;            // optional [9][P][256] saved post-activation tiles (training)
+  int P;
+  int S;                  // samples per ray (mode 1)
+};
+
+// float index of 16-byte chunk `chunk` of row `row` in the swizzled h tile
+__device__ __forceinline__ int h_idx(int row, int chunk) {
+  return row * W + ((chunk ^ (row & 15)) << 2);
+}
+
+// ---------------------------------------------------------------------------
+// k-loop of one layer.  acc[t][p]: n-tile t of this wave x point-tile p.
+//   wp   : this wave's first n-tile, [NT][KB][64] float4, KB = KBP + KBH
+//   pre  : LDS region for the first KBP k-blocks (row stride PRE_STRIDE floats)
+//   hbuf : swizzled h tile for the remaining KBH k-blocks
+// ---------------------------------------------------------------------------
+template <int NT, int KBP, int KBH, int PRE_STRIDE>
+__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], const f32x4* __restrict__ wp,
+                                           const float* pre, const float* hbuf, int lane) {
+  constexpr int KB = KBP + KBH;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
+
+  auto load_b = [&](int kb, f32x4& b0, f32x4& b1) {
+    if (KBP > 0 && kb < KBP) {
+      const float* q = pre + r * PRE_STRIDE + (2 * kb + hh) * 4;
+      b0 = *reinterpret_cast<const f32x4*>(q);
+      b1 = *reinterpret_cast<const f32x4*>(q + 32 * PRE_STRIDE);
+    } else {
+      const float* q = hbuf + h_idx(r, 2 * (kb - KBP) + hh);
+      b0 = *reinterpret_cast<const f32x4*>(q);
+      b1 = *reinterpret_cast<const f32x4*>(q + 32 * W);
+    }
+  };
+
+  f32x4 an[NT], bn[2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + 0) * 64 + lane];
+  load_b(0, bn[0], bn[1]);
+
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    f32x4 a[NT], b[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[t] = an[t];
+    b[0] = bn[0];
+    b[1] = bn[1];
+    const int kn = (kb + 1 < KB) ? kb + 1 : kb;  // last iteration re-reads (no branch)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + kn) * 64 + lane];
+    load_b(kn, bn[0], bn[1]);
+    // keep the next block's loads ABOVE this block's MFMAs (hipcc otherwise sinks
+    // them below the last use of a[]/b[] to reuse the registers: no prefetch)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          acc[t][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[p][j], acc[t][p], 0, 0, 0);
+  }
+}
+
+// bias (+ReLU) and in-place write of the wave's [NT*32 features] x [64 points]
+template <int NT, bool RELU>
+__device__ __forceinline__ void layer_store(const f32x16 (&acc)[NT][2], const float* __restrict__ bias,
+                                            int ntile0, float* hbuf, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = acc[t][p][4 * q + i] + bv[i];
+          v[i] = RELU ? fmaxf(x, 0.f) : x;
+        }
+        const int row = p * 32 + r;
+        *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
+      }
+    }
+}
+
+// coalesced copy of the h tile (first NC columns) to acts[slot][P][256]
+__device__ __forceinline__ void save_tile(const float* hbuf, float* __restrict__ dst, int p0, int P,
+                                          int ncols, int tid) {
+  const int chunks_per_row = ncols >> 2;
+  for (int i = tid; i < TM * chunks_per_row; i += 256) {
+    const int row = i / chunks_per_row, c = i - row * chunks_per_row;
+    if (p0 + row < P)
+      *reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c) =
+          *reinterpret_cast<const f32x4*>(hbuf + h_idx(row, c));
+  }
+}
+
+template <int MODE, bool SAVE>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* hbuf = lds;
+  float* ebuf = lds + H_FLOATS;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = blockIdx.x * TM;
+  const int P = a.P;
+  const float* __restrict__ pk = a.packed;
+
+  // ---------------- prologue: embedding tile [64][60] -----------------------
+  if (MODE == 0) {
+    // x rows are 60 contiguous floats == the tile layout; columns 57..59 carry
+    // the view direction and meet zero weights in layers 0/5.
+    const int nvalid = min(TM, P - p0);
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.in + (size_t)p0 * 60);
+    for (int i = tid; i < TM * 15; i += 256) {
+      const int row = i / 15;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (row < nvalid) v = src[i];
+      reinterpret_cast<f32x4*>(ebuf)[i] = v;
+    }
+  } else {
+    const float cx = a.bb[0], cy = a.bb[1], cz = a.bb[2], sc = a.bb[3];
+    // item = (point, coord c, slot s): s == 0 -> raw x, s = 1..9 -> freq 2^(s-1)
+    for (int i = tid; i < TM * 30; i += 256) {
+      const int row = i / 30, rem = i - row * 30;
+      const int c = rem / 10, s = rem - c * 10;
+      const int pt = min(p0 + row, P - 1);
+      const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
+      const float x = (a.in[(size_t)pt * 3 + c] - ctr) * sc;   // run_scade_scannet.py:52
+      float* e = ebuf + row * EMB_STRIDE;
+      if (s == 0) {
+        e[c] = x;
+        e[57 + c] = 0.f;
+      } else {
+        // helpers:165  p_fn(x * np.pi * freq): fl32(x*pi_f32) * 2^k (exact)
+        const float arg = (x * 3.14159274101257324f) * (float)(1 << (s - 1));
+        float sn, cs;
+        sincosf(arg, &sn, &cs);
+        e[3 + 6 * (s - 1) + c] = sn;
+        e[6 + 6 * (s - 1) + c] = cs;
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+  const int nt0 = wave * 2;
+
+#define PTS_LAYER(L, KBP, PRE)                                                                     \
+  {                                                                                                \
+    layer_gemm<2, KBP, kb_h(L), EMB_STRIDE>(                                                       \
+        acc, reinterpret_cast<const f32x4*>(pk + off_w(L)) + nt0 * kb_total(L) * 64, PRE, hbuf,    \
+        lane);                                                                                     \
+    __syncthreads();                                                                               \
+    layer_store<2, true>(acc, pk + off_b(L), nt0, hbuf, lane);                                     \
+    __syncthreads();                                                                               \
+    if (SAVE) save_tile(hbuf, a.acts + (size_t)(L)*P * W, p0, P, W, tid);                          \
+  }
+
+  PTS_LAYER(0, 8, ebuf)
+  PTS_LAYER(1, 0, ebuf)
+  PTS_LAYER(2, 0, ebuf)
+  PTS_LAYER(3, 0, ebuf)
+  PTS_LAYER(4, 0, ebuf)
+  PTS_LAYER(5, 8, ebuf)
+
+  // embedding tile is dead now: reuse its head as the view pad [64][8]
+  {
+    const int row = tid >> 2, c = tid & 3;  // 64 rows x 4 (3 used)
+    const int pt = min(p0 + row, P - 1);
+    float v = 0.f;
+    if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * 3 + c];
+    ebuf[row * VIEW_PAD + c] = v;
+    ebuf[row * VIEW_PAD + 4 + c] = 0.f;
+  }
+  // (visibility of the view pad is covered by the barriers of layers 6/7)
+
+  PTS_LAYER(6, 0, ebuf)
+  PTS_LAYER(7, 0, ebuf)
+#undef PTS_LAYER
+
+  // ---------------- alpha head: 256 -> 1 on the VALU -------------------------
+  float alpha;
+  {
+    const int row = tid >> 2, sub = tid & 3;
+    const float* wa = pk + OFF_WA;
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      const int chunk = i * 4 + sub;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + h_idx(row, chunk));
+      const f32x4 wv = *reinterpret_cast<const f32x4*>(wa + chunk * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s = fmaf(hv[j], wv[j], s);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    alpha = s + pk[OFF_BA];
+  }
+
+  // ---------------- feature_linear: 256 -> 256, no activation ----------------
+  layer_gemm<2, 0, 32, EMB_STRIDE>(
+      acc, reinterpret_cast<const f32x4*>(pk + off_w(L_FEAT)) + nt0 * kb_total(L_FEAT) * 64, ebuf,
+      hbuf, lane);
+  __syncthreads();
+  layer_store<2, false>(acc, pk + off_b(L_FEAT), nt0, hbuf, lane);
+  __syncthreads();
+
+  // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
+  {
+    f32x16 accv[1][2];
+    layer_gemm<1, 1, 32, VIEW_PAD>(
+        accv, reinterpret_cast<const f32x4*>(pk + off_w(L_VIEWS)) + wave * kb_total(L_VIEWS) * 64,
+        ebuf, hbuf, lane);
+    __syncthreads();
+    layer_store<1, true>(accv, pk + off_b(L_VIEWS), wave, hbuf, lane);
+    __syncthreads();
+    if (SAVE) save_tile(hbuf, a.acts + (size_t)8 * P * W, p0, P, 128, tid);
+  }
+
+  // ---------------- rgb head 128 -> 3, softplus(alpha, beta=10) --------------
+  {
+    const int row = tid >> 2, sub = tid & 3;
+    const float* wr = pk + OFF_WR;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int chunk = i * 4 + sub;
+      const f32x4 hv = *reinterpret_cast<const f32x4*>(hbuf + h_idx(row, chunk));
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        s0 = fmaf(hv[j], w0[j], s0);
+        s1 = fmaf(hv[j], w1[j], s1);
+        s2 = fmaf(hv[j], w2[j], s2);
+      }
+    }
+    s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    if (sub == 0 && p0 + row < P) {
+      // F.softplus(alpha, beta=10): x if 10x > 20 else log1p(exp(10x))/10
+      const float bx = alpha * 10.f;
+      const float sp = bx > 20.f ? alpha : log1pf(expf(bx)) / 10.f;
+      f32x4 o = {s0 + pk[OFF_BR + 0], s1 + pk[OFF_BR + 1], s2 + pk[OFF_BR + 2], sp};
+      *reinterpret_cast<f32x4*>(a.out + (size_t)(p0 + row) * 4) = o;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// parameter packing
+// ---------------------------------------------------------------------------
+struct PackArgs {
+  const float* p[N_PARAM_TENSORS];
+  float* packed;
+};
+
+// source column of padded channel k' for layer l, or -1 for zero padding
+__device__ __forceinline__ int kmap(int l, int kp) {
+  if (l == 0) return kp < EMB ? kp : -1;
+  if (l == 5) return kp < EMB_PAD ? (kp < EMB ? kp : -1) : EMB + (kp - EMB_PAD);
+  if (l == L_VIEWS) return kp < VIEW_PAD ? (kp < 3 ? W + kp : -1) : kp - VIEW_PAD;
+  return kp;
+}
+__device__ __forceinline__ int k_real(int l) {
+  return l == 0 ? EMB : (l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W));
+}
+
+__global__ void mlp_pack_kernel(PackArgs a) {
+  const int l = blockIdx.y;  // 0..9 MFMA layers, 10 = biases + heads
+  if (l < NLAYER_MFMA) {
+    const int widx = l < 8 ? 2 * l : (l == L_FEAT ? 18 : 16);
+    const float* __restrict__ Wsrc = a.p[widx];
+    const int KB = kb_total(l);
+    const int total = w_floats(l);
+    const int kr = k_real(l);
+    const int off = off_w(l);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+      const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+      const int kb = blk % KB, nt = blk / KB;
+      const int n = nt * 32 + (lane & 31);
+      const int src = kmap(l, kb * 8 + 4 * (lane >> 5) + j);
+      a.packed[off + i] = src >= 0 ? Wsrc[(size_t)n * kr + src] : 0.f;
+    }
+  } else {
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = t0; i < NLAYER_MFMA * 256; i += stride) {
+      const int ll = i >> 8, f = i & 255;
+      const int bidx = ll < 8 ? 2 * ll + 1 : (ll == L_FEAT ? 19 : 17);
+      a.packed[OFF_BIAS + i] = (ll == L_VIEWS && f >= 128) ? 0.f : a.p[bidx][f];
+    }
+    for (int i = t0; i < 256; i += stride) a.packed[OFF_WA + i] = a.p[20][i];
+    for (int i = t0; i < 4; i += stride) a.packed[OFF_BA + i] = i == 0 ? a.p[21][0] : 0.f;
+    for (int i = t0; i < 384; i += stride) a.packed[OFF_WR + i] = a.p[22][i];
+    for (int i = t0; i < 4; i += stride) a.packed[OFF_BR + i] = i < 3 ? a.p[23][i] : 0.f;
+    for (int i = t0; i < 256; i += stride) a.packed[OFF_BR + 4 + i] = 0.f;
+  }
+}
+
+}  // namespace scade
+
+// ---------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------
+using namespace scade;
+
+extern "C" long scade_mlp_packed_floats(void) { return PACKED_FWD_FLOATS; }
+
+extern "C" int scade_mlp_pack(const float* const* params, float* packed, void* stream) {
+  SCADE_REQUIRE(params && packed, -1, "scade_mlp_pack: null pointer");
+  PackArgs a;
+  for (int i = 0; i < N_PARAM_TENSORS; ++i) {
+    SCADE_REQUIRE(params[i], -1, "scade_mlp_pack: params[%d] is null", i);
+    a.p[i] = params[i];
+  }
+  a.packed = packed;
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(64, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_mlp_pack");
+}
+
+template <int MODE, bool SAVE>
+static int launch_fwd(const MlpFwdArgs& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = mlp_fwd_kernel<MODE, SAVE>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  const int grid = (a.P + TM - 1) / TM;
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), MLP_LDS_BYTES, s, a);
+  return scade_check_launch("scade_mlp_fwd");
+}
+
+extern "C" int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,
+                             const float* bb, int P, int S, float* out, float* acts, void* stream) {
+  SCADE_REQUIRE(packed && in && out, -1, "scade_mlp_fwd: null pointer");
+  SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd: mode must be 0 (x[P,60]) or 1 (pts[P,3])");
+  if (P == 0) return 0;
+  SCADE_REQUIRE(P > 0, -2, "scade_mlp_fwd: P < 0");
+  if (mode == 1) {
+    SCADE_REQUIRE(viewdirs && bb, -1, "scade_mlp_fwd: mode 1 needs viewdirs and bb");
+    SCADE_REQUIRE(S > 0 && P % S == 0, -2, "scade_mlp_fwd: P (%d) must be a multiple of S (%d)", P, S);
+  }
+  MlpFwdArgs a{packed, in, viewdirs, bb, out, acts, P, S};
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) return acts ? launch_fwd<0, true>(a, s) : launch_fwd<0, false>(a, s);
+  return acts ? launch_fwd<1, true>(a, s) : launch_fwd<1, false>(a, s);
+}
+
+extern "C" int scade_mlp_lds_bytes(void) { return MLP_LDS_BYTES; }

@@ -1,0 +1,59 @@
+"""autograd wrappers of the fused NeRF MLP kernels (scade_mlp_fwd / scade_mlp_bwd)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+N_ACT_SLOTS = 10  # pts 0..7 post-ReLU, views hidden, feature
+
+
+def _needs_grad(params) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for p in params)
+
+
+class MlpEmbeddedFn(torch.autograd.Function):
+    """NeRF.forward(x[P,60])  (model/run_nerf_helpers.py:223-247)."""
+
+    @staticmethod
+    def forward(ctx, net, x, *params):
+        packed = net.packed()
+        train = any(ctx.needs_input_grad)
+        acts = None
+        if train:
+            acts = torch.empty(N_ACT_SLOTS, x.shape[0], 256, device=x.device, dtype=torch.float32)
+        out = ops.mlp_fwd_embedded(packed, x, acts)
+        ctx.net, ctx.mode = net, 0
+        ctx.save_for_backward(x, acts if acts is not None else x.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from .mlp_bwd import mlp_backward
+        x, acts = ctx.saved_tensors
+        grads = mlp_backward(ctx.net, 0, x, None, None, acts, g_out)
+        return (None, None) + tuple(grads)
+
+
+class MlpPointsFn(torch.autograd.Function):
+    """run_network fused with the positional encoding (run_scade_scannet.py:48-63)."""
+
+    @staticmethod
+    def forward(ctx, net, pts, viewdirs, bb, *params):
+        packed = net.packed()
+        train = any(ctx.needs_input_grad)
+        acts = None
+        if train:
+            P = pts.shape[0] * pts.shape[1]
+            acts = torch.empty(N_ACT_SLOTS, P, 256, device=pts.device, dtype=torch.float32)
+        out = ops.mlp_fwd_points(packed, pts, viewdirs, bb, acts)
+        ctx.net, ctx.mode = net, 1
+        ctx.save_for_backward(pts, viewdirs, bb, acts if acts is not None else pts.new_empty(0))
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        from .mlp_bwd import mlp_backward
+        pts, viewdirs, bb, acts = ctx.saved_tensors
+        grads = mlp_backward(ctx.net, 1, pts, viewdirs, bb, acts, g_out)
+        return (None, None, None, None) + tuple(grads)

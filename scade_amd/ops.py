@@ -1,0 +1,365 @@
+"""Tensor-level wrappers of the C ABI (include/scade_hip.h) and the autograd glue.
+
+Everything numeric happens inside libscade_hip.so; this file only validates
+tensors, allocates outputs with torch and records what the backward kernels need.
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import call, check, ptr, stream
+
+Tensor = torch.Tensor
+
+PARAM_ORDER = ([f"pts_linears.{i}.{k}" for i in range(8) for k in ("weight", "bias")]
+               + ["views_linears.0.weight", "views_linears.0.bias",
+                  "feature_linear.weight", "feature_linear.bias",
+                  "alpha_linear.weight", "alpha_linear.bias",
+                  "rgb_linear.weight", "rgb_linear.bias"])
+
+PARAM_SHAPES = {}
+for _i in range(8):
+    _k = 57 if _i == 0 else (313 if _i == 5 else 256)
+    PARAM_SHAPES[f"pts_linears.{_i}.weight"] = (256, _k)
+    PARAM_SHAPES[f"pts_linears.{_i}.bias"] = (256,)
+PARAM_SHAPES.update({
+    "views_linears.0.weight": (128, 259), "views_linears.0.bias": (128,),
+    "feature_linear.weight": (256, 256), "feature_linear.bias": (256,),
+    "alpha_linear.weight": (1, 256), "alpha_linear.bias": (1,),
+    "rgb_linear.weight": (3, 128), "rgb_linear.bias": (3,),
+})
+
+
+def _c(t: Tensor) -> Tensor:
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def _rows(t: Tensor, what: str) -> Tuple[Tensor, int]:
+    """2-D tensor whose rows are unit-stride -> (tensor, row stride in elements)."""
+    check(t, what)
+    if t.dim() != 2:
+        raise ValueError(f"{what}: expected 2-D, got shape {tuple(t.shape)}")
+    if t.shape[1] > 1 and t.stride(1) != 1:
+        t = t.contiguous()
+    if t.shape[0] > 1 and t.stride(0) < t.shape[1]:
+        # expanded (stride 0) rows are fine for read-only inputs handled by the callers
+        if t.stride(0) != 0:
+            t = t.contiguous()
+    return t, (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+
+
+# ---------------------------------------------------------------------------
+# MLP
+# ---------------------------------------------------------------------------
+
+def mlp_packed_floats() -> int:
+    return int(_lib.load().scade_mlp_packed_floats())
+
+
+def mlp_pack(params: Sequence[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """params: the 24 tensors in PARAM_ORDER (device, fp32, contiguous)."""
+    if len(params) != 24:
+        raise ValueError("mlp_pack: expected 24 parameter tensors")
+    keep = []
+    for name, p in zip(PARAM_ORDER, params):
+        check(p, f"mlp_pack[{name}]")
+        if tuple(p.shape) != PARAM_SHAPES[name]:
+            raise ValueError(f"mlp_pack[{name}]: shape {tuple(p.shape)} != {PARAM_SHAPES[name]} "
+                             "(only NeRF(D=8,W=256,input_ch=57,input_ch_views=3,skips=[4],"
+                             "use_viewdirs=True) is implemented)")
+        keep.append(_c(p.detach()))
+    if out is None:
+        out = torch.empty(mlp_packed_floats(), device=keep[0].device, dtype=torch.float32)
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in keep])
+    call("scade_mlp_pack", ctypes.cast(arr, ctypes.c_void_p), ptr(out), stream())
+    return out
+
+
+def mlp_fwd_embedded(packed: Tensor, x: Tensor, acts: Optional[Tensor] = None) -> Tensor:
+    """NeRF.forward on x[P,60] (mode 0)."""
+    check(x, "mlp_fwd: x")
+    if x.dim() != 2 or x.shape[1] != 60:
+        raise ValueError(f"mlp_fwd: x must be [P,60], got {tuple(x.shape)}")
+    x = _c(x)
+    P = x.shape[0]
+    out = torch.empty(P, 4, device=x.device, dtype=torch.float32)
+    call("scade_mlp_fwd", ptr(packed), 0, ptr(x), None, None, P, 1, ptr(out), ptr(acts), stream())
+    return out
+
+
+def mlp_fwd_points(packed: Tensor, pts: Tensor, viewdirs: Tensor, bb: Tensor,
+                   acts: Optional[Tensor] = None) -> Tensor:
+    """run_network fused (mode 1): pts [N,S,3], viewdirs [N,3], bb [4] -> raw [N,S,4]."""
+    check(pts, "mlp_fwd: pts"); check(viewdirs, "mlp_fwd: viewdirs"); check(bb, "mlp_fwd: bb")
+    if pts.dim() != 3 or pts.shape[-1] != 3:
+        raise ValueError(f"mlp_fwd: pts must be [N,S,3], got {tuple(pts.shape)}")
+    N, S = pts.shape[0], pts.shape[1]
+    if tuple(viewdirs.shape) != (N, 3):
+        raise ValueError(f"mlp_fwd: viewdirs must be [{N},3], got {tuple(viewdirs.shape)}")
+    pts, viewdirs, bb = _c(pts), _c(viewdirs), _c(bb)
+    out = torch.empty(N, S, 4, device=pts.device, dtype=torch.float32)
+    call("scade_mlp_fwd", ptr(packed), 1, ptr(pts), ptr(viewdirs), ptr(bb), N * S, S, ptr(out),
+         ptr(acts), stream())
+    return out
+
+
+def embed(x: Tensor, multires: int) -> Tensor:
+    check(x, "embed: x")
+    D = x.shape[-1]
+    flat = _c(x.reshape(-1, D))
+    out = torch.empty(flat.shape[0], D * (1 + 2 * multires), device=x.device, dtype=torch.float32)
+    call("scade_embed", ptr(flat), flat.shape[0], D, multires, ptr(out), stream())
+    return out.reshape(*x.shape[:-1], out.shape[-1])
+
+
+# ---------------------------------------------------------------------------
+# per-ray operators (raw, no autograd)
+# ---------------------------------------------------------------------------
+
+_LINSPACE_CACHE = {}
+
+
+def linspace01(steps: int, device) -> Tensor:
+    """torch.linspace(0,1,steps) computed on the HOST (bit-identical to the CPU
+    reference) and cached on the device."""
+    key = (steps, str(device))
+    t = _LINSPACE_CACHE.get(key)
+    if t is None:
+        t = torch.linspace(0.0, 1.0, steps=steps, device="cpu").to(device)
+        _LINSPACE_CACHE[key] = t
+    return t
+
+
+def ray_points(rays: Tensor, n_samples: int, t_rand: Optional[Tensor], lindisp: bool,
+               want_pts: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
+    rays, stride = _rows(rays, "ray_points: rays")
+    N = rays.shape[0]
+    if rays.shape[1] < 8:
+        raise ValueError("ray_points: rays need >= 8 columns (o, d, near, far)")
+    z = torch.empty(N, n_samples, device=rays.device, dtype=torch.float32)
+    pts = torch.empty(N, n_samples, 3, device=rays.device, dtype=torch.float32) if want_pts else None
+    if t_rand is not None:
+        t_rand = _c(check(t_rand, "ray_points: t_rand"))
+        if tuple(t_rand.shape) != (N, n_samples):
+            raise ValueError("ray_points: t_rand must be [N,S]")
+    call("scade_ray_points", ptr(rays), stride, ptr(linspace01(n_samples, rays.device)), ptr(t_rand),
+         N, n_samples, int(bool(lindisp)), ptr(z), ptr(pts), stream())
+    return z, pts
+
+
+def perturb_z(z_vals: Tensor, t_rand: Tensor) -> Tensor:
+    z = _c(check(z_vals, "perturb_z_vals: z_vals"))
+    t = _c(check(t_rand, "perturb_z_vals: t_rand"))
+    if z.shape != t.shape:
+        raise ValueError("perturb_z_vals: z_vals and t_rand shapes differ")
+    S = z.shape[-1]
+    out = torch.empty_like(z)
+    call("scade_perturb_z", ptr(z), ptr(t), z.numel() // S, S, ptr(out), stream())
+    return out
+
+
+def composite_fwd(raw: Tensor, z_vals: Tensor, rays_d: Tensor, noise: Optional[Tensor] = None):
+    check(raw, "raw2outputs: raw"); check(z_vals, "raw2outputs: z_vals")
+    N, S = z_vals.shape
+    if tuple(raw.shape) != (N, S, 4):
+        raise ValueError(f"raw2outputs: raw must be [{N},{S},4], got {tuple(raw.shape)}")
+    raw, z_vals = _c(raw), _c(z_vals)
+    rays_d, ds = _rows(rays_d, "raw2outputs: rays_d")
+    if noise is not None:
+        noise = _c(check(noise, "raw2outputs: noise"))
+    dev = raw.device
+    rgb = torch.empty(N, 3, device=dev); disp = torch.empty(N, device=dev)
+    acc = torch.empty(N, device=dev); w = torch.empty(N, S, device=dev); depth = torch.empty(N, device=dev)
+    call("scade_composite_fwd", ptr(raw), ptr(z_vals), ptr(rays_d), ds, ptr(noise), N, S, ptr(rgb),
+         ptr(disp), ptr(acc), ptr(w), ptr(depth), stream())
+    return rgb, disp, acc, w, depth
+
+
+def composite_bwd(raw, z_vals, rays_d, noise, g_rgb, g_disp, g_acc, g_w, g_depth) -> Tensor:
+    N, S = z_vals.shape
+    raw, z_vals = _c(raw), _c(z_vals)
+    rays_d, ds = _rows(rays_d, "raw2outputs.backward: rays_d")
+    gs = [None if g is None else _c(g) for g in (g_rgb, g_disp, g_acc, g_w, g_depth)]
+    g_raw = torch.empty(N, S, 4, device=raw.device, dtype=torch.float32)
+    call("scade_composite_bwd", ptr(raw), ptr(z_vals), ptr(rays_d), ds, ptr(noise), N, S,
+         ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]), ptr(g_raw), stream())
+    return g_raw
+
+
+def _u_arg(u: Tensor, N: int, S: int) -> Tuple[Tensor, int]:
+    check(u, "sample_pdf: u")
+    if u.dim() == 1:
+        if u.shape[0] != S:
+            raise ValueError("sample_pdf: 1-D u must have N_samples entries")
+        return _c(u), 0
+    if tuple(u.shape) != (N, S):
+        raise ValueError(f"sample_pdf: u must be [{N},{S}] or [{S}], got {tuple(u.shape)}")
+    if u.stride(0) == 0 and u.stride(1) == 1:
+        return u, 0
+    u = _c(u)
+    return u, S
+
+
+def sample_pdf_fwd(bins: Tensor, weights: Optional[Tensor], u: Tensor, n_samples: int,
+                   bins_are_mids: bool = False, cdf_in: Optional[Tensor] = None,
+                   want_inds: bool = False, want_cdf: bool = False, want_std: bool = False):
+    bins, bstride = _rows(bins, "sample_pdf: bins")
+    N = bins.shape[0]
+    M = bins.shape[1] - (1 if bins_are_mids else 0)
+    wstride = 0
+    if weights is not None:
+        weights, wstride = _rows(weights, "sample_pdf: weights")
+        if tuple(weights.shape) != (N, M - 1):
+            raise ValueError(f"sample_pdf: weights must be [{N},{M - 1}], got {tuple(weights.shape)}")
+    if cdf_in is not None:
+        cdf_in = _c(check(cdf_in, "sample_pdf: cdf"))
+    u, ustride = _u_arg(u, N, n_samples)
+    dev = bins.device
+    samples = torch.empty(N, n_samples, device=dev, dtype=torch.float32)
+    inds = torch.empty(N, n_samples, device=dev, dtype=torch.int64) if want_inds else None
+    cdf = torch.empty(N, M, device=dev, dtype=torch.float32) if want_cdf else None
+    std = torch.empty(N, device=dev, dtype=torch.float32) if want_std else None
+    call("scade_sample_pdf_fwd", ptr(bins), bstride, int(bins_are_mids), ptr(weights), wstride,
+         ptr(cdf_in), ptr(u), ustride, N, M, n_samples, ptr(samples), ptr(inds), ptr(cdf), ptr(std),
+         stream())
+    return samples, inds, cdf, std
+
+
+def sample_pdf_bwd(bins: Tensor, weights: Tensor, u: Tensor, g_samples: Tensor,
+                   bins_are_mids: bool = False) -> Tensor:
+    bins, bstride = _rows(bins, "sample_pdf.backward: bins")
+    N = bins.shape[0]
+    M = bins.shape[1] - (1 if bins_are_mids else 0)
+    weights, wstride = _rows(weights, "sample_pdf.backward: weights")
+    S = g_samples.shape[1]
+    u, ustride = _u_arg(u, N, S)
+    g_samples = _c(g_samples)
+    g_w = torch.empty(N, M - 1, device=bins.device, dtype=torch.float32)
+    call("scade_sample_pdf_bwd", ptr(bins), bstride, int(bins_are_mids), ptr(weights), wstride,
+         ptr(u), ustride, ptr(g_samples), N, M, S, ptr(g_w), stream())
+    return g_w
+
+
+def merge_sorted(z_a: Tensor, z_b: Tensor, rays: Optional[Tensor] = None):
+    z_a, z_b = _c(check(z_a, "merge: z_a")), _c(check(z_b, "merge: z_b"))
+    N, Sa = z_a.shape
+    Sb = z_b.shape[1]
+    out = torch.empty(N, Sa + Sb, device=z_a.device, dtype=torch.float32)
+    pts, rstride = None, 0
+    if rays is not None:
+        rays, rstride = _rows(rays, "merge: rays")
+        pts = torch.empty(N, Sa + Sb, 3, device=z_a.device, dtype=torch.float32)
+    call("scade_merge_sorted", ptr(z_a), Sa, ptr(z_b), Sb, ptr(rays), rstride, N, ptr(out), ptr(pts),
+         stream())
+    return out, pts
+
+
+# ---------------------------------------------------------------------------
+# autograd glue
+# ---------------------------------------------------------------------------
+
+class CompositeFn(torch.autograd.Function):
+    """raw2outputs (run_scade_scannet.py:530-562); differentiable w.r.t. raw."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays_d, noise):
+        outs = composite_fwd(raw, z_vals, rays_d, noise)
+        ctx.save_for_backward(raw, z_vals, rays_d, noise if noise is not None else raw.new_empty(0))
+        ctx.has_noise = noise is not None
+        return outs
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
+        raw, z_vals, rays_d, noise = ctx.saved_tensors
+        g_raw = composite_bwd(raw, z_vals, rays_d, noise if ctx.has_noise else None,
+                              g_rgb, g_disp, g_acc, g_w, g_depth)
+        return g_raw, None, None, None
+
+
+class SamplePdfFn(torch.autograd.Function):
+    """sample_pdf / sample_pdf_return_u (helpers:337-436); differentiable w.r.t. weights."""
+
+    @staticmethod
+    def forward(ctx, bins, weights, u, bins_are_mids, want_std):
+        samples, _, _, std = sample_pdf_fwd(bins, weights, u, u.shape[-1], bins_are_mids,
+                                            want_std=want_std)
+        ctx.save_for_backward(bins, weights, u)
+        ctx.mids = bins_are_mids
+        if want_std:
+            ctx.mark_non_differentiable(std)
+            return samples, std
+        return samples
+
+    @staticmethod
+    def backward(ctx, g_samples, *unused):
+        bins, weights, u = ctx.saved_tensors
+        g_w = sample_pdf_bwd(bins, weights, u, g_samples, ctx.mids)
+        return None, g_w, None, None, None
+
+
+class CarveFn(torch.autograd.Function):
+    """compute_space_carving_loss (helpers:93-128)."""
+
+    @staticmethod
+    def forward(ctx, pred, hyp, mask, threshold, is_joint):
+        check(pred, "space_carving: pred_depth"); check(hyp, "space_carving: target_hypothesis")
+        N, P = pred.shape
+        K = hyp.shape[0]
+        pred_c, hyp_c = _c(pred), _c(hyp.reshape(K, N))
+        mask_c = None if mask is None else _c(check(mask, "space_carving: mask").reshape(N))
+        nws = int(_lib.load().scade_carve_workspace_floats(N, P, K, int(is_joint)))
+        ws = torch.empty(nws, device=pred.device, dtype=torch.float32)
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        call("scade_carve_fwd", ptr(pred_c), ptr(hyp_c), ptr(mask_c), float(threshold), int(is_joint),
+             N, P, K, ptr(ws), ptr(loss), stream())
+        ctx.save_for_backward(pred_c, hyp_c, mask_c if mask_c is not None else pred.new_empty(0), ws)
+        ctx.cfg = (float(threshold), int(is_joint), mask is not None, tuple(hyp.shape))
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, hyp, mask, ws = ctx.saved_tensors
+        thr, joint, has_mask, hyp_shape = ctx.cfg
+        N, P = pred.shape
+        K = hyp.shape[0]
+        g = _c(g.reshape(1).to(torch.float32))
+        g_pred = torch.empty_like(pred)
+        g_hyp = torch.empty_like(hyp)
+        call("scade_carve_bwd", ptr(pred), ptr(hyp), ptr(mask if has_mask else None), thr, joint, N, P,
+             K, ptr(ws), ptr(g), ptr(g_pred), ptr(g_hyp), stream())
+        return g_pred, g_hyp.reshape(hyp_shape), None, None, None
+
+
+class MseFn(torch.autograd.Function):
+    """img2mse (helpers:11), optional per-row mask (run_scade_wild.py:978-986)."""
+
+    @staticmethod
+    def forward(ctx, x, y, mask):
+        check(x, "img2mse: x"); check(y, "img2mse: y")
+        if x.shape != y.shape:
+            raise ValueError(f"img2mse: shapes differ: {tuple(x.shape)} vs {tuple(y.shape)}")
+        xc, yc = _c(x), _c(y)
+        c = x.shape[-1] if x.dim() > 1 else 1
+        n = x.numel() // c
+        mc = None if mask is None else _c(check(mask, "img2mse: mask").reshape(n))
+        loss = torch.empty(1, device=x.device, dtype=torch.float32)
+        call("scade_mse_fwd", ptr(xc), ptr(yc), ptr(mc), n, c, ptr(loss), stream())
+        ctx.save_for_backward(xc, yc, mc if mc is not None else x.new_empty(0))
+        ctx.dims = (n, c, mask is not None, x.shape)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, mask = ctx.saved_tensors
+        n, c, has_mask, shape = ctx.dims
+        g = _c(g.reshape(1).to(torch.float32))
+        gx = torch.empty_like(x)
+        call("scade_mse_bwd", ptr(x), ptr(y), ptr(mask if has_mask else None), n, c, ptr(g), ptr(gx),
+             stream())
+        gx = gx.reshape(shape)
+        return (gx if ctx.needs_input_grad[0] else None,
+                (-gx) if ctx.needs_input_grad[1] else None, None)

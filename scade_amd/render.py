@@ -1,0 +1,279 @@
+"""MI355X drop-in for the render operators that the reference keeps at module
+level of its driver scripts (``run_scade_scannet.py`` / ``run_scade_wild.py``):
+
+  batchify :39-46 · run_network :48-63 · batchify_rays :66-78 · render :80-155 ·
+  render_hyp :157-233 · compute_weights :511-522 · raw2depth :524-528 ·
+  raw2outputs :530-562 · perturb_z_vals :564-579 · render_rays :581-751
+
+Same names / arguments / returned dict keys.  All arithmetic runs in
+libscade_hip.so; torch is used for allocation, slicing and dict plumbing.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import ops
+from .ops import CompositeFn
+from .run_nerf_helpers import (Embedder, NeRF, _draw_u, _sample, get_rays)
+
+
+def batchify(fn, chunk):
+    """run_scade_scannet.py:39-46."""
+    if chunk is None:
+        return fn
+
+    def ret(inputs):
+        return torch.cat([fn(inputs[i:i + chunk]) for i in range(0, inputs.shape[0], chunk)], 0)
+    return ret
+
+
+_BB_CACHE = {}
+
+
+def _bb_tensor(bb_center, bb_scale, device):
+    """{cx,cy,cz,scale} as one device tensor (cached per (center, scale) object/version)."""
+    if not torch.is_tensor(bb_center):
+        bb_center = torch.as_tensor(bb_center, dtype=torch.float32)
+    if not torch.is_tensor(bb_scale):
+        bb_scale = torch.as_tensor(bb_scale, dtype=torch.float32)
+    key = (bb_center.data_ptr(), bb_center._version, bb_scale.data_ptr(), bb_scale._version, str(device))
+    hit = _BB_CACHE.get(key)
+    if hit is None:
+        if len(_BB_CACHE) > 64:
+            _BB_CACHE.clear()
+        hit = torch.cat([bb_center.reshape(-1)[:3].float(), bb_scale.reshape(-1)[:1].float()]).to(device)
+        _BB_CACHE[key] = hit
+    return hit
+
+
+def _is_fusable(fn, embed_fn, embeddirs_fn, embedded_cam):
+    net = fn.module if isinstance(fn, torch.nn.DataParallel) else fn
+    if not isinstance(net, NeRF):
+        return None
+    if not (isinstance(embed_fn, Embedder) and embed_fn.multires == 9 and embed_fn.input_dims == 3):
+        return None
+    if not (isinstance(embeddirs_fn, Embedder) and embeddirs_fn.multires == 0):
+        return None
+    if embedded_cam is not None and embedded_cam.numel() != 0:
+        return None
+    return net
+
+
+def run_network(inputs, viewdirs, embedded_cam, fn, embed_fn, embeddirs_fn, bb_center, bb_scale,
+                netchunk=1024 * 64):
+    """run_scade_scannet.py:48-63.  With the SCADE configuration (get_embedder(9),
+    get_embedder(0), empty camera code, scade_amd.NeRF) the normalisation, both
+    embeddings, the view broadcast and the 12 layers are ONE kernel launch and the
+    [P,60] embedding never exists in HBM; ``netchunk`` (a memory knob of the
+    reference) is then irrelevant."""
+    net = _is_fusable(fn, embed_fn, embeddirs_fn, embedded_cam) if viewdirs is not None else None
+    if net is not None and inputs.dim() == 3:
+        return net.forward_points(inputs, viewdirs, _bb_tensor(bb_center, bb_scale, inputs.device))
+    # generic composition (any callable fn / embedders)
+    flat = torch.reshape(inputs, [-1, inputs.shape[-1]])
+    flat = (flat - bb_center) * bb_scale
+    embedded = embed_fn(flat)
+    if viewdirs is not None:
+        dirs = viewdirs[:, None].expand(inputs.shape)
+        dirs = torch.reshape(dirs, [-1, dirs.shape[-1]])
+        parts = [embedded, embeddirs_fn(dirs)]
+        if embedded_cam is not None and embedded_cam.numel() != 0:
+            parts.append(embedded_cam.unsqueeze(0).expand(dirs.shape[0], embedded_cam.shape[0]))
+        embedded = torch.cat(parts, -1)
+    out = batchify(fn, netchunk)(embedded)
+    return torch.reshape(out, list(inputs.shape[:-1]) + [out.shape[-1]])
+
+
+def make_network_query_fn(embed_fn, embeddirs_fn, bb_center, bb_scale, netchunk=1024 * 64):
+    """The closure create_nerf builds (run_scade_scannet.py:461-466)."""
+    def query(inputs, viewdirs, embedded_cam, network_fn):
+        return run_network(inputs, viewdirs, embedded_cam, network_fn, embed_fn=embed_fn,
+                           embeddirs_fn=embeddirs_fn, bb_center=bb_center, bb_scale=bb_scale,
+                           netchunk=netchunk)
+    return query
+
+
+# ---------------------------------------------------------------------------
+# compositing
+# ---------------------------------------------------------------------------
+
+def _noise_arg(noise, like):
+    if torch.is_tensor(noise):
+        return noise.to(like.device, torch.float32).expand(like.shape).contiguous()
+    if noise == 0:
+        return None
+    return torch.full(like.shape, float(noise), device=like.device, dtype=torch.float32)
+
+
+def compute_weights(raw, z_vals, rays_d, noise=0.):
+    """run_scade_scannet.py:511-522."""
+    return CompositeFn.apply(raw, z_vals, rays_d, _noise_arg(noise, raw[..., 3]))[3]
+
+
+def raw2depth(raw, z_vals, rays_d):
+    """run_scade_scannet.py:524-528 (tiny reductions on the kernel's weights)."""
+    weights = compute_weights(raw, z_vals, rays_d)
+    depth = torch.sum(weights * z_vals, -1)
+    std = (((z_vals - depth.unsqueeze(-1)).pow(2) * weights).sum(-1)).sqrt()
+    return depth, std
+
+
+def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, pytest=False):
+    """run_scade_scannet.py:530-562 -> rgb_map, disp_map, acc_map, weights, depth_map."""
+    noise = None
+    if raw_noise_std > 0.:
+        shape = raw[..., 3].shape
+        if pytest:
+            np.random.seed(0)
+            noise = torch.Tensor(np.random.rand(*list(shape)) * raw_noise_std).to(raw.device)
+        else:
+            noise = torch.randn(shape, device=raw.device) * raw_noise_std
+    return CompositeFn.apply(raw, z_vals, rays_d, noise)
+
+
+def perturb_z_vals(z_vals, pytest):
+    """run_scade_scannet.py:564-579 on an arbitrary (already built) z_vals tensor.
+    render_rays does not call this: its jitter is fused into scade_ray_points."""
+    ops.check(z_vals, "perturb_z_vals: z_vals")
+    if pytest:
+        np.random.seed(0)
+        t_rand = torch.Tensor(np.random.rand(*list(z_vals.shape))).to(z_vals.device)
+    else:
+        t_rand = torch.rand_like(z_vals)
+    return ops.perturb_z(z_vals, t_rand)
+
+
+# ---------------------------------------------------------------------------
+# render_rays
+# ---------------------------------------------------------------------------
+
+def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples,
+                precomputed_z_samples=None, embedded_cam=None, retraw=False, lindisp=False,
+                perturb=0., N_importance=0, network_fine=None, raw_noise_std=0., verbose=False,
+                pytest=False, is_joint=False, cached_u=None, t_rand=None, u_coarse=None):
+    """run_scade_scannet.py:581-751 (live branch ``N_importance > 0``).
+
+    Extra keyword-only knobs beyond the reference signature: ``t_rand`` [N,N_samples]
+    and ``u_coarse`` [N,N_importance] inject the stratified jitter / first sampler
+    draw (the reference can only inject the last draw through ``cached_u``); used by
+    the parity tests because device RNG streams cannot match the CPU's."""
+    if N_importance <= 0:
+        raise NotImplementedError(
+            "render_rays: N_importance == 0 is dead code in the reference (raises UnboundLocalError "
+            "'u' at run_scade_scannet.py:733); only the coarse+fine branch exists")
+    if not use_viewdirs:
+        raise NotImplementedError("render_rays: SCADE always renders with use_viewdirs=True")
+    ops.check(ray_batch, "render_rays: ray_batch")
+    if ray_batch.dim() != 2 or ray_batch.shape[1] < 11:
+        raise ValueError("render_rays: ray_batch must be [N, >=11] = o,d,near,far,viewdir")
+    rays = ray_batch if ray_batch.stride(1) == 1 else ray_batch.contiguous()
+    N = rays.shape[0]
+    rays_d = rays[:, 3:6]
+    viewdirs = rays[:, 8:11]
+    dev = rays.device
+    if embedded_cam is None:
+        embedded_cam = torch.empty(0, device=dev)
+    det = (perturb == 0.)
+
+    # ---- coarse: z (+jitter) and points in one launch (:638-657) -------------
+    if perturb > 0.:
+        if t_rand is None:
+            if pytest:
+                np.random.seed(0)
+                t_rand = torch.Tensor(np.random.rand(N, N_samples)).to(dev)
+            else:
+                t_rand = torch.rand(N, N_samples, device=dev)
+    else:
+        t_rand = None
+    z_vals, pts = ops.ray_points(rays, N_samples, t_rand, lindisp)
+    raw = network_query_fn(pts, viewdirs, embedded_cam, network_fn)
+    rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = raw2outputs(
+        raw, z_vals, rays_d, raw_noise_std, pytest=pytest)
+    z_vals_0 = z_vals
+
+    # ---- importance samples from the coarse pdf, detached (:702-711) ---------
+    uc = u_coarse if u_coarse is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
+    with torch.no_grad():
+        z_samples = _sample(z_vals, weights_0[..., 1:-1], uc, bins_are_mids=True)
+    # ---- merge + fine points (:713-714) --------------------------------------
+    z_vals, pts = ops.merge_sorted(z_vals_0, z_samples, rays)
+    run_fn = network_fn if network_fine is None else network_fine
+    raw = network_query_fn(pts, viewdirs, embedded_cam, run_fn)
+    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(
+        raw, z_vals, rays_d, raw_noise_std, pytest=pytest)
+
+    # ---- depth hypotheses from the fine pdf (:723-730) ------------------------
+    u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
+    pred_depth_hyp, z_std = _sample(z_vals, weights[..., 1:-1], u, bins_are_mids=True, want_std=True)
+    if u.dim() == 1 or u.stride(0) == 0:
+        u = u.expand(N, N_importance)
+
+    ret = {'rgb_map': rgb_map, 'disp_map': disp_map, 'acc_map': acc_map, 'depth_map': depth_map,
+           'z_vals': z_vals, 'weights': weights, 'pred_hyp': pred_depth_hyp, 'u': u}
+    if retraw:
+        ret['raw'] = raw
+    ret['rgb0'] = rgb_map_0
+    ret['disp0'] = disp_map_0
+    ret['acc0'] = acc_map_0
+    ret['depth0'] = depth_map_0
+    ret['z_vals0'] = z_vals_0
+    ret['weights0'] = weights_0
+    ret['z_std'] = z_std
+    # (the reference's per-tensor isnan/isinf host syncs, :747-749, are DEBUG-only prints)
+    return ret
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, use_viewdirs=False, **kwargs):
+    """run_scade_scannet.py:66-78."""
+    all_ret = {}
+    for i in range(0, rays_flat.shape[0], chunk):
+        ret = render_rays(rays_flat[i:i + chunk], use_viewdirs, **kwargs)
+        for k in ret:
+            all_ret.setdefault(k, []).append(ret[k])
+    return {k: torch.cat(all_ret[k], 0) for k in all_ret}
+
+
+def _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs, c2w_staticcam, rays_depth):
+    if c2w is not None:
+        rays_o, rays_d = get_rays(H, W, intrinsic, c2w)
+    elif rays.shape[0] == 2:
+        rays_o, rays_d = rays
+    else:
+        rays_o, rays_d, rays_depth = rays
+    viewdirs = None
+    if use_viewdirs:
+        viewdirs = rays_d
+        if c2w_staticcam is not None:
+            rays_o, rays_d = get_rays(H, W, intrinsic, c2w_staticcam)
+        viewdirs = viewdirs / torch.norm(viewdirs, dim=-1, keepdim=True)
+        viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    sh = rays_d.shape
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    near, far = near * torch.ones_like(rays_d[..., :1]), far * torch.ones_like(rays_d[..., :1])
+    parts = [rays_o, rays_d, near, far]
+    if use_viewdirs:
+        parts.append(viewdirs)
+    if rays_depth is not None:
+        parts.append(torch.reshape(rays_depth, [-1, 3]).float())
+    return torch.cat(parts, -1), sh
+
+
+def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1.,
+           with_5_9=False, use_viewdirs=False, c2w_staticcam=None, rays_depth=None, **kwargs):
+    """run_scade_scannet.py:80-155 (ray-row assembly is host plumbing; with_5_9 cropping is not
+    carried over)."""
+    if with_5_9:
+        raise NotImplementedError("render: with_5_9 cropping is a visualisation option outside the hot path")
+    rays_flat, sh = _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs,
+                                   c2w_staticcam, rays_depth)
+    all_ret = batchify_rays(rays_flat, chunk, use_viewdirs, **kwargs)
+    for k in all_ret:
+        all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
+    k_extract = ['rgb_map', 'disp_map', 'acc_map']
+    return [all_ret[k] for k in k_extract] + [{k: all_ret[k] for k in all_ret if k not in k_extract}]
+
+
+# render_hyp (:157-233) is the same function body in the reference
+render_hyp = render

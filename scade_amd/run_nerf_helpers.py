@@ -1,0 +1,258 @@
+"""MI355X drop-in for the hot-path operators of the reference's
+``model/run_nerf_helpers.py``: same names, arguments and return values, every
+numeric step executed by hand-written HIP kernels through ``libscade_hip.so``.
+
+Mirrored interface (reference file:line):
+  img2mse / mse2psnr / to8b / to16b            helpers:11-14
+  compute_space_carving_loss                    helpers:93-128
+  DenseLayer / Embedder / get_embedder / NeRF   helpers:131-247
+  select_coordinates / get_ray_dirs / get_rays  helpers:279-305
+  sample_pdf / sample_pdf_return_u /
+  sample_pdf_joint / sample_pdf_joint_return_u  helpers:337-538
+
+There is no CPU fallback: tensors must live on the HIP device.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import CarveFn, MseFn, SamplePdfFn
+
+# ---------------------------------------------------------------------------
+# misc  (helpers:11-14)
+# ---------------------------------------------------------------------------
+
+
+def img2mse(x, y):
+    return MseFn.apply(x, y, None)
+
+
+def img2mse_masked(x, y, mask):
+    """mean(((x-y)**2) * mask[:,None])  (run_scade_wild.py:978-986)."""
+    return MseFn.apply(x, y, mask)
+
+
+def mse2psnr(x):
+    return -10.0 * torch.log(x) / torch.log(torch.full((1,), 10.0, device=x.device))
+
+
+def to8b(x):
+    return (255 * np.clip(x, 0, 1)).astype(np.uint8)
+
+
+def to16b(x):
+    return ((2 ** 16 - 1) * np.clip(x, 0, 1)).astype(np.uint16)
+
+
+# ---------------------------------------------------------------------------
+# space-carving loss  (helpers:93-128)
+# ---------------------------------------------------------------------------
+
+
+def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2,
+                               threshold=0.0):
+    """pred_depth [N,P]; target_hypothesis [K,N,1].  The norm runs over a size-1
+    axis, so every ``norm_p`` gives |pred - hyp| (kept for signature parity)."""
+    if target_hypothesis.dim() != 3:
+        raise ValueError("compute_space_carving_loss: target_hypothesis must be [K,N,1]")
+    if target_hypothesis.shape[-1] != 1:
+        raise NotImplementedError(
+            "compute_space_carving_loss: per-quantile hypotheses [K,N,P] (helpers:100-102) are not "
+            "produced by any SCADE driver and are not implemented")
+    if norm_p <= 0:
+        raise ValueError("norm_p must be positive")
+    return CarveFn.apply(pred_depth, target_hypothesis, mask, float(threshold), bool(is_joint))
+
+
+# ---------------------------------------------------------------------------
+# positional encoding  (helpers:142-189)
+# ---------------------------------------------------------------------------
+
+
+class Embedder:
+    """gamma(x) = [x, sin(pi x 2^0), cos(pi x 2^0), ..., cos(pi x 2^(L-1))]."""
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+        if not kwargs.get("include_input", True) or not kwargs.get("log_sampling", True):
+            raise NotImplementedError("Embedder: only include_input=True, log_sampling=True "
+                                      "(the get_embedder configuration) is implemented")
+        self.multires = int(kwargs["num_freqs"])
+        self.input_dims = int(kwargs["input_dims"])
+        self.out_dim = self.input_dims * (1 + 2 * self.multires)
+
+    def embed(self, inputs):
+        return ops.embed(inputs, self.multires)
+
+    __call__ = embed
+
+
+def get_embedder(multires, i=0):
+    if i == -1:
+        return nn.Identity(), 3
+    eo = Embedder(include_input=True, input_dims=3, max_freq_log2=multires - 1, num_freqs=multires,
+                  log_sampling=True, periodic_fns=[torch.sin, torch.cos])
+    return eo, eo.out_dim
+
+
+# ---------------------------------------------------------------------------
+# NeRF MLP  (helpers:131-139, 193-247)
+# ---------------------------------------------------------------------------
+
+
+class DenseLayer(nn.Linear):
+    def __init__(self, in_dim, out_dim, activation="relu", *args, **kwargs):
+        self.activation = activation
+        super().__init__(in_dim, out_dim, *args, **kwargs)
+
+    def reset_parameters(self):
+        nn.init.xavier_uniform_(self.weight, gain=nn.init.calculate_gain(self.activation))
+        if self.bias is not None:
+            nn.init.zeros_(self.bias)
+
+
+class NeRF(nn.Module):
+    """Parameter container + fused HIP forward.  state_dict names match the
+    reference (helpers:205-220); checkpoints saved through nn.DataParallel
+    ('module.' prefix, run_scade_scannet.py:438) load via ``load_reference_state_dict``."""
+
+    def __init__(self, D=8, W=256, input_ch=3, input_ch_views=3, input_ch_cam=0, output_ch=4,
+                 skips=[4], use_viewdirs=False):
+        super().__init__()
+        self.D, self.W = D, W
+        self.input_ch, self.input_ch_views, self.input_ch_cam = input_ch, input_ch_views, input_ch_cam
+        self.skips, self.use_viewdirs = list(skips), use_viewdirs
+        self.pts_linears = nn.ModuleList(
+            [DenseLayer(input_ch, W)] +
+            [DenseLayer(W + input_ch if i in self.skips else W, W) for i in range(D - 1)])
+        self.views_linears = nn.ModuleList([DenseLayer(input_ch_views + input_ch_cam + W, W // 2)])
+        if use_viewdirs:
+            self.feature_linear = DenseLayer(W, W, activation="linear")
+            self.alpha_linear = DenseLayer(W, 1, activation="linear")
+            self.rgb_linear = DenseLayer(W // 2, 3, activation="linear")
+        else:
+            self.output_linear = DenseLayer(W, output_ch, activation="linear")
+        self._packed = None
+        self._packed_key = None
+
+    # -- kernel support ----------------------------------------------------
+    def _require_supported(self):
+        ok = (self.D == 8 and self.W == 256 and self.input_ch == 57 and self.input_ch_views == 3
+              and self.input_ch_cam == 0 and self.skips == [4] and self.use_viewdirs)
+        if not ok:
+            raise NotImplementedError(
+                "scade_amd.NeRF: the HIP kernels implement the SCADE configuration "
+                "NeRF(D=8, W=256, input_ch=57, input_ch_views=3, input_ch_cam=0, skips=[4], "
+                "use_viewdirs=True) only")
+
+    def ordered_params(self):
+        sd = dict(self.named_parameters())
+        return [sd[k] for k in ops.PARAM_ORDER]
+
+    def packed(self):
+        """MFMA-ordered parameter blob, rebuilt whenever a parameter changed in place."""
+        self._require_supported()
+        ps = self.ordered_params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if self._packed is None or key != self._packed_key or self._packed.device != ps[0].device:
+            self._packed = ops.mlp_pack(ps, None if self._packed is None or
+                                        self._packed.device != ps[0].device else self._packed)
+            self._packed_key = key
+        return self._packed
+
+    def forward(self, x):
+        """x [P, 60] = [gamma(pts) | viewdir] -> [P,4] (helpers:223-247)."""
+        from .mlp import MlpEmbeddedFn
+        self._require_supported()
+        return MlpEmbeddedFn.apply(self, x, *self.ordered_params())
+
+    def forward_points(self, pts, viewdirs, bb):
+        """Fused run_network: pts [N,S,3], viewdirs [N,3], bb [4]={center,scale} -> raw [N,S,4]."""
+        from .mlp import MlpPointsFn
+        self._require_supported()
+        return MlpPointsFn.apply(self, pts, viewdirs, bb, *self.ordered_params())
+
+    def load_reference_state_dict(self, state_dict, strict=True):
+        sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}
+        return self.load_state_dict(sd, strict=strict)
+
+
+# ---------------------------------------------------------------------------
+# rays  (helpers:279-305) -- host-side batch assembly, not on the kernel path
+# ---------------------------------------------------------------------------
+
+
+def select_coordinates(coords, N_rand):
+    coords = torch.reshape(coords, [-1, 2])
+    select_inds = np.random.choice(coords.shape[0], size=[N_rand], replace=False)
+    return coords[select_inds].long()
+
+
+def get_ray_dirs(H, W, intrinsic, c2w, coords=None):
+    device = intrinsic.device
+    fx, fy, cx, cy = intrinsic[0], intrinsic[1], intrinsic[2], intrinsic[3]
+    if coords is None:
+        i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device),
+                              torch.linspace(0, H - 1, H, device=device), indexing="ij")
+        i, j = i.t(), j.t()
+    else:
+        i, j = coords[:, 1], coords[:, 0]
+    dirs = torch.stack([((i + 0.5) - cx) / fx, (H - (j + 0.5) - cy) / fy, -torch.ones_like(i)], -1)
+    return torch.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+
+
+def get_rays(H, W, intrinsic, c2w, coords=None):
+    rays_d = get_ray_dirs(H, W, intrinsic, c2w, coords)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+# ---------------------------------------------------------------------------
+# hierarchical sampling  (helpers:337-538)
+# ---------------------------------------------------------------------------
+
+
+def _draw_u(bins, N_samples, det, pytest, joint):
+    """The u the reference draws (helpers:346-361, 449-464); device RNG when random."""
+    n_rays = bins.shape[0]
+    dev = bins.device
+    if pytest:
+        np.random.seed(0)
+        if det:
+            u = np.broadcast_to(np.linspace(0.0, 1.0, N_samples), [n_rays, N_samples])
+        else:
+            u = np.random.rand(n_rays, N_samples)
+        return torch.Tensor(np.ascontiguousarray(u)).to(dev)
+    if det:
+        return ops.linspace01(N_samples, dev).expand(n_rays, N_samples)
+    if joint:
+        return torch.rand(N_samples, device=dev).expand(n_rays, N_samples)
+    return torch.rand(n_rays, N_samples, device=dev)
+
+
+def _sample(bins, weights, u, bins_are_mids=False, want_std=False):
+    return SamplePdfFn.apply(bins, weights, u, bins_are_mids, want_std)
+
+
+def sample_pdf(bins, weights, N_samples, det=False, pytest=False):
+    return _sample(bins, weights, _draw_u(bins, N_samples, det, pytest, False))
+
+
+def sample_pdf_return_u(bins, weights, N_samples, det=False, pytest=False, load_u=None):
+    u = _draw_u(bins, N_samples, det, pytest, False) if load_u is None else load_u
+    return _sample(bins, weights, u), u
+
+
+def sample_pdf_joint(bins, weights, N_samples, det=False, pytest=False):
+    return _sample(bins, weights, _draw_u(bins, N_samples, det, pytest, True))
+
+
+def sample_pdf_joint_return_u(bins, weights, N_samples, det=False, pytest=False, load_u=None):
+    u = _draw_u(bins, N_samples, det, pytest, True) if load_u is None else load_u
+    return _sample(bins, weights, u), u

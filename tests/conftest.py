@@ -1,0 +1,53 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+GOLDEN = os.path.join(REPO, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
+
+
+def load_golden(name):
+    """npz fixture -> dict of torch tensors (see tools/make_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])) for k in z.files}
+
+
+@pytest.fixture(scope="session")
+def dev():
+    if not torch.cuda.is_available():
+        pytest.skip("no HIP device")
+    from scade_amd import _lib
+    _lib.load()  # fail loudly if the extension is missing on a GPU box
+    return torch.device("cuda:0")
+
+
+def assert_close(a, b, rtol=1e-4, atol=1e-6, what=""):
+    """|a-b| <= atol + rtol*|b| element-wise, NaN pattern must agree."""
+    a = a.detach().double().cpu()
+    b = b.detach().double().cpu()
+    assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
+    na, nb = torch.isnan(a), torch.isnan(b)
+    assert torch.equal(na, nb), f"{what}: NaN pattern differs"
+    a, b = torch.nan_to_num(a), torch.nan_to_num(b)
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = err > tol
+    if bad.any():
+        i = torch.argmax(err - tol)
+        raise AssertionError(f"{what}: {int(bad.sum())}/{bad.numel()} outside tol; worst |d|="
+                             f"{err.flatten()[i]:.3e} at ref={b.flatten()[i]:.6e}")
+
+
+def rel_l2(a, b):
+    a = a.detach().double().cpu().flatten()
+    b = b.detach().double().cpu().flatten()
+    return float((a - b).norm() / (b.norm() + 1e-30))

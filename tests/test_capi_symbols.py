@@ -1,0 +1,79 @@
+"""CPU: the C-ABI library loads and exports every symbol include/scade_hip.h declares
+(no compute calls here -- there is no GPU in the build container)."""
+import ctypes
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "scade_hip.h")
+
+
+def declared_symbols():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(scade_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound():
+    from scade_amd import _lib
+    names = declared_symbols()
+    assert len(names) >= 18
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in scade_hip.h but not exported by libscade_hip.so"
+        assert n in _lib.SIGNATURES, f"{n} declared in scade_hip.h but not bound in scade_amd/_lib.py"
+    for n in _lib.SIGNATURES:
+        assert n in names, f"{n} bound in _lib.py but missing from the header"
+
+
+def test_library_loads_and_reports():
+    from scade_amd import _lib
+    lib = _lib.load()
+    assert lib.scade_version() >= 1
+    assert lib.scade_mlp_packed_floats() > 589700          # padded blob is larger than the raw params
+    assert lib.scade_mlp_lds_bytes() <= 80 * 1024          # two workgroups per CU
+    assert lib.scade_carve_workspace_floats(1024, 128, 20, 0) == 1024
+
+
+def test_argument_errors_do_not_need_a_gpu():
+    from scade_amd import _lib
+    lib = _lib.load()
+    rc = lib.scade_mlp_fwd(None, 0, None, None, None, 10, 1, None, None, None)
+    assert rc != 0 and b"null" in lib.scade_last_error()
+    rc = lib.scade_composite_fwd(None, None, None, 3, None, 4, 64, None, None, None, None, None, None)
+    assert rc != 0
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: CPU tensors must raise, not silently compute."""
+    import scade_amd as S
+    bins = torch.rand(4, 63).sort(-1)[0]
+    w = torch.rand(4, 62)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        S.sample_pdf(bins, w, 16, det=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        S.raw2outputs(torch.rand(4, 8, 4), torch.rand(4, 8), torch.rand(4, 3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        S.compute_space_carving_loss(torch.rand(4, 8), torch.rand(3, 4, 1))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        S.img2mse(torch.rand(4, 3), torch.rand(4, 3))
+    net = S.NeRF(D=8, W=256, input_ch=57, input_ch_views=3, skips=[4], use_viewdirs=True)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        net(torch.rand(8, 60))
+
+
+def test_product_does_not_import_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; import scade_amd, scade_amd.render, scade_amd.mlp; "
+            "assert not any(m.startswith('oracle') for m in sys.modules), 'product imports oracle'")
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=REPO)
+    pat = re.compile(r"^\s*(from|import)\s+oracle\b|importlib.*oracle|oracle/_ref", re.M)
+    for root, _, files in os.walk(os.path.join(REPO, "scade_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                assert not pat.search(open(os.path.join(root, f)).read()), f"{f} references oracle/"

@@ -1,0 +1,247 @@
+"""GPU parity of every HIP operator against (a) the golden fixtures captured from the
+real reference and (b) the CPU oracle on seeded inputs.  All calls go through the
+reference-named Python API -> ctypes -> libscade_hip.so.
+
+Tolerance (north_star): fp32 outputs within 1e-4 relative; sample_pdf index
+selection bit-exact given identical (cdf, u)."""
+import numpy as np
+import pytest
+import torch
+
+import scade_amd as S
+from scade_amd import ops
+from conftest import assert_close, load_golden, rel_l2
+from oracle import scade_oracle as O
+from test_oracle_golden import f2_params
+
+pytestmark = pytest.mark.gpu
+TOL = dict(rtol=1e-4, atol=2e-6)
+
+
+def make_net(params, dev):
+    net = S.NeRF(D=8, W=256, input_ch=57, output_ch=5, skips=[4], input_ch_views=3, input_ch_cam=0,
+                 use_viewdirs=True)
+    net.load_state_dict({k: v.detach().clone() for k, v in params.items()})
+    return net.to(dev)
+
+
+# ---------------------------------------------------------------- embed
+def test_embed_golden(dev):
+    g = load_golden("f1_embed")
+    fn, dim = S.get_embedder(9, 0)
+    assert dim == 57
+    y = fn(g["x"].to(dev))
+    assert_close(y, g["y"], rtol=1e-5, atol=2e-6, what="embed")   # |sin| <= 1: absolute 2e-6
+    fn0, dim0 = S.get_embedder(0, 0)
+    assert dim0 == 3 and torch.equal(fn0(g["x"].to(dev)).cpu(), g["x"])
+
+
+# ---------------------------------------------------------------- MLP
+def test_mlp_forward_golden(dev):
+    g = load_golden("f2_mlp")
+    net = make_net(f2_params(g), dev)
+    with torch.no_grad():
+        out = net(g["x"].to(dev))
+    assert_close(out, g["out"], rtol=1e-4, atol=1e-5, what="NeRF.forward")
+    assert rel_l2(out, g["out"]) < 2e-6
+
+
+def test_mlp_forward_points_matches_embedded(dev):
+    """mode 1 (fused embed) == mode 0 on the oracle-embedded input, ragged P (tail tile)."""
+    g = load_golden("f2_mlp")
+    params = f2_params(g)
+    net = make_net(params, dev)
+    torch.manual_seed(3)
+    N, Sm = 37, 5                                     # P = 185: not a multiple of 64
+    pts = torch.rand(N, Sm, 3) * 6 - 3
+    vd = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    bbc, bbs = torch.tensor([0.1, -0.2, 0.3]), torch.tensor(0.2)
+    want = O.run_network(pts, vd, lambda e: O.nerf_forward(params, e), bbc, bbs)
+    embed_fn, _ = S.get_embedder(9, 0)
+    embeddirs_fn, _ = S.get_embedder(0, 0)
+    with torch.no_grad():
+        got = S.run_network(pts.to(dev), vd.to(dev), torch.empty(0, device=dev), net, embed_fn,
+                            embeddirs_fn, bbc.to(dev), bbs.to(dev))
+        # generic (unfused) composition through the same operators
+        got2 = S.run_network(pts.to(dev), vd.to(dev), torch.empty(0, device=dev), lambda e: net(e),
+                             embed_fn, embeddirs_fn, bbc.to(dev), bbs.to(dev), netchunk=64)
+    assert_close(got, want, rtol=1e-4, atol=1e-5, what="run_network fused")
+    assert_close(got2, want, rtol=1e-4, atol=1e-5, what="run_network generic")
+
+
+def test_mlp_edge_sizes(dev):
+    g = load_golden("f2_mlp")
+    params = f2_params(g)
+    net = make_net(params, dev)
+    for P in (0, 1, 63, 64, 65, 129):
+        x = g["x"][:P] if P <= 256 else None
+        with torch.no_grad():
+            out = net(x.to(dev))
+        assert out.shape == (P, 4)
+        if P:
+            assert_close(out, g["out"][:P], rtol=1e-4, atol=1e-5, what=f"P={P}")
+
+
+def test_mlp_repack_after_inplace_update(dev):
+    g = load_golden("f2_mlp")
+    params = f2_params(g)
+    net = make_net(params, dev)
+    x = g["x"].to(dev)
+    with torch.no_grad():
+        a = net(x).clone()
+        net.pts_linears[3].weight.mul_(0.5)
+        b = net(x)
+    params["pts_linears.3.weight"] = params["pts_linears.3.weight"] * 0.5
+    assert_close(b, O.nerf_forward(params, g["x"]), rtol=1e-4, atol=1e-5, what="after in-place update")
+    assert not torch.allclose(a, b)
+
+
+# ---------------------------------------------------------------- composite
+@pytest.mark.parametrize("Sn", [64, 192])
+def test_composite_golden(dev, Sn):
+    g = load_golden(f"f3_composite_{Sn}")
+    raw = g["raw"].to(dev).requires_grad_(True)
+    outs = S.raw2outputs(raw, g["z"].to(dev), g["d"].to(dev), 0)
+    for o, n in zip(outs, ["rgb_map", "disp_map", "acc_map", "weights", "depth_map"]):
+        assert_close(o, g[n], what=f"raw2outputs[{Sn}].{n}", **TOL)
+    Gs = [g[k].to(dev) for k in ("G_rgb", "G_disp", "G_acc", "G_w", "G_depth")]
+    # the empty ray (all sigma == 0) has disp = 1/(0/0) = NaN: keep it out of the backward seed
+    Gs[1] = torch.where(torch.isnan(outs[1]), torch.zeros_like(Gs[1]), Gs[1])
+    loss = sum((o * G).sum() for o, G in zip(outs, Gs) if True)
+    finite = sum((torch.nan_to_num(o) * G).sum() for o, G in zip(outs, Gs))
+    finite.backward()
+    want = g["grad_raw"]
+    ok_rows = ~torch.isnan(want).flatten(1).any(1)
+    assert ok_rows.sum() >= 30
+    assert_close(raw.grad.cpu()[ok_rows], want[ok_rows], rtol=2e-4, atol=1e-6, what=f"d raw2outputs[{Sn}]")
+    w = S.compute_weights(raw.detach(), g["z"].to(dev), g["d"].to(dev))
+    assert_close(w, g["weights"], what="compute_weights", **TOL)
+
+
+def test_composite_noise_and_odd_lengths(dev):
+    torch.manual_seed(5)
+    for Sn in (1, 2, 63, 65, 130, 300):
+        N = 9
+        raw = torch.randn(N, Sn, 4)
+        z = torch.sort(torch.rand(N, Sn) * 4 + 0.1, -1)[0]
+        d = torch.randn(N, 3)
+        noise = torch.randn(N, Sn) * 0.5
+        want = O.raw2outputs(raw, z, d, noise)
+        got = ops.composite_fwd(raw.to(dev), z.to(dev), d.to(dev), noise.to(dev))
+        for a, b, n in zip(got, want, ["rgb", "disp", "acc", "w", "depth"]):
+            assert_close(a, b, what=f"S={Sn} {n}", **TOL)
+
+
+# ---------------------------------------------------------------- sample_pdf
+@pytest.mark.parametrize("M", [63, 191])
+def test_sample_pdf_golden(dev, M):
+    g = load_golden(f"f4_sample_pdf_{M}")
+    bins, u = g["bins"].to(dev), g["u"].to(dev)
+    N, Sn = u.shape
+    # (i) bit-exact index selection given identical (cdf, u)
+    s, inds, _, _ = ops.sample_pdf_fwd(bins, None, u, Sn, cdf_in=g["cdf"].to(dev), want_inds=True)
+    assert torch.equal(inds.cpu(), g["inds"]), "searchsorted(right=True) indices must be bit-exact"
+    assert_close(s, g["samples_u"], rtol=1e-6, atol=1e-7, what="samples from reference cdf")
+    # (ii) from raw weights: cdf within 1 ulp-ish, indices equal except where u sits on a knot
+    w = g["w"].to(dev).requires_grad_(True)
+    s2, inds2, cdf2, _ = ops.sample_pdf_fwd(bins, w.detach(), u, Sn, want_inds=True, want_cdf=True)
+    assert_close(cdf2, g["cdf"], rtol=3e-7, atol=1e-7, what="cdf")
+    diff = inds2.cpu() != g["inds"]
+    if diff.any():
+        # every mismatch must be a u within 2 ulp of the neighbouring cdf knot
+        cdf = g["cdf"]
+        rr, ss = torch.nonzero(diff, as_tuple=True)
+        for r, c in zip(rr.tolist(), ss.tolist()):
+            k = min(int(g["inds"][r, c]), int(inds2[r, c].item()))
+            assert abs(float(cdf[r, k]) - float(g["u"][r, c])) <= 2 * np.spacing(np.float32(cdf[r, k]))
+    assert diff.float().mean() < 1e-3
+    assert_close(s2, g["samples_u"], rtol=1e-4, atol=2e-6, what="samples from weights")
+    # reference-named API: det / pytest / joint / load_u + backward
+    assert_close(S.sample_pdf(bins, w, Sn, det=True), g["samples_det"], rtol=1e-4, atol=2e-6, what="det")
+    assert_close(S.sample_pdf(bins, w, Sn, det=False, pytest=True), g["samples_pytest"], rtol=1e-4,
+                 atol=2e-6, what="pytest")
+    sj, uj = S.sample_pdf_joint_return_u(bins, w, Sn, load_u=g["u_joint"].to(dev).expand(N, Sn))
+    assert_close(sj, g["samples_joint"], rtol=1e-4, atol=2e-6, what="joint")
+    su, ub = S.sample_pdf_return_u(bins, w, Sn, det=False, load_u=u)
+    assert ub is u
+    (su * g["G"].to(dev)).sum().backward()
+    assert_close(w.grad, g["grad_w"], rtol=2e-3, atol=2e-4 * float(g["grad_w"].abs().max()), what="grad w")
+    assert rel_l2(w.grad, g["grad_w"]) < 1e-4
+
+
+def test_sample_pdf_random_draws_are_valid(dev):
+    torch.manual_seed(0)
+    bins = torch.sort(torch.rand(16, 63) * 4 + 0.1, -1)[0].to(dev)
+    w = torch.rand(16, 62).to(dev)
+    s = S.sample_pdf(bins, w, 128, det=False)
+    assert s.shape == (16, 128)
+    assert bool((s >= bins[:, :1]).all()) and bool((s <= bins[:, -1:]).all())
+    s2, u = S.sample_pdf_joint_return_u(bins, w, 128, det=False)
+    assert u.shape == (16, 128) and bool((u[0] == u[5]).all())
+
+
+# ---------------------------------------------------------------- merge
+def test_merge_sorted(dev):
+    torch.manual_seed(1)
+    N = 33
+    za = torch.sort(torch.rand(N, 64) * 5, -1)[0]
+    zb = torch.rand(N, 128) * 5
+    zb[0, :10] = za[0, :10]                                  # exact ties
+    rays = O.synthetic_rays(N, seed=4, unit_dirs=False)
+    want, _ = torch.sort(torch.cat([za, zb], -1), -1)
+    got, pts = ops.merge_sorted(za.to(dev), zb.to(dev), rays.to(dev))
+    assert torch.equal(got.cpu(), want)
+    wpts = rays[:, None, 0:3] + rays[:, None, 3:6] * want[..., None]
+    assert torch.equal(pts.cpu(), wpts)                      # mul then add, no FMA contraction
+
+
+# ---------------------------------------------------------------- ray_points / perturb
+def test_ray_points_and_perturb(dev):
+    g = load_golden("f7_perturb")
+    rays = O.synthetic_rays(32, seed=2, unit_dirs=False)
+    z, pts = ops.ray_points(rays.to(dev), 64, None, False)
+    assert torch.equal(z.cpu(), g["z"])
+    zp, pts2 = ops.ray_points(rays.to(dev), 64, g["t_rand"].to(dev), False)
+    assert torch.equal(zp.cpu(), g["out"])
+    assert torch.equal(pts2.cpu(), rays[:, None, 0:3] + rays[:, None, 3:6] * g["out"][..., None])
+    np.random.seed(0)
+    assert torch.equal(S.perturb_z_vals(g["z"].to(dev), True).cpu(), g["out"])
+    # lindisp
+    zl, _ = ops.ray_points(rays.to(dev), 64, None, True)
+    t = torch.linspace(0., 1., 64)
+    want = 1. / (1. / rays[:, 6:7] * (1. - t) + 1. / rays[:, 7:8] * t)
+    assert_close(zl, want, rtol=1e-6, atol=0, what="lindisp")
+
+
+# ---------------------------------------------------------------- carve / mse
+@pytest.mark.parametrize("K", [20, 40])
+def test_carve_golden(dev, K):
+    g = load_golden(f"f5_carve_{K}")
+    mask = g["mask"].to(dev)
+    variants = {"default": {}, "mask": dict(mask=mask), "thr": dict(threshold=0.05),
+                "joint": dict(is_joint=True), "p1": dict(norm_p=1),
+                "mask_thr": dict(mask=mask, threshold=0.05)}
+    for name, kw in variants.items():
+        p = g["pred"].to(dev).requires_grad_(True)
+        h = g["hyp"].to(dev).requires_grad_(True)
+        loss = S.compute_space_carving_loss(p, h, **kw)
+        (loss * 1.5).backward()
+        assert_close(loss, g[f"{name}/loss"], rtol=1e-5, atol=1e-7, what=f"carve {name}")
+        assert_close(p.grad, 1.5 * g[f"{name}/grad_pred"], rtol=1e-5, atol=1e-9, what=f"{name} dpred")
+        assert_close(h.grad, 1.5 * g[f"{name}/grad_hyp"], rtol=1e-4, atol=1e-8, what=f"{name} dhyp")
+
+
+def test_mse(dev):
+    torch.manual_seed(2)
+    x, y, m = torch.rand(100, 3), torch.rand(100, 3), (torch.rand(100) > 0.5).float()
+    xd = x.to(dev).requires_grad_(True)
+    l = S.img2mse(xd, y.to(dev))
+    l.backward()
+    xr = x.clone().requires_grad_(True)
+    lr = O.img2mse(xr, y)
+    lr.backward()
+    assert_close(l, lr, rtol=1e-6, atol=0, what="mse")
+    assert_close(xd.grad, xr.grad, rtol=1e-6, atol=1e-10, what="dmse")
+    lm = S.img2mse_masked(x.to(dev), y.to(dev), m.to(dev))
+    assert_close(lm, torch.mean((x - y) ** 2 * m[:, None]), rtol=1e-6, atol=0, what="masked mse")
+    assert_close(S.mse2psnr(l.detach()), O.mse2psnr(lr.detach()), rtol=1e-6, atol=0, what="psnr")

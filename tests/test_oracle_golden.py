@@ -1,0 +1,145 @@
+"""CPU: the oracle reproduces every golden fixture captured from the real reference
+(tools/make_golden.py).  On the torch build the fixtures were made with this is
+bit-exact; the tolerances below only absorb a different torch build."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_close, load_golden
+from oracle import scade_oracle as O
+
+TIGHT = dict(rtol=2e-6, atol=1e-7)
+
+
+def _weights(g, seed_key, bias_seed_key, digest_prefix):
+    p = O.nerf_init(int(g[seed_key]))
+    gen = torch.Generator().manual_seed(int(g[bias_seed_key]))
+    return p, gen
+
+
+def f2_params(g):
+    p = O.nerf_init(int(g["seed"]))
+    gen = torch.Generator().manual_seed(int(g["bias_seed"]))
+    for k in p:
+        if k.endswith(".bias"):
+            p[k] = 0.1 * torch.randn(p[k].shape, generator=gen)
+    return p
+
+
+def f6_params(g):
+    pc, pf = O.nerf_init(int(g["seed_coarse"])), O.nerf_init(int(g["seed_fine"]))
+    gen = torch.Generator().manual_seed(int(g["bias_seed"]))
+    for p in (pc, pf):
+        for k in p:
+            if k.endswith(".bias"):
+                p[k] = 0.05 * torch.randn(p[k].shape, generator=gen)
+    return pc, pf
+
+
+def check_digest(params, g, prefix):
+    for k, v in params.items():
+        d = g[f"{prefix}/{k}"].double()
+        got = torch.tensor([v.double().sum(), v.double().abs().sum(), v.flatten()[0], v.flatten()[-1]]).double()
+        assert torch.allclose(got, d, rtol=1e-9, atol=1e-12), f"weight RNG drift in {k}"
+
+
+def test_embed():
+    g = load_golden("f1_embed")
+    assert_close(O.embed(g["x"], 9), g["y"], what="embed", **TIGHT)
+    assert O.embed(g["x"], 0).shape == (64, 3)
+
+
+def test_mlp_forward_and_grads():
+    g = load_golden("f2_mlp")
+    p = f2_params(g)
+    check_digest(p, g, "digest")
+    p = {k: v.requires_grad_(True) for k, v in p.items()}
+    out = O.nerf_forward(p, g["x"])
+    assert_close(out, g["out"], what="NeRF.forward", **TIGHT)
+    (out * g["G"]).sum().backward()
+    for k, v in p.items():
+        f = v.grad.flatten()
+        sub = f if f.numel() <= 4096 else f[::97]
+        assert_close(sub, g["grad/" + k], rtol=1e-5, atol=1e-7, what="grad " + k)
+
+
+@pytest.mark.parametrize("S", [64, 192])
+def test_composite(S):
+    g = load_golden(f"f3_composite_{S}")
+    raw = g["raw"].clone().requires_grad_(True)
+    outs = O.raw2outputs(raw, g["z"], g["d"])
+    for o, n in zip(outs, ["rgb_map", "disp_map", "acc_map", "weights", "depth_map"]):
+        assert_close(o, g[n], what=n, **TIGHT)
+    Gs = [g["G_rgb"], g["G_disp"], g["G_acc"], g["G_w"], g["G_depth"]]
+    sum((o * G).sum() for o, G in zip(outs, Gs)).backward()
+    assert_close(raw.grad, g["grad_raw"], rtol=1e-5, atol=1e-7, what="grad raw")
+
+
+@pytest.mark.parametrize("M", [63, 191])
+def test_sample_pdf(M):
+    g = load_golden(f"f4_sample_pdf_{M}")
+    w = g["w"].clone().requires_grad_(True)
+    N, S = g["u"].shape
+    cdf = O.pdf_to_cdf(w.detach())
+    assert_close(cdf, g["cdf"], what="cdf", **TIGHT)
+    s, inds = O.invert_cdf(g["bins"], g["cdf"], g["u"])
+    assert torch.equal(inds, g["inds"]), "index selection must be bit-exact given (cdf,u)"
+    assert_close(s, g["samples_u"], what="samples(load_u)", **TIGHT)
+    assert_close(O.sample_pdf(g["bins"], w, O.draw_u(N, S, det=True)), g["samples_det"], what="det", **TIGHT)
+    assert_close(O.sample_pdf(g["bins"], w, O.draw_u(N, S, det=False, pytest=True)), g["samples_pytest"],
+                 what="pytest", **TIGHT)
+    assert_close(O.sample_pdf(g["bins"], w, g["u_joint"].expand(N, S)), g["samples_joint"], what="joint", **TIGHT)
+    (O.sample_pdf(g["bins"], w, g["u"]) * g["G"]).sum().backward()
+    assert_close(w.grad, g["grad_w"], rtol=1e-5, atol=1e-6, what="grad w")
+
+
+@pytest.mark.parametrize("K", [20, 40])
+def test_carve(K):
+    g = load_golden(f"f5_carve_{K}")
+    variants = {"default": {}, "mask": dict(mask=g["mask"]), "thr": dict(threshold=0.05),
+                "joint": dict(is_joint=True), "p1": dict(norm_p=1),
+                "mask_thr": dict(mask=g["mask"], threshold=0.05)}
+    for name, kw in variants.items():
+        p = g["pred"].clone().requires_grad_(True)
+        h = g["hyp"].clone().requires_grad_(True)
+        loss = O.compute_space_carving_loss(p, h, **kw)
+        loss.backward()
+        assert_close(loss, g[f"{name}/loss"], what=f"{name} loss", **TIGHT)
+        assert_close(p.grad, g[f"{name}/grad_pred"], what=f"{name} dpred", **TIGHT)
+        assert_close(h.grad, g[f"{name}/grad_hyp"], what=f"{name} dhyp", **TIGHT)
+
+
+def test_perturb():
+    g = load_golden("f7_perturb")
+    assert_close(O.perturb_z_vals(g["z"], g["t_rand"]), g["out"], what="perturb", **TIGHT)
+
+
+def test_render_rays_det_and_train():
+    g = load_golden("f6_render")
+    pc, pf = f6_params(g)
+    check_digest(pc, g, "digest_coarse")
+    check_digest(pf, g, "digest_fine")
+    with torch.no_grad():
+        ret = O.render_rays(g["rays"], pc, pf, g["bb_center"], g["bb_scale"], retraw=True)
+    for k, v in ret.items():
+        assert_close(v, g["det/" + k], rtol=1e-5, atol=1e-6, what="det " + k)
+    # train path with the recorded numpy streams
+    pc = {k: v.requires_grad_(True) for k, v in pc.items()}
+    pf = {k: v.requires_grad_(True) for k, v in pf.items()}
+    scale = torch.ones(1, requires_grad=True)
+    shift = torch.zeros(1, requires_grad=True)
+    ret = O.render_rays(g["rays"], pc, pf, g["bb_center"], g["bb_scale"], t_rand=g["train/t_rand"],
+                        u_coarse=g["train/u"], u_fine=g["train/u"], retraw=True)
+    for k, v in ret.items():
+        assert_close(v, g["train/" + k], rtol=1e-5, atol=1e-6, what="train " + k)
+    loss, il, cv, il0 = O.train_loss(ret, g["target_s"], g["hyp"] * scale + shift)
+    assert_close(loss, g["train/loss"], rtol=1e-6, atol=1e-8, what="loss")
+    loss.backward()
+    for tag, p in (("coarse", pc), ("fine", pf)):
+        for k, v in p.items():
+            gr = v.grad if v.grad is not None else torch.zeros_like(v)
+            f = gr.flatten()
+            sub = f if f.numel() <= 4096 else f[::97]
+            assert_close(sub, g[f"grad_{tag}/{k}"], rtol=1e-4, atol=1e-8, what=f"grad {tag}.{k}")
+    assert_close(scale.grad, g["train/grad_scale"], rtol=1e-5, atol=1e-9, what="grad scale")
+    assert_close(shift.grad, g["train/grad_shift"], rtol=1e-5, atol=1e-9, what="grad shift")
