@@ -386,9 +386,9 @@ static int launch_fwd(const MlpFwdArgs& a, hipStream_t s) {
 
 extern "C" int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,
                              const float* bb, int P, int S, float* out, float* acts, void* stream) {
+  if (P == 0) return 0;
   SCADE_REQUIRE(packed && in && out, -1, "scade_mlp_fwd: null pointer");
   SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd: mode must be 0 (x[P,60]) or 1 (pts[P,3])");
-  if (P == 0) return 0;
   SCADE_REQUIRE(P > 0, -2, "scade_mlp_fwd: P < 0");
   if (mode == 1) {
     SCADE_REQUIRE(viewdirs && bb, -1, "scade_mlp_fwd: mode 1 needs viewdirs and bb");

@@ -120,7 +120,7 @@ def test_composite_golden(dev, Sn):
 
 def test_composite_noise_and_odd_lengths(dev):
     torch.manual_seed(5)
-    for Sn in (1, 2, 63, 65, 130, 300):
+    for Sn in (2, 63, 65, 130, 300):   # S == 1 is degenerate in the reference (empty dists)
         N = 9
         raw = torch.randn(N, Sn, 4)
         z = torch.sort(torch.rand(N, Sn) * 4 + 0.1, -1)[0]
