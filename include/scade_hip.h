@@ -43,14 +43,16 @@ int scade_mlp_pack(const float* const* params, float* packed, void* stream);
 
 /* Fused embed + MLP forward:  out[P,4] = [rgb(3, pre-sigmoid), softplus(alpha, beta=10)].
  *  mode 0: `in` is x[P,60] = [gamma(x)(57) | viewdir(3)]  == NeRF.forward(x), helpers:223-247
- *  mode 1: `in` is pts[P,3]; viewdirs[P/S,3]; bb = {cx,cy,cz,scale}; the kernel applies
+ *  mode 1: `in` is pts[P,3]; viewdirs[P/S] rows of 3 at stride vd_stride; bb = {cx,cy,cz,scale};
+ *          the kernel applies
  *          (pts-bb_center)*bb_scale, the 9-frequency positional encoding and the
  *          per-ray view broadcast  == run_network(...), run_scade_scannet.py:48-63 with
  *          get_embedder(9,0)/get_embedder(0,0), helpers:142-189.
  *  acts (nullable): [10][P][256] workspace receiving the post-activation tile of every
  *          hidden layer (training; consumed by scade_mlp_bwd). */
 int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,
-                  const float* bb, int P, int S, float* out, float* acts, void* stream);
+                  int vd_stride, const float* bb, int P, int S, float* out, float* acts,
+                  void* stream);
 
 /* ---- positional encoding (Embedder.embed, helpers:142-172; get_embedder :174-189) */
 /* out[P, D*(1+2*multires)] = [x, sin(x*pi*2^0), cos(x*pi*2^0), ..., cos(x*pi*2^(L-1))] */

@@ -39,6 +39,7 @@ struct MlpFwdArgs {
   float* acts;            // optional [9][P][256] saved post-activation tiles (training)
   int P;
   int S;                  // samples per ray (mode 1)
+  int vd_stride;          // row stride of viewdirs (mode 1)
 };
 
 // float index of 16-byte chunk `chunk` of row `row` in the swizzled h tile
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int row = tid >> 2, c = tid & 3;  // 64 rows x 4 (3 used)
     const int pt = min(p0 + row, P - 1);
     float v = 0.f;
-    if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * 3 + c];
+    if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
     ebuf[row * VIEW_PAD + c] = v;
     ebuf[row * VIEW_PAD + 4 + c] = 0.f;
   }
@@ -385,16 +386,17 @@ static int launch_fwd(const MlpFwdArgs& a, hipStream_t s) {
 }
 
 extern "C" int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,
-                             const float* bb, int P, int S, float* out, float* acts, void* stream) {
+                             int vd_stride, const float* bb, int P, int S, float* out, float* acts,
+                             void* stream) {
   if (P == 0) return 0;
   SCADE_REQUIRE(packed && in && out, -1, "scade_mlp_fwd: null pointer");
   SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd: mode must be 0 (x[P,60]) or 1 (pts[P,3])");
   SCADE_REQUIRE(P > 0, -2, "scade_mlp_fwd: P < 0");
   if (mode == 1) {
-    SCADE_REQUIRE(viewdirs && bb, -1, "scade_mlp_fwd: mode 1 needs viewdirs and bb");
+    SCADE_REQUIRE(viewdirs && bb && vd_stride >= 3, -1, "scade_mlp_fwd: mode 1 needs viewdirs (stride >= 3) and bb");
     SCADE_REQUIRE(S > 0 && P % S == 0, -2, "scade_mlp_fwd: P (%d) must be a multiple of S (%d)", P, S);
   }
-  MlpFwdArgs a{packed, in, viewdirs, bb, out, acts, P, S};
+  MlpFwdArgs a{packed, in, viewdirs, bb, out, acts, P, S, vd_stride};
   hipStream_t s = (hipStream_t)stream;
   if (mode == 0) return acts ? launch_fwd<0, true>(a, s) : launch_fwd<0, false>(a, s);
   return acts ? launch_fwd<1, true>(a, s) : launch_fwd<1, false>(a, s);

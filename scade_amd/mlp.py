@@ -16,9 +16,8 @@ class MlpEmbeddedFn(torch.autograd.Function):
     """NeRF.forward(x[P,60])  (model/run_nerf_helpers.py:223-247)."""
 
     @staticmethod
-    def forward(ctx, net, x, *params):
+    def forward(ctx, net, train, x, *params):
         packed = net.packed()
-        train = any(ctx.needs_input_grad)
         acts = None
         if train:
             acts = torch.empty(N_ACT_SLOTS, x.shape[0], 256, device=x.device, dtype=torch.float32)
@@ -32,16 +31,15 @@ class MlpEmbeddedFn(torch.autograd.Function):
         from .mlp_bwd import mlp_backward
         x, acts = ctx.saved_tensors
         grads = mlp_backward(ctx.net, 0, x, None, None, acts, g_out)
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
 class MlpPointsFn(torch.autograd.Function):
     """run_network fused with the positional encoding (run_scade_scannet.py:48-63)."""
 
     @staticmethod
-    def forward(ctx, net, pts, viewdirs, bb, *params):
+    def forward(ctx, net, train, pts, viewdirs, bb, *params):
         packed = net.packed()
-        train = any(ctx.needs_input_grad)
         acts = None
         if train:
             P = pts.shape[0] * pts.shape[1]
@@ -56,4 +54,4 @@ class MlpPointsFn(torch.autograd.Function):
         from .mlp_bwd import mlp_backward
         pts, viewdirs, bb, acts = ctx.saved_tensors
         grads = mlp_backward(ctx.net, 1, pts, viewdirs, bb, acts, g_out)
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)

@@ -34,6 +34,39 @@ PARAM_SHAPES.update({
 })
 
 
+class KernelTimer:
+    """HIP-event stopwatch around individual kernel launches on the launch stream
+    (torch.cuda.Event records on torch's current stream, which is the stream every
+    scade_* call is enqueued on).  Used by bench.py for the roofline line."""
+
+    def __init__(self):
+        self.records = []
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, name, e0, work):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((name, e0, e1, work))
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, e0, e1, work in self.records:
+            d = out.setdefault(name, {"launches": 0, "ms": 0.0, "work": 0.0})
+            d["launches"] += 1
+            d["ms"] += e0.elapsed_time(e1)
+            d["work"] += work
+        return out
+
+
+KERNEL_TIMER: Optional[KernelTimer] = None
+MLP_FLOP_PER_POINT = 2 * 587264      # algorithmic, unpadded (SURVEY.md section 8(d))
+
+
 def _c(t: Tensor) -> Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
@@ -87,7 +120,7 @@ def mlp_fwd_embedded(packed: Tensor, x: Tensor, acts: Optional[Tensor] = None) -
     x = _c(x)
     P = x.shape[0]
     out = torch.empty(P, 4, device=x.device, dtype=torch.float32)
-    call("scade_mlp_fwd", ptr(packed), 0, ptr(x), None, None, P, 1, ptr(out), ptr(acts), stream())
+    call("scade_mlp_fwd", ptr(packed), 0, ptr(x), None, 0, None, P, 1, ptr(out), ptr(acts), stream())
     return out
 
 
@@ -100,10 +133,14 @@ def mlp_fwd_points(packed: Tensor, pts: Tensor, viewdirs: Tensor, bb: Tensor,
     N, S = pts.shape[0], pts.shape[1]
     if tuple(viewdirs.shape) != (N, 3):
         raise ValueError(f"mlp_fwd: viewdirs must be [{N},3], got {tuple(viewdirs.shape)}")
-    pts, viewdirs, bb = _c(pts), _c(viewdirs), _c(bb)
+    viewdirs, vstride = _rows(viewdirs, "mlp_fwd: viewdirs")
+    pts, bb = _c(pts), _c(bb)
     out = torch.empty(N, S, 4, device=pts.device, dtype=torch.float32)
-    call("scade_mlp_fwd", ptr(packed), 1, ptr(pts), ptr(viewdirs), ptr(bb), N * S, S, ptr(out),
-         ptr(acts), stream())
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_fwd", ptr(packed), 1, ptr(pts), ptr(viewdirs), vstride, ptr(bb), N * S, S,
+         ptr(out), ptr(acts), stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_fwd_kernel", t0, float(N * S) * MLP_FLOP_PER_POINT)
     return out
 
 

@@ -170,13 +170,17 @@ class NeRF(nn.Module):
         """x [P, 60] = [gamma(pts) | viewdir] -> [P,4] (helpers:223-247)."""
         from .mlp import MlpEmbeddedFn
         self._require_supported()
-        return MlpEmbeddedFn.apply(self, x, *self.ordered_params())
+        ps = self.ordered_params()
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        return MlpEmbeddedFn.apply(self, train, x, *ps)
 
     def forward_points(self, pts, viewdirs, bb):
         """Fused run_network: pts [N,S,3], viewdirs [N,3], bb [4]={center,scale} -> raw [N,S,4]."""
         from .mlp import MlpPointsFn
         self._require_supported()
-        return MlpPointsFn.apply(self, pts, viewdirs, bb, *self.ordered_params())
+        ps = self.ordered_params()
+        train = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        return MlpPointsFn.apply(self, train, pts, viewdirs, bb, *ps)
 
     def load_reference_state_dict(self, state_dict, strict=True):
         sd = {(k[len("module."):] if k.startswith("module.") else k): v for k, v in state_dict.items()}

@@ -42,7 +42,7 @@ def test_library_loads_and_reports():
 def test_argument_errors_do_not_need_a_gpu():
     from scade_amd import _lib
     lib = _lib.load()
-    rc = lib.scade_mlp_fwd(None, 0, None, None, None, 10, 1, None, None, None)
+    rc = lib.scade_mlp_fwd(None, 0, None, None, 0, None, 10, 1, None, None, None)
     assert rc != 0 and b"null" in lib.scade_last_error()
     rc = lib.scade_composite_fwd(None, None, None, 3, None, 4, 64, None, None, None, None, None, None)
     assert rc != 0
