@@ -48,11 +48,25 @@ int scade_mlp_pack(const float* const* params, float* packed, void* stream);
  *          (pts-bb_center)*bb_scale, the 9-frequency positional encoding and the
  *          per-ray view broadcast  == run_network(...), run_scade_scannet.py:48-63 with
  *          get_embedder(9,0)/get_embedder(0,0), helpers:142-189.
- *  acts (nullable): [10][P][256] workspace receiving the post-activation tile of every
- *          hidden layer (training; consumed by scade_mlp_bwd). */
+ *  acts (nullable): training workspace of scade_mlp_acts_floats(P) floats receiving every
+ *          hidden layer's activations, the embedding and alpha (consumed by scade_mlp_bwd). */
 int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,
                   int vd_stride, const float* bb, int P, int S, float* out, float* acts,
                   void* stream);
+
+/* Backward of scade_mlp_fwd w.r.t. the 24 parameter tensors (what autograd computes for
+ * NeRF.forward in the reference).  packed_t = scade_mlp_pack_t(params) (transposed weight
+ * pack, scade_mlp_packed_t_floats() floats); acts = the workspace the forward filled;
+ * g_out[P,4] = dL/d out; workspace = scade_mlp_bwd_workspace_floats(P) floats;
+ * grad_flat[589700] receives the gradients concatenated in the scade_mlp_pack order, each
+ * tensor in its nn.Linear layout. */
+long scade_mlp_acts_floats(long P);
+long scade_mlp_packed_t_floats(void);
+int scade_mlp_pack_t(const float* const* params, float* packed_t, void* stream);
+long scade_mlp_bwd_workspace_floats(int P);
+int scade_mlp_bwd_chunks(int P);
+int scade_mlp_bwd(const float* packed, const float* packed_t, const float* acts,
+                  const float* g_out, int P, float* workspace, float* grad_flat, void* stream);
 
 /* ---- positional encoding (Embedder.embed, helpers:142-172; get_embedder :174-189) */
 /* out[P, D*(1+2*multires)] = [x, sin(x*pi*2^0), cos(x*pi*2^0), ..., cos(x*pi*2^(L-1))] */

@@ -26,6 +26,12 @@ SIGNATURES = {
     "scade_mlp_lds_bytes": (c_int, []),
     "scade_mlp_pack": (c_int, [_P, _P, _P]),
     "scade_mlp_fwd": (c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "scade_mlp_acts_floats": (c_long, [c_long]),
+    "scade_mlp_packed_t_floats": (c_long, []),
+    "scade_mlp_pack_t": (c_int, [_P, _P, _P]),
+    "scade_mlp_bwd_workspace_floats": (c_long, [_I]),
+    "scade_mlp_bwd_chunks": (c_int, [_I]),
+    "scade_mlp_bwd": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P]),
     "scade_embed": (c_int, [_P, _I, _I, _I, _P, _P]),
     "scade_ray_points": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "scade_perturb_z": (c_int, [_P, _P, _I, _I, _P, _P]),

@@ -1,0 +1,539 @@
+// Backward of the fused NeRF MLP for gfx950: what autograd does for
+// NeRF.forward / run_network in the reference (model/run_nerf_helpers.py:223-247
+// reversed: 24 addmm-backward pairs, relu/softplus/cat backward), as two kernels.
+//
+//  B1  mlp_dgrad_kernel  -- same 64-point tile / 4-wave structure as the forward: the
+//      gradient tile lives in LDS (swizzled [64][256]) and walks the layers backwards,
+//      dX^T[k][point] = W^T[k][n] * dZ^T[n][point] on v_mfma_f32_32x32x2_f32 with a
+//      TRANSPOSED weight pack as the A operand (same layer_gemm as the forward).  The
+//      ReLU masks come from the activations the forward saved; every layer's
+//      pre-activation gradient dZ is written to HBM for B2.
+//  B2  mlp_wgrad_kernel  -- dW[n][k] = sum_points dZ[point][n] * In[point][k]: the
+//      reduction runs over POINTS, so a workgroup (8 waves) owns a full 256x256 weight
+//      gradient in registers (128 accumulator VGPRs/lane) for one layer and one chunk of
+//      points, streams dZ / In tiles of 32 points through LDS, and writes a per-chunk
+//      partial; bias, alpha-head, view-column and rgb-head gradients ride along on the
+//      VALU.  mlp_wgrad_reduce_kernel sums the chunk partials (deterministic order)
+//      into one flat gradient in PyTorch parameter layout.
+#include "mlp_tile.h"
+
+namespace scade {
+
+// ---------------------------------------------------------------------------
+// transposed pack
+// ---------------------------------------------------------------------------
+struct PackTArgs {
+  const float* p[N_PARAM_TENSORS];
+  float* packedT;
+};
+
+__global__ void mlp_pack_t_kernel(PackTArgs a) {
+  const int t = blockIdx.y;  // dgrad index 0..8
+  const int l = dgrad_layer(t);
+  const int widx = l <= 7 ? 2 * l : (l == L_FEAT ? 18 : 16);
+  const float* __restrict__ Wsrc = a.p[widx];
+  const int N = n_out(l);
+  const int NB = N / 8;
+  const int ld = l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W);
+  const int hcol0 = l == 5 ? EMB : 0;
+  const int total = 256 * N;
+  const int off = off_wt(t);
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
+    const int nb = blk % NB, kt = blk / NB;
+    const int n = nb * 8 + 4 * (lane >> 5) + j;
+    const int k = kt * 32 + (lane & 31);
+    a.packedT[off + i] = Wsrc[(size_t)n * ld + hcol0 + k];
+  }
+  if (t == 0)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 256; i += gridDim.x * blockDim.x)
+      a.packedT[off_wt(NLAYER_DGRAD) + i] = 0.f;
+}
+
+// ---------------------------------------------------------------------------
+// B1: dgrad chain
+// ---------------------------------------------------------------------------
+struct MlpDgradArgs {
+  const float* packed;    // forward pack (rgb / alpha head weights)
+  const float* packedT;   // transposed pack
+  const float* acts;      // forward workspace
+  const float* g_out;     // [P,4]
+  float* dz;              // dz_floats(P)
+  int P;
+};
+
+// write the wave's [2 k-tiles x 64 points] gradient block: optional alpha-head term,
+// optional ReLU mask (saved activation > 0), in place to LDS and to HBM slot `dst`
+template <bool MASK, bool ADD_ALPHA>
+__device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][2], int ktile0, float* hbuf,
+                                            const float* __restrict__ mask_src,
+                                            float* __restrict__ dst, const float* __restrict__ w_a,
+                                            const float* dalpha_lds, int p0, int P, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = (ktile0 + t) * 32 + 8 * q + 4 * hh;
+      f32x4 wa = {0.f, 0.f, 0.f, 0.f};
+      if (ADD_ALPHA) wa = *reinterpret_cast<const f32x4*>(w_a + f);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = p * 32 + r;
+        const int pt = p0 + row;
+        const bool ok = pt < P;
+        f32x4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) v[i] = acc[t][p][4 * q + i];
+        if (ADD_ALPHA) {
+          const float da = dalpha_lds[row];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = v[i] + wa[i] * da;
+        }
+        if (MASK) {
+          f32x4 m = {0.f, 0.f, 0.f, 0.f};
+          if (ok) m = *reinterpret_cast<const f32x4*>(mask_src + (size_t)pt * W + f);
+#pragma unroll
+          for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
+        if (ok) *reinterpret_cast<f32x4*>(dst + (size_t)pt * W + f) = v;
+      }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* hbuf = lds;
+  float* dal = lds + H_FLOATS;   // d alpha_pre of the tile's 64 points
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = blockIdx.x * TM;
+  const int P = a.P;
+  const float* __restrict__ pk = a.packed;
+  const float* __restrict__ pt_ = a.packedT;
+  const float* __restrict__ acts = a.acts;
+  float* __restrict__ dz = a.dz;
+
+  // ---- heads: d alpha_pre, dZ of the views layer (rgb head + ReLU mask) ----------
+  {
+    const int row = tid >> 2, sub = tid & 3;
+    const int pt = p0 + row;
+    const bool ok = pt < P;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (ok) g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    if (sub == 0) {
+      float da = 0.f;
+      if (ok) {
+        // softplus(x, beta=10)' = sigmoid(10 x)  (1 beyond the linear threshold 10x > 20)
+        const float bx = acts[acts_alpha_off(P) + pt] * 10.f;
+        da = bx > 20.f ? g[3] : g[3] / (1.f + expf(-bx));
+        dz[dz_dalpha_off(P) + pt] = da;
+      }
+      dal[row] = da;
+    }
+    const float* wr = pk + OFF_WR;
+    const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
+    float* dzv = dz + acts_slot_off(P, SLOT_VIEWS_H);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int chunk = i * 4 + sub;
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
+      f32x4 m = {0.f, 0.f, 0.f, 0.f};
+      if (ok) m = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * W + chunk * 4);
+      f32x4 v;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = g[0] * w0[j] + g[1] * w1[j] + g[2] * w2[j];
+        v[j] = m[j] > 0.f ? d : 0.f;
+      }
+      *reinterpret_cast<f32x4*>(hbuf + h_idx(row, chunk)) = v;
+      if (ok) *reinterpret_cast<f32x4*>(dzv + (size_t)pt * W + chunk * 4) = v;
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][2];
+  const int kt0 = wave * 2;
+
+  // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128) --------
+  layer_gemm<2, 0, 16, EMB_STRIDE>(
+      acc, reinterpret_cast<const f32x4*>(pt_ + off_wt(8)) + kt0 * 16 * 64, hbuf, hbuf, lane);
+  __syncthreads();
+  dgrad_store<false, false>(acc, kt0, hbuf, nullptr, dz + acts_slot_off(P, SLOT_FEAT), nullptr, dal,
+                            p0, P, lane);
+  __syncthreads();
+
+  // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 -----
+  layer_gemm<2, 0, 32, EMB_STRIDE>(
+      acc, reinterpret_cast<const f32x4*>(pt_ + off_wt(7)) + kt0 * 32 * 64, hbuf, hbuf, lane);
+  __syncthreads();
+  dgrad_store<true, true>(acc, kt0, hbuf, acts + acts_slot_off(P, 7), dz + acts_slot_off(P, 7),
+                          pk + OFF_WA, dal, p0, P, lane);
+  __syncthreads();
+
+  // ---- pts layers 7..1: dZ_{l-1} = (W_l^T dZ_l) masked by h_{l-1} > 0 -------------
+#define DGRAD_LAYER(L)                                                                         \
+  layer_gemm<2, 0, 32, EMB_STRIDE>(                                                            \
+      acc, reinterpret_cast<const f32x4*>(pt_ + off_wt((L)-1)) + kt0 * 32 * 64, hbuf, hbuf,    \
+      lane);                                                                                   \
+  __syncthreads();                                                                             \
+  dgrad_store<true, false>(acc, kt0, hbuf, acts + acts_slot_off(P, (L)-1),                     \
+                           dz + acts_slot_off(P, (L)-1), nullptr, dal, p0, P, lane);           \
+  __syncthreads();
+
+  DGRAD_LAYER(7)
+  DGRAD_LAYER(6)
+  DGRAD_LAYER(5)
+  DGRAD_LAYER(4)
+  DGRAD_LAYER(3)
+  DGRAD_LAYER(2)
+  DGRAD_LAYER(1)
+#undef DGRAD_LAYER
+}
+
+// ---------------------------------------------------------------------------
+// B2: wgrad
+// ---------------------------------------------------------------------------
+constexpr int WG_PT = 32;                    // points per LDS stage
+constexpr int WGRAD_LDS_BYTES = (2 * WG_PT * 256 + 64 + WG_PT * 4) * 4;
+
+enum { WF_BIAS = 1, WF_ALPHA = 2, WF_VIEWCOLS = 4, WF_RGB = 8 };
+
+struct WgradJob {
+  long dz_off;       // float offset of the dZ matrix (row stride 256) in the dz workspace
+  long in_off;       // float offset of the input matrix in the acts workspace
+  int in_stride;     // 256 (activation slot) or 64 (emb)
+  int kw;            // tile width in k: 256 or 64
+  int n_rows;        // valid output rows (256 or 128)
+  int w_off;         // flat-gradient offset of the weight tensor
+  int ld;            // its row length
+  int kcol0;         // first column written
+  int kvalid;        // columns written
+  int b_off;         // flat-gradient offset of the bias (WF_BIAS)
+  int flags;
+  int aux_off;       // WF_ALPHA: offset of alpha weight (bias follows at +256); WF_VIEWCOLS: unused
+};
+
+constexpr int MAX_WGRAD_JOBS = 16;
+struct WgradArgs {
+  WgradJob jobs[MAX_WGRAD_JOBS];
+  const float* acts;
+  const float* dz;
+  const float* g_out;   // [P,4] (rgb head)
+  float* partial;       // [nchunks][N_PARAM_FLOATS]
+  int P;
+  int chunk;            // points per chunk (multiple of WG_PT)
+  int njobs;
+};
+
+template <int KW>
+__device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJob& jb, float* lds,
+                                               int c0, int c1, float* __restrict__ out) {
+  constexpr int NKT = KW == 256 ? 4 : 1;          // k-tiles of 32 per wave
+  constexpr int B_F4_PER_THR = KW == 256 ? 4 : 1; // float4 staged per thread for the B tile
+  float* As = lds;                                 // [32][256]
+  float* Bs = lds + WG_PT * 256;                   // [32][KW]
+  float* dal = lds + 2 * WG_PT * 256;              // [32] d alpha_pre of the stage
+  float* vws = dal + 64;                           // [32][4] view dirs of the stage
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int n0 = (wave >> 1) * 64;
+  const int k0 = (wave & 1) * (KW / 2);
+  const bool active = n0 < jb.n_rows;
+  const int P = a.P;
+  const float* __restrict__ dzm = a.dz + jb.dz_off;
+  const float* __restrict__ inm = a.acts + jb.in_off;
+
+  f32x16 acc[2][NKT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NKT; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float bias_acc = 0.f, alpha_acc = 0.f, dal_acc = 0.f;
+  float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
+
+  f32x4 pa[4], pb[B_F4_PER_THR];
+  auto issue = [&](int pt0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 512 * j, row = i >> 6, c4 = i & 63;
+      const int pt = pt0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pt < c1) v = *reinterpret_cast<const f32x4*>(dzm + (size_t)pt * 256 + c4 * 4);
+      pa[j] = v;
+    }
+#pragma unroll
+    for (int j = 0; j < B_F4_PER_THR; ++j) {
+      const int i = tid + 512 * j;
+      const int row = KW == 256 ? (i >> 6) : (i >> 4), c4 = KW == 256 ? (i & 63) : (i & 15);
+      const int pt = pt0 + row;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (pt < c1) v = *reinterpret_cast<const f32x4*>(inm + (size_t)pt * jb.in_stride + c4 * 4);
+      pb[j] = v;
+    }
+  };
+  auto commit = [&](int pt0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) reinterpret_cast<f32x4*>(As)[tid + 512 * j] = pa[j];
+#pragma unroll
+    for (int j = 0; j < B_F4_PER_THR; ++j) reinterpret_cast<f32x4*>(Bs)[tid + 512 * j] = pb[j];
+    if ((jb.flags & WF_ALPHA) && tid < WG_PT) {
+      const int pt = pt0 + tid;
+      dal[tid] = pt < c1 ? a.dz[dz_dalpha_off(P) + pt] : 0.f;
+    }
+    if ((jb.flags & WF_VIEWCOLS) && tid < WG_PT * 4) {
+      const int row = tid >> 2, c = tid & 3;
+      const int pt = pt0 + row;
+      vws[tid] = (pt < c1 && c < 3) ? a.acts[acts_emb_off(P) + (size_t)pt * 64 + 60 + c] : 0.f;
+    }
+  };
+
+  issue(c0);
+  for (int pt0 = c0; pt0 < c1; pt0 += WG_PT) {
+    commit(pt0);
+    __syncthreads();
+    if (pt0 + WG_PT < c1) issue(pt0 + WG_PT);
+    if (active) {
+#pragma unroll 4
+      for (int kk = 0; kk < WG_PT / 2; ++kk) {
+        const int row = 2 * kk + hh;
+        float av[2], bv[NKT];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) av[t] = As[row * 256 + n0 + 32 * t + r];
+#pragma unroll
+        for (int u = 0; u < NKT; ++u) bv[u] = Bs[row * KW + k0 + 32 * u + r];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int u = 0; u < NKT; ++u)
+            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[u], acc[t][u], 0, 0, 0);
+      }
+    }
+    // VALU riders: thread tid < 256 owns column tid
+    if (tid < 256) {
+      if (jb.flags & WF_BIAS) {
+#pragma unroll 8
+        for (int row = 0; row < WG_PT; ++row) bias_acc += As[row * 256 + tid];
+      }
+      if (jb.flags & WF_ALPHA) {
+#pragma unroll 8
+        for (int row = 0; row < WG_PT; ++row) alpha_acc = fmaf(dal[row], Bs[row * KW + tid], alpha_acc);
+        if (tid == 0)
+          for (int row = 0; row < WG_PT; ++row) dal_acc += dal[row];
+      }
+      if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
+#pragma unroll 8
+        for (int row = 0; row < WG_PT; ++row) {
+          const float d = As[row * 256 + tid];
+          vc0 = fmaf(d, vws[row * 4 + 0], vc0);
+          vc1 = fmaf(d, vws[row * 4 + 1], vc1);
+          vc2 = fmaf(d, vws[row * 4 + 2], vc2);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write the partial ---------------------------------------------------------
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        const int k = k0 + 32 * u + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (n < jb.n_rows && k < jb.kvalid)
+            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k] = acc[t][u][i];
+        }
+      }
+  }
+  if (tid < 256) {
+    if ((jb.flags & WF_BIAS) && tid < jb.n_rows) out[jb.b_off + tid] = bias_acc;
+    if (jb.flags & WF_ALPHA) {
+      out[jb.aux_off + tid] = alpha_acc;
+      if (tid == 0) out[jb.aux_off + 256] = dal_acc;
+    }
+    if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
+      out[jb.w_off + (size_t)tid * jb.ld + 256] = vc0;
+      out[jb.w_off + (size_t)tid * jb.ld + 257] = vc1;
+      out[jb.w_off + (size_t)tid * jb.ld + 258] = vc2;
+    }
+  }
+}
+
+// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c]
+__device__ __forceinline__ void wgrad_rgb_job(const WgradArgs& a, const WgradJob& jb, float* lds,
+                                              int c0, int c1, float* __restrict__ out) {
+  const int tid = threadIdx.x;
+  const int k = tid & 127, part = tid >> 7;     // 4 point-interleaved parts
+  const float* __restrict__ hv = a.acts + jb.in_off;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (int pt = c0 + part; pt < c1; pt += 4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    const float h = hv[(size_t)pt * 256 + k];
+    s0 = fmaf(g[0], h, s0); s1 = fmaf(g[1], h, s1); s2 = fmaf(g[2], h, s2);
+    b0 += g[0]; b1 += g[1]; b2 += g[2];
+  }
+  float* red = lds;                               // [4][6][128]
+  red[(part * 6 + 0) * 128 + k] = s0; red[(part * 6 + 1) * 128 + k] = s1;
+  red[(part * 6 + 2) * 128 + k] = s2; red[(part * 6 + 3) * 128 + k] = b0;
+  red[(part * 6 + 4) * 128 + k] = b1; red[(part * 6 + 5) * 128 + k] = b2;
+  __syncthreads();
+  if (tid < 384) {
+    const int c = tid >> 7;
+    float s = 0.f;
+    for (int p = 0; p < 4; ++p) s += red[(p * 6 + c) * 128 + k];
+    out[jb.w_off + c * 128 + k] = s;
+  }
+  if (tid < 3) {
+    float s = 0.f;
+    for (int p = 0; p < 4; ++p) s += red[(p * 6 + 3 + tid) * 128 + 0];
+    out[jb.b_off + tid] = s;
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(WgradArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const WgradJob& jb = a.jobs[blockIdx.y];
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = min(a.P, c0 + a.chunk);
+  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
+  if (jb.flags & WF_RGB) {
+    wgrad_rgb_job(a, jb, lds, c0, c1, out);
+  } else if (jb.kw == 256) {
+    wgrad_mfma_job<256>(a, jb, lds, c0, c1, out);
+  } else {
+    wgrad_mfma_job<64>(a, jb, lds, c0, c1, out);
+  }
+}
+
+__global__ void mlp_wgrad_reduce_kernel(const float* partial, int nchunks, float* grad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N_PARAM_FLOATS; i += gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
+    grad[i] = s;
+  }
+}
+
+}  // namespace scade
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+using namespace scade;
+
+extern "C" long scade_mlp_packed_t_floats(void) { return PACKED_BWD_FLOATS; }
+
+extern "C" int scade_mlp_pack_t(const float* const* params, float* packed_t, void* stream) {
+  SCADE_REQUIRE(params && packed_t, -1, "scade_mlp_pack_t: null pointer");
+  PackTArgs a;
+  for (int i = 0; i < N_PARAM_TENSORS; ++i) {
+    SCADE_REQUIRE(params[i], -1, "scade_mlp_pack_t: params[%d] is null", i);
+    a.p[i] = params[i];
+  }
+  a.packedT = packed_t;
+  hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(64, NLAYER_DGRAD), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_mlp_pack_t");
+}
+
+// flat-gradient offsets of the 24 parameter tensors (PARAM order of mlp_layout.h)
+static void param_offsets(int off[N_PARAM_TENSORS + 1]) {
+  int o = 0, i = 0;
+  for (int l = 0; l < 8; ++l) {
+    const int k = l == 0 ? 57 : (l == 5 ? 313 : 256);
+    off[i++] = o; o += 256 * k;
+    off[i++] = o; o += 256;
+  }
+  off[i++] = o; o += 128 * 259;
+  off[i++] = o; o += 128;
+  off[i++] = o; o += 256 * 256;
+  off[i++] = o; o += 256;
+  off[i++] = o; o += 256;
+  off[i++] = o; o += 1;
+  off[i++] = o; o += 3 * 128;
+  off[i++] = o; o += 3;
+  off[i] = o;
+}
+
+static int pick_chunks(int P) {
+  // ~13 job-equivalents per chunk; aim at >= 6 workgroups per CU-slot overall
+  int n = P / 1536;
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return n;
+}
+
+extern "C" int scade_mlp_bwd_chunks(int P) { return pick_chunks(P); }
+
+extern "C" long scade_mlp_bwd_workspace_floats(int P) {
+  return dz_floats(P) + (long)pick_chunks(P) * N_PARAM_FLOATS;
+}
+
+extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const float* acts,
+                             const float* g_out, int P, float* workspace, float* grad_flat,
+                             void* stream) {
+  SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd: P must be positive");
+  SCADE_REQUIRE(packed && packed_t && acts && g_out && workspace && grad_flat, -1,
+                "scade_mlp_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  float* dz = workspace;
+  float* partial = workspace + dz_floats(P);
+
+  MlpDgradArgs d{packed, packed_t, acts, g_out, dz, P};
+  hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((P + TM - 1) / TM), dim3(256), MLP_LDS_BYTES, s, d);
+  if (int e = scade_check_launch("scade_mlp_bwd(dgrad)")) return e;
+
+  int off[N_PARAM_TENSORS + 1];
+  param_offsets(off);
+  WgradArgs w{};
+  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial; w.P = P;
+  const int nchunks = pick_chunks(P);
+  int chunk = (P + nchunks - 1) / nchunks;
+  chunk = (chunk + WG_PT - 1) / WG_PT * WG_PT;
+  w.chunk = chunk;
+  const int grid_x = (P + chunk - 1) / chunk;
+  int nj = 0;
+  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
+  auto add = [&](long dzo, long ino, int ins, int kw, int nrows, int woff, int ld, int kcol0,
+                 int kvalid, int boff, int flags, int aux) {
+    WgradJob& j = w.jobs[nj++];
+    j.dz_off = dzo; j.in_off = ino; j.in_stride = ins; j.kw = kw; j.n_rows = nrows; j.w_off = woff;
+    j.ld = ld; j.kcol0 = kcol0; j.kvalid = kvalid; j.b_off = boff; j.flags = flags; j.aux_off = aux;
+  };
+  // big jobs first, small last (tail filling)
+  for (int l = 1; l <= 7; ++l) {
+    const int ld = l == 5 ? 313 : 256, kc0 = l == 5 ? 57 : 0;
+    add(slot(l), slot(l - 1), 256, 256, 256, off[2 * l], ld, kc0, 256, off[2 * l + 1], WF_BIAS, 0);
+  }
+  add(slot(SLOT_FEAT), slot(7), 256, 256, 256, off[18], 256, 0, 256, off[19], WF_BIAS | WF_ALPHA, off[20]);
+  add(slot(SLOT_VIEWS_H), slot(SLOT_FEAT), 256, 256, 128, off[16], 259, 0, 256, off[17],
+      WF_BIAS | WF_VIEWCOLS, 0);
+  add(slot(0), acts_emb_off(P), 64, 64, 256, off[0], 57, 0, 57, off[1], WF_BIAS, 0);
+  add(slot(5), acts_emb_off(P), 64, 64, 256, off[10], 313, 0, 57, 0, 0, 0);
+  add(0, slot(SLOT_VIEWS_H), 256, 0, 0, off[22], 128, 0, 0, off[23], WF_RGB, 0);
+  w.njobs = nj;
+  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid_x, nj), dim3(512), WGRAD_LDS_BYTES, s, w);
+  if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
+  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);
+  return scade_check_launch("scade_mlp_bwd(reduce)");
+}

@@ -19,16 +19,9 @@
 //    consecutive features of ONE point -> ds_write_b128 epilogue, in place;
 //  * skip-concat (layer 5) and view-concat are extra k-blocks, never a concat;
 //  * the 256->1 and 128->3 heads are VALU dot products.
-#include "common.h"
-#include "mlp_layout.h"
+#include "mlp_tile.h"
 
 namespace scade {
-
-constexpr int TM = 64;                         // points per workgroup
-constexpr int H_FLOATS = TM * W;               // 16384
-constexpr int EMB_STRIDE = 60;                 // floats; 240 B rows -> conflict-free b128
-constexpr int EMB_FLOATS = TM * EMB_STRIDE;    // 3840
-constexpr int MLP_LDS_BYTES = (H_FLOATS + EMB_FLOATS) * 4;  // 80896
 
 struct MlpFwdArgs {
   const float* packed;    // PACKED_FWD_FLOATS
@@ -36,75 +29,11 @@ struct MlpFwdArgs {
   const float* viewdirs;  // mode 1: [P/S,3]
   const float* bb;        // mode 1: {cx,cy,cz,scale}
   float* out;             // [P,4]
-  float* acts;            // optional [9][P][256] saved post-activation tiles (training)
+  float* acts;            // optional training workspace (mlp_layout.h: acts_floats(P))
   int P;
   int S;                  // samples per ray (mode 1)
   int vd_stride;          // row stride of viewdirs (mode 1)
 };
-
-// float index of 16-byte chunk `chunk` of row `row` in the swizzled h tile
-__device__ __forceinline__ int h_idx(int row, int chunk) {
-  return row * W + ((chunk ^ (row & 15)) << 2);
-}
-
-// ---------------------------------------------------------------------------
-// k-loop of one layer.  acc[t][p]: n-tile t of this wave x point-tile p.
-//   wp   : this wave's first n-tile, [NT][KB][64] float4, KB = KBP + KBH
-//   pre  : LDS region for the first KBP k-blocks (row stride PRE_STRIDE floats)
-//   hbuf : swizzled h tile for the remaining KBH k-blocks
-// ---------------------------------------------------------------------------
-template <int NT, int KBP, int KBH, int PRE_STRIDE>
-__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], const f32x4* __restrict__ wp,
-                                           const float* pre, const float* hbuf, int lane) {
-  constexpr int KB = KBP + KBH;
-  const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
-
-  auto load_b = [&](int kb, f32x4& b0, f32x4& b1) {
-    if (KBP > 0 && kb < KBP) {
-      const float* q = pre + r * PRE_STRIDE + (2 * kb + hh) * 4;
-      b0 = *reinterpret_cast<const f32x4*>(q);
-      b1 = *reinterpret_cast<const f32x4*>(q + 32 * PRE_STRIDE);
-    } else {
-      const float* q = hbuf + h_idx(r, 2 * (kb - KBP) + hh);
-      b0 = *reinterpret_cast<const f32x4*>(q);
-      b1 = *reinterpret_cast<const f32x4*>(q + 32 * W);
-    }
-  };
-
-  f32x4 an[NT], bn[2];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + 0) * 64 + lane];
-  load_b(0, bn[0], bn[1]);
-
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
-    f32x4 a[NT], b[2];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a[t] = an[t];
-    b[0] = bn[0];
-    b[1] = bn[1];
-    const int kn = (kb + 1 < KB) ? kb + 1 : kb;  // last iteration re-reads (no branch)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + kn) * 64 + lane];
-    load_b(kn, bn[0], bn[1]);
-    // keep the next block's loads ABOVE this block's MFMAs (hipcc otherwise sinks
-    // them below the last use of a[]/b[] to reuse the registers: no prefetch)
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < NT; ++t)
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-          acc[t][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[p][j], acc[t][p], 0, 0, 0);
-  }
-}
 
 // bias (+ReLU) and in-place write of the wave's [NT*32 features] x [64 points]
 template <int NT, bool RELU>
@@ -191,6 +120,21 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
   }
   __syncthreads();
+  if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0   (coalesced 256-B rows)
+    float* eo = a.acts + acts_emb_off(P);
+    for (int i = tid; i < TM * 64; i += 256) {
+      const int row = i >> 6, c = i & 63;
+      const int pt = p0 + row;
+      if (pt < P) {
+        float v = 0.f;
+        if (c < EMB) v = ebuf[row * EMB_STRIDE + c];
+        else if (c >= 60 && c < 63)
+          v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + (c - 60)]
+                        : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + (c - 60)];
+        eo[(size_t)pt * 64 + c] = v;
+      }
+    }
+  }
 
   f32x16 acc[2][2];
   const int nt0 = wave * 2;
@@ -203,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     __syncthreads();                                                                               \
     layer_store<2, true>(acc, pk + off_b(L), nt0, hbuf, lane);                                     \
     __syncthreads();                                                                               \
-    if (SAVE) save_tile(hbuf, a.acts + (size_t)(L)*P * W, p0, P, W, tid);                          \
+    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, L), p0, P, W, tid);                          \
   }
 
   PTS_LAYER(0, 8, ebuf)
@@ -245,6 +189,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     alpha = s + pk[OFF_BA];
+    if (SAVE && sub == 0 && p0 + row < P) a.acts[acts_alpha_off(P) + p0 + row] = alpha;
   }
 
   // ---------------- feature_linear: 256 -> 256, no activation ----------------
@@ -254,6 +199,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   __syncthreads();
   layer_store<2, false>(acc, pk + off_b(L_FEAT), nt0, hbuf, lane);
   __syncthreads();
+  if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid);
 
   // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
   {
@@ -264,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     __syncthreads();
     layer_store<1, true>(accv, pk + off_b(L_VIEWS), wave, hbuf, lane);
     __syncthreads();
-    if (SAVE) save_tile(hbuf, a.acts + (size_t)8 * P * W, p0, P, 128, tid);
+    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, tid);
   }
 
   // ---------------- rgb head 128 -> 3, softplus(alpha, beta=10) --------------
@@ -403,3 +349,4 @@ extern "C" int scade_mlp_fwd(const float* packed, int mode, const float* in, con
 }
 
 extern "C" int scade_mlp_lds_bytes(void) { return MLP_LDS_BYTES; }
+extern "C" long scade_mlp_acts_floats(long P) { return acts_floats(P); }

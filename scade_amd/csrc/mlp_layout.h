@@ -40,12 +40,38 @@ constexpr int OFF_WR = OFF_BA + 4;                     // rgb_linear.weight  [3]
 constexpr int OFF_BR = OFF_WR + 384;                   // rgb_linear.bias    [3] (+1 pad)
 constexpr int PACKED_FWD_FLOATS = OFF_BR + 4 + 256;    // + one k-block of slack
 
-// Backward ("transposed") packing used by the dgrad chain: for a layer with N
-// outputs and K(padded) inputs,  WT[((kt*NB + nb)*64 + lane)*4 + j] =
-//        W[nb*8 + 4*(lane>>5) + j][kmap(kt*32 + (lane&31))]
-constexpr int wt_floats(int l) { return w_floats(l); }
-constexpr int off_wt(int l) { return off_w(l); }
-constexpr int PACKED_BWD_FLOATS = off_w(NLAYER_MFMA) + 256;
+// Backward ("transposed") packing used by the dgrad chain.  For the 9 layers whose
+// input gradient is needed (pts 1..7, feature, views) only the 256 columns that
+// multiply the hidden state h take part:
+//   WT[((kt*NB + nb)*64 + lane)*4 + j] = W[nb*8 + 4*(lane>>5) + j][hcol0 + kt*32 + (lane&31)]
+// (hcol0 = 57 for pts layer 5, else 0; NB = N/8).  Index t = 0..8 <-> pts 1..7, feature, views.
+constexpr int NLAYER_DGRAD = 9;
+constexpr int dgrad_layer(int t) { return t < 7 ? t + 1 : (t == 7 ? L_FEAT : L_VIEWS); }
+constexpr int dgrad_index(int l) { return l <= 7 ? l - 1 : (l == L_FEAT ? 7 : 8); }
+constexpr int wt_floats(int t) { return 256 * n_out(dgrad_layer(t)); }
+constexpr int off_wt(int t) {
+  int o = 0;
+  for (int i = 0; i < t; ++i) o += wt_floats(i);
+  return o;
+}
+constexpr int PACKED_BWD_FLOATS = off_wt(NLAYER_DGRAD) + 256;
+
+// Training workspace written by the forward (floats, P = points of the launch):
+//   slots 0..7 : post-ReLU output of pts layer l        [P][256]
+//   slot  8    : post-ReLU views hidden (cols 0..127)    [P][256]
+//   slot  9    : feature_linear output (no activation)   [P][256]
+//   emb        : [P][64] = gamma(x)(57) | 0 0 0 | viewdir(3) | 0
+//   alpha_pre  : [P] alpha_linear output before softplus
+constexpr int N_ACT_SLOTS = 10;
+constexpr int SLOT_VIEWS_H = 8, SLOT_FEAT = 9;
+constexpr long acts_slot_off(long P, int s) { return (long)s * P * 256; }
+constexpr long acts_emb_off(long P) { return (long)N_ACT_SLOTS * P * 256; }
+constexpr long acts_alpha_off(long P) { return acts_emb_off(P) + P * 64; }
+constexpr long acts_floats(long P) { return acts_alpha_off(P) + P; }
+// dgrad workspace: dZ slots [10][P][256] (same slot numbering: gradient w.r.t. the
+// PRE-activation of that layer; slot 9 = d feature) followed by d alpha_pre [P]
+constexpr long dz_dalpha_off(long P) { return (long)N_ACT_SLOTS * P * 256; }
+constexpr long dz_floats(long P) { return dz_dalpha_off(P) + P; }
 
 // parameter order of the 24 raw tensors handed to scade_mlp_pack
 //  0..15 : pts_linears.{0..7}.{weight,bias}

@@ -1,0 +1,78 @@
+// Tile-level building blocks shared by the fused MLP forward and dgrad kernels.
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace scade {
+
+constexpr int TM = 64;                         // points per workgroup
+constexpr int H_FLOATS = TM * W;               // 16384
+constexpr int EMB_STRIDE = 60;                 // floats; 240 B rows -> conflict-free b128
+constexpr int EMB_FLOATS = TM * EMB_STRIDE;    // 3840
+constexpr int MLP_LDS_BYTES = (H_FLOATS + EMB_FLOATS) * 4;  // 80896
+
+// float index of 16-byte chunk `chunk` of row `row` in the swizzled h tile
+__device__ __forceinline__ int h_idx(int row, int chunk) {
+  return row * W + ((chunk ^ (row & 15)) << 2);
+}
+
+// ---------------------------------------------------------------------------
+// k-loop of one layer.  acc[t][p]: n-tile t of this wave x point-tile p.
+//   wp   : this wave's first n-tile, [NT][KB][64] float4, KB = KBP + KBH
+//   pre  : LDS region for the first KBP k-blocks (row stride PRE_STRIDE floats)
+//   hbuf : swizzled h tile for the remaining KBH k-blocks
+// ---------------------------------------------------------------------------
+template <int NT, int KBP, int KBH, int PRE_STRIDE>
+__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], const f32x4* __restrict__ wp,
+                                           const float* pre, const float* hbuf, int lane) {
+  constexpr int KB = KBP + KBH;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
+
+  auto load_b = [&](int kb, f32x4& b0, f32x4& b1) {
+    if (KBP > 0 && kb < KBP) {
+      const float* q = pre + r * PRE_STRIDE + (2 * kb + hh) * 4;
+      b0 = *reinterpret_cast<const f32x4*>(q);
+      b1 = *reinterpret_cast<const f32x4*>(q + 32 * PRE_STRIDE);
+    } else {
+      const float* q = hbuf + h_idx(r, 2 * (kb - KBP) + hh);
+      b0 = *reinterpret_cast<const f32x4*>(q);
+      b1 = *reinterpret_cast<const f32x4*>(q + 32 * W);
+    }
+  };
+
+  f32x4 an[NT], bn[2];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + 0) * 64 + lane];
+  load_b(0, bn[0], bn[1]);
+
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    f32x4 a[NT], b[2];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) a[t] = an[t];
+    b[0] = bn[0];
+    b[1] = bn[1];
+    const int kn = (kb + 1 < KB) ? kb + 1 : kb;  // last iteration re-reads (no branch)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + kn) * 64 + lane];
+    load_b(kn, bn[0], bn[1]);
+    // keep the next block's loads ABOVE this block's MFMAs (hipcc otherwise sinks
+    // them below the last use of a[]/b[] to reuse the registers: no prefetch)
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+          acc[t][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[p][j], acc[t][p], 0, 0, 0);
+  }
+}
+
+}  // namespace scade

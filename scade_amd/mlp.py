@@ -5,7 +5,6 @@ import torch
 
 from . import ops
 
-N_ACT_SLOTS = 10  # pts 0..7 post-ReLU, views hidden, feature
 
 
 def _needs_grad(params) -> bool:
@@ -20,7 +19,7 @@ class MlpEmbeddedFn(torch.autograd.Function):
         packed = net.packed()
         acts = None
         if train:
-            acts = torch.empty(N_ACT_SLOTS, x.shape[0], 256, device=x.device, dtype=torch.float32)
+            acts = ops.mlp_acts_alloc(x.shape[0], x.device)
         out = ops.mlp_fwd_embedded(packed, x, acts)
         ctx.net, ctx.mode = net, 0
         ctx.save_for_backward(x, acts if acts is not None else x.new_empty(0))
@@ -30,7 +29,7 @@ class MlpEmbeddedFn(torch.autograd.Function):
     def backward(ctx, g_out):
         from .mlp_bwd import mlp_backward
         x, acts = ctx.saved_tensors
-        grads = mlp_backward(ctx.net, 0, x, None, None, acts, g_out)
+        grads = mlp_backward(ctx.net, acts, g_out)
         return (None, None, None) + tuple(grads)
 
 
@@ -43,7 +42,7 @@ class MlpPointsFn(torch.autograd.Function):
         acts = None
         if train:
             P = pts.shape[0] * pts.shape[1]
-            acts = torch.empty(N_ACT_SLOTS, P, 256, device=pts.device, dtype=torch.float32)
+            acts = ops.mlp_acts_alloc(P, pts.device)
         out = ops.mlp_fwd_points(packed, pts, viewdirs, bb, acts)
         ctx.net, ctx.mode = net, 1
         ctx.save_for_backward(pts, viewdirs, bb, acts if acts is not None else pts.new_empty(0))
@@ -53,5 +52,5 @@ class MlpPointsFn(torch.autograd.Function):
     def backward(ctx, g_out):
         from .mlp_bwd import mlp_backward
         pts, viewdirs, bb, acts = ctx.saved_tensors
-        grads = mlp_backward(ctx.net, 1, pts, viewdirs, bb, acts, g_out)
+        grads = mlp_backward(ctx.net, acts, g_out)
         return (None, None, None, None, None) + tuple(grads)

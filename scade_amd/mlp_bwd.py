@@ -1,8 +1,20 @@
-"""Backward of the fused NeRF MLP (dgrad chain + wgrad) -- binds scade_mlp_bwd."""
+"""Backward of the fused NeRF MLP: binds scade_mlp_bwd (dgrad chain + wgrad + reduce)."""
 from __future__ import annotations
 
+import math
 
-def mlp_backward(net, mode, inp, viewdirs, bb, acts, g_out):
-    raise NotImplementedError(
-        "scade_amd: the MLP backward kernels (scade_mlp_bwd) are not built yet; "
-        "there is no PyTorch fallback")
+from . import ops
+
+
+def mlp_backward(net, acts, g_out):
+    """-> list of 24 gradient tensors in ops.PARAM_ORDER (views of one flat buffer)."""
+    if acts is None or acts.numel() == 0:
+        raise RuntimeError("scade_amd: MLP backward called but the forward did not save activations")
+    flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
+    grads, o = [], 0
+    for name in ops.PARAM_ORDER:
+        shape = ops.PARAM_SHAPES[name]
+        n = math.prod(shape)
+        grads.append(flat[o:o + n].view(shape))
+        o += n
+    return grads

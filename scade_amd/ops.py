@@ -64,6 +64,7 @@ class KernelTimer:
 
 
 KERNEL_TIMER: Optional[KernelTimer] = None
+N_PARAM_FLOATS = 589700
 MLP_FLOP_PER_POINT = 2 * 587264      # algorithmic, unpadded
 
 
@@ -110,6 +111,35 @@ def mlp_pack(params: Sequence[Tensor], out: Optional[Tensor] = None) -> Tensor:
     arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in keep])
     call("scade_mlp_pack", ctypes.cast(arr, ctypes.c_void_p), ptr(out), stream())
     return out
+
+
+def mlp_pack_t(params: Sequence[Tensor], out: Optional[Tensor] = None) -> Tensor:
+    """Transposed weight pack for the dgrad chain (scade_mlp_pack_t)."""
+    keep = [_c(check(p, "mlp_pack_t").detach()) for p in params]
+    if out is None:
+        out = torch.empty(int(_lib.load().scade_mlp_packed_t_floats()), device=keep[0].device,
+                          dtype=torch.float32)
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in keep])
+    call("scade_mlp_pack_t", ctypes.cast(arr, ctypes.c_void_p), ptr(out), stream())
+    return out
+
+
+def mlp_acts_alloc(P: int, device) -> Tensor:
+    return torch.empty(int(_lib.load().scade_mlp_acts_floats(P)), device=device, dtype=torch.float32)
+
+
+def mlp_bwd(packed: Tensor, packed_t: Tensor, acts: Tensor, g_out: Tensor) -> Tensor:
+    """-> flat gradient [589700] in PARAM_ORDER."""
+    g = _c(check(g_out, "mlp_bwd: g_out")).reshape(-1, 4)
+    P = g.shape[0]
+    ws = torch.empty(int(_lib.load().scade_mlp_bwd_workspace_floats(P)), device=g.device,
+                     dtype=torch.float32)
+    grad = torch.empty(N_PARAM_FLOATS, device=g.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_bwd", ptr(packed), ptr(packed_t), ptr(acts), ptr(g), P, ptr(ws), ptr(grad), stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_bwd", t0, float(P) * 2 * MLP_FLOP_PER_POINT)
+    return grad
 
 
 def mlp_fwd_embedded(packed: Tensor, x: Tensor, acts: Optional[Tensor] = None) -> Tensor:

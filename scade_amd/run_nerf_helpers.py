@@ -166,6 +166,16 @@ class NeRF(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def packed_t(self):
+        """Transposed weight pack for the backward, same invalidation rule as packed()."""
+        ps = self.ordered_params()
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_packed_t", None) is None or key != self._packed_t_key \
+                or self._packed_t.device != ps[0].device:
+            self._packed_t = ops.mlp_pack_t(ps)
+            self._packed_t_key = key
+        return self._packed_t
+
     def forward(self, x):
         """x [P, 60] = [gamma(pts) | viewdir] -> [P,4] (helpers:223-247)."""
         from .mlp import MlpEmbeddedFn
