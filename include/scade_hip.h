@@ -136,6 +136,13 @@ int scade_mse_fwd(const float* x, const float* y, const float* row_mask, int n, 
 int scade_mse_bwd(const float* x, const float* y, const float* row_mask, int n, int c,
                   const float* g_loss, float* g_x, void* stream);
 
+/* ---- optimizer step (torch.optim.Adam defaults, run_scade_scannet.py:469, :888, :993-997) -- */
+/* One launch over a flat buffer holding every trainable tensor; grads are multiplied by
+ * grad_scale first (1/world_size after a sum all-reduce).  step counts from 1. */
+int scade_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                    float lr, float beta1, float beta2, float eps, int step, float grad_scale,
+                    void* stream);
+
 #ifdef __cplusplus
 }
 #endif

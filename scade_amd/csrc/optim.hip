@@ -1,0 +1,37 @@
+// Fused multi-tensor Adam over one flat fp32 buffer (both NeRFs + depth scale/shift live in
+// one allocation, scade_amd/parallel.py FlatParams).  Same update as torch.optim.Adam with
+// default flags (run_scade_scannet.py:469, :888): no weight decay, no amsgrad.
+#include "common.h"
+
+namespace scade {
+__global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                 float* __restrict__ m, float* __restrict__ v, long n, float lr,
+                                 float beta1, float beta2, float eps, float bc1, float bc2_sqrt,
+                                 float grad_scale) {
+  const float step_size = lr / bc1;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * grad_scale;
+    const float mi = m[i] * beta1 + gi * (1.0f - beta1);          // exp_avg.lerp_(grad, 1-beta1)
+    const float vi = v[i] * beta2 + (gi * gi) * (1.0f - beta2);   // exp_avg_sq.mul_(b2).addcmul_(g,g,1-b2)
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] = p[i] - step_size * (mi / denom);
+  }
+}
+}  // namespace scade
+
+extern "C" int scade_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
+                               long n, float lr, float beta1, float beta2, float eps, int step,
+                               float grad_scale, void* stream) {
+  SCADE_REQUIRE(params && grads && exp_avg && exp_avg_sq, -1, "scade_adam_step: null pointer");
+  SCADE_REQUIRE(step >= 1, -2, "scade_adam_step: step counts from 1");
+  if (n <= 0) return 0;
+  const double bc1 = 1.0 - pow((double)beta1, step);
+  const double bc2 = 1.0 - pow((double)beta2, step);
+  const int grid = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(scade::adam_step_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, params,
+                     grads, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, (float)bc1,
+                     (float)sqrt(bc2), grad_scale);
+  return scade_check_launch("scade_adam_step");
+}

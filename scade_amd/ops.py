@@ -64,6 +64,7 @@ class KernelTimer:
 
 
 KERNEL_TIMER: Optional[KernelTimer] = None
+PARAM_EPOCH = 0   # bumped by optimizers that update parameters through raw pointers
 N_PARAM_FLOATS = 589700
 MLP_FLOP_PER_POINT = 2 * 587264      # algorithmic, unpadded
 

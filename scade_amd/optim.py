@@ -1,0 +1,31 @@
+"""Fused Adam over FlatParams (scade_adam_step): the optimizer.step() of the reference's
+train loop (run_scade_scannet.py:469, :888, :993-997) as one kernel launch."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+from ._lib import call, check, ptr, stream
+from .parallel import FlatParams
+
+
+class FusedAdam:
+    def __init__(self, flat: FlatParams, lr=5e-4, betas=(0.9, 0.999), eps=1e-8):
+        check(flat.data, "FusedAdam: params")
+        self.flat, self.lr, self.betas, self.eps = flat, lr, betas, eps
+        self.exp_avg = torch.zeros_like(flat.data)
+        self.exp_avg_sq = torch.zeros_like(flat.data)
+        self.steps = 0
+
+    def step(self, grad_scale: float = 1.0, lr=None):
+        self.steps += 1
+        call("scade_adam_step", ptr(self.flat.data), ptr(self.flat.grad), ptr(self.exp_avg),
+             ptr(self.exp_avg_sq), self.flat.numel, float(self.lr if lr is None else lr),
+             float(self.betas[0]), float(self.betas[1]), float(self.eps), self.steps,
+             float(grad_scale), stream())
+        # parameters were updated through a raw pointer (tensor version counters did not
+        # move): advance the global epoch so NeRF.packed()/packed_t() re-pack
+        ops.PARAM_EPOCH += 1
+
+    def zero_grad(self):
+        self.flat.zero_grad()

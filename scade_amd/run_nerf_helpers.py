@@ -159,7 +159,7 @@ class NeRF(nn.Module):
         """MFMA-ordered parameter blob, rebuilt whenever a parameter changed in place."""
         self._require_supported()
         ps = self.ordered_params()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
         if self._packed is None or key != self._packed_key or self._packed.device != ps[0].device:
             self._packed = ops.mlp_pack(ps, None if self._packed is None or
                                         self._packed.device != ps[0].device else self._packed)
@@ -169,7 +169,7 @@ class NeRF(nn.Module):
     def packed_t(self):
         """Transposed weight pack for the backward, same invalidation rule as packed()."""
         ps = self.ordered_params()
-        key = tuple((p.data_ptr(), p._version) for p in ps)
+        key = (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
         if getattr(self, "_packed_t", None) is None or key != self._packed_t_key \
                 or self._packed_t.device != ps[0].device:
             self._packed_t = ops.mlp_pack_t(ps)

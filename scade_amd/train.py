@@ -1,0 +1,90 @@
+"""Thin train-step driver reproducing the reference's per-iteration call sequence
+(run_scade_scannet.py:951-997) on the HIP operators, one process per GPU:
+
+    target_h = hyp*scale + shift                      :954
+    render_hyp -> render_rays(perturb=1)              :963
+    loss = mse(rgb) + w*carve(pred_hyp) + mse(rgb0)   :968-983
+    backward                                          :985
+    [RCCL all-reduce of the flat gradient bucket]     (replaces nn.DataParallel, :438/:455)
+    staircase LR, Adam step (+ scale/shift Adam)      :988-997
+
+Not a port of train_nerf (data loading, logging, checkpoints stay with the caller).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import rendering as R
+from . import run_nerf_helpers as H
+from .optim import FusedAdam
+from .parallel import FlatParams, staircase_lr
+
+
+def make_scade_nets(device, seed: Optional[int] = None):
+    """coarse + fine NeRF in the SCADE configuration (create_nerf, :425-455)."""
+    if seed is not None:
+        torch.manual_seed(seed)
+    mk = lambda: H.NeRF(D=8, W=256, input_ch=57, output_ch=5, skips=[4], input_ch_views=3,
+                        input_ch_cam=0, use_viewdirs=True).to(device)
+    return mk(), mk()
+
+
+class Trainer:
+    def __init__(self, coarse, fine, bb_center, bb_scale, n_images=1, lrate=5e-4, scaleshift_lr=1e-7,
+                 space_carving_weight=0.007, N_samples=64, N_importance=128, lrate_decay_rate=0.1,
+                 lrate_decay_step=400000, freeze_ss=400000, norm_p=2, space_carving_threshold=0.0,
+                 is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0):
+        dev = next(coarse.parameters()).device
+        self.coarse, self.fine = coarse, fine
+        embed_fn, _ = H.get_embedder(9, 0)
+        embeddirs_fn, _ = H.get_embedder(0, 0)
+        self.query = R.make_network_query_fn(embed_fn, embeddirs_fn, bb_center.to(dev), bb_scale.to(dev))
+        # DEPTH_SCALES / DEPTH_SHIFTS, one per training image (:878-888)
+        self.depth_scales = torch.ones(n_images, 1, device=dev, requires_grad=True)
+        self.depth_shifts = torch.zeros(n_images, 1, device=dev, requires_grad=True)
+        self.flat = FlatParams(list(coarse.parameters()) + list(fine.parameters()))
+        self.flat_ss = FlatParams([self.depth_scales, self.depth_shifts])
+        self.opt = FusedAdam(self.flat, lr=lrate, betas=(0.9, 0.999))
+        self.opt_ss = FusedAdam(self.flat_ss, lr=scaleshift_lr)
+        self.cfg = dict(lrate=lrate, rate=lrate_decay_rate, step=lrate_decay_step, w=space_carving_weight,
+                        Ns=N_samples, Ni=N_importance, freeze_ss=freeze_ss, norm_p=norm_p,
+                        thr=space_carving_threshold, joint=is_joint, warm=warm_start_nerf,
+                        lindisp=lindisp, noise=raw_noise_std)
+        self.it = 0
+        self.flat.broadcast_params(0)
+        self.flat_ss.broadcast_params(0)
+
+    def forward_loss(self, rays, target_s, target_hyp, img_i=0, mask=None, **render_kw):
+        c = self.cfg
+        target_h = target_hyp * self.depth_scales[img_i] + self.depth_shifts[img_i]          # :954
+        ret = R.render_rays(rays, True, self.coarse, self.query, c["Ns"], N_importance=c["Ni"],
+                            network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
+                            lindisp=c["lindisp"], is_joint=c["joint"], **render_kw)
+        mse = (lambda a, b: H.img2mse(a, b)) if mask is None else (lambda a, b: H.img2mse_masked(a, b, mask))
+        img_loss = mse(ret["rgb_map"], target_s)                                              # :968
+        loss = img_loss
+        carve = None
+        if c["w"] > 0. and self.it >= c["warm"]:                                              # :973
+            carve = H.compute_space_carving_loss(ret["pred_hyp"], target_h, is_joint=c["joint"],
+                                                 mask=mask, norm_p=c["norm_p"], threshold=c["thr"])
+            loss = loss + c["w"] * carve
+        img_loss0 = mse(ret["rgb0"], target_s)                                                # :981
+        loss = loss + img_loss0
+        return loss, dict(img_loss=img_loss, carve=carve, img_loss0=img_loss0, ret=ret)
+
+    def step(self, rays, target_s, target_hyp, img_i=0, mask=None, **render_kw):
+        """One optimisation step on this rank's shard; returns the (local) loss tensor."""
+        self.opt.zero_grad()
+        self.opt_ss.zero_grad()
+        loss, aux = self.forward_loss(rays, target_s, target_hyp, img_i, mask, **render_kw)
+        loss.backward()                                                                       # :985
+        gs = self.flat.allreduce_grads()
+        gs_ss = self.flat_ss.allreduce_grads()
+        lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it)     # :988-991
+        self.opt.step(grad_scale=gs, lr=lr)                                                   # :993
+        if self.it < self.cfg["freeze_ss"]:                                                   # :996-997
+            self.opt_ss.step(grad_scale=gs_ss)
+        self.it += 1
+        return loss.detach(), aux

@@ -69,7 +69,7 @@ def test_product_path_refuses_cpu_tensors():
 def test_product_does_not_import_oracle():
     import subprocess
     import sys
-    code = ("import sys; import scade_amd, scade_amd.render, scade_amd.mlp; "
+    code = ("import sys; import scade_amd, scade_amd.rendering, scade_amd.mlp; "
             "assert not any(m.startswith('oracle') for m in sys.modules), 'product imports oracle'")
     subprocess.run([sys.executable, "-c", code], check=True, cwd=REPO)
     pat = re.compile(r"^\s*(from|import)\s+oracle\b|importlib.*oracle|oracle/_ref", re.M)
