@@ -35,6 +35,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the secondary train-step measurement")
+    ap.add_argument("--hyp", type=int, default=20, help="depth hypotheses per ray (train step)")
     return ap.parse_args()
 
 
@@ -102,6 +104,48 @@ def cpu_baseline(pc, pf, n_rays):
                       f"{best_thr} threads (best of {cands} on a 128-ray probe)"}
 
 
+def train_region(args, dev, world, rank, barrier):
+    """Secondary measurement (BASELINE.json configs[2]/[3]): full train step = render_rays
+    (perturb=1) + mse + 0.007*space-carving(K hypotheses) + mse0, backward, ONE RCCL
+    all-reduce of the flat gradient bucket (world > 1), fused Adam.  1024 rays per GPU."""
+    import torch.distributed as dist
+    from scade_amd import ops
+    from scade_amd.train import Trainer, make_scade_nets
+    from oracle import scade_oracle as O
+    coarse, fine = make_scade_nets(dev, seed=0)
+    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1)
+    rays = O.synthetic_rays(args.rays, seed=2000 + rank).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(3000 + rank)
+    tgt = torch.rand(args.rays, 3, generator=g).to(dev)
+    hyp = (torch.rand(args.hyp, args.rays, 1, generator=g) * 4.9 + 0.1).to(dev)
+    for _ in range(max(2, args.warmup)):
+        tr.step(rays, tgt, hyp)
+    barrier()
+    timer = ops.KernelTimer()
+    ops.KERNEL_TIMER = timer
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, _ = tr.step(rays, tgt, hyp)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ops.KERNEL_TIMER = None
+    assert bool(torch.isfinite(loss))
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ks = timer.summary()
+    kb = ks["mlp_bwd"]
+    flops = 3.0 * args.rays * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT   # fwd + dgrad + wgrad
+    return {"value": args.rays * world * args.steps / elapsed, "unit": "rays/s",
+            "ms_per_step": elapsed / args.steps * 1e3, "rays_per_gpu": args.rays, "hypotheses": args.hyp,
+            "collective": (f"RCCL all-reduce(sum, fp32) of {tr.flat.numel + tr.flat_ss.numel} floats per step"
+                           if world > 1 else "none (1 GPU)"),
+            "whole_step_tflops_per_gpu": flops / (elapsed / args.steps) / 1e12,
+            "whole_step_frac_of_fp32_mfma_peak": flops / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
+            "mlp_bwd_tflops": kb["work"] / (kb["ms"] * 1e-3) / 1e12}
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,6 +205,14 @@ def main():
     avg_ms = k["ms"] / k["launches"]
     flops_per_launch = k["work"] / k["launches"]
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
+    traffic, traffic_src, pmc_util = None, None, None
+    try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
+        import glob
+        f = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))[-1]
+        pmc = json.load(open(f))["mlp_fwd_kernel"]
+        traffic, pmc_util, traffic_src = pmc["hbm_bytes_per_launch"], pmc["mfma_util"], os.path.basename(f)
+    except Exception:
+        pass
     total_rays = args.rays * world * args.steps
     out = {
         "metric": "rays/sec (64c+128f samples)",
@@ -182,12 +234,16 @@ def main():
                    "parallelism": f"ray-sharded x{world}, no data-path collective (inference)"},
         "roofline": {"bound": "mfma", "kernel": "mlp_fwd_kernel", "achieved": achieved,
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc)",
+                     "traffic_source": traffic_src, "mfma_util_pmc": pmc_util,
                      "launches_timed": k["launches"], "avg_launch_ms": avg_ms,
                      "flops_per_launch": flops_per_launch,
                      "note": "algorithmic 1,174,528 FLOP/point x mean points per launch "
                              "(coarse 65,536 + fine 196,608 per step), HIP events on the launch stream"},
     }
+    if not args.no_train:
+        out["train_step"] = train_region(args, dev, world, rank, barrier)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pc, pf, 1024)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

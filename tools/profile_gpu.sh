@@ -1,0 +1,40 @@
+#!/bin/bash
+# Run ON THE GPU BOX (via gpurun): rocprofv3 per-kernel stats + separate PMC passes of the
+# default bench command.  Usage: tools/profile_gpu.sh <round-tag>   (outputs under gpurun_out/)
+set -u
+TAG=${1:-r01}
+ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+CMD="python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
+tail -1 $OUT/stats.log | grep -o '^{.*}' > $OUT/bench_line_under_rocprof.json
+# PMC passes: one counter group per run, kernel-trace only (no other trace domains)
+i=0
+for GROUP in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
+             "TCC_HIT_sum TCC_MISS_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d $OUT/pmc$i -o bench -- $CMD > $OUT/pmc$i.log 2>&1
+done
+python - "$OUT" <<'PY'
+import csv, glob, os, sys, collections
+out = sys.argv[1]
+rows = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(out, "pmc*", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        rows[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(os.path.join(out, "pmc_summary.csv"), "w") as fo:
+    fo.write("kernel,counter,dispatches,mean_per_dispatch,total\n")
+    for k in sorted(rows):
+        if "scade" not in k:
+            continue
+        for c, v in sorted(rows[k].items()):
+            fo.write(f"\"{k[:90]}\",{c},{len(v)},{sum(v)/len(v):.6g},{sum(v):.6g}\n")
+print(open(os.path.join(out, "pmc_summary.csv")).read()[:6000])
+PY
+find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
+cp $OUT/stats/*/bench_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
+du -sh $OUT
