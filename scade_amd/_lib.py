@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libscade_hip.so")
+LIB_PATH = os.environ.get("SCADE_LIB") or os.path.join(_HERE, "lib", "libscade_hip.so")  # SCADE_LIB: kernel experiments
 
 _P = c_void_p
 _I = c_int

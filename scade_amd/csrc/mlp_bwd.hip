@@ -62,13 +62,12 @@ struct MlpDgradArgs {
   int P;
 };
 
-// write the wave's [2 k-tiles x 64 points] gradient block: optional alpha-head term,
-// optional ReLU mask (saved activation > 0), in place to LDS and to HBM slot `dst`
+// write the wave's [2 k-tiles x 64 points] gradient block in place to LDS: optional
+// alpha-head term, optional ReLU mask from the lane-private sign bits the forward saved
 template <bool MASK, bool ADD_ALPHA>
 __device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][2], int ktile0, float* hbuf,
-                                            const float* __restrict__ mask_src,
-                                            float* __restrict__ dst, const float* __restrict__ w_a,
-                                            const float* dalpha_lds, int p0, int P, int lane) {
+                                            unsigned long long bits, const float* __restrict__ w_a,
+                                            const float* dalpha_lds, int lane) {
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -80,8 +79,6 @@ __device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][2], int ktile
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int row = p * 32 + r;
-        const int pt = p0 + row;
-        const bool ok = pt < P;
         f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) v[i] = acc[t][p][4 * q + i];
@@ -91,13 +88,11 @@ __device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][2], int ktile
           for (int i = 0; i < 4; ++i) v[i] = v[i] + wa[i] * da;
         }
         if (MASK) {
-          f32x4 m = {0.f, 0.f, 0.f, 0.f};
-          if (ok) m = *reinterpret_cast<const f32x4*>(mask_src + (size_t)pt * W + f);
 #pragma unroll
-          for (int i = 0; i < 4; ++i) v[i] = m[i] > 0.f ? v[i] : 0.f;
+          for (int i = 0; i < 4; ++i)
+            v[i] = ((bits >> (((t * 4 + q) * 2 + p) * 4 + i)) & 1ull) ? v[i] : 0.f;
         }
         *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
-        if (ok) *reinterpret_cast<f32x4*>(dst + (size_t)pt * W + f) = v;
       }
     }
 }
@@ -115,6 +110,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
   const float* __restrict__ pt_ = a.packedT;
   const float* __restrict__ acts = a.acts;
   float* __restrict__ dz = a.dz;
+  const unsigned long long* __restrict__ masks =
+      reinterpret_cast<const unsigned long long*>(acts + acts_mask_off(P));
+  auto mask_of = [&](int layer) { return masks[((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid]; };
 
   // ---- heads: d alpha_pre, dZ of the views layer (rgb head + ReLU mask) ----------
   {
@@ -157,33 +155,37 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
   __syncthreads();
 
   f32x16 acc[2][2];
+  f32x4 an[2];
   const int kt0 = wave * 2;
+  // transposed-pack base of this wave for dgrad index T (NB = reduction blocks per k-tile)
+#define WTBASE(T, NB) (reinterpret_cast<const f32x4*>(pt_ + off_wt(T)) + kt0 * (NB) * 64)
+  an[0] = WTBASE(8, 16)[lane];
+  an[1] = WTBASE(8, 16)[16 * 64 + lane];
 
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128) --------
-  layer_gemm<2, 0, 16, EMB_STRIDE>(
-      acc, reinterpret_cast<const f32x4*>(pt_ + off_wt(8)) + kt0 * 16 * 64, hbuf, hbuf, lane);
+  layer_gemm<2, 0, 16, EMB_STRIDE>(acc, an, WTBASE(8, 16), WTBASE(7, 32), 32, hbuf, hbuf, lane);
   __syncthreads();
-  dgrad_store<false, false>(acc, kt0, hbuf, nullptr, dz + acts_slot_off(P, SLOT_FEAT), nullptr, dal,
-                            p0, P, lane);
+  dgrad_store<false, false>(acc, kt0, hbuf, 0ull, nullptr, dal, lane);
   __syncthreads();
+  save_tile(hbuf, dz + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 -----
-  layer_gemm<2, 0, 32, EMB_STRIDE>(
-      acc, reinterpret_cast<const f32x4*>(pt_ + off_wt(7)) + kt0 * 32 * 64, hbuf, hbuf, lane);
+  unsigned long long mbits = mask_of(7);
+  layer_gemm<2, 0, 32, EMB_STRIDE>(acc, an, WTBASE(7, 32), WTBASE(6, 32), 32, hbuf, hbuf, lane);
   __syncthreads();
-  dgrad_store<true, true>(acc, kt0, hbuf, acts + acts_slot_off(P, 7), dz + acts_slot_off(P, 7),
-                          pk + OFF_WA, dal, p0, P, lane);
+  dgrad_store<true, true>(acc, kt0, hbuf, mbits, pk + OFF_WA, dal, lane);
   __syncthreads();
+  save_tile(hbuf, dz + acts_slot_off(P, 7), p0, P, W, tid);
 
   // ---- pts layers 7..1: dZ_{l-1} = (W_l^T dZ_l) masked by h_{l-1} > 0 -------------
 #define DGRAD_LAYER(L)                                                                         \
-  layer_gemm<2, 0, 32, EMB_STRIDE>(                                                            \
-      acc, reinterpret_cast<const f32x4*>(pt_ + off_wt((L)-1)) + kt0 * 32 * 64, hbuf, hbuf,    \
-      lane);                                                                                   \
+  mbits = mask_of((L)-1);                                                                      \
+  layer_gemm<2, 0, 32, EMB_STRIDE>(acc, an, WTBASE((L)-1, 32), WTBASE((L) > 1 ? (L)-2 : 0, 32), \
+                                   32, hbuf, hbuf, lane);                                      \
   __syncthreads();                                                                             \
-  dgrad_store<true, false>(acc, kt0, hbuf, acts + acts_slot_off(P, (L)-1),                     \
-                           dz + acts_slot_off(P, (L)-1), nullptr, dal, p0, P, lane);           \
-  __syncthreads();
+  dgrad_store<true, false>(acc, kt0, hbuf, mbits, nullptr, dal, lane);                         \
+  __syncthreads();                                                                             \
+  save_tile(hbuf, dz + acts_slot_off(P, (L)-1), p0, P, W, tid);
 
   DGRAD_LAYER(7)
   DGRAD_LAYER(6)
@@ -193,6 +195,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
   DGRAD_LAYER(2)
   DGRAD_LAYER(1)
 #undef DGRAD_LAYER
+#undef WTBASE
 }
 
 // ---------------------------------------------------------------------------

@@ -36,16 +36,32 @@ struct MlpFwdArgs {
 };
 
 // bias (+ReLU) and in-place write of the wave's [NT*32 features] x [64 points]
+// this lane's 16 bias values per n-tile (issued before the k-loop, consumed in layer_store)
+template <int NT>
+__device__ __forceinline__ void load_bias(f32x4 (&bv)[NT][4], const float* __restrict__ bias,
+                                          int ntile0, int lane) {
+  const int hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bv[t][q] = *reinterpret_cast<const f32x4*>(bias + (ntile0 + t) * 32 + 8 * q + 4 * hh);
+}
+
+// returns this lane's ReLU sign bits: bit ((t*4+q)*2+p)*4+i <-> value (t,q,p,i) > 0, the
+// same (t,q,p,i) -> (feature, point) map the dgrad kernel uses for its output fragment
 template <int NT, bool RELU>
-__device__ __forceinline__ void layer_store(const f32x16 (&acc)[NT][2], const float* __restrict__ bias,
-                                            int ntile0, float* hbuf, int lane) {
+__device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT][2],
+                                                          const f32x4 (&bias)[NT][4], int ntile0,
+                                                          float* hbuf, int lane) {
   const int r = lane & 31, hh = lane >> 5;
+  unsigned long long bits = 0ull;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f);
+      const f32x4 bv = bias[t][q];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         f32x4 v;
@@ -53,23 +69,13 @@ __device__ __forceinline__ void layer_store(const f32x16 (&acc)[NT][2], const fl
         for (int i = 0; i < 4; ++i) {
           float x = acc[t][p][4 * q + i] + bv[i];
           v[i] = RELU ? fmaxf(x, 0.f) : x;
+          if (RELU && x > 0.f) bits |= 1ull << (((t * 4 + q) * 2 + p) * 4 + i);
         }
         const int row = p * 32 + r;
         *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
       }
     }
-}
-
-// coalesced copy of the h tile (first NC columns) to acts[slot][P][256]
-__device__ __forceinline__ void save_tile(const float* hbuf, float* __restrict__ dst, int p0, int P,
-                                          int ncols, int tid) {
-  const int chunks_per_row = ncols >> 2;
-  for (int i = tid; i < TM * chunks_per_row; i += 256) {
-    const int row = i / chunks_per_row, c = i - row * chunks_per_row;
-    if (p0 + row < P)
-      *reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c) =
-          *reinterpret_cast<const f32x4*>(hbuf + h_idx(row, c));
-  }
+  return bits;
 }
 
 template <int MODE, bool SAVE>
@@ -84,7 +90,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   const int P = a.P;
   const float* __restrict__ pk = a.packed;
 
-  // ---------------- prologue: embedding tile [64][60] -----------------------
+  // ---------------- prologue: embedding tile [64][60] (+ zeroed tail pad) ----
+  if (tid < 4) ebuf[TM * EMB_STRIDE + tid] = 0.f;
   if (MODE == 0) {
     // x rows are 60 contiguous floats == the tile layout; columns 57..59 carry
     // the view direction and meet zero weights in layers 0/5.
@@ -137,25 +144,34 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   }
 
   f32x16 acc[2][2];
+  f32x4 an[2], bias[2][4];
   const int nt0 = wave * 2;
+  // weight base of this wave for MFMA layer L (views layer: one n-tile per wave)
+#define WBASE(L) (reinterpret_cast<const f32x4*>(pk + off_w(L)) + \
+                  ((L) == L_VIEWS ? wave : nt0) * kb_total(L) * 64)
 
-#define PTS_LAYER(L, KBP, PRE)                                                                     \
+#define PTS_LAYER(L, LNEXT, KBP, PRE)                                                              \
   {                                                                                                \
-    layer_gemm<2, KBP, kb_h(L), EMB_STRIDE>(                                                       \
-        acc, reinterpret_cast<const f32x4*>(pk + off_w(L)) + nt0 * kb_total(L) * 64, PRE, hbuf,    \
-        lane);                                                                                     \
+    load_bias<2>(bias, pk + off_b(L), nt0, lane);                                                  \
+    layer_gemm<2, KBP, kb_h(L), EMB_STRIDE>(acc, an, WBASE(L), WBASE(LNEXT), kb_total(LNEXT), PRE, \
+                                            hbuf, lane);                                           \
     __syncthreads();                                                                               \
-    layer_store<2, true>(acc, pk + off_b(L), nt0, hbuf, lane);                                     \
+    const unsigned long long bits_ = layer_store<2, true>(acc, bias, nt0, hbuf, lane);             \
+    if (SAVE)                                                                                      \
+      reinterpret_cast<unsigned long long*>(a.acts + acts_mask_off(P))[                            \
+          ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = bits_;                               \
     __syncthreads();                                                                               \
     if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, L), p0, P, W, tid);                          \
   }
 
-  PTS_LAYER(0, 8, ebuf)
-  PTS_LAYER(1, 0, ebuf)
-  PTS_LAYER(2, 0, ebuf)
-  PTS_LAYER(3, 0, ebuf)
-  PTS_LAYER(4, 0, ebuf)
-  PTS_LAYER(5, 8, ebuf)
+  an[0] = WBASE(0)[lane];
+  an[1] = WBASE(0)[kb_total(0) * 64 + lane];
+  PTS_LAYER(0, 1, 8, ebuf)
+  PTS_LAYER(1, 2, 0, ebuf)
+  PTS_LAYER(2, 3, 0, ebuf)
+  PTS_LAYER(3, 4, 0, ebuf)
+  PTS_LAYER(4, 5, 0, ebuf)
+  PTS_LAYER(5, 6, 8, ebuf)
 
   // embedding tile is dead now: reuse its head as the view pad [64][8]
   {
@@ -168,8 +184,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   }
   // (visibility of the view pad is covered by the barriers of layers 6/7)
 
-  PTS_LAYER(6, 0, ebuf)
-  PTS_LAYER(7, 0, ebuf)
+  PTS_LAYER(6, 7, 0, ebuf)
+  PTS_LAYER(7, L_FEAT, 0, ebuf)
 #undef PTS_LAYER
 
   // ---------------- alpha head: 256 -> 1 on the VALU -------------------------
@@ -193,26 +209,27 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   }
 
   // ---------------- feature_linear: 256 -> 256, no activation ----------------
-  layer_gemm<2, 0, 32, EMB_STRIDE>(
-      acc, reinterpret_cast<const f32x4*>(pk + off_w(L_FEAT)) + nt0 * kb_total(L_FEAT) * 64, ebuf,
-      hbuf, lane);
+  load_bias<2>(bias, pk + off_b(L_FEAT), nt0, lane);
+  layer_gemm<2, 0, 32, EMB_STRIDE>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
   __syncthreads();
-  layer_store<2, false>(acc, pk + off_b(L_FEAT), nt0, hbuf, lane);
+  layer_store<2, false>(acc, bias, nt0, hbuf, lane);
   __syncthreads();
   if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid);
 
   // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
   {
     f32x16 accv[1][2];
-    layer_gemm<1, 1, 32, VIEW_PAD>(
-        accv, reinterpret_cast<const f32x4*>(pk + off_w(L_VIEWS)) + wave * kb_total(L_VIEWS) * 64,
-        ebuf, hbuf, lane);
+    f32x4 biasv[1][4];
+    load_bias<1>(biasv, pk + off_b(L_VIEWS), wave, lane);
+    // (an[1] is unused by the one-tile views layer; the trailing prefetch re-reads block 0)
+    layer_gemm<1, 1, 32, VIEW_PAD>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
     __syncthreads();
-    layer_store<1, true>(accv, pk + off_b(L_VIEWS), wave, hbuf, lane);
+    layer_store<1, true>(accv, biasv, wave, hbuf, lane);
     __syncthreads();
     if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, tid);
   }
 
+#undef WBASE
   // ---------------- rgb head 128 -> 3, softplus(alpha, beta=10) --------------
   {
     const int row = tid >> 2, sub = tid & 3;

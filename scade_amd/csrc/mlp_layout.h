@@ -62,12 +62,15 @@ constexpr int PACKED_BWD_FLOATS = off_wt(NLAYER_DGRAD) + 256;
 //   slot  9    : feature_linear output (no activation)   [P][256]
 //   emb        : [P][64] = gamma(x)(57) | 0 0 0 | viewdir(3) | 0
 //   alpha_pre  : [P] alpha_linear output before softplus
+//   masks      : [8][ceil(P/64)][256] u64, lane-private ReLU sign bits of pts layers 0..7
 constexpr int N_ACT_SLOTS = 10;
 constexpr int SLOT_VIEWS_H = 8, SLOT_FEAT = 9;
 constexpr long acts_slot_off(long P, int s) { return (long)s * P * 256; }
 constexpr long acts_emb_off(long P) { return (long)N_ACT_SLOTS * P * 256; }
 constexpr long acts_alpha_off(long P) { return acts_emb_off(P) + P * 64; }
-constexpr long acts_floats(long P) { return acts_alpha_off(P) + P; }
+// ReLU sign bits of pts layers 0..7: [8][tiles][256 lanes] u64 (2 floats each), 8-byte aligned
+constexpr long acts_mask_off(long P) { return (acts_alpha_off(P) + P + 1) / 2 * 2; }
+constexpr long acts_floats(long P) { return acts_mask_off(P) + 8L * ((P + 63) / 64) * 256 * 2; }
 // dgrad workspace: dZ slots [10][P][256] (same slot numbering: gradient w.r.t. the
 // PRE-activation of that layer; slot 9 = d feature) followed by d alpha_pre [P]
 constexpr long dz_dalpha_off(long P) { return (long)N_ACT_SLOTS * P * 256; }

@@ -8,8 +8,9 @@ namespace scade {
 constexpr int TM = 64;                         // points per workgroup
 constexpr int H_FLOATS = TM * W;               // 16384
 constexpr int EMB_STRIDE = 60;                 // floats; 240 B rows -> conflict-free b128
-constexpr int EMB_FLOATS = TM * EMB_STRIDE;    // 3840
-constexpr int MLP_LDS_BYTES = (H_FLOATS + EMB_FLOATS) * 4;  // 80896
+constexpr int EMB_FLOATS = TM * EMB_STRIDE + 4;  // 3840 + one zeroed 16-byte pad: the last
+                                                // row's k-block 7 reads columns 60..63
+constexpr int MLP_LDS_BYTES = (H_FLOATS + EMB_FLOATS) * 4;  // 80912
 
 // float index of 16-byte chunk `chunk` of row `row` in the swizzled h tile
 __device__ __forceinline__ int h_idx(int row, int chunk) {
@@ -18,12 +19,17 @@ __device__ __forceinline__ int h_idx(int row, int chunk) {
 
 // ---------------------------------------------------------------------------
 // k-loop of one layer.  acc[t][p]: n-tile t of this wave x point-tile p.
-//   wp   : this wave's first n-tile, [NT][KB][64] float4, KB = KBP + KBH
-//   pre  : LDS region for the first KBP k-blocks (row stride PRE_STRIDE floats)
-//   hbuf : swizzled h tile for the remaining KBH k-blocks
+//   wp      : this wave's first n-tile, [NT][KB][64] float4, KB = KBP + KBH
+//   an      : in  = the layer's k-block 0 A fragments (prefetched by the previous layer)
+//             out = k-block 0 of the NEXT layer (wp_next, kb_next k-blocks per n-tile), so
+//             the L2 latency of a layer's first weights hides under the previous layer
+//   pre     : LDS region for the first KBP k-blocks (row stride PRE_STRIDE floats)
+//   hbuf    : swizzled h tile for the remaining KBH k-blocks
 // ---------------------------------------------------------------------------
 template <int NT, int KBP, int KBH, int PRE_STRIDE>
-__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], const f32x4* __restrict__ wp,
+__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], f32x4 (&an)[2],
+                                           const f32x4* __restrict__ wp,
+                                           const f32x4* __restrict__ wp_next, int kb_next,
                                            const float* pre, const float* hbuf, int lane) {
   constexpr int KB = KBP + KBH;
   const int r = lane & 31, hh = lane >> 5;
@@ -45,26 +51,7 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], const f32x4* __
       b1 = *reinterpret_cast<const f32x4*>(q + 32 * W);
     }
   };
-
-  f32x4 an[NT], bn[2];
-#pragma unroll
-  for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + 0) * 64 + lane];
-  load_b(0, bn[0], bn[1]);
-
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
-    f32x4 a[NT], b[2];
-#pragma unroll
-    for (int t = 0; t < NT; ++t) a[t] = an[t];
-    b[0] = bn[0];
-    b[1] = bn[1];
-    const int kn = (kb + 1 < KB) ? kb + 1 : kb;  // last iteration re-reads (no branch)
-#pragma unroll
-    for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + kn) * 64 + lane];
-    load_b(kn, bn[0], bn[1]);
-    // keep the next block's loads ABOVE this block's MFMAs (hipcc otherwise sinks
-    // them below the last use of a[]/b[] to reuse the registers: no prefetch)
-    __builtin_amdgcn_sched_barrier(0);
+  auto mfma_block = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
@@ -72,6 +59,44 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], const f32x4* __
 #pragma unroll
         for (int p = 0; p < 2; ++p)
           acc[t][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[p][j], acc[t][p], 0, 0, 0);
+  };
+
+  f32x4 bn[2];
+  load_b(0, bn[0], bn[1]);
+
+#pragma unroll 2
+  for (int kb = 0; kb < KB - 1; ++kb) {
+    f32x4 a[2], b[2];
+    a[0] = an[0]; a[1] = an[1];
+    b[0] = bn[0]; b[1] = bn[1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + kb + 1) * 64 + lane];
+    load_b(kb + 1, bn[0], bn[1]);
+    // keep the next block's loads ABOVE this block's MFMAs (hipcc otherwise sinks
+    // them below the last use of a[]/b[] to reuse the registers: no prefetch)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(a, b);
+  }
+  {  // last k-block: prefetch the next layer's first weights instead
+    f32x4 a[2], b[2];
+    a[0] = an[0]; a[1] = an[1];
+    b[0] = bn[0]; b[1] = bn[1];
+    an[0] = wp_next[lane];
+    an[1] = wp_next[kb_next * 64 + lane];
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_block(a, b);
+  }
+}
+
+// coalesced copy of the h tile (first ncols columns) to dst[P][256] (full 1-KiB rows)
+__device__ __forceinline__ void save_tile(const float* hbuf, float* __restrict__ dst, int p0, int P,
+                                          int ncols, int tid) {
+  const int chunks_per_row = ncols >> 2;
+  for (int i = tid; i < TM * chunks_per_row; i += 256) {
+    const int row = i / chunks_per_row, c = i - row * chunks_per_row;
+    if (p0 + row < P)
+      *reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c) =
+          *reinterpret_cast<const f32x4*>(hbuf + h_idx(row, c));
   }
 }
 
