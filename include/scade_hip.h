@@ -136,6 +136,18 @@ int scade_mse_fwd(const float* x, const float* y, const float* row_mask, int n, 
 int scade_mse_bwd(const float* x, const float* y, const float* row_mask, int n, int c,
                   const float* g_loss, float* g_x, void* stream);
 
+/* ---- ray generation + training-batch gather (helpers:285-305 get_ray_dirs/get_rays; the ray
+ *      rows of render()/render_hyp(), run_scade_scannet.py:122-141; the gathers of
+ *      get_ray_batch_from_one_image_hypothesis_idx, :784-821) ------------------------------- */
+/* coords[N,2] int32 (row, col) or NULL for every pixel row-major (N = H*W); intrinsic = fx fy cx
+ * cy; c2w rows 0..2 of [R|t].  Any output may be NULL.  rays rows: o d near far viewdir.
+ * target_s gathers image[H,W,3]; target_h[K,N] gathers hyps[K,H,W]; mask[N] is 0 inside the
+ * corner_px corner squares (--mask_corners) / the edge_px border (wild --mask_edges). */
+int scade_gen_rays(const int* coords, int N, int H, int W, const float* intrinsic, const float* c2w,
+                   int c2w_stride, float near, float far, const float* image, const float* hyps,
+                   int K, int corner_px, int edge_px, float* rays, float* rays_o, float* rays_d,
+                   float* target_s, float* target_h, float* mask, void* stream);
+
 /* ---- optimizer step (torch.optim.Adam defaults, run_scade_scannet.py:469, :888, :993-997) -- */
 /* One launch over a flat buffer holding every trainable tensor; grads are multiplied by
  * grad_scale first (1/world_size after a sum all-reduce).  step counts from 1. */

@@ -335,6 +335,35 @@ def train_loss(ret: Dict[str, Tensor], target_s: Tensor, target_h: Tensor,
 
 
 # ----------------------------------------------------------------------------
+# ray generation  (model/run_nerf_helpers.py:285-305; run_scade_scannet.py:122-141)
+# ----------------------------------------------------------------------------
+
+
+def get_rays(H: int, W: int, intrinsic: Tensor, c2w: Tensor, coords: Optional[Tensor] = None):
+    """helpers:285-305: pixel-centre rays, OpenGL -z convention.  coords [N,2] = (row, col)."""
+    fx, fy, cx, cy = intrinsic[0], intrinsic[1], intrinsic[2], intrinsic[3]
+    if coords is None:
+        i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+        i, j = i.t(), j.t()
+    else:
+        i, j = coords[:, 1], coords[:, 0]
+    dirs = torch.stack([((i + 0.5) - cx) / fx, (H - (j + 0.5) - cy) / fy, -torch.ones_like(i)], -1)
+    rays_d = torch.sum(dirs[..., None, :] * c2w[:3, :3], -1)
+    rays_o = c2w[:3, -1].expand(rays_d.shape)
+    return rays_o, rays_d
+
+
+def ray_rows(rays_o: Tensor, rays_d: Tensor, near: float, far: float) -> Tensor:
+    """render()/render_hyp() row assembly with use_viewdirs (run_scade_scannet.py:122-141)."""
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    viewdirs = torch.reshape(viewdirs, [-1, 3]).float()
+    rays_o = torch.reshape(rays_o, [-1, 3]).float()
+    rays_d = torch.reshape(rays_d, [-1, 3]).float()
+    nf = torch.ones_like(rays_d[..., :1])
+    return torch.cat([rays_o, rays_d, near * nf, far * nf, viewdirs], -1)
+
+
+# ----------------------------------------------------------------------------
 # synthetic workload shared by tests / bench (BASELINE.md section 3)
 # ----------------------------------------------------------------------------
 

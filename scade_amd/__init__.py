@@ -5,7 +5,7 @@ Operator API mirrors the reference (mikacuy/scade):
   scade_amd.rendering          <->  the render operators of run_scade_scannet.py / run_scade_wild.py
 All arithmetic is executed by libscade_hip.so (hand-written HIP for gfx950).
 """
-from .run_nerf_helpers import (NeRF, DenseLayer, Embedder, get_embedder, get_rays, get_ray_dirs,
+from .run_nerf_helpers import (NeRF, DenseLayer, Embedder, get_embedder, get_rays, get_ray_dirs, get_ray_batch,
                                select_coordinates, sample_pdf, sample_pdf_joint,
                                sample_pdf_return_u, sample_pdf_joint_return_u, img2mse,
                                img2mse_masked, mse2psnr, to8b, to16b, compute_space_carving_loss)

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
 // B2: wgrad
 // ---------------------------------------------------------------------------
 constexpr int WG_PT = 32;                    // points per LDS stage
-constexpr int WGRAD_LDS_BYTES = (2 * WG_PT * 256 + 64 + WG_PT * 4) * 4;
+constexpr int WGRAD_LDS_BYTES = (2 * (2 * WG_PT * 256) + 2 * 64 + 2 * WG_PT * 4) * 4;  // double-buffered
 
 enum { WF_BIAS = 1, WF_ALPHA = 2, WF_VIEWCOLS = 4, WF_RGB = 8 };
 
@@ -238,10 +238,10 @@ __device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJo
                                                int c0, int c1, float* __restrict__ out) {
   constexpr int NKT = KW == 256 ? 4 : 1;          // k-tiles of 32 per wave
   constexpr int B_F4_PER_THR = KW == 256 ? 4 : 1; // float4 staged per thread for the B tile
-  float* As = lds;                                 // [32][256]
-  float* Bs = lds + WG_PT * 256;                   // [32][KW]
-  float* dal = lds + 2 * WG_PT * 256;              // [32] d alpha_pre of the stage
-  float* vws = dal + 64;                           // [32][4] view dirs of the stage
+  // two stage buffers: As[32][256] | Bs[32][KW], then dal[2][64], vws[2][128]
+  constexpr int STAGE_FLOATS = 2 * WG_PT * 256;
+  float* dal_base = lds + 2 * STAGE_FLOATS;
+  float* vws_base = dal_base + 2 * 64;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,7 +283,11 @@ __device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJo
       pb[j] = v;
     }
   };
-  auto commit = [&](int pt0) {
+  auto commit = [&](int pt0, int buf) {
+    float* As = lds + buf * STAGE_FLOATS;
+    float* Bs = As + WG_PT * 256;
+    float* dal = dal_base + buf * 64;
+    float* vws = vws_base + buf * 128;
 #pragma unroll
     for (int j = 0; j < 4; ++j) reinterpret_cast<f32x4*>(As)[tid + 512 * j] = pa[j];
 #pragma unroll
@@ -299,20 +303,40 @@ __device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJo
     }
   };
 
+  // software pipeline: stage s+2 in flight to registers, stage s+1 committed to the other
+  // LDS buffer while stage s is multiplied; ONE barrier per stage
   issue(c0);
-  for (int pt0 = c0; pt0 < c1; pt0 += WG_PT) {
-    commit(pt0);
-    __syncthreads();
-    if (pt0 + WG_PT < c1) issue(pt0 + WG_PT);
+  commit(c0, 0);
+  if (c0 + WG_PT < c1) issue(c0 + WG_PT);
+  __syncthreads();
+  int buf = 0;
+  for (int pt0 = c0; pt0 < c1; pt0 += WG_PT, buf ^= 1) {
+    if (pt0 + WG_PT < c1) commit(pt0 + WG_PT, buf ^ 1);
+    if (pt0 + 2 * WG_PT < c1) issue(pt0 + 2 * WG_PT);
+    const float* As = lds + buf * STAGE_FLOATS;
+    const float* Bs = As + WG_PT * 256;
+    const float* dal = dal_base + buf * 64;
+    const float* vws = vws_base + buf * 128;
     if (active) {
-#pragma unroll 4
-      for (int kk = 0; kk < WG_PT / 2; ++kk) {
+      // operands of k-step kk+1 are read from LDS before the 8 MFMAs of k-step kk
+      float avn[2], bvn[NKT];
+      auto lds_frag = [&](int kk) {
         const int row = 2 * kk + hh;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) avn[t] = As[row * 256 + n0 + 32 * t + r];
+#pragma unroll
+        for (int u = 0; u < NKT; ++u) bvn[u] = Bs[row * KW + k0 + 32 * u + r];
+      };
+      lds_frag(0);
+#pragma unroll 8
+      for (int kk = 0; kk < WG_PT / 2; ++kk) {
         float av[2], bv[NKT];
 #pragma unroll
-        for (int t = 0; t < 2; ++t) av[t] = As[row * 256 + n0 + 32 * t + r];
+        for (int t = 0; t < 2; ++t) av[t] = avn[t];
 #pragma unroll
-        for (int u = 0; u < NKT; ++u) bv[u] = Bs[row * KW + k0 + 32 * u + r];
+        for (int u = 0; u < NKT; ++u) bv[u] = bvn[u];
+        lds_frag((kk + 1) & (WG_PT / 2 - 1));
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int t = 0; t < 2; ++t)
 #pragma unroll

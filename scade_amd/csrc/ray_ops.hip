@@ -874,3 +874,90 @@ extern "C" int scade_perturb_z(const float* z_vals, const float* t_rand, int N, 
   hipLaunchKernelGGL(scade::perturb_z_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_vals, t_rand, N, S, out);
   return scade_check_launch("scade_perturb_z");
 }
+
+// ---------------------------------------------------------------------------
+// ray generation + training-batch gather:
+// get_ray_dirs/get_rays (model/run_nerf_helpers.py:285-305), the ray-row assembly of
+// render()/render_hyp() (run_scade_scannet.py:122-141) and the per-pixel gathers of
+// get_ray_batch_from_one_image_hypothesis_idx (:784-821) in ONE launch: the reference
+// generates all H*W rays every step and then gathers N_rand of them.
+// ---------------------------------------------------------------------------
+namespace scade {
+struct GenRaysArgs {
+  const int* coords;      // [N,2] (row j, col i) or null == every pixel, row-major
+  const float* intrinsic; // fx fy cx cy
+  const float* c2w;       // rows 0..2, 4 columns, row stride c2w_stride
+  const float* image;     // [H,W,3] or null
+  const float* hyps;      // [K,H,W] or null
+  float* rays;            // [N,11] or null: o d near far viewdir
+  float* rays_o;          // [N,3] or null
+  float* rays_d;          // [N,3] or null
+  float* target_s;        // [N,3]
+  float* target_h;        // [K,N]
+  float* mask;            // [N] or null
+  float near, far;
+  int N, H, W, K, c2w_stride, corner_px, edge_px;
+};
+
+__global__ void gen_rays_kernel(GenRaysArgs a) {
+  const float fx = a.intrinsic[0], fy = a.intrinsic[1], cx = a.intrinsic[2], cy = a.intrinsic[3];
+  float R[3][3], T[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) R[r][c] = a.c2w[r * a.c2w_stride + c];
+    T[r] = a.c2w[r * a.c2w_stride + 3];
+  }
+  for (int n = blockIdx.x * 256 + threadIdx.x; n < a.N; n += gridDim.x * 256) {
+    int j, i;
+    if (a.coords) { j = a.coords[2 * n]; i = a.coords[2 * n + 1]; }
+    else { j = n / a.W; i = n - j * a.W; }
+    // helpers:296  dirs = [((i+.5)-cx)/fx, (H-(j+.5)-cy)/fy, -1]
+    const float d0 = (((float)i + 0.5f) - cx) / fx;
+    const float d1 = ((float)a.H - ((float)j + 0.5f) - cy) / fy;
+    const float d2 = -1.0f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = (d0 * R[r][0] + d1 * R[r][1]) + d2 * R[r][2];   // helpers:298
+    if (a.rays_o) { a.rays_o[3 * n] = T[0]; a.rays_o[3 * n + 1] = T[1]; a.rays_o[3 * n + 2] = T[2]; }
+    if (a.rays_d) { a.rays_d[3 * n] = d[0]; a.rays_d[3 * n + 1] = d[1]; a.rays_d[3 * n + 2] = d[2]; }
+    if (a.rays) {
+      float* o = a.rays + (size_t)n * 11;
+      const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);     // :128 viewdirs / norm
+      o[0] = T[0]; o[1] = T[1]; o[2] = T[2];
+      o[3] = d[0]; o[4] = d[1]; o[5] = d[2];
+      o[6] = a.near; o[7] = a.far;
+      o[8] = d[0] / nrm; o[9] = d[1] / nrm; o[10] = d[2] / nrm;
+    }
+    const size_t pix = (size_t)j * a.W + i;
+    if (a.image && a.target_s) {
+      a.target_s[3 * n] = a.image[pix * 3]; a.target_s[3 * n + 1] = a.image[pix * 3 + 1];
+      a.target_s[3 * n + 2] = a.image[pix * 3 + 2];
+    }
+    if (a.hyps && a.target_h)
+      for (int k = 0; k < a.K; ++k) a.target_h[(size_t)k * a.N + n] = a.hyps[(size_t)k * a.H * a.W + pix];
+    if (a.mask) {
+      float m = 1.f;
+      const int c = a.corner_px, e = a.edge_px;
+      if (c > 0 && (j < c || j >= a.H - c) && (i < c || i >= a.W - c)) m = 0.f;     // :810-817
+      if (e > 0 && (j < e || j >= a.H - e || i < e || i >= a.W - e)) m = 0.f;       // wild :818-830
+      a.mask[n] = m;
+    }
+  }
+}
+}  // namespace scade
+
+extern "C" int scade_gen_rays(const int* coords, int N, int H, int W, const float* intrinsic,
+                              const float* c2w, int c2w_stride, float near, float far,
+                              const float* image, const float* hyps, int K, int corner_px,
+                              int edge_px, float* rays, float* rays_o, float* rays_d,
+                              float* target_s, float* target_h, float* mask, void* stream) {
+  SCADE_REQUIRE(intrinsic && c2w && c2w_stride >= 4, -1, "scade_gen_rays: intrinsic/c2w missing");
+  SCADE_REQUIRE(H > 0 && W > 0, -2, "scade_gen_rays: bad image size");
+  if (N <= 0) return 0;
+  scade::GenRaysArgs a{coords, intrinsic, c2w, image, hyps, rays, rays_o, rays_d, target_s, target_h,
+                       mask, near, far, N, H, W, K, c2w_stride, corner_px, edge_px};
+  const int grid = (N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048;
+  hipLaunchKernelGGL(scade::gen_rays_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_gen_rays");
+}

@@ -326,6 +326,40 @@ def merge_sorted(z_a: Tensor, z_b: Tensor, rays: Optional[Tensor] = None):
     return out, pts
 
 
+def gen_rays(H: int, W: int, intrinsic: Tensor, c2w: Tensor, coords: Optional[Tensor] = None,
+             near: float = 0.0, far: float = 1.0, image: Optional[Tensor] = None,
+             hyps: Optional[Tensor] = None, corner_px: int = 0, edge_px: int = 0,
+             want_rows: bool = True, want_od: bool = False, want_mask: bool = False):
+    """scade_gen_rays -> dict(rays, rays_o, rays_d, target_s, target_h, mask) (absent = None)."""
+    intrinsic = _c(check(intrinsic, "gen_rays: intrinsic").reshape(-1))
+    check(c2w, "gen_rays: c2w")
+    if c2w.dim() != 2 or c2w.shape[0] < 3 or c2w.shape[1] < 4 or c2w.stride(1) != 1:
+        c2w = c2w.reshape(-1, c2w.shape[-1])[:, :4].contiguous()
+    dev = c2w.device
+    if coords is not None:
+        coords = _c(coords.to(device=dev, dtype=torch.int32))
+        N = coords.shape[0]
+    else:
+        N = H * W
+    K = 0
+    if image is not None:
+        image = _c(check(image, "gen_rays: image"))
+    if hyps is not None:
+        hyps = _c(check(hyps, "gen_rays: hyps"))
+        K = hyps.shape[0]
+    mk = lambda *s: torch.empty(*s, device=dev, dtype=torch.float32)
+    out = {"rays": mk(N, 11) if want_rows else None,
+           "rays_o": mk(N, 3) if want_od else None, "rays_d": mk(N, 3) if want_od else None,
+           "target_s": mk(N, 3) if image is not None else None,
+           "target_h": mk(K, N) if hyps is not None else None,
+           "mask": mk(N) if want_mask else None}
+    call("scade_gen_rays", ptr(coords), N, H, W, ptr(intrinsic), ptr(c2w), c2w.stride(0), float(near),
+         float(far), ptr(image), ptr(hyps), K, int(corner_px), int(edge_px), ptr(out["rays"]),
+         ptr(out["rays_o"]), ptr(out["rays_d"]), ptr(out["target_s"]), ptr(out["target_h"]),
+         ptr(out["mask"]), stream())
+    return out
+
+
 # ---------------------------------------------------------------------------
 # autograd glue
 # ---------------------------------------------------------------------------

@@ -266,8 +266,13 @@ def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near
     carried over)."""
     if with_5_9:
         raise NotImplementedError("render: with_5_9 cropping is a visualisation option outside the hot path")
-    rays_flat, sh = _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs,
-                                   c2w_staticcam, rays_depth)
+    if c2w is not None and use_viewdirs and c2w_staticcam is None and rays_depth is None:
+        # full image: ray rows straight from the generation kernel (no [H,W,3] intermediates)
+        rays_flat = ops.gen_rays(H, W, intrinsic, c2w, near=near, far=far)["rays"]
+        sh = (H, W, 3)
+    else:
+        rays_flat, sh = _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs,
+                                       c2w_staticcam, rays_depth)
     all_ret = batchify_rays(rays_flat, chunk, use_viewdirs, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))

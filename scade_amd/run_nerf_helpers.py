@@ -208,23 +208,38 @@ def select_coordinates(coords, N_rand):
     return coords[select_inds].long()
 
 
+def _coords_rc(coords):
+    """reference coords are [N,2] = (row, col), float (meshgrid of linspace) or long"""
+    return None if coords is None else coords.reshape(-1, 2).to(torch.int32)
+
+
 def get_ray_dirs(H, W, intrinsic, c2w, coords=None):
-    device = intrinsic.device
-    fx, fy, cx, cy = intrinsic[0], intrinsic[1], intrinsic[2], intrinsic[3]
-    if coords is None:
-        i, j = torch.meshgrid(torch.linspace(0, W - 1, W, device=device),
-                              torch.linspace(0, H - 1, H, device=device), indexing="ij")
-        i, j = i.t(), j.t()
-    else:
-        i, j = coords[:, 1], coords[:, 0]
-    dirs = torch.stack([((i + 0.5) - cx) / fx, (H - (j + 0.5) - cy) / fy, -torch.ones_like(i)], -1)
-    return torch.sum(dirs[..., np.newaxis, :] * c2w[:3, :3], -1)
+    """helpers:285-299 (scade_gen_rays)."""
+    out = ops.gen_rays(H, W, intrinsic, c2w, coords=_coords_rc(coords), want_rows=False, want_od=True)
+    return out["rays_d"] if coords is not None else out["rays_d"].reshape(H, W, 3)
 
 
 def get_rays(H, W, intrinsic, c2w, coords=None):
-    rays_d = get_ray_dirs(H, W, intrinsic, c2w, coords)
-    rays_o = c2w[:3, -1].expand(rays_d.shape)
-    return rays_o, rays_d
+    """helpers:301-305 -> (rays_o, rays_d); (H,W,3) each without coords, (N,3) with."""
+    out = ops.gen_rays(H, W, intrinsic, c2w, coords=_coords_rc(coords), want_rows=False, want_od=True)
+    if coords is not None:
+        return out["rays_o"], out["rays_d"]
+    return out["rays_o"].reshape(H, W, 3), out["rays_d"].reshape(H, W, 3)
+
+
+def get_ray_batch(H, W, intrinsic, c2w, coords, near, far, image=None, hypotheses=None,
+                  mask_corners=False, mask_edges=False):
+    """The gathers of get_ray_batch_from_one_image_hypothesis_idx (run_scade_scannet.py:784-821)
+    fused with the ray-row assembly of render_hyp (:200-219): only the N selected pixels are
+    touched (the reference generates all H*W rays every step).
+      image [H,W,3]; hypotheses [K,H,W] or [K,H,W,1]
+    -> rays [N,11], target_s [N,3] | None, target_h [K,N,1] | None, mask [N] | None"""
+    hy = None if hypotheses is None else hypotheses.reshape(hypotheses.shape[0], H, W)
+    out = ops.gen_rays(H, W, intrinsic, c2w, coords=_coords_rc(coords), near=near, far=far, image=image,
+                       hyps=hy, corner_px=20 if mask_corners else 0, edge_px=10 if mask_edges else 0,
+                       want_rows=True, want_mask=bool(mask_corners or mask_edges))
+    th = None if out["target_h"] is None else out["target_h"].unsqueeze(-1)
+    return out["rays"], out["target_s"], th, out["mask"]
 
 
 # ---------------------------------------------------------------------------

@@ -245,3 +245,29 @@ def test_mse(dev):
     lm = S.img2mse_masked(x.to(dev), y.to(dev), m.to(dev))
     assert_close(lm, torch.mean((x - y) ** 2 * m[:, None]), rtol=1e-6, atol=0, what="masked mse")
     assert_close(S.mse2psnr(l.detach()), O.mse2psnr(lr.detach()), rtol=1e-6, atol=0, what="psnr")
+
+
+# ---------------------------------------------------------------- ray generation / batch gather
+def test_gen_rays_golden(dev):
+    g = load_golden("f8_rays")
+    Hh, Ww = int(g["H"]), int(g["W"])
+    intr, c2w = g["intrinsic"].to(dev), g["c2w"].to(dev)
+    ro, rd = S.get_rays(Hh, Ww, intr, c2w)
+    assert ro.shape == (Hh, Ww, 3)
+    assert_close(rd, g["rays_d_full"], rtol=2e-6, atol=1e-7, what="get_rays d")
+    assert torch.equal(ro.cpu(), g["rays_o_full"])
+    sel = g["sel"]
+    ro2, rd2 = S.get_rays(Hh, Ww, intr, c2w, coords=sel.float().to(dev))
+    assert_close(rd2, g["rays_d_full"][sel[:, 0], sel[:, 1]], rtol=2e-6, atol=1e-7, what="get_rays coords")
+    rays, ts, th, mask = S.get_ray_batch(Hh, Ww, intr, c2w, sel.to(dev), float(g["near"]), float(g["far"]),
+                                        image=g["image"].to(dev), hypotheses=g["hyps"].to(dev),
+                                        mask_corners=True)
+    assert_close(rays, g["rows"], rtol=2e-6, atol=1e-7, what="ray rows")
+    assert torch.equal(ts.cpu(), g["target_s"]) and torch.equal(th.cpu(), g["target_h"])
+    want_mask = torch.ones(Hh, Ww)
+    want_mask[:20, :20] = 0; want_mask[:20, -20:] = 0; want_mask[-20:, :20] = 0; want_mask[-20:, -20:] = 0
+    assert torch.equal(mask.cpu(), want_mask[sel[:, 0], sel[:, 1]])
+    # full-image render() path builds the same rows
+    rows_full = ops.gen_rays(Hh, Ww, intr, c2w, near=0.1, far=5.0)["rays"]
+    want = O.ray_rows(g["rays_o_full"], g["rays_d_full"], 0.1, 5.0)
+    assert_close(rows_full, want, rtol=2e-6, atol=1e-7, what="full rows")

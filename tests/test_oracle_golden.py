@@ -143,3 +143,13 @@ def test_render_rays_det_and_train():
             assert_close(sub, g[f"grad_{tag}/{k}"], rtol=1e-4, atol=1e-8, what=f"grad {tag}.{k}")
     assert_close(scale.grad, g["train/grad_scale"], rtol=1e-5, atol=1e-9, what="grad scale")
     assert_close(shift.grad, g["train/grad_shift"], rtol=1e-5, atol=1e-9, what="grad shift")
+
+
+def test_rays():
+    g = load_golden("f8_rays")
+    Hh, Ww = int(g["H"]), int(g["W"])
+    ro, rd = O.get_rays(Hh, Ww, g["intrinsic"], g["c2w"])
+    assert_close(rd, g["rays_d_full"], what="rays_d", **TIGHT)
+    sel = g["sel"]
+    rows = O.ray_rows(ro[sel[:, 0], sel[:, 1]], rd[sel[:, 0], sel[:, 1]], float(g["near"]), float(g["far"]))
+    assert_close(rows, g["rows"], what="rows", **TIGHT)

@@ -374,7 +374,40 @@ def f6_render():
     save("f6_render", **arrs)
 
 
+# ---------------------------------------------------------------- F8 rays
+def f8_rays():
+    torch.manual_seed(50)
+    Hh, Ww = 24, 32
+    intrinsic = torch.tensor([28.9, 29.3, 15.7, 12.2])
+    ang = torch.tensor(0.3)
+    c2w = torch.tensor([[torch.cos(ang), 0.0, torch.sin(ang), 0.5],
+                        [0.1, 0.99, 0.05, -0.25],
+                        [-torch.sin(ang), 0.02, torch.cos(ang), 1.5],
+                        [0.0, 0.0, 0.0, 1.0]])
+    ro, rd = H.get_rays(Hh, Ww, intrinsic, c2w)                       # full image
+    same(O.get_rays(Hh, Ww, intrinsic, c2w)[1], rd, "get_rays full")
+    coords_f = torch.stack(torch.meshgrid(torch.linspace(0, Hh - 1, Hh), torch.linspace(0, Ww - 1, Ww),
+                                          indexing='ij'), -1)
+    np.random.seed(3)
+    sel = H.select_coordinates(coords_f, 64)                          # [64,2] long (row, col)
+    rays_o = ro[sel[:, 0], sel[:, 1]]
+    rays_d = rd[sel[:, 0], sel[:, 1]]
+    # the row assembly of render_hyp (run_scade_scannet.py:200-219) with use_viewdirs
+    viewdirs = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+    near, far = 0.1, 5.0
+    rows = torch.cat([rays_o, rays_d, near * torch.ones_like(rays_d[..., :1]),
+                      far * torch.ones_like(rays_d[..., :1]), viewdirs], -1)
+    same(O.ray_rows(rays_o, rays_d, near, far), rows, "ray rows")
+    image = torch.rand(Hh, Ww, 3)
+    hyps = torch.rand(5, Hh, Ww, 1) * 4.9 + 0.1
+    target_s = image[sel[:, 0], sel[:, 1]]
+    target_h = hyps[:, sel[:, 0], sel[:, 1]]                          # [K,N,1]
+    save("f8_rays", H=Hh, W=Ww, intrinsic=intrinsic, c2w=c2w, rays_o_full=ro, rays_d_full=rd, sel=sel,
+         rows=rows, image=image, hyps=hyps, target_s=target_s, target_h=target_h, near=near, far=far)
+
+
 if __name__ == "__main__":
+    f8_rays()
     f1_embed()
     f2_mlp()
     f3_composite()
