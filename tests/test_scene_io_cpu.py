@@ -1,0 +1,74 @@
+"""CPU: the scene / checkpoint I/O (host logic) on a tiny synthetic
+scene written to disk in the reference's file formats."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+
+def write_scene(root, Hh=12, Ww=16, n_train=2, n_test=1, K=3):
+    from PIL import Image
+    rng = np.random.RandomState(0)
+    os.makedirs(os.path.join(root, "train", "rgb"), exist_ok=True)
+    os.makedirs(os.path.join(root, "train", "depth"), exist_ok=True)
+    os.makedirs(os.path.join(root, "test", "rgb"), exist_ok=True)
+    os.makedirs(os.path.join(root, "test", "depth"), exist_ok=True)
+    os.makedirs(os.path.join(root, "train", "leres_cimle", "dump"), exist_ok=True)
+
+    def frames(split, n):
+        fr = []
+        for i in range(n):
+            rgb = (rng.rand(Hh, Ww, 3) * 255).astype(np.uint8)
+            dep = (rng.rand(Hh, Ww) * 3000 + 500).astype(np.uint16)
+            dep[0, 0] = 0                                              # invalid depth pixel
+            Image.fromarray(rgb).save(os.path.join(root, split, "rgb", f"{i}.png"))
+            Image.fromarray(dep).save(os.path.join(root, split, "depth", f"{i}.png"))
+            pose = np.eye(4)
+            pose[:3, 3] = [0.1 * i, 0.0, 0.2]
+            fr.append({"file_path": f"{split}/rgb/{i}.png", "depth_file_path": f"{split}/depth/{i}.png",
+                       "transform_matrix": pose.tolist(), "fx": 14.0, "fy": 14.0, "cx": Ww / 2, "cy": Hh / 2})
+        return fr
+    for split, n in (("train", n_train), ("test", n_test)):
+        meta = {"near": 0.1, "far": 5.0, "depth_scaling_factor": 1000.0, "frames": frames(split, n)}
+        json.dump(meta, open(os.path.join(root, f"transforms_{split}.json"), "w"))
+    for i in range(n_train):
+        for j in range(K):
+            np.save(os.path.join(root, "train", "leres_cimle", "dump", f"{i}_{j}.npy"),
+                    (rng.rand(Hh, Ww) * 8).astype(np.float32))        # some beyond far -> clipped
+    return Hh, Ww
+
+
+def test_load_scene_scannet(tmp_path):
+    from scade_amd.scene import load_scene_scannet
+    Hh, Ww = write_scene(str(tmp_path))
+    (imgs, depths, valid, poses, H2, W2, intr, near, far, i_split, gt_d, gt_v, hyp) = \
+        load_scene_scannet(str(tmp_path), "dump", num_hypothesis=3)
+    assert (H2, W2) == (Hh, Ww) and (near, far) == (0.1, 5.0)
+    assert imgs.shape == (3, Hh, Ww, 3) and imgs.dtype == np.float32 and imgs.max() <= 1.0
+    assert depths.shape == (3, Hh, Ww, 1) and not valid[0, 0, 0] and valid[0, 1, 1]
+    assert poses.shape == (3, 4, 4) and intr.shape == (3, 4)
+    assert [len(s) for s in i_split] == [2, 0, 1, 0]
+    assert hyp.shape == (2, 3, Hh, Ww, 1) and hyp.min() >= near and hyp.max() <= far
+    assert gt_d.shape == (3, Hh, Ww, 1) and not gt_v.any()
+
+
+def test_checkpoint_roundtrip_reference_format(tmp_path):
+    import scade_amd as S
+    from scade_amd.scene import load_checkpoint, restore, save_checkpoint
+    torch.manual_seed(0)
+    mk = lambda: S.NeRF(D=8, W=256, input_ch=57, output_ch=5, skips=[4], input_ch_views=3, use_viewdirs=True)
+    c, f = mk(), mk()
+    p = os.path.join(tmp_path, "exp", "100000.tar")
+    save_checkpoint(p, 100000, c, f, torch.zeros(2, 1), torch.ones(2, 1))
+    raw = torch.load(p, weights_only=False)
+    assert all(k.startswith("module.") for k in raw["network_fn_state_dict"])          # DataParallel layout
+    assert set(raw) >= {"global_step", "network_fn_state_dict", "network_fine_state_dict",
+                        "optimizer_state_dict", "depth_shifts", "depth_scales"}
+    c2, f2 = mk(), mk()
+    step = restore(c2, f2, load_checkpoint(str(tmp_path), "exp"))
+    assert step == 100000
+    for a, b in zip(list(c.parameters()) + list(f.parameters()), list(c2.parameters()) + list(f2.parameters())):
+        assert torch.equal(a, b)
+    assert load_checkpoint(str(tmp_path), "missing") is None
