@@ -130,7 +130,7 @@ def train_region(args, dev, world, rank, barrier):
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
     assert bool(torch.isfinite(loss))
-    if world > 1:
+    if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -158,10 +158,13 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("SCADE_BENCH_FORCE_DIST") == "1"   # the latter: 1-GPU RCCL self-test
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import scade_amd as S
     from scade_amd import ops
@@ -179,7 +182,7 @@ def main():
                                  network_fine=fine, perturb=0., raw_noise_std=0.)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -196,7 +199,7 @@ def main():
     ops.KERNEL_TIMER = None
     assert bool(torch.isfinite(ret["rgb_map"]).all())
 
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -242,6 +245,20 @@ def main():
                      "note": "algorithmic 1,174,528 FLOP/point x mean points per launch "
                              "(coarse 65,536 + fine 196,608 per step), HIP events on the launch stream"},
     }
+    # secondary: the same test-render work as a 16-chunk image render, chunks pipelined over 2 streams
+    big = O.synthetic_rays(args.rays * 16, seed=5000 + rank).to(dev)
+    for ns in (1, 2):
+        with torch.no_grad():
+            S.batchify_rays(big, args.rays, True, streams=ns, network_fn=coarse, network_query_fn=query,
+                            N_samples=N_COARSE, N_importance=N_FINE, network_fine=fine, perturb=0.)
+        barrier()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            S.batchify_rays(big, args.rays, True, streams=ns, network_fn=coarse, network_query_fn=query,
+                            N_samples=N_COARSE, N_importance=N_FINE, network_fine=fine, perturb=0.)
+        barrier()
+        out.setdefault("image_render_16x1024", {})[f"rays_per_s_per_gpu_{ns}_stream"] = \
+            big.shape[0] / (time.perf_counter() - t0)
     if not args.no_train:
         out["train_step"] = train_region(args, dev, world, rank, barrier)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -249,7 +266,7 @@ def main():
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
     if rank == 0:
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

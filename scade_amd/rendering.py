@@ -224,13 +224,39 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     return ret
 
 
-def batchify_rays(rays_flat, chunk=1024 * 32, use_viewdirs=False, **kwargs):
-    """run_scade_scannet.py:66-78."""
+_SIDE_STREAMS = {}
+
+
+def _side_streams(device, n):
+    key = (str(device), n)
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = [torch.cuda.Stream(device=device) for _ in range(n)]
+    return _SIDE_STREAMS[key]
+
+
+def batchify_rays(rays_flat, chunk=1024 * 32, use_viewdirs=False, streams=1, **kwargs):
+    """run_scade_scannet.py:66-78.  ``streams`` > 1 (inference only) issues consecutive chunks
+    on alternating HIP streams: ray chunks are independent, so the tail of one chunk's MLP launch
+    overlaps the head of the next chunk's."""
     all_ret = {}
-    for i in range(0, rays_flat.shape[0], chunk):
-        ret = render_rays(rays_flat[i:i + chunk], use_viewdirs, **kwargs)
-        for k in ret:
-            all_ret.setdefault(k, []).append(ret[k])
+    if streams > 1 and not torch.is_grad_enabled() and rays_flat.shape[0] > chunk:
+        cur = torch.cuda.current_stream(rays_flat.device)
+        side = _side_streams(rays_flat.device, streams)
+        for st in side:
+            st.wait_stream(cur)
+        for n, i in enumerate(range(0, rays_flat.shape[0], chunk)):
+            with torch.cuda.stream(side[n % streams]):
+                ret = render_rays(rays_flat[i:i + chunk], use_viewdirs, **kwargs)
+            for k in ret:
+                ret[k].record_stream(side[n % streams])
+                all_ret.setdefault(k, []).append(ret[k])
+        for st in side:
+            cur.wait_stream(st)
+    else:
+        for i in range(0, rays_flat.shape[0], chunk):
+            ret = render_rays(rays_flat[i:i + chunk], use_viewdirs, **kwargs)
+            for k in ret:
+                all_ret.setdefault(k, []).append(ret[k])
     return {k: torch.cat(all_ret[k], 0) for k in all_ret}
 
 
@@ -261,7 +287,7 @@ def _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs, c2w_stat
 
 
 def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1.,
-           with_5_9=False, use_viewdirs=False, c2w_staticcam=None, rays_depth=None, **kwargs):
+           with_5_9=False, use_viewdirs=False, c2w_staticcam=None, rays_depth=None, streams=1, **kwargs):
     """run_scade_scannet.py:80-155 (ray-row assembly is host plumbing; with_5_9 cropping is not
     carried over)."""
     if with_5_9:
@@ -273,7 +299,7 @@ def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near
     else:
         rays_flat, sh = _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs,
                                        c2w_staticcam, rays_depth)
-    all_ret = batchify_rays(rays_flat, chunk, use_viewdirs, **kwargs)
+    all_ret = batchify_rays(rays_flat, chunk, use_viewdirs, streams=streams, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map']

@@ -150,6 +150,13 @@ def test_render_rays_full_size_properties(dev):
                                   N_importance=128, network_fine=fine, perturb=0., retraw=True)
     for k in ret2:
         assert torch.equal(torch.nan_to_num(all_ret[k]), torch.nan_to_num(ret2[k])), k
+    # ... nor does pipelining the chunks over two HIP streams
+    with torch.no_grad():
+        two = S.batchify_rays(rays, 256, True, streams=2, network_fn=coarse, network_query_fn=query,
+                              N_samples=64, N_importance=128, network_fine=fine, perturb=0., retraw=True)
+    torch.cuda.synchronize()
+    for k in ret2:
+        assert torch.equal(torch.nan_to_num(two[k]), torch.nan_to_num(ret2[k])), k
 
 
 def test_render_api_unsupported_paths_fail_loudly(dev):
