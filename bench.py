@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary train-step measurement")
+    ap.add_argument("--no-image", action="store_true", help="skip the secondary 16-chunk image-render measurement")
     ap.add_argument("--hyp", type=int, default=20, help="depth hypotheses per ray (train step)")
     return ap.parse_args()
 
@@ -247,7 +248,7 @@ def main():
     }
     # secondary: the same test-render work as a 16-chunk image render, chunks pipelined over 2 streams
     big = O.synthetic_rays(args.rays * 16, seed=5000 + rank).to(dev)
-    for ns in (1, 2):
+    for ns in (() if args.no_image else (1, 2)):
         with torch.no_grad():
             S.batchify_rays(big, args.rays, True, streams=ns, network_fn=coarse, network_query_fn=query,
                             N_samples=N_COARSE, N_importance=N_FINE, network_fine=fine, perturb=0.)

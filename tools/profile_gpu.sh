@@ -7,16 +7,20 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --no-cpu-baseline --steps 10 --warmup 2"
+# the headline region only, so per-kernel averages are those of the timed render steps
+CMD="python $ROOT/bench.py --no-cpu-baseline --no-train --no-image --steps 20 --warmup 3"
+TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --steps 10 --warmup 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
-tail -1 $OUT/stats.log | grep -o '^{.*}' > $OUT/bench_line_under_rocprof.json
+grep -o '^{"metric.*}' $OUT/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train -o bench -- $TRAIN_CMD > $OUT/stats_train.log 2>&1
+grep -o '^{"metric.*}' $OUT/stats_train.log | tail -1 > $OUT/bench_line_train_under_rocprof.json
 # PMC passes: one counter group per run, kernel-trace only (no other trace domains)
 i=0
 for GROUP in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE" \
              "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAVES" \
              "TCC_HIT_sum TCC_MISS_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d $OUT/pmc$i -o bench -- $CMD > $OUT/pmc$i.log 2>&1
+  rocprofv3 --kernel-trace --pmc $GROUP --output-format csv -d $OUT/pmc$i -o bench -- $TRAIN_CMD > $OUT/pmc$i.log 2>&1
 done
 python - "$OUT" <<'PY'
 import csv, glob, os, sys, collections
@@ -37,4 +41,5 @@ print(open(os.path.join(out, "pmc_summary.csv")).read()[:6000])
 PY
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 cp $OUT/stats/*/bench_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
+cp $OUT/stats_train/*/bench_kernel_stats.csv $OUT/kernel_stats_train.csv 2>/dev/null || cp $OUT/stats_train/bench_kernel_stats.csv $OUT/kernel_stats_train.csv
 du -sh $OUT
