@@ -36,6 +36,7 @@ def parse():
     ap.add_argument("--rays", type=int, default=1024, help="rays per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the secondary train-step measurement")
+    ap.add_argument("--no-fast", action="store_true", help="skip the secondary split-precision (f16x3) measurement")
     ap.add_argument("--no-image", action="store_true", help="skip the secondary 16-chunk image-render measurement")
     ap.add_argument("--hyp", type=int, default=20, help="depth hypotheses per ray (train step)")
     return ap.parse_args()
@@ -103,6 +104,44 @@ def cpu_baseline(pc, pf, n_rays):
             "sample": f"render_rays forward (no_grad, perturb=0) on {n_rays} synthetic rays x (64+128) "
                       f"samples, best of <=3 after 1 warm-up, torch {torch.__version__} CPU, "
                       f"{best_thr} threads (best of {cands} on a 128-ray probe)"}
+
+
+F16X3_EFFECTIVE_PEAK_TFLOPS = 2500.0 / 3.0   # dense f16 MFMA peak / 3 MFMAs per fp32-class product
+
+
+def fast_region(args, dev, world, barrier, step, coarse, fine):
+    """Secondary measurement: the SAME render step with the opt-in split-precision inference
+    kernel (NeRF.inference_precision = "f16x3": every fp32 value carried as two fp16 numbers,
+    three f16 MFMAs per product, fp32 accumulate; parity tests hold it to the same 1e-4 bar)."""
+    import torch.distributed as dist
+    from scade_amd import ops
+    coarse.inference_precision = fine.inference_precision = "f16x3"
+    try:
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        timer = ops.KernelTimer()
+        ops.KERNEL_TIMER = timer
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        ops.KERNEL_TIMER = None
+    finally:
+        coarse.inference_precision = fine.inference_precision = "f32"
+    if dist.is_initialized():
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    k = timer.summary()["mlp_fwd_f16_kernel"]
+    ach = k["work"] / (k["ms"] * 1e-3) / 1e12
+    return {"value": args.rays * world * args.steps / elapsed, "unit": "rays/s",
+            "ms_per_step": elapsed / args.steps * 1e3, "dtype": "f16x3 split (2 fp16 planes per fp32 value, fp32 accumulate)",
+            "roofline": {"bound": "mfma", "kernel": "mlp_fwd_f16_kernel", "achieved": ach,
+                         "peak": F16X3_EFFECTIVE_PEAK_TFLOPS, "unit": "TFLOP/s (algorithmic fp32-equivalent)",
+                         "frac": ach / F16X3_EFFECTIVE_PEAK_TFLOPS,
+                         "avg_launch_ms": k["ms"] / k["launches"]}}
 
 
 def train_region(args, dev, world, rank, barrier):
@@ -260,6 +299,8 @@ def main():
         barrier()
         out.setdefault("image_render_16x1024", {})[f"rays_per_s_per_gpu_{ns}_stream"] = \
             big.shape[0] / (time.perf_counter() - t0)
+    if not args.no_fast:
+        out["fast_path_f16x3"] = fast_region(args, dev, world, barrier, step, coarse, fine)
     if not args.no_train:
         out["train_step"] = train_region(args, dev, world, rank, barrier)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

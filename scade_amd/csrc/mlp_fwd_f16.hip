@@ -1,0 +1,444 @@
+// Split-precision inference variant of the fused NeRF MLP forward (opt-in).
+//
+// The exact kernel (mlp_fwd.hip) is bound by the fp32 MFMA pipe (v_mfma_f32_32x32x2_f32,
+// 157 TFLOP/s).  Here every fp32 value x is carried as TWO fp16 numbers
+//        x  ~=  h + l * 2^-11,    h = fp16(x),   l = fp16((x - h) * 2^11)
+// (22 significant bits; the 2^11 pre-scale keeps l out of the fp16 subnormal range), and
+//        x*w ~=  h_x h_w  +  (h_x l_w + l_x h_w) * 2^-11
+// is evaluated with THREE v_mfma_f32_32x32x16_f16 into two fp32 accumulators (the dropped
+// l*l term and the split residuals are ~2^-21 relative per product): fp32-class results at
+// 3/16 of the fp32-MFMA cost.  Same tile structure as mlp_fwd.hip: 64 points per workgroup,
+// activations resident in LDS as two fp16 planes (64 KiB, same bytes as the fp32 tile),
+// weights streamed from L2 in a packed two-plane fragment order, transposed product so the
+// epilogue writes 4 consecutive features of one point.
+//
+// Validity: |activation| and |weight| < 65504 (fp16 range).  Inference only (no saved
+// activations); training uses the exact fp32 kernels.
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace scade {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int HM = 64;                       // points per workgroup
+constexpr int XPLANE = HM * W;               // halves per activation plane
+constexpr int EPLANE = HM * 64;              // halves per embedding plane
+constexpr int F16_LDS_BYTES = (2 * XPLANE + 2 * EPLANE) * 2;   // 81920
+constexpr float LSCALE = 2048.0f, LINV = 1.0f / 2048.0f;
+
+// k-blocks of 16 channels
+constexpr int kbp16(int l) { return l == 0 ? 4 : (l == 5 ? 4 : (l == L_VIEWS ? 1 : 0)); }
+constexpr int kbh16(int l) { return l == 0 ? 0 : 16; }
+constexpr int kb16(int l) { return kbp16(l) + kbh16(l); }
+// packed blob: per layer [ntile][kb][plane 2][64 lanes][8 halves]  (counted in halves)
+constexpr long wh_halves(int l) { return (long)n_out(l) / 32 * kb16(l) * 2 * 64 * 8; }
+constexpr long off_wh(int l) {
+  long o = 0;
+  for (int i = 0; i < l; ++i) o += wh_halves(i);
+  return o;
+}
+constexpr long PACKED_F16_HALVES = off_wh(NLAYER_MFMA) + 2 * 64 * 8;   // + slack block
+// fp32 tail (biases + head weights) reuses the fp32 blob layout after the MFMA weights
+constexpr long F16_TAIL_FLOATS = PACKED_FWD_FLOATS - OFF_BIAS;
+constexpr long PACKED_F16_BYTES = PACKED_F16_HALVES * 2 + F16_TAIL_FLOATS * 4;
+
+__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  l = (_Float16)((x - (float)h) * LSCALE);
+}
+
+// halves index of the 8-half chunk c of row r in an activation plane / embedding plane
+__device__ __forceinline__ int x_idx(int row, int c) { return row * W + ((c ^ (row & 15)) << 3); }
+__device__ __forceinline__ int e_idx(int row, int c) { return row * 64 + ((c ^ ((row >> 1) & 7)) << 3); }
+
+struct MlpF16Args {
+  const void* packed;     // PACKED_F16_BYTES
+  const float* in;        // mode 0: x [P,60];  mode 1: pts [P,3]
+  const float* viewdirs;
+  const float* bb;
+  float* out;             // [P,4]
+  int P, S, vd_stride;
+};
+
+// A fragments of one k-block for the wave's (up to) two n-tiles, both planes.  Plain named
+// members (no arrays passed by reference): hipcc (ROCm 7.2) mis-allocates registers for the
+// array-reference form of this loop on gfx950 (address temporaries land in a live operand).
+struct AFrag { half8 t0h, t0l, t1h, t1l; };
+
+template <int NT, int KBP, int KBH, bool PRE_VIEW>
+__device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc1)[NT][2], AFrag& an,
+                                             const half8* __restrict__ wp,
+                                             const half8* __restrict__ wp_next, int kb_next,
+                                             const _Float16* eh, const _Float16* el,
+                                             const _Float16* xh, const _Float16* xl, int lane) {
+  constexpr int KB = KBP + KBH;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[t][p][i] = 0.f; acc1[t][p][i] = 0.f; }
+
+  // activation fragment (both planes) of point tile p for k-block kb
+#define LOAD_B(KBX, PX, BH, BL)                                                              \
+  {                                                                                          \
+    const int kb_ = (KBX);                                                                   \
+    if (KBP > 0 && kb_ < KBP) {                                                              \
+      if (PRE_VIEW) {                                                                        \
+        BH = *reinterpret_cast<const half8*>(eh + ((PX)*32 + r) * 16 + hh * 8);               \
+        BL = *reinterpret_cast<const half8*>(el + ((PX)*32 + r) * 16 + hh * 8);               \
+      } else {                                                                               \
+        const int o_ = e_idx((PX)*32 + r, 2 * kb_ + hh);                                     \
+        BH = *reinterpret_cast<const half8*>(eh + o_);                                       \
+        BL = *reinterpret_cast<const half8*>(el + o_);                                       \
+      }                                                                                      \
+    } else {                                                                                 \
+      const int o_ = x_idx((PX)*32 + r, 2 * (kb_ - KBP) + hh);                               \
+      BH = *reinterpret_cast<const half8*>(xh + o_);                                         \
+      BL = *reinterpret_cast<const half8*>(xl + o_);                                         \
+    }                                                                                        \
+  }
+#define MFMA3(T, PX, WH, WL, VH, VL)                                                          \
+  acc0[T][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, VH, acc0[T][PX], 0, 0, 0);         \
+  acc1[T][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WH, VL, acc1[T][PX], 0, 0, 0);         \
+  acc1[T][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(WL, VH, acc1[T][PX], 0, 0, 0);
+
+  // register plan: A (weights, L2 latency) is fetched a whole k-block ahead; B (LDS) ping-pongs
+  // between the two point tiles inside the block: b1 of this block loads under the p=0 MFMAs,
+  // b0 of the next block under the p=1 MFMAs.
+  half8 b0h, b0l, b1h, b1l;
+  LOAD_B(0, 0, b0h, b0l)
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    const AFrag a = an;
+    if (kb + 1 < KB) {
+      an.t0h = wp[((kb + 1) * 2 + 0) * 64 + lane];
+      an.t0l = wp[((kb + 1) * 2 + 1) * 64 + lane];
+      if (NT > 1) {
+        an.t1h = wp[((KB + kb + 1) * 2 + 0) * 64 + lane];
+        an.t1l = wp[((KB + kb + 1) * 2 + 1) * 64 + lane];
+      }
+    } else {   // last k-block: the next layer's first weights
+      an.t0h = wp_next[lane];
+      an.t0l = wp_next[64 + lane];
+      an.t1h = wp_next[(kb_next * 2 + 0) * 64 + lane];
+      an.t1l = wp_next[(kb_next * 2 + 1) * 64 + lane];
+    }
+    LOAD_B(kb, 1, b1h, b1l)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA3(0, 0, a.t0h, a.t0l, b0h, b0l)
+    if (NT > 1) { MFMA3(NT - 1, 0, a.t1h, a.t1l, b0h, b0l) }
+    __builtin_amdgcn_sched_barrier(0);
+    LOAD_B(kb + 1 < KB ? kb + 1 : kb, 0, b0h, b0l)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA3(0, 1, a.t0h, a.t0l, b1h, b1l)
+    if (NT > 1) { MFMA3(NT - 1, 1, a.t1h, a.t1l, b1h, b1l) }
+  }
+#undef LOAD_B
+#undef MFMA3
+}
+
+template <int NT, bool RELU>
+__device__ __forceinline__ void layer_store_h(const f32x16 (&acc0)[NT][2], const f32x16 (&acc1)[NT][2],
+                                              const float* __restrict__ bias, int ntile0, _Float16* xh,
+                                              _Float16* xl, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
+      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        half4 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = (acc0[t][p][4 * q + i] + acc1[t][p][4 * q + i] * LINV) + bv[i];
+          if (RELU) x = fmaxf(x, 0.f);
+          _Float16 h, l;
+          split2(x, h, l);
+          vh[i] = h; vl[i] = l;
+        }
+        const int row = p * 32 + r;
+        const int o = x_idx(row, f >> 3) + (f & 7);
+        *reinterpret_cast<half4*>(xh + o) = vh;
+        *reinterpret_cast<half4*>(xl + o) = vl;
+      }
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+  _Float16* xh = ldsh;
+  _Float16* xl = ldsh + XPLANE;
+  _Float16* eh = ldsh + 2 * XPLANE;
+  _Float16* el = eh + EPLANE;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = blockIdx.x * HM;
+  const int P = a.P;
+  const _Float16* __restrict__ wpk = reinterpret_cast<const _Float16*>(a.packed);
+  const float* __restrict__ tail = reinterpret_cast<const float*>(wpk + PACKED_F16_HALVES);
+  // fp32 tail uses the fp32 blob's offsets relative to OFF_BIAS
+#define TAIL(off) (tail + ((off) - OFF_BIAS))
+
+  // ---- prologue: embedding planes [64][64] (57 real channels, zero padded) ----------
+  {
+    float cx = 0.f, cy = 0.f, cz = 0.f, sc = 1.f;
+    if (MODE == 1) { cx = a.bb[0]; cy = a.bb[1]; cz = a.bb[2]; sc = a.bb[3]; }
+    // zero the pad columns 57..63
+    for (int i = tid; i < HM * 7; i += 256) {
+      const int row = i / 7, c = 57 + (i - row * 7);
+      const int o = e_idx(row, c >> 3) + (c & 7);
+      eh[o] = (_Float16)0.f; el[o] = (_Float16)0.f;
+    }
+    for (int i = tid; i < HM * 30; i += 256) {
+      const int row = i / 30, rem = i - row * 30;
+      const int c = rem / 10, s = rem - c * 10;
+      const int pt = min(p0 + row, P - 1);
+      float v0, v1 = 0.f;
+      int col0, col1 = -1;
+      if (MODE == 0) {
+        // x rows already hold gamma(x): copy channel pairs (s==0: raw, s>=1: sin/cos of freq s-1)
+        const float* xr = a.in + (size_t)pt * 60;
+        if (s == 0) { col0 = c; v0 = xr[c]; }
+        else { col0 = 3 + 6 * (s - 1) + c; col1 = col0 + 3; v0 = xr[col0]; v1 = xr[col1]; }
+      } else {
+        const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
+        const float x = (a.in[(size_t)pt * 3 + c] - ctr) * sc;
+        if (s == 0) { col0 = c; v0 = x; }
+        else {
+          const float arg = (x * 3.14159274101257324f) * (float)(1 << (s - 1));
+          sincosf(arg, &v0, &v1);
+          col0 = 3 + 6 * (s - 1) + c; col1 = col0 + 3;
+        }
+      }
+      _Float16 h, l;
+      split2(v0, h, l);
+      int o = e_idx(row, col0 >> 3) + (col0 & 7);
+      eh[o] = h; el[o] = l;
+      if (col1 >= 0) {
+        split2(v1, h, l);
+        o = e_idx(row, col1 >> 3) + (col1 & 7);
+        eh[o] = h; el[o] = l;
+      }
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc0[2][2], acc1[2][2];
+  AFrag an;
+  const int nt0 = wave * 2;
+#define WHBASE(L) (reinterpret_cast<const half8*>(wpk + off_wh(L)) + \
+                   ((L) == L_VIEWS ? wave : nt0) * kb16(L) * 2 * 64)
+
+#define PTS_LAYER_H(L, LNEXT, KBP)                                                               \
+  {                                                                                              \
+    layer_gemm_h<2, KBP, kbh16(L), false>(acc0, acc1, an, WHBASE(L), WHBASE(LNEXT), kb16(LNEXT), \
+                                          eh, el, xh, xl, lane);                                 \
+    __syncthreads();                                                                             \
+    layer_store_h<2, true>(acc0, acc1, TAIL(off_b(L)), nt0, xh, xl, lane);                       \
+    __syncthreads();                                                                             \
+  }
+
+  an.t0h = WHBASE(0)[lane];
+  an.t0l = WHBASE(0)[64 + lane];
+  an.t1h = WHBASE(0)[(kb16(0) * 2 + 0) * 64 + lane];
+  an.t1l = WHBASE(0)[(kb16(0) * 2 + 1) * 64 + lane];
+  PTS_LAYER_H(0, 1, 4)
+  PTS_LAYER_H(1, 2, 0)
+  PTS_LAYER_H(2, 3, 0)
+  PTS_LAYER_H(3, 4, 0)
+  PTS_LAYER_H(4, 5, 0)
+  PTS_LAYER_H(5, 6, 4)
+
+  // embedding planes are dead: view pad [64][16] halves per plane (3 real channels)
+  {
+    const int row = tid >> 2, c = tid & 3;
+    const int pt = min(p0 + row, P - 1);
+    float v = 0.f;
+    if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
+    _Float16 h, l;
+    split2(v, h, l);
+    eh[row * 16 + c] = h; el[row * 16 + c] = l;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) { eh[row * 16 + 4 * j + c] = (_Float16)0.f; el[row * 16 + 4 * j + c] = (_Float16)0.f; }
+  }
+
+  PTS_LAYER_H(6, 7, 0)
+  PTS_LAYER_H(7, L_FEAT, 0)
+#undef PTS_LAYER_H
+
+  // ---- alpha head on the VALU (fp32 weights, x = h + l/2048) ------------------------
+  float alpha;
+  {
+    const int row = tid >> 2, sub = tid & 3;
+    const float* wa = TAIL(OFF_WA);
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int c = i * 4 + sub;                       // 8-half chunk
+      const half8 vh = *reinterpret_cast<const half8*>(xh + x_idx(row, c));
+      const half8 vl = *reinterpret_cast<const half8*>(xl + x_idx(row, c));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s = fmaf((float)vh[j] + (float)vl[j] * LINV, wa[c * 8 + j], s);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    alpha = s + TAIL(OFF_BA)[0];
+  }
+
+  // ---- feature_linear ------------------------------------------------------------------
+  layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WHBASE(L_FEAT), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane);
+  __syncthreads();
+  layer_store_h<2, false>(acc0, acc1, TAIL(off_b(L_FEAT)), nt0, xh, xl, lane);
+  __syncthreads();
+
+  // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
+  {
+    f32x16 av0[1][2], av1[1][2];
+    layer_gemm_h<1, 1, 16, true>(av0, av1, an, WHBASE(L_VIEWS), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane);
+    __syncthreads();
+    layer_store_h<1, true>(av0, av1, TAIL(off_b(L_VIEWS)), wave, xh, xl, lane);
+    __syncthreads();
+  }
+#undef WHBASE
+
+  // ---- rgb head + softplus ---------------------------------------------------------------
+  {
+    const int row = tid >> 2, sub = tid & 3;
+    const float* wr = TAIL(OFF_WR);
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int c = i * 4 + sub;
+      const half8 vh = *reinterpret_cast<const half8*>(xh + x_idx(row, c));
+      const half8 vl = *reinterpret_cast<const half8*>(xl + x_idx(row, c));
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float x = (float)vh[j] + (float)vl[j] * LINV;
+        s0 = fmaf(x, wr[c * 8 + j], s0);
+        s1 = fmaf(x, wr[128 + c * 8 + j], s1);
+        s2 = fmaf(x, wr[256 + c * 8 + j], s2);
+      }
+    }
+    s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
+    s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
+    s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
+    if (sub == 0 && p0 + row < P) {
+      const float bx = alpha * 10.f;
+      const float sp = bx > 20.f ? alpha : log1pf(expf(bx)) / 10.f;
+      const float* br = TAIL(OFF_BR);
+      f32x4 o = {s0 + br[0], s1 + br[1], s2 + br[2], sp};
+      *reinterpret_cast<f32x4*>(a.out + (size_t)(p0 + row) * 4) = o;
+    }
+  }
+#undef TAIL
+}
+
+// ---------------------------------------------------------------------------
+// pack: fp32 parameters -> two fp16 planes in fragment order + fp32 tail
+// ---------------------------------------------------------------------------
+struct PackF16Args {
+  const float* p[N_PARAM_TENSORS];
+  void* packed;
+};
+
+__device__ __forceinline__ int kmap16(int l, int kp) {
+  // padded channel kp -> source column of layer l's weight, or -1 (zero)
+  if (l == 0) return kp < EMB ? kp : -1;
+  if (l == 5) return kp < 64 ? (kp < EMB ? kp : -1) : EMB + (kp - 64);
+  if (l == L_VIEWS) return kp < 16 ? (kp < 3 ? W + kp : -1) : kp - 16;
+  return kp;
+}
+
+__global__ void mlp_pack_f16_kernel(PackF16Args a) {
+  const int l = blockIdx.y;
+  _Float16* wpk = reinterpret_cast<_Float16*>(a.packed);
+  if (l < NLAYER_MFMA) {
+    const int widx = l < 8 ? 2 * l : (l == L_FEAT ? 18 : 16);
+    const float* __restrict__ Wsrc = a.p[widx];
+    const int KB = kb16(l);
+    const long total = wh_halves(l) / 2;              // elements per plane pair
+    const int kr = l == 0 ? EMB : (l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W));
+    const long off = off_wh(l);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+      const long blk = i >> 9;                        // (nt*KB + kb)
+      const int kb = (int)(blk % KB), nt = (int)(blk / KB);
+      const int n = nt * 32 + (lane & 31);
+      const int src = kmap16(l, kb * 16 + 8 * (lane >> 5) + j);
+      const float w = src >= 0 ? Wsrc[(size_t)n * kr + src] : 0.f;
+      _Float16 h, lo;
+      split2(w, h, lo);
+      const long base = off + (blk * 2) * 512 + lane * 8 + j;
+      wpk[base] = h;
+      wpk[base + 512] = lo;
+    }
+  } else {
+    float* tail = reinterpret_cast<float*>(wpk + PACKED_F16_HALVES);
+    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+    for (int i = t0; i < NLAYER_MFMA * 256; i += stride) {
+      const int ll = i >> 8, f = i & 255;
+      const int bidx = ll < 8 ? 2 * ll + 1 : (ll == L_FEAT ? 19 : 17);
+      tail[i] = (ll == L_VIEWS && f >= 128) ? 0.f : a.p[bidx][f];
+    }
+    for (int i = t0; i < 256; i += stride) tail[OFF_WA - OFF_BIAS + i] = a.p[20][i];
+    for (int i = t0; i < 4; i += stride) tail[OFF_BA - OFF_BIAS + i] = i == 0 ? a.p[21][0] : 0.f;
+    for (int i = t0; i < 384; i += stride) tail[OFF_WR - OFF_BIAS + i] = a.p[22][i];
+    for (int i = t0; i < 4; i += stride) tail[OFF_BR - OFF_BIAS + i] = i < 3 ? a.p[23][i] : 0.f;
+    for (int i = t0; i < 2 * 64 * 8; i += stride) wpk[off_wh(NLAYER_MFMA) + i] = (_Float16)0.f;
+  }
+}
+
+}  // namespace scade
+
+using namespace scade;
+
+extern "C" long scade_mlp_packed_f16_bytes(void) { return PACKED_F16_BYTES; }
+
+extern "C" int scade_mlp_pack_f16(const float* const* params, void* packed, void* stream) {
+  SCADE_REQUIRE(params && packed, -1, "scade_mlp_pack_f16: null pointer");
+  PackF16Args a;
+  for (int i = 0; i < N_PARAM_TENSORS; ++i) {
+    SCADE_REQUIRE(params[i], -1, "scade_mlp_pack_f16: params[%d] is null", i);
+    a.p[i] = params[i];
+  }
+  a.packed = packed;
+  hipLaunchKernelGGL(mlp_pack_f16_kernel, dim3(64, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_mlp_pack_f16");
+}
+
+template <int MODE>
+static int launch_f16(const MlpF16Args& a, hipStream_t s) {
+  static bool attr_set = false;
+  auto kern = mlp_fwd_f16_kernel<MODE>;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, F16_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_fwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, dim3((a.P + HM - 1) / HM), dim3(256), F16_LDS_BYTES, s, a);
+  return scade_check_launch("scade_mlp_fwd_f16");
+}
+
+extern "C" int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in,
+                                 const float* viewdirs, int vd_stride, const float* bb, int P, int S,
+                                 float* out, void* stream) {
+  if (P == 0) return 0;
+  SCADE_REQUIRE(packed_f16 && in && out, -1, "scade_mlp_fwd_f16: null pointer");
+  SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd_f16: mode must be 0 or 1");
+  if (mode == 1) {
+    SCADE_REQUIRE(viewdirs && bb && vd_stride >= 3, -1, "scade_mlp_fwd_f16: mode 1 needs viewdirs and bb");
+    SCADE_REQUIRE(S > 0 && P % S == 0, -2, "scade_mlp_fwd_f16: P must be a multiple of S");
+  }
+  MlpF16Args a{packed_f16, in, viewdirs, bb, out, P, S, vd_stride};
+  return mode == 0 ? launch_f16<0>(a, (hipStream_t)stream) : launch_f16<1>(a, (hipStream_t)stream);
+}

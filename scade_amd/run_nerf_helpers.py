@@ -140,6 +140,9 @@ class NeRF(nn.Module):
             self.output_linear = DenseLayer(W, output_ch, activation="linear")
         self._packed = None
         self._packed_key = None
+        # "f32": exact fp32 MFMA everywhere.  "f16x3": no-grad forwards use the split-precision
+        # kernel (two fp16 planes per value, three f16 MFMAs per product; ~1e-6 relative error)
+        self.inference_precision = "f32"
 
     # -- kernel support ----------------------------------------------------
     def _require_supported(self):
@@ -176,12 +179,28 @@ class NeRF(nn.Module):
             self._packed_t_key = key
         return self._packed_t
 
+    def packed_f16(self):
+        ps = self.ordered_params()
+        key = (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_packed_f16", None) is None or key != self._packed_f16_key \
+                or self._packed_f16.device != ps[0].device:
+            self._packed_f16 = ops.mlp_pack_f16(ps)
+            self._packed_f16_key = key
+        return self._packed_f16
+
+    def _fast(self, train):
+        if self.inference_precision not in ("f32", "f16x3"):
+            raise ValueError("NeRF.inference_precision must be 'f32' or 'f16x3'")
+        return self.inference_precision == "f16x3" and not train
+
     def forward(self, x):
         """x [P, 60] = [gamma(pts) | viewdir] -> [P,4] (helpers:223-247)."""
         from .mlp import MlpEmbeddedFn
         self._require_supported()
         ps = self.ordered_params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        if self._fast(train):
+            return ops.mlp_fwd_f16(self.packed_f16(), x, None, None)
         return MlpEmbeddedFn.apply(self, train, x, *ps)
 
     def forward_points(self, pts, viewdirs, bb):
@@ -190,6 +209,8 @@ class NeRF(nn.Module):
         self._require_supported()
         ps = self.ordered_params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
+        if self._fast(train):
+            return ops.mlp_fwd_f16(self.packed_f16(), pts, viewdirs, bb)
         return MlpPointsFn.apply(self, train, pts, viewdirs, bb, *ps)
 
     def load_reference_state_dict(self, state_dict, strict=True):

@@ -1,0 +1,110 @@
+"""GPU: the opt-in split-precision inference path (NeRF.inference_precision = "f16x3":
+x ~= h + l*2^-11 in fp16, three f16 MFMAs per product, fp32 accumulate) is held to the SAME
+parity bar as the exact fp32 kernels."""
+import pytest
+import torch
+
+import scade_amd as S
+from conftest import assert_close, load_golden, rel_l2
+from oracle import scade_oracle as O
+from test_oracle_golden import f2_params, f6_params
+from test_gpu_ops import make_net
+from test_gpu_render import build, check_ret, stagewise
+
+pytestmark = pytest.mark.gpu
+
+
+def fast(net):
+    net.inference_precision = "f16x3"
+    return net
+
+
+def test_f16x3_forward_golden(dev):
+    g = load_golden("f2_mlp")
+    net = fast(make_net(f2_params(g), dev))
+    with torch.no_grad():
+        out = net(g["x"].to(dev))
+    assert_close(out, g["out"], rtol=1e-4, atol=1e-5, what="NeRF.forward f16x3")
+    assert rel_l2(out, g["out"]) < 2e-6
+    # with grad enabled the module silently uses the exact training kernels
+    out2 = net(g["x"].to(dev))
+    assert out2.requires_grad
+    assert_close(out2, g["out"], rtol=1e-4, atol=1e-5, what="training forward stays exact")
+
+
+def test_f16x3_points_ragged_and_edge_sizes(dev):
+    g = load_golden("f2_mlp")
+    params = f2_params(g)
+    net = fast(make_net(params, dev))
+    torch.manual_seed(3)
+    N, Sm = 37, 5
+    pts = torch.rand(N, Sm, 3) * 6 - 3
+    vd = torch.nn.functional.normalize(torch.randn(N, 3), dim=-1)
+    bbc, bbs = torch.tensor([0.1, -0.2, 0.3]), torch.tensor(0.2)
+    want = O.run_network(pts, vd, lambda e: O.nerf_forward(params, e), bbc, bbs)
+    e, _ = S.get_embedder(9, 0)
+    ed, _ = S.get_embedder(0, 0)
+    with torch.no_grad():
+        got = S.run_network(pts.to(dev), vd.to(dev), torch.empty(0, device=dev), net, e, ed, bbc.to(dev),
+                            bbs.to(dev))
+        for P in (0, 1, 63, 64, 65, 129):
+            o = net(g["x"][:P].to(dev))
+            assert o.shape == (P, 4)
+            if P:
+                assert_close(o, g["out"][:P], rtol=1e-4, atol=1e-5, what=f"f16x3 P={P}")
+    assert_close(got, want, rtol=1e-4, atol=1e-5, what="run_network f16x3")
+
+
+def test_f16x3_large_activations_and_small_values(dev):
+    """Dynamic range: activations of a few thousand and tiny weights stay accurate (the low
+    plane is pre-scaled by 2^11, so it never falls into the fp16 subnormal range)."""
+    params = O.nerf_init(7)
+    params["pts_linears.0.weight"] = params["pts_linears.0.weight"] * 300.0      # |h0| ~ 1e3
+    params["pts_linears.1.weight"] = params["pts_linears.1.weight"] * 1e-3
+    params["pts_linears.2.weight"] = params["pts_linears.2.weight"] * 30.0
+    net = fast(make_net(params, dev))
+    torch.manual_seed(4)
+    x = torch.cat([O.embed(torch.rand(200, 3) * 2 - 1, 9),
+                   torch.nn.functional.normalize(torch.randn(200, 3), dim=-1)], -1)
+    want = O.nerf_forward({k: v.double() for k, v in params.items()}, x.double())
+    with torch.no_grad():
+        got = net(x.to(dev))
+        net.inference_precision = "f32"
+        exact = net(x.to(dev))
+    e_fast, e_exact = rel_l2(got, want), rel_l2(exact, want)
+    assert e_fast < 3e-6 and e_fast < 4 * e_exact + 1e-7, (e_fast, e_exact)
+
+
+def test_f16x3_render_rays_golden(dev):
+    g = load_golden("f6_render")
+    pc, pf = f6_params(g)
+    coarse, fine, query = build(dev, pc, pf, g["bb_center"], g["bb_scale"])
+    fast(coarse); fast(fine)
+    with torch.no_grad():
+        ret = S.render_rays(g["rays"].to(dev), True, coarse, query, 64, embedded_cam=torch.empty(0, device=dev),
+                            N_importance=128, network_fine=fine, perturb=0., retraw=True)
+        want = {k[4:]: v for k, v in g.items() if k.startswith("det/")}
+        check_ret(ret, want, "det f16x3")
+        stagewise(dev, want, g["rays"], fine, query, want["u"])
+        ret2 = S.render_rays(g["rays"].to(dev), True, coarse, query, 64, N_importance=128, network_fine=fine,
+                             perturb=0., retraw=True)
+    for k in ret:
+        assert torch.equal(torch.nan_to_num(ret[k]), torch.nan_to_num(ret2[k])), f"non-deterministic {k}"
+
+
+def test_f16x3_repack_and_bad_mode(dev):
+    g = load_golden("f2_mlp")
+    params = f2_params(g)
+    net = fast(make_net(params, dev))
+    x = g["x"].to(dev)
+    with torch.no_grad():
+        a = net(x).clone()
+        net.pts_linears[2].weight.mul_(0.5)
+        b = net(x)
+    params["pts_linears.2.weight"] = params["pts_linears.2.weight"] * 0.5
+    assert_close(b, O.nerf_forward(params, g["x"]), rtol=1e-4, atol=1e-5, what="f16x3 after update")
+    assert not torch.allclose(a, b)
+    net.inference_precision = "bf16"
+    with pytest.raises(ValueError):
+        with torch.no_grad():
+            net(x)

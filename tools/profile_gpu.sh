@@ -8,8 +8,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # the headline region only, so per-kernel averages are those of the timed render steps
-CMD="python $ROOT/bench.py --no-cpu-baseline --no-train --no-image --steps 20 --warmup 3"
-TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --steps 10 --warmup 2"
+CMD="python $ROOT/bench.py --no-cpu-baseline --no-train --no-image --no-fast --steps 20 --warmup 3"
+TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --steps 10 --warmup 2"   # render + f16x3 + train regions
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 grep -o '^{"metric.*}' $OUT/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train -o bench -- $TRAIN_CMD > $OUT/stats_train.log 2>&1
