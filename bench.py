@@ -144,7 +144,7 @@ def fast_region(args, dev, world, barrier, step, coarse, fine):
                          "avg_launch_ms": k["ms"] / k["launches"]}}
 
 
-def train_region(args, dev, world, rank, barrier):
+def train_region(args, dev, world, rank, barrier, precision="f32"):
     """Secondary measurement (BASELINE.json configs[2]/[3]): full train step = render_rays
     (perturb=1) + mse + 0.007*space-carving(K hypotheses) + mse0, backward, ONE RCCL
     all-reduce of the flat gradient bucket (world > 1), fused Adam.  1024 rays per GPU."""
@@ -153,7 +153,7 @@ def train_region(args, dev, world, rank, barrier):
     from scade_amd.train import Trainer, make_scade_nets
     from oracle import scade_oracle as O
     coarse, fine = make_scade_nets(dev, seed=0)
-    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1)
+    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
     rays = O.synthetic_rays(args.rays, seed=2000 + rank).to(dev)
     g = torch.Generator(device="cpu").manual_seed(3000 + rank)
     tgt = torch.rand(args.rays, 3, generator=g).to(dev)
@@ -177,7 +177,7 @@ def train_region(args, dev, world, rank, barrier):
     ks = timer.summary()
     kb = ks["mlp_bwd"]
     flops = 3.0 * args.rays * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT   # fwd + dgrad + wgrad
-    return {"value": args.rays * world * args.steps / elapsed, "unit": "rays/s",
+    return {"value": args.rays * world * args.steps / elapsed, "unit": "rays/s", "precision": precision,
             "ms_per_step": elapsed / args.steps * 1e3, "rays_per_gpu": args.rays, "hypotheses": args.hyp,
             "collective": (f"RCCL all-reduce(sum, fp32) of {tr.flat.numel + tr.flat_ss.numel} floats per step"
                            if world > 1 else "none (1 GPU)"),
@@ -303,6 +303,8 @@ def main():
         out["fast_path_f16x3"] = fast_region(args, dev, world, barrier, step, coarse, fine)
     if not args.no_train:
         out["train_step"] = train_region(args, dev, world, rank, barrier)
+        if not args.no_fast:   # opt-in: forward + dgrad on the split-precision kernels, exact wgrad
+            out["train_step_f16x3"] = train_region(args, dev, world, rank, barrier, precision="f16x3")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pc, pf, 1024)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

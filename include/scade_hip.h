@@ -72,11 +72,21 @@ int scade_mlp_bwd(const float* packed, const float* packed_t, const float* acts,
  * carried as two fp16 numbers x ~= h + l*2^-11 and every product as three f16 MFMAs into two fp32
  * accumulators (~2^-21 relative error per product; requires |activations|,|weights| < 65504).
  * packed_f16 = scade_mlp_pack_f16(params), scade_mlp_packed_f16_bytes() bytes.  Same modes,
- * arguments and output as scade_mlp_fwd; no training workspace. */
+ * arguments, output and (optional) training workspace as scade_mlp_fwd. */
 long scade_mlp_packed_f16_bytes(void);
 int scade_mlp_pack_f16(const float* const* params, void* packed_f16, void* stream);
 int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in, const float* viewdirs,
-                      int vd_stride, const float* bb, int P, int S, float* out, void* stream);
+                      int vd_stride, const float* bb, int P, int S, float* out, float* acts,
+                      void* stream);
+
+/* Split-precision variant of scade_mlp_bwd (opt-in training mode): the dgrad chain runs on
+ * f16 MFMAs with a per-point power-of-two gradient scale (exactly removed on store); the weight
+ * gradient stays on the exact fp32 kernel.  packed = the fp32 forward pack (head weights);
+ * packed_t_f16 = scade_mlp_pack_t_f16(params); other arguments as scade_mlp_bwd. */
+long scade_mlp_packed_t_f16_bytes(void);
+int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f16, void* stream);
+int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* acts,
+                      const float* g_out, int P, float* workspace, float* grad_flat, void* stream);
 
 /* ---- positional encoding (Embedder.embed, helpers:142-172; get_embedder :174-189) */
 /* out[P, D*(1+2*multires)] = [x, sin(x*pi*2^0), cos(x*pi*2^0), ..., cos(x*pi*2^(L-1))] */

@@ -20,6 +20,10 @@ int scade_check_launch(const char* what);
     }                                         \
   } while (0)
 
+// wgrad + reduce launcher shared by the backward variants (mlp_bwd.hip)
+int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
+                       float* grad_flat, hipStream_t s);
+
 // ---- wave-level primitives -------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 

@@ -506,30 +506,16 @@ extern "C" long scade_mlp_bwd_workspace_floats(int P) {
   return dz_floats(P) + (long)pick_chunks(P) * N_PARAM_FLOATS;
 }
 
-extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const float* acts,
-                             const float* g_out, int P, float* workspace, float* grad_flat,
-                             void* stream) {
-  SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd: P must be positive");
-  SCADE_REQUIRE(packed && packed_t && acts && g_out && workspace && grad_flat, -1,
-                "scade_mlp_bwd: null pointer");
-  hipStream_t s = (hipStream_t)stream;
+// wgrad + reduce (shared by the exact and the split-precision backward)
+int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
+                       float* grad_flat, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
-    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  float* dz = workspace;
-  float* partial = workspace + dz_floats(P);
-
-  MlpDgradArgs d{packed, packed_t, acts, g_out, dz, P};
-  hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((P + TM - 1) / TM), dim3(256), MLP_LDS_BYTES, s, d);
-  if (int e = scade_check_launch("scade_mlp_bwd(dgrad)")) return e;
-
   int off[N_PARAM_TENSORS + 1];
   param_offsets(off);
   WgradArgs w{};
@@ -563,4 +549,28 @@ extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const f
   if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
   hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd(reduce)");
+}
+
+extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const float* acts,
+                             const float* g_out, int P, float* workspace, float* grad_flat,
+                             void* stream) {
+  SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd: P must be positive");
+  SCADE_REQUIRE(packed && packed_t && acts && g_out && workspace && grad_flat, -1,
+                "scade_mlp_bwd: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  float* dz = workspace;
+  float* partial = workspace + dz_floats(P);
+
+  MlpDgradArgs d{packed, packed_t, acts, g_out, dz, P};
+  hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((P + TM - 1) / TM), dim3(256), MLP_LDS_BYTES, s, d);
+  if (int e = scade_check_launch("scade_mlp_bwd(dgrad)")) return e;
+
+  return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
 }

@@ -1,0 +1,259 @@
+// Split-precision (f16x3) variant of the dgrad chain of mlp_bwd.hip (opt-in training mode).
+//
+// Same structure as mlp_dgrad_kernel -- 64-point tile, 4 waves, the gradient tile walks the 9
+// layers backwards in LDS, transposed weight pack as the A operand, ReLU masks from the lane-
+// private sign words, every layer's dZ written to HBM as fp32 rows for the (exact fp32) wgrad --
+// but the tile is carried as two fp16 planes (x ~= h + l*2^-11) and every product is three
+// v_mfma_f32_32x32x16_f16 (see mlp_fwd_f16.hip).
+//
+// Gradients are small (1e-8 .. 1e-3) and would underflow fp16, so each POINT's gradient chain
+// is scaled by its own power of two s_p = 2^(-4 - exponent(max|g_out[p]|, |d alpha_pre[p]|)):
+// the chain is linear in g_out[p] and the product only mixes features, never points, so the
+// scale factors out exactly and is removed when the fp32 rows are stored.
+#include "mlp_tile_f16.h"
+
+namespace scade {
+
+// transposed two-plane pack: for dgrad index t (mlp_layout.h), layer l = dgrad_layer(t):
+//   WT16[((kt*NB16 + nb)*2 + plane)*64*8 + lane*8 + j] = split(W[nb*16 + 8*(lane>>5) + j][hcol0 + kt*32 + (lane&31)])
+constexpr long wt16_halves(int t) { return (long)256 * n_out(dgrad_layer(t)) * 2; }
+constexpr long off_wt16(int t) {
+  long o = 0;
+  for (int i = 0; i < t; ++i) o += wt16_halves(i);
+  return o;
+}
+constexpr long PACKED_T_F16_HALVES = off_wt16(NLAYER_DGRAD) + 2 * 64 * 8;
+
+struct PackTF16Args {
+  const float* p[N_PARAM_TENSORS];
+  _Float16* packed;
+};
+
+__global__ void mlp_pack_t_f16_kernel(PackTF16Args a) {
+  const int t = blockIdx.y;
+  const int l = dgrad_layer(t);
+  const int widx = l <= 7 ? 2 * l : (l == L_FEAT ? 18 : 16);
+  const float* __restrict__ Wsrc = a.p[widx];
+  const int N = n_out(l);
+  const int NB = N / 16;
+  const int ld = l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W);
+  const int hcol0 = l == 5 ? EMB : 0;
+  const long total = (long)256 * N;
+  const long off = off_wt16(t);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long blk = i >> 9;
+    const int nb = (int)(blk % NB), kt = (int)(blk / NB);
+    const int n = nb * 16 + 8 * (lane >> 5) + j;
+    const int k = kt * 32 + (lane & 31);
+    _Float16 h, lo;
+    split2(Wsrc[(size_t)n * ld + hcol0 + k], h, lo);
+    const long base = off + blk * 1024 + lane * 8 + j;
+    a.packed[base] = h;
+    a.packed[base + 512] = lo;
+  }
+  if (t == 0)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 64 * 8; i += gridDim.x * blockDim.x)
+      a.packed[off_wt16(NLAYER_DGRAD) + i] = (_Float16)0.f;
+}
+
+struct MlpDgradF16Args {
+  const float* packed;       // fp32 forward pack (rgb / alpha head weights)
+  const _Float16* packedT;   // transposed two-plane pack
+  const float* acts;
+  const float* g_out;        // [P,4]
+  float* dz;                 // dz_floats(P)
+  int P;
+};
+
+template <bool MASK, bool ADD_ALPHA>
+__device__ __forceinline__ void dgrad_store_h(const f32x16 (&acc0)[2][2], const f32x16 (&acc1)[2][2],
+                                              int ktile0, _Float16* gh, _Float16* gl,
+                                              unsigned long long bits, const float* __restrict__ w_a,
+                                              const float* dal_scaled, int lane) {
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = (ktile0 + t) * 32 + 8 * q + 4 * hh;
+      f32x4 wa = {0.f, 0.f, 0.f, 0.f};
+      if (ADD_ALPHA) wa = *reinterpret_cast<const f32x4*>(w_a + f);
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int row = p * 32 + r;
+        half4 vh, vl;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
+          if (ADD_ALPHA) x = x + wa[i] * dal_scaled[row];
+          if (MASK) x = ((bits >> (((t * 4 + q) * 2 + p) * 4 + i)) & 1ull) ? x : 0.f;
+          _Float16 h, l;
+          split2(x, h, l);
+          vh[i] = h; vl[i] = l;
+        }
+        const int o = x_idx(row, f >> 3) + (f & 7);
+        *reinterpret_cast<half4*>(gh + o) = vh;
+        *reinterpret_cast<half4*>(gl + o) = vl;
+      }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
+  _Float16* gh = ldsh;
+  _Float16* gl = ldsh + XPLANE;
+  float* dal = reinterpret_cast<float*>(ldsh + 2 * XPLANE);   // [64] d alpha_pre * scale
+  float* inv_s = dal + 64;                                    // [64] 1/scale of the point
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = blockIdx.x * HM;
+  const int P = a.P;
+  const float* __restrict__ pk = a.packed;
+  const _Float16* __restrict__ pt_ = a.packedT;
+  const float* __restrict__ acts = a.acts;
+  float* __restrict__ dz = a.dz;
+  const unsigned long long* __restrict__ masks =
+      reinterpret_cast<const unsigned long long*>(acts + acts_mask_off(P));
+  auto mask_of = [&](int layer) { return masks[((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid]; };
+
+  // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
+  {
+    const int row = tid >> 2, sub = tid & 3;
+    const int pt = p0 + row;
+    const bool ok = pt < P;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    if (ok) g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    float da = 0.f;
+    if (ok) {
+      const float bx = acts[acts_alpha_off(P) + pt] * 10.f;
+      da = bx > 20.f ? g[3] : g[3] / (1.f + expf(-bx));
+    }
+    const float m = fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(da)));
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
+      s = ldexpf(1.f, -4 - e);
+    }
+    if (sub == 0) {
+      if (ok) dz[dz_dalpha_off(P) + pt] = da;
+      dal[row] = da * s;
+      inv_s[row] = 1.f / s;
+    }
+    const float* wr = pk + OFF_WR;
+    const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
+    float* dzv = dz + acts_slot_off(P, SLOT_VIEWS_H);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int chunk = i * 4 + sub;                       // 4-float chunk of the 128 columns
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
+      f32x4 mk = {0.f, 0.f, 0.f, 0.f};
+      if (ok) mk = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * W + chunk * 4);
+      f32x4 v;
+      half4 vh, vl;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = g[0] * w0[j] + g[1] * w1[j] + g[2] * w2[j];
+        v[j] = mk[j] > 0.f ? d : 0.f;
+        _Float16 h, l;
+        split2(v[j] * s, h, l);
+        vh[j] = h; vl[j] = l;
+      }
+      const int o = x_idx(row, chunk >> 1) + (chunk & 1) * 4;
+      *reinterpret_cast<half4*>(gh + o) = vh;
+      *reinterpret_cast<half4*>(gl + o) = vl;
+      if (ok) *reinterpret_cast<f32x4*>(dzv + (size_t)pt * W + chunk * 4) = v;
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc0[2][2], acc1[2][2];
+  AFrag an;
+  const int kt0 = wave * 2;
+  // this wave's k-tile pair of dgrad index T: [kt][NB16][2][64] half8
+#define WT16(T, NB) (reinterpret_cast<const half8*>(pt_ + off_wt16(T)) + kt0 * (NB) * 128)
+  an.t0h = WT16(8, 8)[lane];
+  an.t0l = WT16(8, 8)[64 + lane];
+  an.t1h = WT16(8, 8)[(8 * 2 + 0) * 64 + lane];
+  an.t1l = WT16(8, 8)[(8 * 2 + 1) * 64 + lane];
+
+  // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
+  layer_gemm_h<2, 0, 8, false>(acc0, acc1, an, WT16(8, 8), WT16(7, 16), 16, gh, gl, gh, gl, lane);
+  __syncthreads();
+  dgrad_store_h<false, false>(acc0, acc1, kt0, gh, gl, 0ull, nullptr, dal, lane);
+  __syncthreads();
+  save_tile_h(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, W, inv_s, tid);
+
+  // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
+  unsigned long long mbits = mask_of(7);
+  layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16(7, 16), WT16(6, 16), 16, gh, gl, gh, gl, lane);
+  __syncthreads();
+  dgrad_store_h<true, true>(acc0, acc1, kt0, gh, gl, mbits, pk + OFF_WA, dal, lane);
+  __syncthreads();
+  save_tile_h(gh, gl, dz + acts_slot_off(P, 7), p0, P, W, inv_s, tid);
+
+#define DGRAD_LAYER_H(L)                                                                         \
+  mbits = mask_of((L)-1);                                                                        \
+  layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16((L)-1, 16), WT16((L) > 1 ? (L)-2 : 0, 16), 16, \
+                                gh, gl, gh, gl, lane);                                           \
+  __syncthreads();                                                                               \
+  dgrad_store_h<true, false>(acc0, acc1, kt0, gh, gl, mbits, nullptr, dal, lane);                \
+  __syncthreads();                                                                               \
+  save_tile_h(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, W, inv_s, tid);
+
+  DGRAD_LAYER_H(7)
+  DGRAD_LAYER_H(6)
+  DGRAD_LAYER_H(5)
+  DGRAD_LAYER_H(4)
+  DGRAD_LAYER_H(3)
+  DGRAD_LAYER_H(2)
+  DGRAD_LAYER_H(1)
+#undef DGRAD_LAYER_H
+#undef WT16
+}
+
+constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4;
+
+}  // namespace scade
+
+using namespace scade;
+
+extern "C" long scade_mlp_packed_t_f16_bytes(void) { return PACKED_T_F16_HALVES * 2; }
+
+extern "C" int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f16, void* stream) {
+  SCADE_REQUIRE(params && packed_t_f16, -1, "scade_mlp_pack_t_f16: null pointer");
+  PackTF16Args a;
+  for (int i = 0; i < N_PARAM_TENSORS; ++i) {
+    SCADE_REQUIRE(params[i], -1, "scade_mlp_pack_t_f16: params[%d] is null", i);
+    a.p[i] = params[i];
+  }
+  a.packed = reinterpret_cast<_Float16*>(packed_t_f16);
+  hipLaunchKernelGGL(mlp_pack_t_f16_kernel, dim3(64, NLAYER_DGRAD), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_mlp_pack_t_f16");
+}
+
+extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* acts,
+                                 const float* g_out, int P, float* workspace, float* grad_flat,
+                                 void* stream) {
+  SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd_f16: P must be positive");
+  SCADE_REQUIRE(packed && packed_t_f16 && acts && g_out && workspace && grad_flat, -1,
+                "scade_mlp_bwd_f16: null pointer");
+  hipStream_t s = (hipStream_t)stream;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_f16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DGRAD_F16_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  float* dz = workspace;
+  float* partial = workspace + dz_floats(P);
+  MlpDgradF16Args d{packed, reinterpret_cast<const _Float16*>(packed_t_f16), acts, g_out, dz, P};
+  hipLaunchKernelGGL(mlp_dgrad_f16_kernel, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
+  if (int e = scade_check_launch("scade_mlp_bwd_f16(dgrad)")) return e;
+  return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
+}

@@ -20,44 +20,9 @@
 //
 // Validity: |activation| and |weight| < 65504 (fp16 range).  Inference only (no saved
 // activations); training uses the exact fp32 kernels.
-#include "common.h"
-#include "mlp_layout.h"
+#include "mlp_tile_f16.h"
 
 namespace scade {
-
-typedef _Float16 half8 __attribute__((ext_vector_type(8)));
-typedef _Float16 half4 __attribute__((ext_vector_type(4)));
-
-constexpr int HM = 64;                       // points per workgroup
-constexpr int XPLANE = HM * W;               // halves per activation plane
-constexpr int EPLANE = HM * 64;              // halves per embedding plane
-constexpr int F16_LDS_BYTES = (2 * XPLANE + 2 * EPLANE) * 2;   // 81920
-constexpr float LSCALE = 2048.0f, LINV = 1.0f / 2048.0f;
-
-// k-blocks of 16 channels
-constexpr int kbp16(int l) { return l == 0 ? 4 : (l == 5 ? 4 : (l == L_VIEWS ? 1 : 0)); }
-constexpr int kbh16(int l) { return l == 0 ? 0 : 16; }
-constexpr int kb16(int l) { return kbp16(l) + kbh16(l); }
-// packed blob: per layer [ntile][kb][plane 2][64 lanes][8 halves]  (counted in halves)
-constexpr long wh_halves(int l) { return (long)n_out(l) / 32 * kb16(l) * 2 * 64 * 8; }
-constexpr long off_wh(int l) {
-  long o = 0;
-  for (int i = 0; i < l; ++i) o += wh_halves(i);
-  return o;
-}
-constexpr long PACKED_F16_HALVES = off_wh(NLAYER_MFMA) + 2 * 64 * 8;   // + slack block
-// fp32 tail (biases + head weights) reuses the fp32 blob layout after the MFMA weights
-constexpr long F16_TAIL_FLOATS = PACKED_FWD_FLOATS - OFF_BIAS;
-constexpr long PACKED_F16_BYTES = PACKED_F16_HALVES * 2 + F16_TAIL_FLOATS * 4;
-
-__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
-  h = (_Float16)x;
-  l = (_Float16)((x - (float)h) * LSCALE);
-}
-
-// halves index of the 8-half chunk c of row r in an activation plane / embedding plane
-__device__ __forceinline__ int x_idx(int row, int c) { return row * W + ((c ^ (row & 15)) << 3); }
-__device__ __forceinline__ int e_idx(int row, int c) { return row * 64 + ((c ^ ((row >> 1) & 7)) << 3); }
 
 struct MlpF16Args {
   const void* packed;     // PACKED_F16_BYTES
@@ -65,98 +30,18 @@ struct MlpF16Args {
   const float* viewdirs;
   const float* bb;
   float* out;             // [P,4]
+  float* acts;            // optional training workspace (mlp_layout.h), same contents as the exact kernel's
   int P, S, vd_stride;
 };
 
-// A fragments of one k-block for the wave's (up to) two n-tiles, both planes.  Plain named
-// members (no arrays passed by reference): hipcc (ROCm 7.2) mis-allocates registers for the
-// array-reference form of this loop on gfx950 (address temporaries land in a live operand).
-struct AFrag { half8 t0h, t0l, t1h, t1l; };
-
-template <int NT, int KBP, int KBH, bool PRE_VIEW>
-__device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc1)[NT][2], AFrag& an,
-                                             const half8* __restrict__ wp,
-                                             const half8* __restrict__ wp_next, int kb_next,
-                                             const _Float16* eh, const _Float16* el,
-                                             const _Float16* xh, const _Float16* xl, int lane) {
-  constexpr int KB = KBP + KBH;
-  const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[t][p][i] = 0.f; acc1[t][p][i] = 0.f; }
-
-  // activation fragment (both planes) of point tile p for k-block kb
-#define LOAD_B(KBX, PX, BH, BL)                                                              \
-  {                                                                                          \
-    const int kb_ = (KBX);                                                                   \
-    if (KBP > 0 && kb_ < KBP) {                                                              \
-      if (PRE_VIEW) {                                                                        \
-        BH = *reinterpret_cast<const half8*>(eh + ((PX)*32 + r) * 16 + hh * 8);               \
-        BL = *reinterpret_cast<const half8*>(el + ((PX)*32 + r) * 16 + hh * 8);               \
-      } else {                                                                               \
-        const int o_ = e_idx((PX)*32 + r, 2 * kb_ + hh);                                     \
-        BH = *reinterpret_cast<const half8*>(eh + o_);                                       \
-        BL = *reinterpret_cast<const half8*>(el + o_);                                       \
-      }                                                                                      \
-    } else {                                                                                 \
-      const int o_ = x_idx((PX)*32 + r, 2 * (kb_ - KBP) + hh);                               \
-      BH = *reinterpret_cast<const half8*>(xh + o_);                                         \
-      BL = *reinterpret_cast<const half8*>(xl + o_);                                         \
-    }                                                                                        \
-  }
-// six MFMAs of one point tile: the two dependent updates of each acc1 are kept >= 3 MFMAs apart
-#define MFMA6(PX, A, VH, VL)                                                                   \
-  acc0[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0h, VH, acc0[0][PX], 0, 0, 0);        \
-  acc1[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0h, VL, acc1[0][PX], 0, 0, 0);        \
-  if (NT > 1) {                                                                                \
-    acc0[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1h, VH, acc0[NT - 1][PX], 0, 0, 0); \
-    acc1[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1h, VL, acc1[NT - 1][PX], 0, 0, 0); \
-  }                                                                                            \
-  acc1[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0l, VH, acc1[0][PX], 0, 0, 0);        \
-  if (NT > 1)                                                                                  \
-    acc1[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1l, VH, acc1[NT - 1][PX], 0, 0, 0);
-
-  // register plan: A (weights, L2 latency) is fetched a whole k-block ahead; B (LDS) ping-pongs
-  // between the two point tiles inside the block: b1 of this block loads under the p=0 MFMAs,
-  // b0 of the next block under the p=1 MFMAs.
-  half8 b0h, b0l, b1h, b1l;
-  LOAD_B(0, 0, b0h, b0l)
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
-    const AFrag a = an;
-    if (kb + 1 < KB) {
-      an.t0h = wp[((kb + 1) * 2 + 0) * 64 + lane];
-      an.t0l = wp[((kb + 1) * 2 + 1) * 64 + lane];
-      if (NT > 1) {
-        an.t1h = wp[((KB + kb + 1) * 2 + 0) * 64 + lane];
-        an.t1l = wp[((KB + kb + 1) * 2 + 1) * 64 + lane];
-      }
-    } else {   // last k-block: the next layer's first weights
-      an.t0h = wp_next[lane];
-      an.t0l = wp_next[64 + lane];
-      an.t1h = wp_next[(kb_next * 2 + 0) * 64 + lane];
-      an.t1l = wp_next[(kb_next * 2 + 1) * 64 + lane];
-    }
-    LOAD_B(kb, 1, b1h, b1l)
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA6(0, a, b0h, b0l)
-    __builtin_amdgcn_sched_barrier(0);
-    LOAD_B(kb + 1 < KB ? kb + 1 : kb, 0, b0h, b0l)
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA6(1, a, b1h, b1l)
-  }
-#undef LOAD_B
-#undef MFMA6
-}
-
+// returns the lane's ReLU sign bits in the exact kernel's format (mlp_fwd.hip layer_store)
 template <int NT, bool RELU>
-__device__ __forceinline__ void layer_store_h(const f32x16 (&acc0)[NT][2], const f32x16 (&acc1)[NT][2],
-                                              const float* __restrict__ bias, int ntile0, _Float16* xh,
-                                              _Float16* xl, int lane) {
+__device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)[NT][2],
+                                                            const f32x16 (&acc1)[NT][2],
+                                                            const float* __restrict__ bias, int ntile0,
+                                                            _Float16* xh, _Float16* xl, int lane) {
   const int r = lane & 31, hh = lane >> 5;
+  unsigned long long bits = 0ull;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -169,6 +54,7 @@ __device__ __forceinline__ void layer_store_h(const f32x16 (&acc0)[NT][2], const
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]) + bv[i];
+          if (RELU && x > 0.f) bits |= 1ull << (((t * 4 + q) * 2 + p) * 4 + i);
           if (RELU) x = fmaxf(x, 0.f);
           _Float16 h, l;
           split2(x, h, l);
@@ -180,9 +66,10 @@ __device__ __forceinline__ void layer_store_h(const f32x16 (&acc0)[NT][2], const
         *reinterpret_cast<half4*>(xl + o) = vl;
       }
     }
+  return bits;
 }
 
-template <int MODE>
+template <int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* xh = ldsh;
@@ -242,6 +129,24 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     }
   }
   __syncthreads();
+  if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0  (same layout as the exact kernel)
+    float* eo = a.acts + acts_emb_off(P);
+    for (int i = tid; i < HM * 64; i += 256) {
+      const int row = i >> 6, c = i & 63;
+      const int pt = p0 + row;
+      if (pt < P) {
+        float v = 0.f;
+        if (c < EMB) {
+          const int o = e_idx(row, c >> 3) + (c & 7);
+          v = (float)eh[o] + (float)el[o] * LINV;
+        } else if (c >= 60 && c < 63) {
+          v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + (c - 60)]
+                        : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + (c - 60)];
+        }
+        eo[(size_t)pt * 64 + c] = v;
+      }
+    }
+  }
 
   f32x16 acc0[2][2], acc1[2][2];
   AFrag an;
@@ -254,8 +159,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     layer_gemm_h<2, KBP, kbh16(L), false>(acc0, acc1, an, WHBASE(L), WHBASE(LNEXT), kb16(LNEXT), \
                                           eh, el, xh, xl, lane);                                 \
     __syncthreads();                                                                             \
-    layer_store_h<2, true>(acc0, acc1, TAIL(off_b(L)), nt0, xh, xl, lane);                       \
+    const unsigned long long bits_ =                                                             \
+        layer_store_h<2, true>(acc0, acc1, TAIL(off_b(L)), nt0, xh, xl, lane);                   \
+    if (SAVE)                                                                                    \
+      reinterpret_cast<unsigned long long*>(a.acts + acts_mask_off(P))[                          \
+          ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = bits_;                             \
     __syncthreads();                                                                             \
+    if (SAVE) save_tile_h(xh, xl, a.acts + acts_slot_off(P, L), p0, P, W, nullptr, tid);         \
   }
 
   an.t0h = WHBASE(0)[lane];
@@ -303,6 +213,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     alpha = s + TAIL(OFF_BA)[0];
+    if (SAVE && sub == 0 && p0 + row < P) a.acts[acts_alpha_off(P) + p0 + row] = alpha;
   }
 
   // ---- feature_linear ------------------------------------------------------------------
@@ -310,6 +221,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   __syncthreads();
   layer_store_h<2, false>(acc0, acc1, TAIL(off_b(L_FEAT)), nt0, xh, xl, lane);
   __syncthreads();
+  if (SAVE) save_tile_h(xh, xl, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, W, nullptr, tid);
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
@@ -318,6 +230,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     __syncthreads();
     layer_store_h<1, true>(av0, av1, TAIL(off_b(L_VIEWS)), wave, xh, xl, lane);
     __syncthreads();
+    if (SAVE) save_tile_h(xh, xl, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, nullptr, tid);
   }
 #undef WHBASE
 
@@ -426,10 +339,10 @@ extern "C" int scade_mlp_pack_f16(const float* const* params, void* packed, void
   return scade_check_launch("scade_mlp_pack_f16");
 }
 
-template <int MODE>
+template <int MODE, bool SAVE>
 static int launch_f16(const MlpF16Args& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = mlp_fwd_f16_kernel<MODE>;
+  auto kern = mlp_fwd_f16_kernel<MODE, SAVE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, F16_LDS_BYTES);
@@ -442,7 +355,7 @@ static int launch_f16(const MlpF16Args& a, hipStream_t s) {
 
 extern "C" int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in,
                                  const float* viewdirs, int vd_stride, const float* bb, int P, int S,
-                                 float* out, void* stream) {
+                                 float* out, float* acts, void* stream) {
   if (P == 0) return 0;
   SCADE_REQUIRE(packed_f16 && in && out, -1, "scade_mlp_fwd_f16: null pointer");
   SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd_f16: mode must be 0 or 1");
@@ -450,6 +363,8 @@ extern "C" int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* 
     SCADE_REQUIRE(viewdirs && bb && vd_stride >= 3, -1, "scade_mlp_fwd_f16: mode 1 needs viewdirs and bb");
     SCADE_REQUIRE(S > 0 && P % S == 0, -2, "scade_mlp_fwd_f16: P must be a multiple of S");
   }
-  MlpF16Args a{packed_f16, in, viewdirs, bb, out, P, S, vd_stride};
-  return mode == 0 ? launch_f16<0>(a, (hipStream_t)stream) : launch_f16<1>(a, (hipStream_t)stream);
+  MlpF16Args a{packed_f16, in, viewdirs, bb, out, acts, P, S, vd_stride};
+  hipStream_t s = (hipStream_t)stream;
+  if (mode == 0) return acts ? launch_f16<0, true>(a, s) : launch_f16<0, false>(a, s);
+  return acts ? launch_f16<1, true>(a, s) : launch_f16<1, false>(a, s);
 }

@@ -1,0 +1,151 @@
+// Building blocks shared by the split-precision (f16x3) forward and dgrad kernels: the
+// two-plane fp16 representation x ~= h + l*2^-11, LDS plane indexing, and the k-loop.
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace scade {
+
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+typedef _Float16 half4 __attribute__((ext_vector_type(4)));
+
+constexpr int HM = 64;                       // points per workgroup
+constexpr int XPLANE = HM * W;               // halves per activation plane
+constexpr int EPLANE = HM * 64;              // halves per embedding plane
+constexpr int F16_LDS_BYTES = (2 * XPLANE + 2 * EPLANE) * 2;   // 81920
+constexpr float LSCALE = 2048.0f, LINV = 1.0f / 2048.0f;
+
+// k-blocks of 16 channels
+constexpr int kbp16(int l) { return l == 0 ? 4 : (l == 5 ? 4 : (l == L_VIEWS ? 1 : 0)); }
+constexpr int kbh16(int l) { return l == 0 ? 0 : 16; }
+constexpr int kb16(int l) { return kbp16(l) + kbh16(l); }
+// packed blob: per layer [ntile][kb][plane 2][64 lanes][8 halves]  (counted in halves)
+constexpr long wh_halves(int l) { return (long)n_out(l) / 32 * kb16(l) * 2 * 64 * 8; }
+constexpr long off_wh(int l) {
+  long o = 0;
+  for (int i = 0; i < l; ++i) o += wh_halves(i);
+  return o;
+}
+constexpr long PACKED_F16_HALVES = off_wh(NLAYER_MFMA) + 2 * 64 * 8;   // + slack block
+// fp32 tail (biases + head weights) reuses the fp32 blob layout after the MFMA weights
+constexpr long F16_TAIL_FLOATS = PACKED_FWD_FLOATS - OFF_BIAS;
+constexpr long PACKED_F16_BYTES = PACKED_F16_HALVES * 2 + F16_TAIL_FLOATS * 4;
+
+__device__ __forceinline__ void split2(float x, _Float16& h, _Float16& l) {
+  h = (_Float16)x;
+  l = (_Float16)((x - (float)h) * LSCALE);
+}
+
+// halves index of the 8-half chunk c of row r in an activation plane / embedding plane
+__device__ __forceinline__ int x_idx(int row, int c) { return row * W + ((c ^ (row & 15)) << 3); }
+__device__ __forceinline__ int e_idx(int row, int c) { return row * 64 + ((c ^ ((row >> 1) & 7)) << 3); }
+
+// A fragments of one k-block for the wave's (up to) two n-tiles, both planes.  Plain named
+// members (no arrays passed by reference): hipcc (ROCm 7.2) mis-allocates registers for the
+// array-reference form of this loop on gfx950 (address temporaries land in a live operand).
+struct AFrag { half8 t0h, t0l, t1h, t1l; };
+
+template <int NT, int KBP, int KBH, bool PRE_VIEW>
+__device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc1)[NT][2], AFrag& an,
+                                             const half8* __restrict__ wp,
+                                             const half8* __restrict__ wp_next, int kb_next,
+                                             const _Float16* eh, const _Float16* el,
+                                             const _Float16* xh, const _Float16* xl, int lane) {
+  constexpr int KB = KBP + KBH;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { acc0[t][p][i] = 0.f; acc1[t][p][i] = 0.f; }
+
+  // activation fragment (both planes) of point tile p for k-block kb
+#define LOAD_B(KBX, PX, BH, BL)                                                              \
+  {                                                                                          \
+    const int kb_ = (KBX);                                                                   \
+    if (KBP > 0 && kb_ < KBP) {                                                              \
+      if (PRE_VIEW) {                                                                        \
+        BH = *reinterpret_cast<const half8*>(eh + ((PX)*32 + r) * 16 + hh * 8);               \
+        BL = *reinterpret_cast<const half8*>(el + ((PX)*32 + r) * 16 + hh * 8);               \
+      } else {                                                                               \
+        const int o_ = e_idx((PX)*32 + r, 2 * kb_ + hh);                                     \
+        BH = *reinterpret_cast<const half8*>(eh + o_);                                       \
+        BL = *reinterpret_cast<const half8*>(el + o_);                                       \
+      }                                                                                      \
+    } else {                                                                                 \
+      const int o_ = x_idx((PX)*32 + r, 2 * (kb_ - KBP) + hh);                               \
+      BH = *reinterpret_cast<const half8*>(xh + o_);                                         \
+      BL = *reinterpret_cast<const half8*>(xl + o_);                                         \
+    }                                                                                        \
+  }
+// six MFMAs of one point tile: the two dependent updates of each acc1 are kept >= 3 MFMAs apart
+#define MFMA6(PX, A, VH, VL)                                                                   \
+  acc0[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0h, VH, acc0[0][PX], 0, 0, 0);        \
+  acc1[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0h, VL, acc1[0][PX], 0, 0, 0);        \
+  if (NT > 1) {                                                                                \
+    acc0[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1h, VH, acc0[NT - 1][PX], 0, 0, 0); \
+    acc1[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1h, VL, acc1[NT - 1][PX], 0, 0, 0); \
+  }                                                                                            \
+  acc1[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0l, VH, acc1[0][PX], 0, 0, 0);        \
+  if (NT > 1)                                                                                  \
+    acc1[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1l, VH, acc1[NT - 1][PX], 0, 0, 0);
+
+  // register plan: A (weights, L2 latency) is fetched a whole k-block ahead; B (LDS) ping-pongs
+  // between the two point tiles inside the block: b1 of this block loads under the p=0 MFMAs,
+  // b0 of the next block under the p=1 MFMAs.
+  half8 b0h, b0l, b1h, b1l;
+  LOAD_B(0, 0, b0h, b0l)
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    const AFrag a = an;
+    if (kb + 1 < KB) {
+      an.t0h = wp[((kb + 1) * 2 + 0) * 64 + lane];
+      an.t0l = wp[((kb + 1) * 2 + 1) * 64 + lane];
+      if (NT > 1) {
+        an.t1h = wp[((KB + kb + 1) * 2 + 0) * 64 + lane];
+        an.t1l = wp[((KB + kb + 1) * 2 + 1) * 64 + lane];
+      }
+    } else {   // last k-block: the next layer's first weights
+      an.t0h = wp_next[lane];
+      an.t0l = wp_next[64 + lane];
+      an.t1h = wp_next[(kb_next * 2 + 0) * 64 + lane];
+      an.t1l = wp_next[(kb_next * 2 + 1) * 64 + lane];
+    }
+    LOAD_B(kb, 1, b1h, b1l)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA6(0, a, b0h, b0l)
+    __builtin_amdgcn_sched_barrier(0);
+    LOAD_B(kb + 1 < KB ? kb + 1 : kb, 0, b0h, b0l)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA6(1, a, b1h, b1l)
+  }
+#undef LOAD_B
+#undef MFMA6
+}
+
+// coalesced fp32 copy of the two-plane tile (first ncols columns, optional per-row scale) to
+// dst[P][256] as full rows
+__device__ __forceinline__ void save_tile_h(const _Float16* xh, const _Float16* xl, float* __restrict__ dst,
+                                            int p0, int P, int ncols, const float* row_scale, int tid) {
+  const int cpr = ncols >> 3;                           // 8-half chunks per row
+  for (int i = tid; i < HM * cpr; i += 256) {
+    const int row = i / cpr, c = i - row * cpr;
+    if (p0 + row < P) {
+      const half8 vh = *reinterpret_cast<const half8*>(xh + x_idx(row, c));
+      const half8 vl = *reinterpret_cast<const half8*>(xl + x_idx(row, c));
+      const float sc = row_scale ? row_scale[row] : 1.0f;
+      f32x4 o0, o1;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        o0[j] = ((float)vh[j] + (float)vl[j] * LINV) * sc;
+        o1[j] = ((float)vh[4 + j] + (float)vl[4 + j] * LINV) * sc;
+      }
+      float* o = dst + (size_t)(p0 + row) * W + 8 * c;
+      *reinterpret_cast<f32x4*>(o) = o0;
+      *reinterpret_cast<f32x4*>(o + 4) = o1;
+    }
+  }
+}
+
+}  // namespace scade

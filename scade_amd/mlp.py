@@ -20,7 +20,10 @@ class MlpEmbeddedFn(torch.autograd.Function):
         acts = None
         if train:
             acts = ops.mlp_acts_alloc(x.shape[0], x.device)
-        out = ops.mlp_fwd_embedded(packed, x, acts)
+        if train and net.train_precision == "f16x3":
+            out = ops.mlp_fwd_f16(net.packed_f16(), x, None, None, acts)
+        else:
+            out = ops.mlp_fwd_embedded(packed, x, acts)
         ctx.net, ctx.mode = net, 0
         ctx.save_for_backward(x, acts if acts is not None else x.new_empty(0))
         return out
@@ -43,7 +46,10 @@ class MlpPointsFn(torch.autograd.Function):
         if train:
             P = pts.shape[0] * pts.shape[1]
             acts = ops.mlp_acts_alloc(P, pts.device)
-        out = ops.mlp_fwd_points(packed, pts, viewdirs, bb, acts)
+        if train and net.train_precision == "f16x3":
+            out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts)
+        else:
+            out = ops.mlp_fwd_points(packed, pts, viewdirs, bb, acts)
         ctx.net, ctx.mode = net, 1
         ctx.save_for_backward(pts, viewdirs, bb, acts if acts is not None else pts.new_empty(0))
         return out

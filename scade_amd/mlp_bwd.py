@@ -10,7 +10,12 @@ def mlp_backward(net, acts, g_out):
     """-> list of 24 gradient tensors in ops.PARAM_ORDER (views of one flat buffer)."""
     if acts is None or acts.numel() == 0:
         raise RuntimeError("scade_amd: MLP backward called but the forward did not save activations")
-    flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
+    if net.train_precision == "f16x3":
+        flat = ops.mlp_bwd_f16(net.packed(), net.packed_t_f16(), acts, g_out)
+    elif net.train_precision == "f32":
+        flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
+    else:
+        raise ValueError("NeRF.train_precision must be 'f32' or 'f16x3'")
     grads, o = [], 0
     for name in ops.PARAM_ORDER:
         shape = ops.PARAM_SHAPES[name]

@@ -154,7 +154,29 @@ def mlp_pack_f16(params: Sequence[Tensor], out: Optional[Tensor] = None) -> Tens
     return out
 
 
-def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb: Optional[Tensor]) -> Tensor:
+def mlp_pack_t_f16(params: Sequence[Tensor]) -> Tensor:
+    keep = [_c(check(p, "mlp_pack_t_f16").detach()) for p in params]
+    out = torch.empty(int(_lib.load().scade_mlp_packed_t_f16_bytes()), device=keep[0].device, dtype=torch.uint8)
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in keep])
+    call("scade_mlp_pack_t_f16", ctypes.cast(arr, ctypes.c_void_p), ptr(out), stream())
+    return out
+
+
+def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tensor) -> Tensor:
+    """Split-precision dgrad + exact wgrad -> flat gradient [589700] in PARAM_ORDER."""
+    g = _c(check(g_out, "mlp_bwd_f16: g_out")).reshape(-1, 4)
+    P = g.shape[0]
+    ws = torch.empty(int(_lib.load().scade_mlp_bwd_workspace_floats(P)), device=g.device, dtype=torch.float32)
+    grad = torch.empty(N_PARAM_FLOATS, device=g.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_bwd_f16", ptr(packed), ptr(packed_t_f16), ptr(acts), ptr(g), P, ptr(ws), ptr(grad), stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_bwd", t0, float(P) * 2 * MLP_FLOP_PER_POINT)
+    return grad
+
+
+def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb: Optional[Tensor],
+                acts: Optional[Tensor] = None) -> Tensor:
     """Split-precision forward: inp [P,60] (viewdirs None) or pts [N,S,3] + viewdirs [N,3] + bb [4]."""
     check(inp, "mlp_fwd_f16: input")
     inp = _c(inp)
@@ -163,7 +185,7 @@ def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb:
             raise ValueError("mlp_fwd_f16: x must be [P,60]")
         P = inp.shape[0]
         out = torch.empty(P, 4, device=inp.device, dtype=torch.float32)
-        call("scade_mlp_fwd_f16", ptr(packed_f16), 0, ptr(inp), None, 0, None, P, 1, ptr(out), stream())
+        call("scade_mlp_fwd_f16", ptr(packed_f16), 0, ptr(inp), None, 0, None, P, 1, ptr(out), ptr(acts), stream())
         return out
     N, S = inp.shape[0], inp.shape[1]
     viewdirs, vstride = _rows(viewdirs, "mlp_fwd_f16: viewdirs")
@@ -171,7 +193,7 @@ def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb:
     out = torch.empty(N, S, 4, device=inp.device, dtype=torch.float32)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
     call("scade_mlp_fwd_f16", ptr(packed_f16), 1, ptr(inp), ptr(viewdirs), vstride, ptr(bb), N * S, S,
-         ptr(out), stream())
+         ptr(out), ptr(acts), stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_fwd_f16_kernel", t0, float(N * S) * MLP_FLOP_PER_POINT)
     return out

@@ -143,6 +143,9 @@ class NeRF(nn.Module):
         # "f32": exact fp32 MFMA everywhere.  "f16x3": no-grad forwards use the split-precision
         # kernel (two fp16 planes per value, three f16 MFMAs per product; ~1e-6 relative error)
         self.inference_precision = "f32"
+        # "f32": exact training kernels.  "f16x3": forward + input-gradient chain on the
+        # split-precision kernels (weight gradient stays exact fp32)
+        self.train_precision = "f32"
 
     # -- kernel support ----------------------------------------------------
     def _require_supported(self):
@@ -187,6 +190,15 @@ class NeRF(nn.Module):
             self._packed_f16 = ops.mlp_pack_f16(ps)
             self._packed_f16_key = key
         return self._packed_f16
+
+    def packed_t_f16(self):
+        ps = self.ordered_params()
+        key = (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_packed_t_f16", None) is None or key != self._packed_t_f16_key \
+                or self._packed_t_f16.device != ps[0].device:
+            self._packed_t_f16 = ops.mlp_pack_t_f16(ps)
+            self._packed_t_f16_key = key
+        return self._packed_t_f16
 
     def _fast(self, train):
         if self.inference_precision not in ("f32", "f16x3"):

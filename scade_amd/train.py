@@ -35,9 +35,10 @@ class Trainer:
     def __init__(self, coarse, fine, bb_center, bb_scale, n_images=1, lrate=5e-4, scaleshift_lr=1e-7,
                  space_carving_weight=0.007, N_samples=64, N_importance=128, lrate_decay_rate=0.1,
                  lrate_decay_step=400000, freeze_ss=400000, norm_p=2, space_carving_threshold=0.0,
-                 is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0):
+                 is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0, precision="f32"):
         dev = next(coarse.parameters()).device
         self.coarse, self.fine = coarse, fine
+        coarse.train_precision = fine.train_precision = precision      # "f32" (exact) | "f16x3"
         embed_fn, _ = H.get_embedder(9, 0)
         embeddirs_fn, _ = H.get_embedder(0, 0)
         self.query = R.make_network_query_fn(embed_fn, embeddirs_fn, bb_center.to(dev), bb_scale.to(dev))

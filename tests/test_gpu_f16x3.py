@@ -108,3 +108,66 @@ def test_f16x3_repack_and_bad_mode(dev):
     with pytest.raises(ValueError):
         with torch.no_grad():
             net(x)
+
+
+# ---------------------------------------------------------------- split-precision TRAINING mode
+def sub(g):
+    f = g.flatten()
+    return f if f.numel() <= 4096 else f[::97]
+
+
+def test_f16x3_training_gradients_golden(dev):
+    """train_precision='f16x3': forward + dgrad on f16 MFMAs (per-point gradient scale), exact
+    wgrad -- same gradient bar as the exact backward (tests/test_gpu_train.py)."""
+    from test_gpu_train import grad_close
+    g = load_golden("f2_mlp")
+    net = make_net(f2_params(g), dev)
+    net.train_precision = "f16x3"
+    out = net(g["x"].to(dev))
+    # tiny upstream gradients (mean-loss scale) must survive the fp16 dgrad planes
+    (out * g["G"].to(dev) * 1e-6).sum().backward()
+    assert_close(out, g["out"], rtol=1e-4, atol=1e-5, what="f16x3 training forward")
+    for k, p in net.named_parameters():
+        grad_close(sub(p.grad) * 1e6, g["grad/" + k], f"f16x3 d/d{k}")
+        assert rel_l2(sub(p.grad) * 1e6, g["grad/" + k]) < 2e-5, k
+
+
+def test_f16x3_training_many_chunks_and_zero_rows(dev):
+    from test_gpu_train import grad_close
+    params = O.nerf_init(5)
+    net = make_net(params, dev)
+    net.train_precision = "f16x3"
+    torch.manual_seed(9)
+    P = 4000
+    pts = torch.rand(P, 3) * 2 - 1
+    vd = torch.nn.functional.normalize(torch.randn(P, 3), dim=-1)
+    x = torch.cat([O.embed(pts, 9), vd], -1)
+    G = torch.randn(P, 4) * torch.logspace(-9, 0, P)[:, None]      # 9 decades of per-point scale
+    G[::7] = 0.0                                                    # points without gradient
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    (O.nerf_forward(po, x) * G).sum().backward()
+    out = net(x.to(dev))
+    (out * G.to(dev)).sum().backward()
+    for k, p in net.named_parameters():
+        grad_close(p.grad, po[k].grad, f"d/d{k}", rtol=2e-4, scale_atol=5e-5)
+        assert rel_l2(p.grad, po[k].grad) < 2e-5, k
+
+
+def test_f16x3_train_step_golden(dev):
+    from test_gpu_train import grad_close, train_step
+    g = load_golden("f6_render")
+    pc, pf = f6_params(g)
+    coarse, fine, query = build(dev, pc, pf, g["bb_center"], g["bb_scale"])
+    coarse.train_precision = fine.train_precision = "f16x3"
+    scale = torch.ones(1, device=dev, requires_grad=True)
+    shift = torch.zeros(1, device=dev, requires_grad=True)
+    ret, loss = train_step(dev, g, coarse, fine, query, scale, shift)
+    loss.backward()
+    assert_close(loss, g["train/loss"], rtol=1e-4, atol=1e-7, what="loss")
+    for k, p in coarse.named_parameters():
+        want = g[f"grad_coarse/{k}"]
+        got = sub(p.grad) if p.grad is not None else torch.zeros_like(want)
+        if float(want.abs().max()) == 0.0:
+            assert float(got.abs().max()) == 0.0
+        else:
+            grad_close(got, want, f"f16x3 grad coarse.{k}", rtol=2e-4, scale_atol=5e-5)

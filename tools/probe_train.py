@@ -13,6 +13,8 @@ def mk(p):
     net = S.NeRF(D=8, W=256, input_ch=57, output_ch=5, skips=[4], input_ch_views=3, use_viewdirs=True)
     net.load_state_dict(p); return net.to(dev)
 coarse, fine = mk(O.nerf_init(0)), mk(O.nerf_init(1))
+PREC = sys.argv[1] if len(sys.argv) > 1 else "f32"
+coarse.train_precision = fine.train_precision = PREC
 e, _ = S.get_embedder(9, 0); ed, _ = S.get_embedder(0, 0)
 query = S.make_network_query_fn(e, ed, torch.zeros(3, device=dev), torch.tensor(0.2, device=dev))
 rays = O.synthetic_rays(N, seed=0).to(dev)
@@ -36,7 +38,7 @@ t0 = time.perf_counter(); reps = 10
 for _ in range(reps): l = step()
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
 ops.KERNEL_TIMER = None
-print(f"train step: {dt*1e3:.3f} ms  -> {N/dt:.0f} rays/s   loss {float(l):.5f}")
+print(f"[{PREC}] train step: {dt*1e3:.3f} ms  -> {N/dt:.0f} rays/s   loss {float(l):.5f}")
 for k, v in timer.summary().items():
     ms = v['ms'] / v['launches']
     print(f"  {k:16s} launches {v['launches']:3d}  avg {ms:.3f} ms  {v['work']/v['launches']/ms/1e9:.1f} TFLOP/s")
