@@ -1,3 +1,4 @@
+# Run on the GPU box: PMC breakdown (MFMA busy, VALU/LDS/VMEM activity, waits, L2 hits) of the MLP forward kernels
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 CMD="python $R/bench.py --no-cpu-baseline --no-image --no-train --steps 10 --warmup 2"
