@@ -81,12 +81,14 @@ int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in, const f
 
 /* Split-precision variant of scade_mlp_bwd (opt-in training mode): the dgrad chain runs on
  * f16 MFMAs with a per-point power-of-two gradient scale (exactly removed on store); the weight
- * gradient stays on the exact fp32 kernel.  packed = the fp32 forward pack (head weights);
+ * gradient runs on the exact fp32 kernel (wgrad_f16 = 0) or on f16 MFMAs with one power-of-two
+ * scale per launch (wgrad_f16 = 1).  packed = the fp32 forward pack (head weights);
  * packed_t_f16 = scade_mlp_pack_t_f16(params); other arguments as scade_mlp_bwd. */
 long scade_mlp_packed_t_f16_bytes(void);
 int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f16, void* stream);
 int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* acts,
-                      const float* g_out, int P, float* workspace, float* grad_flat, void* stream);
+                      const float* g_out, int P, int wgrad_f16, float* workspace, float* grad_flat,
+                      void* stream);
 
 /* ---- positional encoding (Embedder.embed, helpers:142-172; get_embedder :174-189) */
 /* out[P, D*(1+2*multires)] = [x, sin(x*pi*2^0), cos(x*pi*2^0), ..., cos(x*pi*2^(L-1))] */

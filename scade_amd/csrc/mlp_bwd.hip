@@ -16,6 +16,7 @@
 //      VALU.  mlp_wgrad_reduce_kernel sums the chunk partials (deterministic order)
 //      into one flat gradient in PyTorch parameter layout.
 #include "mlp_tile.h"
+#include "mlp_wgrad.h"
 
 namespace scade {
 
@@ -204,35 +205,6 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
 constexpr int WG_PT = 32;                    // points per LDS stage
 constexpr int WGRAD_LDS_BYTES = (2 * (2 * WG_PT * 256) + 2 * 64 + 2 * WG_PT * 4) * 4;  // double-buffered
 
-enum { WF_BIAS = 1, WF_ALPHA = 2, WF_VIEWCOLS = 4, WF_RGB = 8 };
-
-struct WgradJob {
-  long dz_off;       // float offset of the dZ matrix (row stride 256) in the dz workspace
-  long in_off;       // float offset of the input matrix in the acts workspace
-  int in_stride;     // 256 (activation slot) or 64 (emb)
-  int kw;            // tile width in k: 256 or 64
-  int n_rows;        // valid output rows (256 or 128)
-  int w_off;         // flat-gradient offset of the weight tensor
-  int ld;            // its row length
-  int kcol0;         // first column written
-  int kvalid;        // columns written
-  int b_off;         // flat-gradient offset of the bias (WF_BIAS)
-  int flags;
-  int aux_off;       // WF_ALPHA: offset of alpha weight (bias follows at +256); WF_VIEWCOLS: unused
-};
-
-constexpr int MAX_WGRAD_JOBS = 16;
-struct WgradArgs {
-  WgradJob jobs[MAX_WGRAD_JOBS];
-  const float* acts;
-  const float* dz;
-  const float* g_out;   // [P,4] (rgb head)
-  float* partial;       // [nchunks][N_PARAM_FLOATS]
-  int P;
-  int chunk;            // points per chunk (multiple of WG_PT)
-  int njobs;
-};
-
 template <int KW>
 __device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJob& jb, float* lds,
                                                int c0, int c1, float* __restrict__ out) {
@@ -398,37 +370,6 @@ __device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJo
   }
 }
 
-// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c]
-__device__ __forceinline__ void wgrad_rgb_job(const WgradArgs& a, const WgradJob& jb, float* lds,
-                                              int c0, int c1, float* __restrict__ out) {
-  const int tid = threadIdx.x;
-  const int k = tid & 127, part = tid >> 7;     // 4 point-interleaved parts
-  const float* __restrict__ hv = a.acts + jb.in_off;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  for (int pt = c0 + part; pt < c1; pt += 4) {
-    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
-    const float h = hv[(size_t)pt * 256 + k];
-    s0 = fmaf(g[0], h, s0); s1 = fmaf(g[1], h, s1); s2 = fmaf(g[2], h, s2);
-    b0 += g[0]; b1 += g[1]; b2 += g[2];
-  }
-  float* red = lds;                               // [4][6][128]
-  red[(part * 6 + 0) * 128 + k] = s0; red[(part * 6 + 1) * 128 + k] = s1;
-  red[(part * 6 + 2) * 128 + k] = s2; red[(part * 6 + 3) * 128 + k] = b0;
-  red[(part * 6 + 4) * 128 + k] = b1; red[(part * 6 + 5) * 128 + k] = b2;
-  __syncthreads();
-  if (tid < 384) {
-    const int c = tid >> 7;
-    float s = 0.f;
-    for (int p = 0; p < 4; ++p) s += red[(p * 6 + c) * 128 + k];
-    out[jb.w_off + c * 128 + k] = s;
-  }
-  if (tid < 3) {
-    float s = 0.f;
-    for (int p = 0; p < 4; ++p) s += red[(p * 6 + 3 + tid) * 128 + 0];
-    out[jb.b_off + tid] = s;
-  }
-}
-
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const WgradJob& jb = a.jobs[blockIdx.y];
@@ -473,37 +414,10 @@ extern "C" int scade_mlp_pack_t(const float* const* params, float* packed_t, voi
   return scade_check_launch("scade_mlp_pack_t");
 }
 
-// flat-gradient offsets of the 24 parameter tensors (PARAM order of mlp_layout.h)
-static void param_offsets(int off[N_PARAM_TENSORS + 1]) {
-  int o = 0, i = 0;
-  for (int l = 0; l < 8; ++l) {
-    const int k = l == 0 ? 57 : (l == 5 ? 313 : 256);
-    off[i++] = o; o += 256 * k;
-    off[i++] = o; o += 256;
-  }
-  off[i++] = o; o += 128 * 259;
-  off[i++] = o; o += 128;
-  off[i++] = o; o += 256 * 256;
-  off[i++] = o; o += 256;
-  off[i++] = o; o += 256;
-  off[i++] = o; o += 1;
-  off[i++] = o; o += 3 * 128;
-  off[i++] = o; o += 3;
-  off[i] = o;
-}
-
-static int pick_chunks(int P) {
-  // ~13 job-equivalents per chunk; aim at >= 6 workgroups per CU-slot overall
-  int n = P / 1536;
-  if (n < 1) n = 1;
-  if (n > 256) n = 256;
-  return n;
-}
-
 extern "C" int scade_mlp_bwd_chunks(int P) { return pick_chunks(P); }
 
 extern "C" long scade_mlp_bwd_workspace_floats(int P) {
-  return dz_floats(P) + (long)pick_chunks(P) * N_PARAM_FLOATS;
+  return dz_floats(P) + (long)pick_chunks(P) * N_PARAM_FLOATS + 4;   // + launch-wide max slot (f16x3 mode)
 }
 
 // wgrad + reduce (shared by the exact and the split-precision backward)
@@ -516,35 +430,9 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  int off[N_PARAM_TENSORS + 1];
-  param_offsets(off);
   WgradArgs w{};
-  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial; w.P = P;
-  const int nchunks = pick_chunks(P);
-  int chunk = (P + nchunks - 1) / nchunks;
-  chunk = (chunk + WG_PT - 1) / WG_PT * WG_PT;
-  w.chunk = chunk;
-  const int grid_x = (P + chunk - 1) / chunk;
-  int nj = 0;
-  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
-  auto add = [&](long dzo, long ino, int ins, int kw, int nrows, int woff, int ld, int kcol0,
-                 int kvalid, int boff, int flags, int aux) {
-    WgradJob& j = w.jobs[nj++];
-    j.dz_off = dzo; j.in_off = ino; j.in_stride = ins; j.kw = kw; j.n_rows = nrows; j.w_off = woff;
-    j.ld = ld; j.kcol0 = kcol0; j.kvalid = kvalid; j.b_off = boff; j.flags = flags; j.aux_off = aux;
-  };
-  // big jobs first, small last (tail filling)
-  for (int l = 1; l <= 7; ++l) {
-    const int ld = l == 5 ? 313 : 256, kc0 = l == 5 ? 57 : 0;
-    add(slot(l), slot(l - 1), 256, 256, 256, off[2 * l], ld, kc0, 256, off[2 * l + 1], WF_BIAS, 0);
-  }
-  add(slot(SLOT_FEAT), slot(7), 256, 256, 256, off[18], 256, 0, 256, off[19], WF_BIAS | WF_ALPHA, off[20]);
-  add(slot(SLOT_VIEWS_H), slot(SLOT_FEAT), 256, 256, 128, off[16], 259, 0, 256, off[17],
-      WF_BIAS | WF_VIEWCOLS, 0);
-  add(slot(0), acts_emb_off(P), 64, 64, 256, off[0], 57, 0, 57, off[1], WF_BIAS, 0);
-  add(slot(5), acts_emb_off(P), 64, 64, 256, off[10], 313, 0, 57, 0, 0, 0);
-  add(0, slot(SLOT_VIEWS_H), 256, 0, 0, off[22], 128, 0, 0, off[23], WF_RGB, 0);
-  w.njobs = nj;
+  const int grid_x = build_wgrad_jobs(w, acts, dz, g_out, partial, P, WG_PT);
+  const int nj = w.njobs;
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid_x, nj), dim3(512), WGRAD_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
   hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);

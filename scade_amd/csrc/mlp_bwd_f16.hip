@@ -11,6 +11,7 @@
 // the chain is linear in g_out[p] and the product only mixes features, never points, so the
 // scale factors out exactly and is removed when the fp32 rows are stored.
 #include "mlp_tile_f16.h"
+#include "mlp_wgrad.h"
 
 namespace scade {
 
@@ -63,6 +64,7 @@ struct MlpDgradF16Args {
   const float* acts;
   const float* g_out;        // [P,4]
   float* dz;                 // dz_floats(P)
+  unsigned int* gmax;        // launch-wide max of |g_out| (float bits; zeroed before the launch)
   int P;
 };
 
@@ -142,6 +144,12 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
       dal[row] = da * s;
       inv_s[row] = 1.f / s;
     }
+    {   // launch-wide max for the weight-gradient kernel's dZ scale: one atomic per wave
+      float wm = (m < 3.0e38f) ? m : 0.f;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
+      if (lane == 0 && wm > 0.f) atomicMax(a.gmax, __float_as_uint(wm));
+    }
     const float* wr = pk + OFF_WR;
     const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
     float* dzv = dz + acts_slot_off(P, SLOT_VIEWS_H);
@@ -218,6 +226,223 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
 
 constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4;
 
+// ---------------------------------------------------------------------------
+// B2': split-precision weight gradient.  dW[n][k] = sum_points dZ[p][n] * In[p][k] contracts
+// over POINTS, so both MFMA operands need 8 consecutive points of ONE column per lane: tiles are
+// transposed on their way into LDS -- a thread loads one column of 8 consecutive point rows
+// (a wave load = 64 consecutive columns of one row, 256 B coalesced), splits the 8 values into
+// two fp16 planes and stores each with ONE ds_write_b128 into [column][16 points + pad]; both
+// write and ds_read_b128 fragment patterns are bank-conflict free at a 48-byte row.
+//   x = h + l' with l' = fp16(x - h) UNSCALED (may be fp16-subnormal: absolute error <= 2^-25 of
+//   the operand scale), so ONE fp32 accumulator set (128 VGPRs for the 256x256 output) takes
+//   h*h + h*l' + l'*h.  dZ is multiplied by ONE power of two per launch (from max|g_out|, found
+//   by the dgrad kernel) so its large entries sit near 2^8; the partial is scaled back exactly.
+// The VALU riders (bias / alpha head / view columns) use the exact fp32 values in flight.
+// This kernel is HBM-bound (2 KB per point-layer at 5x the fp32 MFMA rate).
+// ---------------------------------------------------------------------------
+constexpr int HW_PT = 16;                                 // points per stage = one k16 block
+constexpr int HW_ROW = 24;                                // halves per LDS row: 16 points + 8 pad (48 B)
+constexpr int HW_PLANE = 256 * HW_ROW;                    // halves per plane
+constexpr int HW_STAGE = 4 * HW_PLANE;                    // Ah Al Bh Bl
+constexpr int WGRAD_F16_LDS_BYTES = 2 * HW_STAGE * 2;     // double buffered: 98304
+
+struct WgradF16Args {
+  WgradArgs w;
+  const float* gmax;    // device scalar: max |g_out| of the launch (float bits)
+};
+
+template <int KW>
+__device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob& jb, _Float16* lds,
+                                              int c0, int c1, float S, float* __restrict__ out) {
+  constexpr int NKT = KW == 256 ? 4 : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int n0 = (wave >> 1) * 64;
+  const int k0 = (wave & 1) * (KW / 2);
+  const bool active = n0 < jb.n_rows;
+  const int P = a.P;
+  const float* __restrict__ dzm = a.dz + jb.dz_off;
+  const float* __restrict__ inm = a.acts + jb.in_off;
+  // staging item of this thread: column `col`, point group g (8 consecutive points)
+  const int col = tid & 255, g = tid >> 8;
+  const bool has_b = KW == 256 || col < 64;
+
+  f32x16 acc[2][NKT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NKT; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float bias_acc = 0.f, alpha_acc = 0.f, dal_acc = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
+
+  float pa[8], pb[8];
+  auto issue = [&](int pt0) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int pt = pt0 + 8 * g + j;
+      pa[j] = pt < c1 ? dzm[(size_t)pt * 256 + col] : 0.f;
+      pb[j] = (has_b && pt < c1) ? inm[(size_t)pt * jb.in_stride + col] : 0.f;
+    }
+  };
+  auto commit = [&](int pt0, int buf) {
+    _Float16* st = lds + buf * HW_STAGE;
+    half8 h, l;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = pa[j] * S;
+      const _Float16 hx = (_Float16)x;
+      h[j] = hx; l[j] = (_Float16)(x - (float)hx);
+    }
+    *reinterpret_cast<half8*>(st + 0 * HW_PLANE + col * HW_ROW + 8 * g) = h;
+    *reinterpret_cast<half8*>(st + 1 * HW_PLANE + col * HW_ROW + 8 * g) = l;
+    if (has_b) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const _Float16 hx = (_Float16)pb[j];
+        h[j] = hx; l[j] = (_Float16)(pb[j] - (float)hx);
+      }
+      *reinterpret_cast<half8*>(st + 2 * HW_PLANE + col * HW_ROW + 8 * g) = h;
+      *reinterpret_cast<half8*>(st + 3 * HW_PLANE + col * HW_ROW + 8 * g) = l;
+    }
+    // exact fp32 riders on the values in flight
+    if (jb.flags & WF_BIAS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bias_acc += pa[j];
+    }
+    if (jb.flags & WF_ALPHA) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pt = pt0 + 8 * g + j;
+        const float da = pt < c1 ? a.dz[dz_dalpha_off(P) + pt] : 0.f;
+        alpha_acc = fmaf(da, pb[j], alpha_acc);
+        if (col == 0) dal_acc += da;
+      }
+    }
+    if ((jb.flags & WF_VIEWCOLS) && col < 128) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int pt = pt0 + 8 * g + j;
+        if (pt < c1) {
+          const float* vw = a.acts + acts_emb_off(P) + (size_t)pt * 64 + 60;
+          vc0 = fmaf(pa[j], vw[0], vc0);
+          vc1 = fmaf(pa[j], vw[1], vc1);
+          vc2 = fmaf(pa[j], vw[2], vc2);
+        }
+      }
+    }
+  };
+
+  issue(c0);
+  commit(c0, 0);
+  if (c0 + HW_PT < c1) issue(c0 + HW_PT);
+  __syncthreads();
+  int buf = 0;
+  for (int pt0 = c0; pt0 < c1; pt0 += HW_PT, buf ^= 1) {
+    if (pt0 + HW_PT < c1) commit(pt0 + HW_PT, buf ^ 1);
+    if (pt0 + 2 * HW_PT < c1) issue(pt0 + 2 * HW_PT);
+    if (active) {
+      const _Float16* st = lds + buf * HW_STAGE;
+      half8 ah[2], al[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int o = (n0 + 32 * t + r) * HW_ROW + 8 * hh;
+        ah[t] = *reinterpret_cast<const half8*>(st + 0 * HW_PLANE + o);
+        al[t] = *reinterpret_cast<const half8*>(st + 1 * HW_PLANE + o);
+      }
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        const int o = (k0 + 32 * u + r) * HW_ROW + 8 * hh;
+        const half8 bh = *reinterpret_cast<const half8*>(st + 2 * HW_PLANE + o);
+        const half8 bl = *reinterpret_cast<const half8*>(st + 3 * HW_PLANE + o);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][u], 0, 0, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- write the partial (dZ scale removed) ---------------------------------------------
+  const float invS = 1.0f / S;
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        const int k = k0 + 32 * u + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (n < jb.n_rows && k < jb.kvalid)
+            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k] = acc[t][u][i] * invS;
+        }
+      }
+  }
+  // riders: the two point groups of a column are combined through LDS
+  float* red = reinterpret_cast<float*>(lds);      // [2][256][5]
+  red[(g * 256 + col) * 5 + 0] = bias_acc;
+  red[(g * 256 + col) * 5 + 1] = alpha_acc;
+  red[(g * 256 + col) * 5 + 2] = vc0;
+  red[(g * 256 + col) * 5 + 3] = vc1;
+  red[(g * 256 + col) * 5 + 4] = vc2;
+  __syncthreads();
+  if (tid < 256) {
+    const float* r0 = red + (size_t)tid * 5, *r1 = red + (size_t)(256 + tid) * 5;
+    if ((jb.flags & WF_BIAS) && tid < jb.n_rows) out[jb.b_off + tid] = r0[0] + r1[0];
+    if (jb.flags & WF_ALPHA) out[jb.aux_off + tid] = r0[1] + r1[1];
+    if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
+      out[jb.w_off + (size_t)tid * jb.ld + 256] = r0[2] + r1[2];
+      out[jb.w_off + (size_t)tid * jb.ld + 257] = r0[3] + r1[3];
+      out[jb.w_off + (size_t)tid * jb.ld + 258] = r0[4] + r1[4];
+    }
+  }
+  if (jb.flags & WF_ALPHA) {
+    // d alpha bias: the two group partials held by the col == 0 threads (tid 0 and 256); no
+    // static __shared__ here (it would shift the 16-byte aligned dynamic LDS base)
+    float* dsum = red + 2 * 256 * 5;
+    if (col == 0) dsum[g] = dal_acc;
+    __syncthreads();
+    if (tid == 0) out[jb.aux_off + 256] = dsum[0] + dsum[1];
+  }
+}
+
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 ldsw[];
+  const WgradArgs& a = fa.w;
+  const WgradJob& jb = a.jobs[blockIdx.y];
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = min(a.P, c0 + a.chunk);
+  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
+  // one power-of-two scale for dZ: max|g_out| * S in [2^7, 2^8)
+  float S = 1.f;
+  const float m = fa.gmax[0];
+  if (m > 0.f && m < 3.0e38f) {
+    int e;
+    frexpf(m, &e);
+    S = ldexpf(1.f, 8 - e);
+  }
+  if (jb.flags & WF_RGB) {
+    wgrad_rgb_job(a, jb, reinterpret_cast<float*>(ldsw), c0, c1, out);
+  } else if (jb.kw == 256) {
+    wgrad_f16_job<256>(a, jb, ldsw, c0, c1, S, out);
+  } else {
+    wgrad_f16_job<64>(a, jb, ldsw, c0, c1, S, out);
+  }
+}
+
+__global__ void wgrad_reduce_f16_kernel(const float* partial, int nchunks, float* grad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N_PARAM_FLOATS; i += gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
+    grad[i] = s;
+  }
+}
+
 }  // namespace scade
 
 using namespace scade;
@@ -237,8 +462,8 @@ extern "C" int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f
 }
 
 extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* acts,
-                                 const float* g_out, int P, float* workspace, float* grad_flat,
-                                 void* stream) {
+                                 const float* g_out, int P, int wgrad_f16, float* workspace,
+                                 float* grad_flat, void* stream) {
   SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd_f16: P must be positive");
   SCADE_REQUIRE(packed && packed_t_f16 && acts && g_out && workspace && grad_flat, -1,
                 "scade_mlp_bwd_f16: null pointer");
@@ -252,8 +477,27 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   }
   float* dz = workspace;
   float* partial = workspace + dz_floats(P);
-  MlpDgradF16Args d{packed, reinterpret_cast<const _Float16*>(packed_t_f16), acts, g_out, dz, P};
+  // workspace tail: [dz | partial | gmax]
+  const int nchunks = pick_chunks(P);
+  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)nchunks * N_PARAM_FLOATS);
+  hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
+  SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_f16: hipMemsetAsync: %s", hipGetErrorString(me));
+  MlpDgradF16Args d{packed, reinterpret_cast<const _Float16*>(packed_t_f16), acts, g_out, dz, gmax, P};
   hipLaunchKernelGGL(mlp_dgrad_f16_kernel, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(dgrad)")) return e;
-  return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
+  if (!wgrad_f16) return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
+  static bool wattr = false;
+  if (!wattr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_f16_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_F16_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    wattr = true;
+  }
+  WgradF16Args fa{};
+  const int grid_x = build_wgrad_jobs(fa.w, acts, dz, g_out, partial, P, HW_PT);
+  fa.gmax = reinterpret_cast<const float*>(gmax);
+  hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(grid_x, fa.w.njobs), dim3(512), WGRAD_F16_LDS_BYTES, s, fa);
+  if (int e = scade_check_launch("scade_mlp_bwd_f16(wgrad)")) return e;
+  hipLaunchKernelGGL(wgrad_reduce_f16_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);
+  return scade_check_launch("scade_mlp_bwd_f16(reduce)");
 }

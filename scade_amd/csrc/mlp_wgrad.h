@@ -1,0 +1,128 @@
+// Job table of the weight-gradient kernels (exact fp32 and split-precision variants share it).
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+
+namespace scade {
+
+enum { WF_BIAS = 1, WF_ALPHA = 2, WF_VIEWCOLS = 4, WF_RGB = 8 };
+
+struct WgradJob {
+  long dz_off;       // float offset of the dZ matrix (row stride 256) in the dz workspace
+  long in_off;       // float offset of the input matrix in the acts workspace
+  int in_stride;     // 256 (activation slot) or 64 (emb)
+  int kw;            // tile width in k: 256 or 64
+  int n_rows;        // valid output rows (256 or 128)
+  int w_off;         // flat-gradient offset of the weight tensor
+  int ld;            // its row length
+  int kcol0;         // first column written
+  int kvalid;        // columns written
+  int b_off;         // flat-gradient offset of the bias (WF_BIAS)
+  int flags;
+  int aux_off;       // WF_ALPHA: offset of alpha weight (bias follows at +256); WF_VIEWCOLS: unused
+};
+
+constexpr int MAX_WGRAD_JOBS = 16;
+struct WgradArgs {
+  WgradJob jobs[MAX_WGRAD_JOBS];
+  const float* acts;
+  const float* dz;
+  const float* g_out;   // [P,4] (rgb head)
+  float* partial;       // [nchunks][N_PARAM_FLOATS]
+  int P;
+  int chunk;            // points per chunk (multiple of WG_PT)
+  int njobs;
+};
+
+// flat-gradient offsets of the 24 parameter tensors (PARAM order of mlp_layout.h)
+inline void param_offsets(int off[N_PARAM_TENSORS + 1]) {
+  int o = 0, i = 0;
+  for (int l = 0; l < 8; ++l) {
+    const int k = l == 0 ? 57 : (l == 5 ? 313 : 256);
+    off[i++] = o; o += 256 * k;
+    off[i++] = o; o += 256;
+  }
+  off[i++] = o; o += 128 * 259;
+  off[i++] = o; o += 128;
+  off[i++] = o; o += 256 * 256;
+  off[i++] = o; o += 256;
+  off[i++] = o; o += 256;
+  off[i++] = o; o += 1;
+  off[i++] = o; o += 3 * 128;
+  off[i++] = o; o += 3;
+  off[i] = o;
+}
+
+inline int pick_chunks(int P) {
+  // ~13 job-equivalents per chunk; aim at >= 6 workgroups per CU-slot overall
+  int n = P / 1536;
+  if (n < 1) n = 1;
+  if (n > 256) n = 256;
+  return n;
+}
+
+// fills w (12 jobs, chunking) and returns grid.x; chunk is rounded to a multiple of `stage_pts`
+inline int build_wgrad_jobs(WgradArgs& w, const float* acts, const float* dz, const float* g_out,
+                            float* partial, int P, int stage_pts) {
+  int off[N_PARAM_TENSORS + 1];
+  param_offsets(off);
+  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial; w.P = P;
+  const int nchunks = pick_chunks(P);
+  int chunk = (P + nchunks - 1) / nchunks;
+  chunk = (chunk + stage_pts - 1) / stage_pts * stage_pts;
+  w.chunk = chunk;
+  int nj = 0;
+  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
+  auto add = [&](long dzo, long ino, int ins, int kw, int nrows, int woff, int ld, int kcol0,
+                 int kvalid, int boff, int flags, int aux) {
+    WgradJob& j = w.jobs[nj++];
+    j.dz_off = dzo; j.in_off = ino; j.in_stride = ins; j.kw = kw; j.n_rows = nrows; j.w_off = woff;
+    j.ld = ld; j.kcol0 = kcol0; j.kvalid = kvalid; j.b_off = boff; j.flags = flags; j.aux_off = aux;
+  };
+  // big jobs first, small last (tail filling)
+  for (int l = 1; l <= 7; ++l) {
+    const int ld = l == 5 ? 313 : 256, kc0 = l == 5 ? 57 : 0;
+    add(slot(l), slot(l - 1), 256, 256, 256, off[2 * l], ld, kc0, 256, off[2 * l + 1], WF_BIAS, 0);
+  }
+  add(slot(SLOT_FEAT), slot(7), 256, 256, 256, off[18], 256, 0, 256, off[19], WF_BIAS | WF_ALPHA, off[20]);
+  add(slot(SLOT_VIEWS_H), slot(SLOT_FEAT), 256, 256, 128, off[16], 259, 0, 256, off[17],
+      WF_BIAS | WF_VIEWCOLS, 0);
+  add(slot(0), acts_emb_off(P), 64, 64, 256, off[0], 57, 0, 57, off[1], WF_BIAS, 0);
+  add(slot(5), acts_emb_off(P), 64, 64, 256, off[10], 313, 0, 57, 0, 0, 0);
+  add(0, slot(SLOT_VIEWS_H), 256, 0, 0, off[22], 128, 0, 0, off[23], WF_RGB, 0);
+  w.njobs = nj;
+  return (P + chunk - 1) / chunk;
+}
+
+// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c]
+__device__ __forceinline__ void wgrad_rgb_job(const WgradArgs& a, const WgradJob& jb, float* lds,
+                                              int c0, int c1, float* __restrict__ out) {
+  const int tid = threadIdx.x;
+  const int k = tid & 127, part = tid >> 7;     // 4 point-interleaved parts
+  const float* __restrict__ hv = a.acts + jb.in_off;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (int pt = c0 + part; pt < c1; pt += 4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    const float h = hv[(size_t)pt * 256 + k];
+    s0 = fmaf(g[0], h, s0); s1 = fmaf(g[1], h, s1); s2 = fmaf(g[2], h, s2);
+    b0 += g[0]; b1 += g[1]; b2 += g[2];
+  }
+  float* red = lds;                               // [4][6][128]
+  red[(part * 6 + 0) * 128 + k] = s0; red[(part * 6 + 1) * 128 + k] = s1;
+  red[(part * 6 + 2) * 128 + k] = s2; red[(part * 6 + 3) * 128 + k] = b0;
+  red[(part * 6 + 4) * 128 + k] = b1; red[(part * 6 + 5) * 128 + k] = b2;
+  __syncthreads();
+  if (tid < 384) {
+    const int c = tid >> 7;
+    float s = 0.f;
+    for (int p = 0; p < 4; ++p) s += red[(p * 6 + c) * 128 + k];
+    out[jb.w_off + c * 128 + k] = s;
+  }
+  if (tid < 3) {
+    float s = 0.f;
+    for (int p = 0; p < 4; ++p) s += red[(p * 6 + 3 + tid) * 128 + 0];
+    out[jb.b_off + tid] = s;
+  }
+}
+
+}  // namespace scade

@@ -20,7 +20,7 @@ class MlpEmbeddedFn(torch.autograd.Function):
         acts = None
         if train:
             acts = ops.mlp_acts_alloc(x.shape[0], x.device)
-        if train and net.train_precision == "f16x3":
+        if train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), x, None, None, acts)
         else:
             out = ops.mlp_fwd_embedded(packed, x, acts)
@@ -46,7 +46,7 @@ class MlpPointsFn(torch.autograd.Function):
         if train:
             P = pts.shape[0] * pts.shape[1]
             acts = ops.mlp_acts_alloc(P, pts.device)
-        if train and net.train_precision == "f16x3":
+        if train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts)
         else:
             out = ops.mlp_fwd_points(packed, pts, viewdirs, bb, acts)

@@ -10,12 +10,13 @@ def mlp_backward(net, acts, g_out):
     """-> list of 24 gradient tensors in ops.PARAM_ORDER (views of one flat buffer)."""
     if acts is None or acts.numel() == 0:
         raise RuntimeError("scade_amd: MLP backward called but the forward did not save activations")
-    if net.train_precision == "f16x3":
-        flat = ops.mlp_bwd_f16(net.packed(), net.packed_t_f16(), acts, g_out)
+    if net.train_precision in ("f16x3", "f16x3-dgrad"):
+        flat = ops.mlp_bwd_f16(net.packed(), net.packed_t_f16(), acts, g_out,
+                               wgrad_f16=net.train_precision == "f16x3")
     elif net.train_precision == "f32":
         flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
     else:
-        raise ValueError("NeRF.train_precision must be 'f32' or 'f16x3'")
+        raise ValueError("NeRF.train_precision must be 'f32', 'f16x3' or 'f16x3-dgrad'")
     grads, o = [], 0
     for name in ops.PARAM_ORDER:
         shape = ops.PARAM_SHAPES[name]

@@ -162,14 +162,16 @@ def mlp_pack_t_f16(params: Sequence[Tensor]) -> Tensor:
     return out
 
 
-def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tensor) -> Tensor:
+def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tensor,
+                wgrad_f16: bool = True) -> Tensor:
     """Split-precision dgrad + exact wgrad -> flat gradient [589700] in PARAM_ORDER."""
     g = _c(check(g_out, "mlp_bwd_f16: g_out")).reshape(-1, 4)
     P = g.shape[0]
     ws = torch.empty(int(_lib.load().scade_mlp_bwd_workspace_floats(P)), device=g.device, dtype=torch.float32)
     grad = torch.empty(N_PARAM_FLOATS, device=g.device, dtype=torch.float32)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
-    call("scade_mlp_bwd_f16", ptr(packed), ptr(packed_t_f16), ptr(acts), ptr(g), P, ptr(ws), ptr(grad), stream())
+    call("scade_mlp_bwd_f16", ptr(packed), ptr(packed_t_f16), ptr(acts), ptr(g), P, int(wgrad_f16), ptr(ws),
+         ptr(grad), stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P) * 2 * MLP_FLOP_PER_POINT)
     return grad
