@@ -642,9 +642,9 @@ static inline int grid_rays(int N) { return (N + RAYS_PER_WG - 1) / RAYS_PER_WG;
 extern "C" int scade_ray_points(const float* rays, int ray_stride, const float* t_vals,
                                 const float* t_rand, int N, int S, int lindisp, float* z_vals,
                                 float* pts, void* stream) {
+  if (N <= 0) return 0;
   SCADE_REQUIRE(rays && t_vals && z_vals, -1, "scade_ray_points: null pointer");
   SCADE_REQUIRE(ray_stride >= 8 && S >= 1, -2, "scade_ray_points: ray_stride >= 8 and S >= 1 required");
-  if (N <= 0) return 0;
   RayPointsArgs a{rays, t_vals, t_rand, z_vals, pts, N, S, ray_stride, lindisp};
   hipLaunchKernelGGL(ray_points_kernel, dim3(grid_rays(N)), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_ray_points");
@@ -670,10 +670,10 @@ extern "C" int scade_composite_fwd(const float* raw, const float* z_vals, const 
                                    int d_stride, const float* noise, int N, int S, float* rgb_map,
                                    float* disp_map, float* acc_map, float* weights,
                                    float* depth_map, void* stream) {
+  if (N <= 0) return 0;
   SCADE_REQUIRE(raw && z_vals && rays_d && rgb_map && disp_map && acc_map && weights && depth_map, -1,
                 "scade_composite_fwd: null pointer");
   SCADE_REQUIRE(S >= 1 && S <= 512, -2, "scade_composite_fwd: S=%d outside [1,512]", S);
-  if (N <= 0) return 0;
   CompositeArgs a{};
   a.raw = raw; a.z = z_vals; a.rays_d = rays_d; a.noise = noise; a.rgb_map = rgb_map;
   a.disp_map = disp_map; a.acc_map = acc_map; a.weights = weights; a.depth_map = depth_map;
@@ -687,9 +687,9 @@ extern "C" int scade_composite_bwd(const float* raw, const float* z_vals, const 
                                    const float* g_rgb, const float* g_disp, const float* g_acc,
                                    const float* g_weights, const float* g_depth, float* g_raw,
                                    void* stream) {
+  if (N <= 0) return 0;
   SCADE_REQUIRE(raw && z_vals && rays_d && g_raw, -1, "scade_composite_bwd: null pointer");
   SCADE_REQUIRE(S >= 1 && S <= 512, -2, "scade_composite_bwd: S=%d outside [1,512]", S);
-  if (N <= 0) return 0;
   CompositeArgs a{};
   a.raw = raw; a.z = z_vals; a.rays_d = rays_d; a.noise = noise;
   a.g_rgb = g_rgb; a.g_disp = g_disp; a.g_acc = g_acc; a.g_w = g_weights; a.g_depth = g_depth;
@@ -713,9 +713,9 @@ extern "C" int scade_sample_pdf_fwd(const float* bins, int bins_stride, int bins
   a.bins = bins; a.w = weights; a.u = u; a.cdf_in = cdf_in; a.samples = samples; a.inds = inds;
   a.cdf_out = cdf_out; a.z_std = z_std; a.N = N; a.M = M; a.S = S; a.bins_stride = bins_stride;
   a.w_stride = w_stride; a.u_stride = u_stride; a.bins_are_mids = bins_are_mids;
+  if (N <= 0) return 0;
   if (int e = check_pdf("scade_sample_pdf_fwd", a)) return e;
   SCADE_REQUIRE(samples, -1, "scade_sample_pdf_fwd: samples is null");
-  if (N <= 0) return 0;
   const size_t lds = (size_t)RAYS_PER_WG * 2 * M * sizeof(float);
   hipLaunchKernelGGL(sample_pdf_fwd_kernel, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a);
   return scade_check_launch("scade_sample_pdf_fwd");
@@ -729,9 +729,9 @@ extern "C" int scade_sample_pdf_bwd(const float* bins, int bins_stride, int bins
   a.bins = bins; a.w = weights; a.u = u; a.g_samples = g_samples; a.g_w = g_weights; a.N = N;
   a.M = M; a.S = S; a.bins_stride = bins_stride; a.w_stride = w_stride; a.u_stride = u_stride;
   a.bins_are_mids = bins_are_mids;
+  if (N <= 0) return 0;
   if (int e = check_pdf("scade_sample_pdf_bwd", a)) return e;
   SCADE_REQUIRE(weights && g_samples && g_weights, -1, "scade_sample_pdf_bwd: null pointer");
-  if (N <= 0) return 0;
   const size_t lds = (size_t)RAYS_PER_WG * 4 * M * sizeof(float);
   hipLaunchKernelGGL(sample_pdf_bwd_kernel, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a);
   return scade_check_launch("scade_sample_pdf_bwd");
@@ -740,10 +740,10 @@ extern "C" int scade_sample_pdf_bwd(const float* bins, int bins_stride, int bins
 extern "C" int scade_merge_sorted(const float* z_a, int Sa, const float* z_b, int Sb,
                                   const float* rays, int ray_stride, int N, float* z_out,
                                   float* pts, void* stream) {
+  if (N <= 0 || Sa + Sb == 0) return 0;
   SCADE_REQUIRE(z_a && z_b && z_out, -1, "scade_merge_sorted: null pointer");
   SCADE_REQUIRE(!pts || (rays && ray_stride >= 6), -1, "scade_merge_sorted: pts needs rays");
   SCADE_REQUIRE(Sa >= 0 && Sb >= 0 && Sa + Sb <= 4096, -2, "scade_merge_sorted: Sa+Sb > 4096");
-  if (N <= 0 || Sa + Sb == 0) return 0;
   MergeArgs a{z_a, z_b, rays, z_out, pts, N, Sa, Sb, ray_stride};
   const size_t lds = (size_t)RAYS_PER_WG * (Sa + Sb) * sizeof(float);
   hipLaunchKernelGGL(merge_sorted_kernel, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a);
@@ -840,9 +840,9 @@ __global__ void embed_kernel(const float* x, int P, int D, int L, float* out) {
 }  // namespace scade
 
 extern "C" int scade_embed(const float* x, int P, int D, int multires, float* out, void* stream) {
+  if (P <= 0) return 0;
   SCADE_REQUIRE(x && out, -1, "scade_embed: null pointer");
   SCADE_REQUIRE(D >= 1 && multires >= 0 && multires <= 24, -2, "scade_embed: bad D/multires");
-  if (P <= 0) return 0;
   const size_t items = (size_t)P * D * (1 + multires);
   const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
   hipLaunchKernelGGL(scade::embed_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, P, D, multires, out);
@@ -867,8 +867,8 @@ __global__ void perturb_z_kernel(const float* z, const float* t_rand, int N, int
 
 extern "C" int scade_perturb_z(const float* z_vals, const float* t_rand, int N, int S, float* out,
                                void* stream) {
-  SCADE_REQUIRE(z_vals && t_rand && out, -1, "scade_perturb_z: null pointer");
   if (N <= 0 || S <= 0) return 0;
+  SCADE_REQUIRE(z_vals && t_rand && out, -1, "scade_perturb_z: null pointer");
   const size_t items = (size_t)N * S;
   const int grid = (int)((items + 255) / 256 < 4096 ? (items + 255) / 256 : 4096);
   hipLaunchKernelGGL(scade::perturb_z_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, z_vals, t_rand, N, S, out);
@@ -952,9 +952,9 @@ extern "C" int scade_gen_rays(const int* coords, int N, int H, int W, const floa
                               const float* image, const float* hyps, int K, int corner_px,
                               int edge_px, float* rays, float* rays_o, float* rays_d,
                               float* target_s, float* target_h, float* mask, void* stream) {
+  if (N <= 0) return 0;
   SCADE_REQUIRE(intrinsic && c2w && c2w_stride >= 4, -1, "scade_gen_rays: intrinsic/c2w missing");
   SCADE_REQUIRE(H > 0 && W > 0, -2, "scade_gen_rays: bad image size");
-  if (N <= 0) return 0;
   scade::GenRaysArgs a{coords, intrinsic, c2w, image, hyps, rays, rays_o, rays_d, target_s, target_h,
                        mask, near, far, N, H, W, K, c2w_stride, corner_px, edge_px};
   const int grid = (N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048;

@@ -46,6 +46,9 @@ def test_argument_errors_do_not_need_a_gpu():
     assert rc != 0 and b"null" in lib.scade_last_error()
     rc = lib.scade_composite_fwd(None, None, None, 3, None, 4, 64, None, None, None, None, None, None)
     assert rc != 0
+    # empty problems are no-ops, not errors
+    assert lib.scade_composite_fwd(None, None, None, 3, None, 0, 64, None, None, None, None, None, None) == 0
+    assert lib.scade_mlp_fwd(None, 0, None, None, 0, None, 0, 1, None, None, None) == 0
 
 
 def test_product_path_refuses_cpu_tensors():

@@ -196,3 +196,22 @@ def test_full_image_eval_loop(dev, tmp_path):
 
 
 import numpy as np  # noqa: E402
+
+
+def test_render_rays_ragged_batches(dev):
+    """N = 1, 3, 5 rays (partial workgroups everywhere) and N = 0 (empty batch)."""
+    pc, pf = O.nerf_init(0), O.nerf_init(1)
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+    coarse, fine, query = build(dev, pc, pf, bbc, bbs)
+    rays = O.synthetic_rays(5, seed=9)
+    with torch.no_grad():
+        want = O.render_rays(rays, pc, pf, bbc, bbs, retraw=True)
+        for n in (1, 3, 5):
+            ret = S.render_rays(rays[:n].to(dev), True, coarse, query, 64, N_importance=128, network_fine=fine,
+                                perturb=0., retraw=True)
+            for k in ("rgb0", "weights0", "depth0", "z_vals0"):
+                assert_close(ret[k], want[k][:n], rtol=1e-4, atol=1e-5, what=f"N={n} {k}")
+            assert rel_l2(ret["rgb_map"], want["rgb_map"][:n]) < 1e-4
+        empty = S.render_rays(rays[:0].to(dev), True, coarse, query, 64, N_importance=128, network_fine=fine,
+                              perturb=0., retraw=True)
+    assert empty["rgb_map"].shape == (0, 3) and empty["z_vals"].shape == (0, 192) and empty["raw"].shape == (0, 192, 4)

@@ -278,3 +278,27 @@ def test_training_trajectory_matches_oracle(dev):
     assert want[-1] < 0.5 * want[0] and got[-1] < 0.5 * got[0]
     for a, b in zip(got, want):
         assert abs(a - b) <= 3e-2 * abs(b), (got, want)
+
+
+def test_full_size_backward_properties(dev):
+    """BASELINE size (196,608 points = 1024 rays x 192): the MLP backward is linear in the upstream
+    gradient, deterministic (fixed-order chunk reduction), and blind to a permutation of the points."""
+    params = O.nerf_init(2)
+    net = make_net(params, dev)
+    torch.manual_seed(0)
+    P = 1024 * 192
+    pts = (torch.rand(P, 3) * 2 - 1)
+    vd = torch.nn.functional.normalize(torch.randn(P, 3), dim=-1)
+    x = torch.cat([O.embed(pts, 9), vd], -1).to(dev)
+    G1, G2 = torch.randn(P, 4, device=dev), torch.randn(P, 4, device=dev)
+
+    def grads(inp, G):
+        net.zero_grad(set_to_none=True)
+        (net(inp) * G).sum().backward()
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+
+    g1, g2, g12 = grads(x, G1), grads(x, G2), grads(x, G1 + G2)
+    assert rel_l2(g1 + g2, g12) < 2e-6, "linearity"
+    assert torch.equal(grads(x, G1), g1), "bit-wise deterministic"
+    perm = torch.randperm(P, device=dev)
+    assert rel_l2(grads(x[perm], G1[perm]), g1) < 2e-6, "permutation invariance"
