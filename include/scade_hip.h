@@ -79,6 +79,18 @@ int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in, const f
                       int vd_stride, const float* bb, int P, int S, float* out, float* acts,
                       void* stream);
 
+/* Single-plane 16-bit INFERENCE variant of scade_mlp_fwd (opt-in; BASELINE.json config 5's "bf16 MFMA
+ * path"): activations and weights rounded to fp16 (bf16 = 0) or bfloat16
+ * (bf16 = 1), one v_mfma_f32_32x32x16_{f16,bf16} per product, fp32 accumulate, fp32 biases, heads and
+ * outputs.  Ordinary mixed-precision accuracy (relative ~1e-3 fp16 / ~1e-2 bf16), NOT the 1e-4 parity
+ * bar.  packed_lp = scade_mlp_pack_lp(params, bf16), scade_mlp_packed_lp_bytes() bytes (the format is
+ * baked into the pack: pass the same bf16 flag to both).  Same modes and arguments as scade_mlp_fwd;
+ * no training workspace. */
+long scade_mlp_packed_lp_bytes(void);
+int scade_mlp_pack_lp(const float* const* params, void* packed_lp, int bf16, void* stream);
+int scade_mlp_fwd_lp(const void* packed_lp, int bf16, int mode, const float* in, const float* viewdirs,
+                     int vd_stride, const float* bb, int P, int S, float* out, void* stream);
+
 /* Split-precision variant of scade_mlp_bwd (opt-in training mode): the dgrad chain runs on
  * f16 MFMAs with a per-point power-of-two gradient scale (exactly removed on store); the weight
  * gradient runs on the exact fp32 kernel (wgrad_f16 = 0) or on f16 MFMAs with one power-of-two

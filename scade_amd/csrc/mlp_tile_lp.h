@@ -1,0 +1,111 @@
+// Building blocks of the single-plane 16-bit ("lp": fp16 or bf16 operands, fp32 accumulate)
+// variant of the fused NeRF MLP - BASELINE.json config 5's "bf16 MFMA path".
+//
+// Tile: 128 points per workgroup (4 point tiles of 32), 4 waves, every wave owns 64 output
+// features (2 n-tiles) of all 128 points -> 8 independent v_mfma_f32_32x32x16_{f16,bf16}
+// per 16-channel k-block and 128 accumulator registers per lane.  128 points (not the exact
+// kernel's 64) because the weight stream is the scarce resource at this MFMA rate: every
+// A fragment fetched from L2 now feeds 4 MFMAs, which halves the bytes per point through the
+// vector-memory path (32 B/clk/CU at the full matrix rate instead of 64, the L1 peak).
+// LDS: activations [128][256] + embedding [128][64], 16-bit each = 80 KiB -> 2 workgroups/CU.
+#pragma once
+#include "common.h"
+#include "mlp_layout.h"
+#include "mlp_tile_f16.h"   // kb16/kbp16/kbh16, kmap helpers, x_idx/e_idx swizzles
+
+namespace scade {
+
+template <bool BF> struct LP;
+template <> struct LP<false> {
+  typedef _Float16 T;
+  typedef _Float16 V8 __attribute__((ext_vector_type(8)));
+  typedef _Float16 V4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+  }
+};
+template <> struct LP<true> {
+  typedef __bf16 T;
+  typedef __bf16 V8 __attribute__((ext_vector_type(8)));
+  typedef __bf16 V4 __attribute__((ext_vector_type(4)));
+  static __device__ __forceinline__ f32x16 mfma(V8 a, V8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  }
+};
+
+constexpr int LM = 128;                      // points per workgroup
+constexpr int LPT = LM / 32;                 // point tiles
+constexpr int LXPLANE = LM * W;              // elements of the activation tile
+constexpr int LEPLANE = LM * 64;             // elements of the embedding tile
+constexpr int LP_LDS_BYTES = (LXPLANE + LEPLANE) * 2;   // 81920
+
+// packed blob: per layer [ntile][kb][64 lanes][8 elements]  (counted in 16-bit elements)
+constexpr long wl_elems(int l) { return (long)n_out(l) / 32 * kb16(l) * 64 * 8; }
+constexpr long off_wl(int l) {
+  long o = 0;
+  for (int i = 0; i < l; ++i) o += wl_elems(i);
+  return o;
+}
+constexpr long PACKED_LP_ELEMS = off_wl(NLAYER_MFMA) + 2 * 64 * 8;   // + slack for the prefetch
+constexpr long PACKED_LP_BYTES = PACKED_LP_ELEMS * 2 + F16_TAIL_FLOATS * 4;
+
+template <bool BF>
+struct AFragL { typename LP<BF>::V8 t0, t1; };
+
+// acc[t][p] += W[n-tile t] * act[point tile p] over the layer's k-blocks.  The A operand of the
+// NEXT k-block (or the next layer's first) is in flight during the 8 MFMAs of the current one;
+// the four B fragments of the next block are read from LDS under the same MFMAs.
+template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW>
+__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragL<BF>& an,
+                                              const typename LP<BF>::V8* __restrict__ wp,
+                                              const typename LP<BF>::V8* __restrict__ wp_next, int kb_next,
+                                              const typename LP<BF>::T* e, const typename LP<BF>::T* x,
+                                              int lane) {
+  typedef typename LP<BF>::V8 V8;
+  constexpr int KB = KBP + KBH;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int p = 0; p < LPT; ++p)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
+
+#define LOAD_BL(KBX, PX, B)                                                         \
+  {                                                                                 \
+    const int kb_ = (KBX);                                                          \
+    if (KBP > 0 && kb_ < KBP) {                                                     \
+      if (PRE_VIEW) B = *reinterpret_cast<const V8*>(e + ((PX)*32 + r) * 16 + hh * 8); \
+      else B = *reinterpret_cast<const V8*>(e + e_idx((PX)*32 + r, 2 * kb_ + hh));  \
+    } else {                                                                        \
+      B = *reinterpret_cast<const V8*>(x + x_idx((PX)*32 + r, 2 * (kb_ - KBP) + hh)); \
+    }                                                                               \
+  }
+#define MFMA2(PX, A, B)                                                 \
+  acc[0][PX] = LP<BF>::mfma(A.t0, B, acc[0][PX]);                       \
+  if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(A.t1, B, acc[NT - 1][PX]);
+
+  V8 b0, b1, b2, b3, c0, c1, c2, c3;
+  LOAD_BL(0, 0, b0) LOAD_BL(0, 1, b1) LOAD_BL(0, 2, b2) LOAD_BL(0, 3, b3)
+#pragma unroll 2
+  for (int kb = 0; kb < KB; ++kb) {
+    const AFragL<BF> a = an;
+    if (kb + 1 < KB) {
+      an.t0 = wp[(kb + 1) * 64 + lane];
+      if (NT > 1) an.t1 = wp[(KB + kb + 1) * 64 + lane];
+    } else {   // last k-block: the next layer's first weights
+      an.t0 = wp_next[lane];
+      an.t1 = wp_next[kb_next * 64 + lane];
+    }
+    const int kn = kb + 1 < KB ? kb + 1 : kb;
+    LOAD_BL(kn, 0, c0) LOAD_BL(kn, 1, c1) LOAD_BL(kn, 2, c2) LOAD_BL(kn, 3, c3)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA2(0, a, b0) MFMA2(1, a, b1) MFMA2(2, a, b2) MFMA2(3, a, b3)
+    __builtin_amdgcn_sched_barrier(0);
+    b0 = c0; b1 = c1; b2 = c2; b3 = c3;
+  }
+#undef LOAD_BL
+#undef MFMA2
+}
+
+}  // namespace scade

@@ -201,6 +201,39 @@ def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb:
     return out
 
 
+def mlp_pack_lp(params: Sequence[Tensor], bf16: bool) -> Tensor:
+    """Single-plane 16-bit weight pack (fp16, or bf16 when ``bf16``) for scade_mlp_fwd_lp."""
+    keep = [_c(check(p, "mlp_pack_lp").detach()) for p in params]
+    out = torch.empty(int(_lib.load().scade_mlp_packed_lp_bytes()), device=keep[0].device, dtype=torch.uint8)
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in keep])
+    call("scade_mlp_pack_lp", ctypes.cast(arr, ctypes.c_void_p), ptr(out), int(bf16), stream())
+    return out
+
+
+def mlp_fwd_lp(packed_lp: Tensor, bf16: bool, inp: Tensor, viewdirs: Optional[Tensor],
+               bb: Optional[Tensor]) -> Tensor:
+    """16-bit-operand forward: inp [P,60] (viewdirs None) or pts [N,S,3] + viewdirs [N,3] + bb [4]."""
+    check(inp, "mlp_fwd_lp: input")
+    inp = _c(inp)
+    if viewdirs is None:
+        if inp.dim() != 2 or inp.shape[1] != 60:
+            raise ValueError("mlp_fwd_lp: x must be [P,60]")
+        P = inp.shape[0]
+        out = torch.empty(P, 4, device=inp.device, dtype=torch.float32)
+        call("scade_mlp_fwd_lp", ptr(packed_lp), int(bf16), 0, ptr(inp), None, 0, None, P, 1, ptr(out), stream())
+        return out
+    N, S = inp.shape[0], inp.shape[1]
+    viewdirs, vstride = _rows(viewdirs, "mlp_fwd_lp: viewdirs")
+    bb = _c(check(bb, "mlp_fwd_lp: bb"))
+    out = torch.empty(N, S, 4, device=inp.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_fwd_lp", ptr(packed_lp), int(bf16), 1, ptr(inp), ptr(viewdirs), vstride, ptr(bb), N * S, S,
+         ptr(out), stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_fwd_lp_kernel", t0, float(N * S) * MLP_FLOP_PER_POINT)
+    return out
+
+
 def mlp_fwd_embedded(packed: Tensor, x: Tensor, acts: Optional[Tensor] = None) -> Tensor:
     """NeRF.forward on x[P,60] (mode 0)."""
     check(x, "mlp_fwd: x")

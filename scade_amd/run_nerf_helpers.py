@@ -141,7 +141,9 @@ class NeRF(nn.Module):
         self._packed = None
         self._packed_key = None
         # "f32": exact fp32 MFMA everywhere.  "f16x3": no-grad forwards use the split-precision
-        # kernel (two fp16 planes per value, three f16 MFMAs per product; ~1e-6 relative error)
+        # kernel (two fp16 planes per value, three f16 MFMAs per product; ~1e-6 relative error).
+        # "f16" / "bf16": single-plane 16-bit operands, fp32 accumulate (ordinary mixed precision,
+        # ~1e-3 / ~1e-2 relative error: BASELINE.json config 5's "bf16 MFMA path")
         self.inference_precision = "f32"
         # "f32": exact training kernels.  "f16x3": forward + input-gradient chain on the
         # split-precision kernels (weight gradient stays exact fp32)
@@ -200,10 +202,28 @@ class NeRF(nn.Module):
             self._packed_t_f16_key = key
         return self._packed_t_f16
 
+    def packed_lp(self, bf16):
+        """Single-plane fp16 / bf16 weight pack of the 16-bit inference kernel (same invalidation rule)."""
+        ps = self.ordered_params()
+        key = (bool(bf16), ops.PARAM_EPOCH) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_packed_lp", None) is None or key != self._packed_lp_key \
+                or self._packed_lp.device != ps[0].device:
+            self._packed_lp = ops.mlp_pack_lp(ps, bf16)
+            self._packed_lp_key = key
+        return self._packed_lp
+
+    INFERENCE_PRECISIONS = ("f32", "f16x3", "f16", "bf16")
+
     def _fast(self, train):
-        if self.inference_precision not in ("f32", "f16x3"):
-            raise ValueError("NeRF.inference_precision must be 'f32' or 'f16x3'")
-        return self.inference_precision == "f16x3" and not train
+        if self.inference_precision not in self.INFERENCE_PRECISIONS:
+            raise ValueError("NeRF.inference_precision must be one of %s" % (self.INFERENCE_PRECISIONS,))
+        return self.inference_precision != "f32" and not train
+
+    def _fast_forward(self, inp, viewdirs, bb):
+        if self.inference_precision == "f16x3":
+            return ops.mlp_fwd_f16(self.packed_f16(), inp, viewdirs, bb)
+        bf16 = self.inference_precision == "bf16"
+        return ops.mlp_fwd_lp(self.packed_lp(bf16), bf16, inp, viewdirs, bb)
 
     def forward(self, x):
         """x [P, 60] = [gamma(pts) | viewdir] -> [P,4] (helpers:223-247)."""
@@ -212,7 +232,7 @@ class NeRF(nn.Module):
         ps = self.ordered_params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
         if self._fast(train):
-            return ops.mlp_fwd_f16(self.packed_f16(), x, None, None)
+            return self._fast_forward(x, None, None)
         return MlpEmbeddedFn.apply(self, train, x, *ps)
 
     def forward_points(self, pts, viewdirs, bb):
@@ -222,7 +242,7 @@ class NeRF(nn.Module):
         ps = self.ordered_params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
         if self._fast(train):
-            return ops.mlp_fwd_f16(self.packed_f16(), pts, viewdirs, bb)
+            return self._fast_forward(pts, viewdirs, bb)
         return MlpPointsFn.apply(self, train, pts, viewdirs, bb, *ps)
 
     def load_reference_state_dict(self, state_dict, strict=True):

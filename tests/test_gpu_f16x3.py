@@ -104,7 +104,7 @@ def test_f16x3_repack_and_bad_mode(dev):
     params["pts_linears.2.weight"] = params["pts_linears.2.weight"] * 0.5
     assert_close(b, O.nerf_forward(params, g["x"]), rtol=1e-4, atol=1e-5, what="f16x3 after update")
     assert not torch.allclose(a, b)
-    net.inference_precision = "bf16"
+    net.inference_precision = "fp8"
     with pytest.raises(ValueError):
         with torch.no_grad():
             net(x)

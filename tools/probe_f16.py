@@ -36,11 +36,19 @@ stats("cpu fp32 oracle vs fp64", want32, want)
 stats("exact fp32 kernel vs fp64", exact, want)
 stats("f16x3 kernel vs fp64", fast, want)
 stats("f16x3 vs exact kernel", fast, exact)
+with torch.no_grad():
+    for prec in ("f16", "bf16"):
+        net.inference_precision = prec
+        lp = net.forward_points(pts.to(dev), vd.to(dev), bb).cpu()
+        stats(prec + " kernel vs fp64", lp, want)
+        xe = torch.cat([O.embed((pts.reshape(-1, 3) - bbc) * bbs, 9), vd[:, None, :].expand(N, Sn, 3).reshape(-1, 3)], -1)
+        lp0 = net(xe.to(dev)).cpu().reshape(N, Sn, 4)
+        stats(prec + " mode0 vs mode1", lp0, lp)
 bad = ((fast.double() - want32.double()).abs() > 1e-4 * want32.double().abs() + 1e-5).sum()
 print("elements outside rtol 1e-4 + atol 1e-5 vs the fp32 oracle:", int(bad), "of", fast.numel())
 
 FLOP_PT = 2 * 587264
-for prec in ("f32", "f16x3"):
+for prec in ("f32", "f16x3", "f16", "bf16"):
     net.inference_precision = prec
     for Nn, Ss in ((1024, 64), (1024, 192), (4096, 192)):
         p = torch.rand(Nn, Ss, 3, device=dev) * 10 - 5
