@@ -317,6 +317,8 @@ def main():
         out["train_step"] = train_region(args, dev, world, rank, barrier)
         if not args.no_fast:   # opt-in: forward + dgrad on the split-precision kernels, exact wgrad
             out["train_step_f16x3"] = train_region(args, dev, world, rank, barrier, precision="f16x3")
+            # mixed precision (BASELINE config 5's bf16 MFMA path): 16-bit forward, dgrad and wgrad
+            out["train_step_bf16"] = train_region(args, dev, world, rank, barrier, precision="bf16")
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pc, pf, 1024)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

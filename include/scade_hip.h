@@ -85,11 +85,25 @@ int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in, const f
  * outputs.  Ordinary mixed-precision accuracy (relative ~1e-3 fp16 / ~1e-2 bf16), NOT the 1e-4 parity
  * bar.  packed_lp = scade_mlp_pack_lp(params, bf16), scade_mlp_packed_lp_bytes() bytes (the format is
  * baked into the pack: pass the same bf16 flag to both).  Same modes and arguments as scade_mlp_fwd;
- * no training workspace. */
+ * acts (nullable) = training workspace of scade_mlp_acts_lp_bytes(P) bytes: 16-bit activations, the
+ * embedding rows, fp32 alpha_pre and the ReLU sign words consumed by scade_mlp_bwd_lp. */
 long scade_mlp_packed_lp_bytes(void);
+long scade_mlp_acts_lp_bytes(long P);
 int scade_mlp_pack_lp(const float* const* params, void* packed_lp, int bf16, void* stream);
 int scade_mlp_fwd_lp(const void* packed_lp, int bf16, int mode, const float* in, const float* viewdirs,
-                     int vd_stride, const float* bb, int P, int S, float* out, void* stream);
+                     int vd_stride, const float* bb, int P, int S, float* out, void* acts, void* stream);
+
+/* Mixed-precision backward of scade_mlp_fwd_lp (same mathematics as scade_mlp_bwd): 16-bit dgrad chain
+ * with a per-point power-of-two gradient scale, every layer's dZ stored as 16-bit rows under ONE
+ * launch-wide power-of-two loss scale (from max|g_out|, removed exactly from the result), weight
+ * gradient on 16-bit MFMAs with fp32 accumulation.  packed = the fp32 forward pack (head weights);
+ * packed_t_lp = scade_mlp_pack_t_lp(params, bf16); workspace = scade_mlp_bwd_lp_workspace_bytes(P)
+ * bytes; grad_flat[589700] fp32 as in scade_mlp_bwd. */
+long scade_mlp_packed_t_lp_bytes(void);
+int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp, int bf16, void* stream);
+long scade_mlp_bwd_lp_workspace_bytes(int P);
+int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, const void* acts,
+                     const float* g_out, int P, void* workspace, float* grad_flat, void* stream);
 
 /* Split-precision variant of scade_mlp_bwd (opt-in training mode): the dgrad chain runs on
  * f16 MFMAs with a per-point power-of-two gradient scale (exactly removed on store); the weight

@@ -37,7 +37,12 @@ SIGNATURES = {
     "scade_mlp_fwd_f16": (c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "scade_mlp_packed_lp_bytes": (c_long, []),
     "scade_mlp_pack_lp": (c_int, [_P, _P, _I, _P]),
-    "scade_mlp_fwd_lp": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P]),
+    "scade_mlp_fwd_lp": (c_int, [_P, _I, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
+    "scade_mlp_acts_lp_bytes": (c_long, [c_long]),
+    "scade_mlp_packed_t_lp_bytes": (c_long, []),
+    "scade_mlp_pack_t_lp": (c_int, [_P, _P, _I, _P]),
+    "scade_mlp_bwd_lp_workspace_bytes": (c_long, [_I]),
+    "scade_mlp_bwd_lp": (c_int, [_P, _P, _I, _P, _P, _I, _P, _P, _P]),
     "scade_mlp_packed_t_f16_bytes": (c_long, []),
     "scade_mlp_pack_t_f16": (c_int, [_P, _P, _P]),
     "scade_mlp_bwd_f16": (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),

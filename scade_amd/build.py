@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libscade_hip.so")
-SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_fwd_f16.hip", "mlp_bwd_f16.hip", "mlp_fwd_lp.hip", "ray_ops.hip", "optim.hip"]
+SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_fwd_f16.hip", "mlp_bwd_f16.hip", "mlp_fwd_lp.hip", "mlp_bwd_lp.hip", "ray_ops.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC", "-shared"]
 
 

@@ -1,0 +1,628 @@
+// Backward of the single-plane 16-bit ("lp": fp16 / bf16 operands, fp32 accumulate) NeRF MLP -
+// the training half of BASELINE.json config 5's "bf16 MFMA path".  Same mathematics as
+// mlp_bwd.hip (autograd of model/run_nerf_helpers.py:223-247), three launches:
+//
+//   G  lp_gmax_kernel      max|g_out| of the launch -> one power-of-two loss scale S
+//   B1 mlp_dgrad_lp_kernel 128-point tile, the gradient tile walks the 9 layers backwards in LDS
+//                          (one 16-bit plane, per-POINT power-of-two scale s_p so small gradients
+//                          survive fp16; the chain is linear in g_out[p] and never mixes points, so
+//                          s_p factors out exactly); every layer's dZ goes to HBM as 16-bit rows
+//                          multiplied by S (s_p removed, S applied: one exact power-of-two factor)
+//   B2 mlp_wgrad_lp_kernel dW[n][k] = sum_p dZ[p][n] In[p][k]: both operands are point-major rows
+//                          in HBM but the MFMA contracts over points, so tiles are copied row-major
+//                          into LDS (16-byte chunks, no transposition on the way in) and the MFMA
+//                          fragments are gathered with gfx950's transposing LDS read
+//                          ds_read_b64_tr_b16 (4 points x 16 columns per 16-lane group).
+//                          HBM-bound by design: 1 KB per point-layer at the 16-bit MFMA rate.
+//   B3 wgrad_reduce        sum of the per-chunk partials, S removed.
+#include "mlp_tile_lp.h"
+#include "mlp_wgrad.h"
+
+namespace scade {
+
+// transposed single-plane pack: dgrad index t (mlp_layout.h), layer l = dgrad_layer(t):
+//   WTL[((kt*NB16 + nb)*64 + lane)*8 + j] = W[nb*16 + 8*(lane>>5) + j][hcol0 + kt*32 + (lane&31)]
+constexpr long wtl_elems(int t) { return 256L * n_out(dgrad_layer(t)); }
+constexpr long off_wtl(int t) {
+  long o = 0;
+  for (int i = 0; i < t; ++i) o += wtl_elems(i);
+  return o;
+}
+constexpr long PACKED_T_LP_ELEMS = off_wtl(NLAYER_DGRAD) + 2 * 64 * 8;
+
+struct PackTLpArgs {
+  const float* p[N_PARAM_TENSORS];
+  void* packed;
+};
+
+template <bool BF>
+__global__ void mlp_pack_t_lp_kernel(PackTLpArgs a) {
+  typedef typename LP<BF>::T T;
+  T* out = reinterpret_cast<T*>(a.packed);
+  const int t = blockIdx.y;
+  const int l = dgrad_layer(t);
+  const int widx = l <= 7 ? 2 * l : (l == L_FEAT ? 18 : 16);
+  const float* __restrict__ Wsrc = a.p[widx];
+  const int N = n_out(l);
+  const int NB = N / 16;
+  const int ld = l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W);
+  const int hcol0 = l == 5 ? EMB : 0;
+  const long total = 256L * N;
+  const long off = off_wtl(t);
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long blk = i >> 9;
+    const int nb = (int)(blk % NB), kt = (int)(blk / NB);
+    const int n = nb * 16 + 8 * (lane >> 5) + j;
+    const int k = kt * 32 + (lane & 31);
+    out[off + i] = (T)Wsrc[(size_t)n * ld + hcol0 + k];
+  }
+  if (t == 0)
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 64 * 8; i += gridDim.x * blockDim.x)
+      out[off_wtl(NLAYER_DGRAD) + i] = (T)0.f;
+}
+
+// ---------------------------------------------------------------------------
+// G: launch-wide max |g_out| (finite values only) -> gmax (float bits, zeroed before the launch)
+// ---------------------------------------------------------------------------
+__global__ void lp_gmax_kernel(const float* __restrict__ g, long n, unsigned int* gmax) {
+  float m = 0.f;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float v = fabsf(g[i]);
+    if (v < 3.0e38f) m = fmaxf(m, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(gmax, __float_as_uint(m));
+}
+
+// loss scale: max|g_out| * S in [2^5, 2^6)  (dZ entries can exceed max|g_out| by the layer gains;
+// 2^6 leaves three decades of fp16 headroom and nine below before the subnormal floor)
+__device__ __forceinline__ float lp_loss_scale(float m) {
+  if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
+  int e;
+  frexpf(m, &e);
+  return ldexpf(1.f, 6 - e);
+}
+
+// ---------------------------------------------------------------------------
+// B1: dgrad chain
+// ---------------------------------------------------------------------------
+struct MlpDgradLpArgs {
+  const float* packed;          // fp32 forward pack (rgb / alpha head weights)
+  const void* packedT;          // transposed 16-bit pack
+  const unsigned char* acts;    // lp_acts_bytes(P)
+  const float* g_out;           // [P,4]
+  unsigned char* dz;            // lp_dz_bytes(P)
+  const float* gmax;
+  int P;
+};
+
+template <bool BF, bool MASK, bool ADD_ALPHA>
+__device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][LPT], int ktile0, typename LP<BF>::T* g,
+                                               const unsigned long long (&bits)[2],
+                                               const float* __restrict__ w_a, const float* dal_scaled,
+                                               int lane) {
+  typedef typename LP<BF>::T T;
+  typedef typename LP<BF>::V4 V4;
+  const int r = lane & 31, hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int f = (ktile0 + t) * 32 + 8 * q + 4 * hh;
+      f32x4 wa = {0.f, 0.f, 0.f, 0.f};
+      if (ADD_ALPHA) wa = *reinterpret_cast<const f32x4*>(w_a + f);
+#pragma unroll
+      for (int p = 0; p < LPT; ++p) {
+        const int row = p * 32 + r;
+        V4 v;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          float y = acc[t][p][4 * q + i];
+          if (ADD_ALPHA) y = y + wa[i] * dal_scaled[row];
+          if (MASK) y = ((bits[t] >> ((q * 4 + p) * 4 + i)) & 1ull) ? y : 0.f;
+          v[i] = (T)y;
+        }
+        *reinterpret_cast<V4*>(g + x_idx(row, f >> 3) + (f & 7)) = v;
+      }
+    }
+}
+
+constexpr int DGRAD_LP_LDS_BYTES = LXPLANE * 2 + 2 * LM * 4;
+
+template <bool BF>
+__global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) {
+  typedef typename LP<BF>::T T;
+  typedef typename LP<BF>::V4 V4;
+  typedef typename LP<BF>::V8 V8;
+  extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
+  T* g = reinterpret_cast<T*>(lds16);
+  float* dal = reinterpret_cast<float*>(lds16 + LXPLANE);   // [128] d alpha_pre * s_p
+  float* fac = dal + LM;                                    // [128] S / s_p
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p0 = blockIdx.x * LM;
+  const int P = a.P;
+  const float* __restrict__ pk = a.packed;
+  const T* __restrict__ pt_ = reinterpret_cast<const T*>(a.packedT);
+  const T* __restrict__ actsT = reinterpret_cast<const T*>(a.acts);
+  T* __restrict__ dzT = reinterpret_cast<T*>(a.dz);
+  const float* __restrict__ alpha_pre = reinterpret_cast<const float*>(a.acts + lp_acts_alpha_byte(P));
+  float* __restrict__ dalpha = reinterpret_cast<float*>(a.dz + lp_dz_dalpha_byte(P));
+  const unsigned long long* __restrict__ masks =
+      reinterpret_cast<const unsigned long long*>(a.acts + lp_acts_mask_byte(P));
+  const float S = lp_loss_scale(a.gmax[0]);
+
+  // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
+#pragma unroll
+  for (int rb = 0; rb < LM / 64; ++rb) {
+    const int row = rb * 64 + (tid >> 2), sub = tid & 3;
+    const int pt = p0 + row;
+    const bool ok = pt < P;
+    f32x4 go = {0.f, 0.f, 0.f, 0.f};
+    if (ok) go = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    float da = 0.f;
+    if (ok) {
+      const float bx = alpha_pre[pt] * 10.f;
+      da = bx > 20.f ? go[3] : go[3] / (1.f + expf(-bx));
+    }
+    const float m = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(da)));
+    float s = 1.f;
+    if (m > 0.f && m < 3.0e38f) {
+      int e;
+      frexpf(m, &e);
+      s = ldexpf(1.f, -4 - e);
+    }
+    if (sub == 0) {
+      if (ok) dalpha[pt] = da;
+      dal[row] = da * s;
+      fac[row] = S / s;
+    }
+    const float* wr = pk + OFF_WR;
+    const T* hv = actsT + acts_slot_off(P, SLOT_VIEWS_H);
+    T* dzv = dzT + acts_slot_off(P, SLOT_VIEWS_H);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int chunk = i * 4 + sub;                       // 4-column chunk of the 128 columns
+      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
+      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
+      const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
+      V4 mk;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) mk[j] = (T)0.f;
+      if (ok) mk = *reinterpret_cast<const V4*>(hv + (size_t)pt * W + chunk * 4);
+      V4 vs, vS;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float d = go[0] * w0[j] + go[1] * w1[j] + go[2] * w2[j];
+        const float v = (float)mk[j] > 0.f ? d : 0.f;
+        vs[j] = (T)(v * s);
+        vS[j] = (T)(v * S);
+      }
+      *reinterpret_cast<V4*>(g + x_idx(row, chunk >> 1) + (chunk & 1) * 4) = vs;
+      if (ok) *reinterpret_cast<V4*>(dzv + (size_t)pt * W + chunk * 4) = vS;
+    }
+  }
+  __syncthreads();
+
+  f32x16 acc[2][LPT];
+  unsigned long long mb[2] = {0ull, 0ull};
+  AFragL<BF> an;
+  const int kt0 = wave * 2;
+  auto load_mask = [&](int layer) {
+    const unsigned long long* mw = masks + (((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid) * 2;
+    mb[0] = mw[0]; mb[1] = mw[1];
+  };
+  // this wave's k-tile pair of dgrad index TT: [kt][NB16][64] V8
+#define WTL(TT, NB) (reinterpret_cast<const V8*>(pt_ + off_wtl(TT)) + kt0 * (NB) * 64)
+  an.t0 = WTL(8, 8)[lane];
+  an.t1 = WTL(8, 8)[8 * 64 + lane];
+
+  // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
+  layer_gemm_lp<BF, 2, 0, 8, false>(acc, an, WTL(8, 8), WTL(7, 16), 16, g, g, lane);
+  __syncthreads();
+  dgrad_store_lp<BF, false, false>(acc, kt0, g, mb, nullptr, dal, lane);
+  __syncthreads();
+  save_tile_lp<BF>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, W, fac, tid);
+
+  // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
+  load_mask(7);
+  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL(7, 16), WTL(6, 16), 16, g, g, lane);
+  __syncthreads();
+  dgrad_store_lp<BF, true, true>(acc, kt0, g, mb, pk + OFF_WA, dal, lane);
+  __syncthreads();
+  save_tile_lp<BF>(g, dzT + acts_slot_off(P, 7), p0, P, W, fac, tid);
+
+#define DGRAD_LAYER_L(L)                                                                            \
+  load_mask((L)-1);                                                                                 \
+  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, g, g, lane); \
+  __syncthreads();                                                                                  \
+  dgrad_store_lp<BF, true, false>(acc, kt0, g, mb, nullptr, dal, lane);                             \
+  __syncthreads();                                                                                  \
+  save_tile_lp<BF>(g, dzT + acts_slot_off(P, (L)-1), p0, P, W, fac, tid);
+
+  DGRAD_LAYER_L(7)
+  DGRAD_LAYER_L(6)
+  DGRAD_LAYER_L(5)
+  DGRAD_LAYER_L(4)
+  DGRAD_LAYER_L(3)
+  DGRAD_LAYER_L(2)
+  DGRAD_LAYER_L(1)
+#undef DGRAD_LAYER_L
+#undef WTL
+}
+
+// ---------------------------------------------------------------------------
+// B2: weight gradient
+// ---------------------------------------------------------------------------
+struct WgradLpJob {
+  long dz_off;       // element offset of the dZ matrix (row stride 256) in the dz workspace
+  long in_off;       // element offset of the input matrix in the acts workspace
+  int in_stride;     // 256 (activation slot) or 64 (emb)
+  int kw;            // tile width in k: 256 or 64
+  int n_rows;        // valid output rows (256 or 128)
+  int w_off;         // flat-gradient offset of the weight tensor
+  int ld;            // its row length
+  int kcol0;         // output column of input column kfirst
+  int kfirst;        // input columns [kfirst, kvalid) are written
+  int kvalid;
+  int b_off;         // flat-gradient offset of the bias (WF_BIAS)
+  int flags;
+  int aux_off;       // WF_ALPHA: offset of alpha weight (bias follows at +256)
+};
+
+struct WgradLpArgs {
+  WgradLpJob jobs[MAX_WGRAD_JOBS];
+  const unsigned char* acts;
+  const unsigned char* dz;
+  const float* g_out;   // [P,4] (rgb head)
+  float* partial;       // [nchunks][N_PARAM_FLOATS]
+  const float* gmax;
+  int P;
+  int chunk;            // points per chunk (multiple of WL_PT)
+  int njobs;
+};
+
+constexpr int WL_PT = 32;                          // points per stage = two k16 blocks
+constexpr int WL_PITCH = 288;                      // elements per LDS row: 256 + 32 pad (576 B: the four
+                                                   // rows of a transposing read land 16 banks apart)
+constexpr int WL_TILE = WL_PT * WL_PITCH;          // elements per operand tile
+constexpr int WL_STAGE = 2 * WL_TILE;              // dZ tile + input tile
+constexpr int WGRAD_LP_LDS_BYTES = 2 * WL_STAGE * 2;   // double buffered: 73728
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+// MFMA operand fragment (32 columns x 16 points, lane = column lane&31, points 8*(lane>>5)..+7)
+// gathered from a row-major [point][column] LDS tile with two transposing reads
+template <bool BF>
+__device__ __forceinline__ typename LP<BF>::V8 tr_frag(const typename LP<BF>::T* tile, int row0, int col0,
+                                                       int lane) {
+  const int i = lane & 15, cb = (lane >> 4) & 1, hh = lane >> 5;
+  const typename LP<BF>::T* p = tile + (row0 + 8 * hh + (i >> 2)) * WL_PITCH + col0 + 16 * cb + 4 * (i & 3);
+  typedef s16x4 __attribute__((address_space(3))) * lds_ptr;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_ptr)(p + 4 * WL_PITCH));
+  s16x8 v;
+  v.lo = lo; v.hi = hi;
+  return __builtin_bit_cast(typename LP<BF>::V8, v);
+}
+
+template <bool BF>
+struct WStage { typename LP<BF>::V8 a0, a1, b0, b1; };
+
+template <bool BF, int KW>
+__device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLpJob& jb, typename LP<BF>::T* lds,
+                                             int c0, int c1, float invS, float* __restrict__ out) {
+  typedef typename LP<BF>::T T;
+  typedef typename LP<BF>::V8 V8;
+  constexpr int NKT = KW == 256 ? 4 : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int n0 = (wave >> 1) * 64;
+  const int k0 = (wave & 1) * (KW / 2);
+  const bool active = n0 < jb.n_rows;
+  const int P = a.P;
+  const T* __restrict__ dzm = reinterpret_cast<const T*>(a.dz) + jb.dz_off;
+  const T* __restrict__ inm = reinterpret_cast<const T*>(a.acts) + jb.in_off;
+  const float* __restrict__ dalp = reinterpret_cast<const float*>(a.dz + lp_dz_dalpha_byte(P));
+  // staging item of this thread: 8-column chunk cc of rows rr and rr+16 of the stage
+  const int cc = tid & 31, rr = tid >> 5;
+  const V8 zero8 = __builtin_bit_cast(V8, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+
+  f32x16 acc[2][NKT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NKT; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float bias_acc[8], alpha_acc[8], dal_acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) { bias_acc[j] = 0.f; alpha_acc[j] = 0.f; }
+
+  auto issue = [&](WStage<BF>& s, int pt0) {
+    const int pa = pt0 + rr, pb = pt0 + rr + 16;
+    s.a0 = pa < c1 ? *reinterpret_cast<const V8*>(dzm + (size_t)pa * 256 + 8 * cc) : zero8;
+    s.a1 = pb < c1 ? *reinterpret_cast<const V8*>(dzm + (size_t)pb * 256 + 8 * cc) : zero8;
+    if (KW == 256) {
+      s.b0 = pa < c1 ? *reinterpret_cast<const V8*>(inm + (size_t)pa * 256 + 8 * cc) : zero8;
+      s.b1 = pb < c1 ? *reinterpret_cast<const V8*>(inm + (size_t)pb * 256 + 8 * cc) : zero8;
+    } else if (tid < 256) {
+      const int pe = pt0 + (tid >> 3);
+      s.b0 = pe < c1 ? *reinterpret_cast<const V8*>(inm + (size_t)pe * 64 + 8 * (tid & 7)) : zero8;
+    }
+  };
+  auto commit = [&](const WStage<BF>& s, int pt0, int buf) {
+    T* st = lds + buf * WL_STAGE;
+    *reinterpret_cast<V8*>(st + rr * WL_PITCH + 8 * cc) = s.a0;
+    *reinterpret_cast<V8*>(st + (rr + 16) * WL_PITCH + 8 * cc) = s.a1;
+    if (KW == 256) {
+      *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 8 * cc) = s.b0;
+      *reinterpret_cast<V8*>(st + WL_TILE + (rr + 16) * WL_PITCH + 8 * cc) = s.b1;
+    } else if (tid < 256) {
+      *reinterpret_cast<V8*>(st + WL_TILE + (tid >> 3) * WL_PITCH + 8 * (tid & 7)) = s.b0;
+    }
+    // fp32 riders on the values in flight
+    if (jb.flags & WF_BIAS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) bias_acc[j] += (float)s.a0[j] + (float)s.a1[j];
+    }
+    if (KW == 256 && (jb.flags & WF_ALPHA)) {
+      const int pa = pt0 + rr, pb = pt0 + rr + 16;
+      const float d0 = pa < c1 ? dalp[pa] : 0.f;
+      const float d1 = pb < c1 ? dalp[pb] : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        alpha_acc[j] = fmaf(d1, (float)s.b1[j], fmaf(d0, (float)s.b0[j], alpha_acc[j]));
+      if (cc == 0) dal_acc += d0 + d1;
+    }
+  };
+  auto compute = [&](int buf) {
+    if (!active) return;
+    const T* st = lds + buf * WL_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const V8 a0 = tr_frag<BF>(st, 16 * kk, n0, lane);
+      const V8 a1 = tr_frag<BF>(st, 16 * kk, n0 + 32, lane);
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        const V8 b = tr_frag<BF>(st + WL_TILE, 16 * kk, k0 + 32 * u, lane);
+        acc[0][u] = LP<BF>::mfma(a0, b, acc[0][u]);
+        acc[1][u] = LP<BF>::mfma(a1, b, acc[1][u]);
+      }
+    }
+  };
+
+  // two register stages in flight ahead of the LDS double buffer
+  WStage<BF> r0, r1;
+  r0.a0 = r0.a1 = r0.b0 = r0.b1 = zero8;
+  r1 = r0;
+  issue(r0, c0);
+  if (c0 + WL_PT < c1) issue(r1, c0 + WL_PT);
+  commit(r0, c0, 0);
+  if (c0 + 2 * WL_PT < c1) issue(r0, c0 + 2 * WL_PT);
+  __syncthreads();
+  for (int pt0 = c0; pt0 < c1; pt0 += 2 * WL_PT) {
+    // even stage: LDS buffer 0 holds pt0; r1 holds pt0+32, r0 holds pt0+64
+    if (pt0 + WL_PT < c1) commit(r1, pt0 + WL_PT, 1);
+    if (pt0 + 3 * WL_PT < c1) issue(r1, pt0 + 3 * WL_PT);
+    compute(0);
+    __syncthreads();
+    if (pt0 + WL_PT >= c1) break;
+    // odd stage: buffer 1 holds pt0+32; r0 holds pt0+64, r1 holds pt0+96
+    if (pt0 + 2 * WL_PT < c1) commit(r0, pt0 + 2 * WL_PT, 0);
+    if (pt0 + 4 * WL_PT < c1) issue(r0, pt0 + 4 * WL_PT);
+    compute(1);
+    __syncthreads();
+  }
+
+  // ---- write the partial (loss scale removed) -------------------------------------------
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        const int k = k0 + 32 * u + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (n < jb.n_rows && k >= jb.kfirst && k < jb.kvalid)
+            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + (k - jb.kfirst)] = acc[t][u][i] * invS;
+        }
+      }
+  }
+  // riders: the 16 row groups of a column are combined through LDS
+  float* red = reinterpret_cast<float*>(lds);      // [16][256]
+  if (jb.flags & WF_BIAS) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rr * 256 + 8 * cc + j] = bias_acc[j];
+    __syncthreads();
+    if (tid < jb.n_rows) {
+      float s = 0.f;
+      for (int g = 0; g < 16; ++g) s += red[g * 256 + tid];
+      out[jb.b_off + tid] = s * invS;
+    }
+    __syncthreads();
+  }
+  if (KW == 256 && (jb.flags & WF_ALPHA)) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[rr * 256 + 8 * cc + j] = alpha_acc[j];
+    if (cc == 0) red[16 * 256 + rr] = dal_acc;
+    __syncthreads();
+    if (tid < 256) {
+      float s = 0.f;
+      for (int g = 0; g < 16; ++g) s += red[g * 256 + tid];
+      out[jb.aux_off + tid] = s;
+    }
+    if (tid == 0) {
+      float s = 0.f;
+      for (int g = 0; g < 16; ++g) s += red[16 * 256 + g];
+      out[jb.aux_off + 256] = s;
+    }
+  }
+}
+
+// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c]
+template <bool BF>
+__device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpArgs& a, const WgradLpJob& jb, float* lds,
+                                                 int c0, int c1, float* __restrict__ out) {
+  typedef typename LP<BF>::T T;
+  const int tid = threadIdx.x;
+  const int k = tid & 127, part = tid >> 7;     // 4 point-interleaved parts
+  const T* __restrict__ hv = reinterpret_cast<const T*>(a.acts) + jb.in_off;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
+  for (int pt = c0 + part; pt < c1; pt += 4) {
+    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    const float h = (float)hv[(size_t)pt * 256 + k];
+    s0 = fmaf(g[0], h, s0); s1 = fmaf(g[1], h, s1); s2 = fmaf(g[2], h, s2);
+    b0 += g[0]; b1 += g[1]; b2 += g[2];
+  }
+  float* red = lds;                               // [4][6][128]
+  red[(part * 6 + 0) * 128 + k] = s0; red[(part * 6 + 1) * 128 + k] = s1;
+  red[(part * 6 + 2) * 128 + k] = s2; red[(part * 6 + 3) * 128 + k] = b0;
+  red[(part * 6 + 4) * 128 + k] = b1; red[(part * 6 + 5) * 128 + k] = b2;
+  __syncthreads();
+  if (tid < 384) {
+    const int c = tid >> 7;
+    float s = 0.f;
+    for (int p = 0; p < 4; ++p) s += red[(p * 6 + c) * 128 + k];
+    out[jb.w_off + c * 128 + k] = s;
+  }
+  if (tid < 3) {
+    float s = 0.f;
+    for (int p = 0; p < 4; ++p) s += red[(p * 6 + 3 + tid) * 128 + 0];
+    out[jb.b_off + tid] = s;
+  }
+}
+
+template <bool BF>
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs a) {
+  typedef typename LP<BF>::T T;
+  extern __shared__ __attribute__((aligned(16))) unsigned short ldsw16[];
+  const WgradLpJob& jb = a.jobs[blockIdx.y];
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = min(a.P, c0 + a.chunk);
+  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
+  const float invS = 1.0f / lp_loss_scale(a.gmax[0]);
+  if (jb.flags & WF_RGB) {
+    wgrad_rgb_lp_job<BF>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);
+  } else if (jb.kw == 256) {
+    wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
+  } else {
+    wgrad_lp_job<BF, 64>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
+  }
+}
+
+__global__ void wgrad_reduce_lp_kernel(const float* partial, int nchunks, float* grad) {
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N_PARAM_FLOATS; i += gridDim.x * 256) {
+    float s = 0.f;
+    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
+    grad[i] = s;
+  }
+}
+
+// fills the job table (13 jobs) and the chunking; returns grid.x
+static int build_wgrad_lp_jobs(WgradLpArgs& w, int P) {
+  int off[N_PARAM_TENSORS + 1];
+  param_offsets(off);
+  const int nchunks = pick_chunks(P);
+  int chunk = (P + nchunks - 1) / nchunks;
+  chunk = (chunk + WL_PT - 1) / WL_PT * WL_PT;
+  w.chunk = chunk;
+  int nj = 0;
+  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
+  auto add = [&](long dzo, long ino, int ins, int kw, int nrows, int woff, int ld, int kcol0, int kfirst,
+                 int kvalid, int boff, int flags, int aux) {
+    WgradLpJob& j = w.jobs[nj++];
+    j.dz_off = dzo; j.in_off = ino; j.in_stride = ins; j.kw = kw; j.n_rows = nrows; j.w_off = woff;
+    j.ld = ld; j.kcol0 = kcol0; j.kfirst = kfirst; j.kvalid = kvalid; j.b_off = boff; j.flags = flags;
+    j.aux_off = aux;
+  };
+  for (int l = 1; l <= 7; ++l) {
+    const int ld = l == 5 ? 313 : 256, kc0 = l == 5 ? 57 : 0;
+    add(slot(l), slot(l - 1), 256, 256, 256, off[2 * l], ld, kc0, 0, 256, off[2 * l + 1], WF_BIAS, 0);
+  }
+  add(slot(SLOT_FEAT), slot(7), 256, 256, 256, off[18], 256, 0, 0, 256, off[19], WF_BIAS | WF_ALPHA, off[20]);
+  add(slot(SLOT_VIEWS_H), slot(SLOT_FEAT), 256, 256, 128, off[16], 259, 0, 0, 256, off[17], WF_BIAS, 0);
+  add(slot(0), acts_emb_off(P), 64, 64, 256, off[0], 57, 0, 0, 57, off[1], WF_BIAS, 0);
+  add(slot(5), acts_emb_off(P), 64, 64, 256, off[10], 313, 0, 0, 57, 0, 0, 0);
+  // view-direction columns of views_linears.0: emb columns 60..62 -> weight columns 256..258
+  add(slot(SLOT_VIEWS_H), acts_emb_off(P), 64, 64, 128, off[16], 259, 256, 60, 63, 0, 0, 0);
+  add(0, slot(SLOT_VIEWS_H), 256, 0, 0, off[22], 128, 0, 0, 0, off[23], WF_RGB, 0);
+  w.njobs = nj;
+  return (P + chunk - 1) / chunk;
+}
+
+}  // namespace scade
+
+using namespace scade;
+
+extern "C" long scade_mlp_packed_t_lp_bytes(void) { return PACKED_T_LP_ELEMS * 2; }
+
+extern "C" long scade_mlp_bwd_lp_workspace_bytes(int P) {
+  return lp_dz_bytes(P) + (long)pick_chunks(P) * N_PARAM_FLOATS * 4 + 256;
+}
+
+extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp, int bf16, void* stream) {
+  SCADE_REQUIRE(params && packed_t_lp, -1, "scade_mlp_pack_t_lp: null pointer");
+  PackTLpArgs a;
+  for (int i = 0; i < N_PARAM_TENSORS; ++i) {
+    SCADE_REQUIRE(params[i], -1, "scade_mlp_pack_t_lp: params[%d] is null", i);
+    a.p[i] = params[i];
+  }
+  a.packed = packed_t_lp;
+  if (bf16) hipLaunchKernelGGL(mlp_pack_t_lp_kernel<true>, dim3(64, NLAYER_DGRAD), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mlp_pack_t_lp_kernel<false>, dim3(64, NLAYER_DGRAD), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_mlp_pack_t_lp");
+}
+
+template <bool BF>
+static int launch_bwd_lp(const float* packed, const void* packed_t, const unsigned char* acts, const float* g_out,
+                         int P, unsigned char* ws, float* grad_flat, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, DGRAD_LP_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_lp_kernel<BF>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LP_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  unsigned char* dz = ws;
+  float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
+  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)pick_chunks(P) * N_PARAM_FLOATS);
+  hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
+  SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
+  const long ng = 4L * P;
+  const int gblocks = (int)((ng + 256 * 8 - 1) / (256 * 8) < 1024 ? (ng + 256 * 8 - 1) / (256 * 8) : 1024);
+  hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(256), 0, s, g_out, ng, gmax);
+  if (int e = scade_check_launch("scade_mlp_bwd_lp(gmax)")) return e;
+  MlpDgradLpArgs d{packed, packed_t, acts, g_out, dz, reinterpret_cast<const float*>(gmax), P};
+  hipLaunchKernelGGL(mlp_dgrad_lp_kernel<BF>, dim3((P + LM - 1) / LM), dim3(256), DGRAD_LP_LDS_BYTES, s, d);
+  if (int e = scade_check_launch("scade_mlp_bwd_lp(dgrad)")) return e;
+  WgradLpArgs w{};
+  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial;
+  w.gmax = reinterpret_cast<const float*>(gmax); w.P = P;
+  const int grid_x = build_wgrad_lp_jobs(w, P);
+  hipLaunchKernelGGL(mlp_wgrad_lp_kernel<BF>, dim3(grid_x, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
+  if (int e = scade_check_launch("scade_mlp_bwd_lp(wgrad)")) return e;
+  hipLaunchKernelGGL(wgrad_reduce_lp_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);
+  return scade_check_launch("scade_mlp_bwd_lp(reduce)");
+}
+
+extern "C" int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, const void* acts,
+                                const float* g_out, int P, void* workspace, float* grad_flat, void* stream) {
+  SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd_lp: P must be positive");
+  SCADE_REQUIRE(packed && packed_t_lp && acts && g_out && workspace && grad_flat, -1,
+                "scade_mlp_bwd_lp: null pointer");
+  const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts);
+  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+  hipStream_t s = (hipStream_t)stream;
+  return bf16 ? launch_bwd_lp<true>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s)
+              : launch_bwd_lp<false>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s);
+}

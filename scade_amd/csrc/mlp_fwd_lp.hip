@@ -18,15 +18,20 @@ struct MlpLpArgs {
   const float* viewdirs;
   const float* bb;
   float* out;             // [P,4]
+  unsigned char* acts;    // optional training workspace (mlp_tile_lp.h: lp_acts_bytes(P))
   int P, S, vd_stride;
 };
 
+// bits[t] bit (q*4+p)*4+i <-> value (t,q,p,i) > 0: the (feature, point) map the dgrad kernel's
+// output fragment uses too
 template <bool BF, int NT, bool RELU>
 __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], const float* __restrict__ bias,
-                                               int ntile0, typename LP<BF>::T* x, int lane) {
+                                               int ntile0, typename LP<BF>::T* x, int lane,
+                                               unsigned long long (&bits)[2]) {
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V4 V4;
   const int r = lane & 31, hh = lane >> 5;
+  bits[0] = bits[1] = 0ull;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -39,6 +44,7 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], con
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float y = acc[t][p][4 * q + i] + bv[i];
+          if (RELU && y > 0.f) bits[t] |= 1ull << ((q * 4 + p) * 4 + i);
           if (RELU) y = fmaxf(y, 0.f);
           v[i] = (T)y;
         }
@@ -48,7 +54,7 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], con
     }
 }
 
-template <bool BF, int MODE>
+template <bool BF, int MODE, bool SAVE>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V8 V8;
@@ -97,8 +103,25 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     }
   }
   __syncthreads();
+  T* actsT = reinterpret_cast<T*>(a.acts);
+  if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0
+    T* eo = actsT + acts_emb_off(P);
+    for (int i = tid; i < LM * 64; i += 256) {
+      const int row = i >> 6, c = i & 63;
+      const int pt = p0 + row;
+      if (pt < P) {
+        T v = (T)0.f;
+        if (c < EMB) v = e[e_idx(row, c >> 3) + (c & 7)];
+        else if (c >= 60 && c < 63)
+          v = (T)(MODE == 0 ? a.in[(size_t)pt * 60 + 57 + (c - 60)]
+                            : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + (c - 60)]);
+        eo[(size_t)pt * 64 + c] = v;
+      }
+    }
+  }
 
   f32x16 acc[2][LPT];
+  unsigned long long bits[2];
   AFragL<BF> an;
   const int nt0 = wave * 2;
 #define WLBASE(L) (reinterpret_cast<const V8*>(wpk + off_wl(L)) + ((L) == L_VIEWS ? wave : nt0) * kb16(L) * 64)
@@ -108,8 +131,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     layer_gemm_lp<BF, 2, KBP, kbh16(L), false>(acc, an, WLBASE(L), WLBASE(LNEXT), kb16(LNEXT),  \
                                                e, x, lane);                                     \
     __syncthreads();                                                                            \
-    layer_store_lp<BF, 2, true>(acc, TAIL(off_b(L)), nt0, x, lane);                             \
+    layer_store_lp<BF, 2, true>(acc, TAIL(off_b(L)), nt0, x, lane, bits);                       \
+    if (SAVE) {                                                                                 \
+      unsigned long long* mw = reinterpret_cast<unsigned long long*>(a.acts + lp_acts_mask_byte(P)) + \
+                               (((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid) * 2;          \
+      mw[0] = bits[0]; mw[1] = bits[1];                                                         \
+    }                                                                                           \
     __syncthreads();                                                                            \
+    if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, L), p0, P, W, nullptr, tid);         \
   }
 
   an.t0 = WLBASE(0)[lane];
@@ -154,22 +183,26 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       alpha[rb] = s + TAIL(OFF_BA)[0];
+      if (SAVE && sub == 0 && p0 + row < P)
+        reinterpret_cast<float*>(a.acts + lp_acts_alpha_byte(P))[p0 + row] = alpha[rb];
     }
   }
 
   // ---- feature_linear ------------------------------------------------------------------
   layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane);
   __syncthreads();
-  layer_store_lp<BF, 2, false>(acc, TAIL(off_b(L_FEAT)), nt0, x, lane);
+  layer_store_lp<BF, 2, false>(acc, TAIL(off_b(L_FEAT)), nt0, x, lane, bits);
   __syncthreads();
+  if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, W, nullptr, tid);
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av[1][LPT];
     layer_gemm_lp<BF, 1, 1, 16, true>(av, an, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane);
     __syncthreads();
-    layer_store_lp<BF, 1, true>(av, TAIL(off_b(L_VIEWS)), wave, x, lane);
+    layer_store_lp<BF, 1, true>(av, TAIL(off_b(L_VIEWS)), wave, x, lane, bits);
     __syncthreads();
+    if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, nullptr, tid);
   }
 #undef WLBASE
 
@@ -265,6 +298,7 @@ __global__ void mlp_pack_lp_kernel(PackLpArgs a) {
 using namespace scade;
 
 extern "C" long scade_mlp_packed_lp_bytes(void) { return PACKED_LP_BYTES; }
+extern "C" long scade_mlp_acts_lp_bytes(long P) { return lp_acts_bytes(P); }
 
 extern "C" int scade_mlp_pack_lp(const float* const* params, void* packed, int bf16, void* stream) {
   SCADE_REQUIRE(params && packed, -1, "scade_mlp_pack_lp: null pointer");
@@ -279,10 +313,10 @@ extern "C" int scade_mlp_pack_lp(const float* const* params, void* packed, int b
   return scade_check_launch("scade_mlp_pack_lp");
 }
 
-template <bool BF, int MODE>
+template <bool BF, int MODE, bool SAVE>
 static int launch_lp(const MlpLpArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = mlp_fwd_lp_kernel<BF, MODE>;
+  auto kern = mlp_fwd_lp_kernel<BF, MODE, SAVE>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES);
@@ -295,7 +329,7 @@ static int launch_lp(const MlpLpArgs& a, hipStream_t s) {
 
 extern "C" int scade_mlp_fwd_lp(const void* packed_lp, int bf16, int mode, const float* in,
                                 const float* viewdirs, int vd_stride, const float* bb, int P, int S,
-                                float* out, void* stream) {
+                                float* out, void* acts, void* stream) {
   if (P == 0) return 0;
   SCADE_REQUIRE(packed_lp && in && out, -1, "scade_mlp_fwd_lp: null pointer");
   SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd_lp: mode must be 0 or 1");
@@ -303,8 +337,17 @@ extern "C" int scade_mlp_fwd_lp(const void* packed_lp, int bf16, int mode, const
     SCADE_REQUIRE(viewdirs && bb && vd_stride >= 3, -1, "scade_mlp_fwd_lp: mode 1 needs viewdirs and bb");
     SCADE_REQUIRE(S > 0 && P % S == 0, -2, "scade_mlp_fwd_lp: P must be a multiple of S");
   }
-  MlpLpArgs a{packed_lp, in, viewdirs, bb, out, P, S, vd_stride};
+  MlpLpArgs a{packed_lp, in, viewdirs, bb, out, reinterpret_cast<unsigned char*>(acts), P, S, vd_stride};
   hipStream_t s = (hipStream_t)stream;
-  if (bf16) return mode == 0 ? launch_lp<true, 0>(a, s) : launch_lp<true, 1>(a, s);
-  return mode == 0 ? launch_lp<false, 0>(a, s) : launch_lp<false, 1>(a, s);
+  const int sel = (bf16 ? 4 : 0) + (mode ? 2 : 0) + (acts ? 1 : 0);
+  switch (sel) {
+    case 0: return launch_lp<false, 0, false>(a, s);
+    case 1: return launch_lp<false, 0, true>(a, s);
+    case 2: return launch_lp<false, 1, false>(a, s);
+    case 3: return launch_lp<false, 1, true>(a, s);
+    case 4: return launch_lp<true, 0, false>(a, s);
+    case 5: return launch_lp<true, 0, true>(a, s);
+    case 6: return launch_lp<true, 1, false>(a, s);
+    default: return launch_lp<true, 1, true>(a, s);
+  }
 }

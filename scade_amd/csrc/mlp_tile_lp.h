@@ -49,6 +49,39 @@ constexpr long off_wl(int l) {
 constexpr long PACKED_LP_ELEMS = off_wl(NLAYER_MFMA) + 2 * 64 * 8;   // + slack for the prefetch
 constexpr long PACKED_LP_BYTES = PACKED_LP_ELEMS * 2 + F16_TAIL_FLOATS * 4;
 
+// ---- training workspaces of the 16-bit path (BYTE offsets; T = 16-bit element) ------------
+// acts: slots [10][P][256] T (same slot numbering as mlp_layout.h) | emb [P][64] T |
+//       alpha_pre [P] fp32 | ReLU sign words of pts layers 0..7: [8][tiles][256 lanes][2] u64
+constexpr long lp_align(long b) { return (b + 255) / 256 * 256; }
+constexpr long lp_tiles(long P) { return (P + LM - 1) / LM; }
+constexpr long lp_acts_alpha_byte(long P) { return lp_align((acts_emb_off(P) + P * 64) * 2); }
+constexpr long lp_acts_mask_byte(long P) { return lp_align(lp_acts_alpha_byte(P) + P * 4); }
+constexpr long lp_acts_bytes(long P) { return lp_acts_mask_byte(P) + 8L * lp_tiles(P) * 256 * 16; }
+// dz: slots [10][P][256] T, every row multiplied by the launch-wide power of two S | d alpha_pre [P] fp32
+constexpr long lp_dz_dalpha_byte(long P) { return lp_align((long)N_ACT_SLOTS * P * 256 * 2); }
+constexpr long lp_dz_bytes(long P) { return lp_align(lp_dz_dalpha_byte(P) + P * 4); }
+
+// coalesced copy of the first ncols columns of the LDS tile to dst[P][256] (optional per-row factor)
+template <bool BF>
+__device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typename LP<BF>::T* __restrict__ dst,
+                                             int p0, int P, int ncols, const float* row_fac, int tid) {
+  typedef typename LP<BF>::T T;
+  typedef typename LP<BF>::V8 V8;
+  const int cpr = ncols >> 3;
+  for (int i = tid; i < LM * cpr; i += 256) {
+    const int row = i / cpr, c = i - row * cpr;
+    if (p0 + row < P) {
+      V8 v = *reinterpret_cast<const V8*>(x + x_idx(row, c));
+      if (row_fac) {
+        const float f = row_fac[row];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (T)((float)v[j] * f);
+      }
+      *reinterpret_cast<V8*>(dst + (size_t)(p0 + row) * W + 8 * c) = v;
+    }
+  }
+}
+
 template <bool BF>
 struct AFragL { typename LP<BF>::V8 t0, t1; };
 

@@ -7,6 +7,11 @@ from . import ops
 
 
 
+def _check_train_precision(net):
+    if net.train_precision not in net.TRAIN_PRECISIONS:
+        raise ValueError("NeRF.train_precision must be one of %s" % (net.TRAIN_PRECISIONS,))
+
+
 def _needs_grad(params) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for p in params)
 
@@ -18,9 +23,14 @@ class MlpEmbeddedFn(torch.autograd.Function):
     def forward(ctx, net, train, x, *params):
         packed = net.packed()
         acts = None
+        lp = train and net.train_precision in ("f16", "bf16")
         if train:
-            acts = ops.mlp_acts_alloc(x.shape[0], x.device)
-        if train and net.train_precision in ("f16x3", "f16x3-dgrad"):
+            _check_train_precision(net)
+            acts = (ops.mlp_acts_lp_alloc if lp else ops.mlp_acts_alloc)(x.shape[0], x.device)
+        if lp:
+            bf16 = net.train_precision == "bf16"
+            out = ops.mlp_fwd_lp(net.packed_lp(bf16), bf16, x, None, None, acts)
+        elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), x, None, None, acts)
         else:
             out = ops.mlp_fwd_embedded(packed, x, acts)
@@ -43,10 +53,15 @@ class MlpPointsFn(torch.autograd.Function):
     def forward(ctx, net, train, pts, viewdirs, bb, *params):
         packed = net.packed()
         acts = None
+        lp = train and net.train_precision in ("f16", "bf16")
         if train:
+            _check_train_precision(net)
             P = pts.shape[0] * pts.shape[1]
-            acts = ops.mlp_acts_alloc(P, pts.device)
-        if train and net.train_precision in ("f16x3", "f16x3-dgrad"):
+            acts = (ops.mlp_acts_lp_alloc if lp else ops.mlp_acts_alloc)(P, pts.device)
+        if lp:
+            bf16 = net.train_precision == "bf16"
+            out = ops.mlp_fwd_lp(net.packed_lp(bf16), bf16, pts, viewdirs, bb, acts)
+        elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts)
         else:
             out = ops.mlp_fwd_points(packed, pts, viewdirs, bb, acts)

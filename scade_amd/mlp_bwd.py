@@ -13,10 +13,13 @@ def mlp_backward(net, acts, g_out):
     if net.train_precision in ("f16x3", "f16x3-dgrad"):
         flat = ops.mlp_bwd_f16(net.packed(), net.packed_t_f16(), acts, g_out,
                                wgrad_f16=net.train_precision == "f16x3")
+    elif net.train_precision in ("f16", "bf16"):
+        bf16 = net.train_precision == "bf16"
+        flat = ops.mlp_bwd_lp(net.packed(), net.packed_t_lp(bf16), bf16, acts, g_out)
     elif net.train_precision == "f32":
         flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
     else:
-        raise ValueError("NeRF.train_precision must be 'f32', 'f16x3' or 'f16x3-dgrad'")
+        raise ValueError("NeRF.train_precision must be one of %s" % (net.TRAIN_PRECISIONS,))
     grads, o = [], 0
     for name in ops.PARAM_ORDER:
         shape = ops.PARAM_SHAPES[name]

@@ -210,8 +210,34 @@ def mlp_pack_lp(params: Sequence[Tensor], bf16: bool) -> Tensor:
     return out
 
 
+def mlp_acts_lp_alloc(P: int, device) -> Tensor:
+    return torch.empty(int(_lib.load().scade_mlp_acts_lp_bytes(P)), device=device, dtype=torch.uint8)
+
+
+def mlp_pack_t_lp(params: Sequence[Tensor], bf16: bool) -> Tensor:
+    keep = [_c(check(p, "mlp_pack_t_lp").detach()) for p in params]
+    out = torch.empty(int(_lib.load().scade_mlp_packed_t_lp_bytes()), device=keep[0].device, dtype=torch.uint8)
+    arr = (ctypes.c_void_p * 24)(*[t.data_ptr() for t in keep])
+    call("scade_mlp_pack_t_lp", ctypes.cast(arr, ctypes.c_void_p), ptr(out), int(bf16), stream())
+    return out
+
+
+def mlp_bwd_lp(packed: Tensor, packed_t_lp: Tensor, bf16: bool, acts: Tensor, g_out: Tensor) -> Tensor:
+    """16-bit dgrad + wgrad (fp32 accumulate, power-of-two loss scaling) -> flat gradient [589700]."""
+    g = _c(check(g_out, "mlp_bwd_lp: g_out")).reshape(-1, 4)
+    P = g.shape[0]
+    ws = torch.empty(int(_lib.load().scade_mlp_bwd_lp_workspace_bytes(P)), device=g.device, dtype=torch.uint8)
+    grad = torch.empty(N_PARAM_FLOATS, device=g.device, dtype=torch.float32)
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_bwd_lp", ptr(packed), ptr(packed_t_lp), int(bf16), ptr(acts), ptr(g), P, ptr(ws), ptr(grad),
+         stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_bwd", t0, float(P) * 2 * MLP_FLOP_PER_POINT)
+    return grad
+
+
 def mlp_fwd_lp(packed_lp: Tensor, bf16: bool, inp: Tensor, viewdirs: Optional[Tensor],
-               bb: Optional[Tensor]) -> Tensor:
+               bb: Optional[Tensor], acts: Optional[Tensor] = None) -> Tensor:
     """16-bit-operand forward: inp [P,60] (viewdirs None) or pts [N,S,3] + viewdirs [N,3] + bb [4]."""
     check(inp, "mlp_fwd_lp: input")
     inp = _c(inp)
@@ -220,7 +246,8 @@ def mlp_fwd_lp(packed_lp: Tensor, bf16: bool, inp: Tensor, viewdirs: Optional[Te
             raise ValueError("mlp_fwd_lp: x must be [P,60]")
         P = inp.shape[0]
         out = torch.empty(P, 4, device=inp.device, dtype=torch.float32)
-        call("scade_mlp_fwd_lp", ptr(packed_lp), int(bf16), 0, ptr(inp), None, 0, None, P, 1, ptr(out), stream())
+        call("scade_mlp_fwd_lp", ptr(packed_lp), int(bf16), 0, ptr(inp), None, 0, None, P, 1, ptr(out), ptr(acts),
+             stream())
         return out
     N, S = inp.shape[0], inp.shape[1]
     viewdirs, vstride = _rows(viewdirs, "mlp_fwd_lp: viewdirs")
@@ -228,7 +255,7 @@ def mlp_fwd_lp(packed_lp: Tensor, bf16: bool, inp: Tensor, viewdirs: Optional[Te
     out = torch.empty(N, S, 4, device=inp.device, dtype=torch.float32)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
     call("scade_mlp_fwd_lp", ptr(packed_lp), int(bf16), 1, ptr(inp), ptr(viewdirs), vstride, ptr(bb), N * S, S,
-         ptr(out), stream())
+         ptr(out), ptr(acts), stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_fwd_lp_kernel", t0, float(N * S) * MLP_FLOP_PER_POINT)
     return out

@@ -145,8 +145,9 @@ class NeRF(nn.Module):
         # "f16" / "bf16": single-plane 16-bit operands, fp32 accumulate (ordinary mixed precision,
         # ~1e-3 / ~1e-2 relative error: BASELINE.json config 5's "bf16 MFMA path")
         self.inference_precision = "f32"
-        # "f32": exact training kernels.  "f16x3": forward + input-gradient chain on the
-        # split-precision kernels (weight gradient stays exact fp32)
+        # "f32": exact training kernels.  "f16x3": forward, dgrad and wgrad on the split-precision
+        # kernels ("f16x3-dgrad": wgrad stays exact fp32).  "f16" / "bf16": mixed-precision training,
+        # 16-bit activations / gradients / weight copies, fp32 accumulate and fp32 master weights
         self.train_precision = "f32"
 
     # -- kernel support ----------------------------------------------------
@@ -212,7 +213,17 @@ class NeRF(nn.Module):
             self._packed_lp_key = key
         return self._packed_lp
 
+    def packed_t_lp(self, bf16):
+        ps = self.ordered_params()
+        key = (bool(bf16), ops.PARAM_EPOCH) + tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_packed_t_lp", None) is None or key != self._packed_t_lp_key \
+                or self._packed_t_lp.device != ps[0].device:
+            self._packed_t_lp = ops.mlp_pack_t_lp(ps, bf16)
+            self._packed_t_lp_key = key
+        return self._packed_t_lp
+
     INFERENCE_PRECISIONS = ("f32", "f16x3", "f16", "bf16")
+    TRAIN_PRECISIONS = ("f32", "f16x3", "f16x3-dgrad", "f16", "bf16")
 
     def _fast(self, train):
         if self.inference_precision not in self.INFERENCE_PRECISIONS:
