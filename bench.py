@@ -310,12 +310,15 @@ def main():
         barrier()
         out.setdefault("image_render_16x1024", {})[f"rays_per_s_per_gpu_{ns}_stream"] = \
             big.shape[0] / (time.perf_counter() - t0)
+    # exact fp32 regions first, the opt-in reduced-precision regions after them (the 16-bit bursts
+    # leave the chip in a different power state for a few milliseconds)
+    if not args.no_train:
+        out["train_step"] = train_region(args, dev, world, rank, barrier)
     if not args.no_fast:
         for prec in ("f16x3", "bf16", "f16"):
             out["fast_path_" + prec] = fast_region(args, dev, world, barrier, step, coarse, fine, prec)
-    if not args.no_train:
-        out["train_step"] = train_region(args, dev, world, rank, barrier)
-        if not args.no_fast:   # opt-in: forward + dgrad on the split-precision kernels, exact wgrad
+        if not args.no_train:
+            # forward + dgrad + wgrad on the split-precision kernels
             out["train_step_f16x3"] = train_region(args, dev, world, rank, barrier, precision="f16x3")
             # mixed precision (BASELINE config 5's bf16 MFMA path): 16-bit forward, dgrad and wgrad
             out["train_step_bf16"] = train_region(args, dev, world, rank, barrier, precision="bf16")
