@@ -13,7 +13,7 @@
 //      gradient in registers (128 accumulator VGPRs/lane) for one layer and one chunk of
 //      points, streams dZ / In tiles of 32 points through LDS, and writes a per-chunk
 //      partial; bias, alpha-head, view-column and rgb-head gradients ride along on the
-//      VALU.  mlp_wgrad_reduce_kernel sums the chunk partials (deterministic order)
+//      VALU.  wgrad_reduce4_kernel (mlp_wgrad.h) sums the chunk partials (deterministic order)
 //      into one flat gradient in PyTorch parameter layout.
 #include "mlp_tile.h"
 #include "mlp_wgrad.h"
@@ -385,14 +385,6 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(WgradArgs a) {
   }
 }
 
-__global__ void mlp_wgrad_reduce_kernel(const float* partial, int nchunks, float* grad) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < N_PARAM_FLOATS; i += gridDim.x * 256) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
-    grad[i] = s;
-  }
-}
-
 }  // namespace scade
 
 // ===========================================================================
@@ -435,7 +427,7 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
   const int nj = w.njobs;
   hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid_x, nj), dim3(512), WGRAD_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
-  hipLaunchKernelGGL(mlp_wgrad_reduce_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd(reduce)");
 }
 

@@ -435,14 +435,6 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) 
   }
 }
 
-__global__ void wgrad_reduce_f16_kernel(const float* partial, int nchunks, float* grad) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < N_PARAM_FLOATS; i += gridDim.x * 256) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
-    grad[i] = s;
-  }
-}
-
 }  // namespace scade
 
 using namespace scade;
@@ -498,6 +490,6 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   fa.gmax = reinterpret_cast<const float*>(gmax);
   hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(grid_x, fa.w.njobs), dim3(512), WGRAD_F16_LDS_BYTES, s, fa);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(wgrad)")) return e;
-  hipLaunchKernelGGL(wgrad_reduce_f16_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd_f16(reduce)");
 }

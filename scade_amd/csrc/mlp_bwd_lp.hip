@@ -290,7 +290,7 @@ constexpr int WL_PITCH = 288;                      // elements per LDS row: 256 
                                                    // rows of a transposing read land 16 banks apart)
 constexpr int WL_TILE = WL_PT * WL_PITCH;          // elements per operand tile
 constexpr int WL_STAGE = 2 * WL_TILE;              // dZ tile + input tile
-constexpr int WGRAD_LP_LDS_BYTES = 2 * WL_STAGE * 2;   // double buffered: 73728
+constexpr int WGRAD_LP_LDS_BYTES = 3 * WL_STAGE * 2;   // triple buffered: 110592
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -311,7 +311,10 @@ __device__ __forceinline__ typename LP<BF>::V8 tr_frag(const typename LP<BF>::T*
 }
 
 template <bool BF>
-struct WStage { typename LP<BF>::V8 a0, a1, b0, b1; };
+struct WStage {
+  typename LP<BF>::V8 a0, a1, b0, b1;
+  float d0, d1;      // d alpha_pre of the two rows (WF_ALPHA job)
+};
 
 template <bool BF, int KW>
 __device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLpJob& jb, typename LP<BF>::T* lds,
@@ -344,40 +347,49 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLp
 #pragma unroll
   for (int j = 0; j < 8; ++j) { bias_acc[j] = 0.f; alpha_acc[j] = 0.f; }
 
+  // Loads are UNCONDITIONAL (row index clamped to the last point, zeroed at commit time): a
+  // wave-uniform or per-lane branch around them would make the outstanding-load count path
+  // dependent and force s_waitcnt vmcnt(0) at every commit, i.e. no prefetch at all.
+  const bool want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
   auto issue = [&](WStage<BF>& s, int pt0) {
-    const int pa = pt0 + rr, pb = pt0 + rr + 16;
-    s.a0 = pa < c1 ? *reinterpret_cast<const V8*>(dzm + (size_t)pa * 256 + 8 * cc) : zero8;
-    s.a1 = pb < c1 ? *reinterpret_cast<const V8*>(dzm + (size_t)pb * 256 + 8 * cc) : zero8;
+    const int pa = min(pt0 + rr, P - 1), pb = min(pt0 + rr + 16, P - 1);
+    s.a0 = *reinterpret_cast<const V8*>(dzm + (size_t)pa * 256 + 8 * cc);
+    s.a1 = *reinterpret_cast<const V8*>(dzm + (size_t)pb * 256 + 8 * cc);
     if (KW == 256) {
-      s.b0 = pa < c1 ? *reinterpret_cast<const V8*>(inm + (size_t)pa * 256 + 8 * cc) : zero8;
-      s.b1 = pb < c1 ? *reinterpret_cast<const V8*>(inm + (size_t)pb * 256 + 8 * cc) : zero8;
-    } else if (tid < 256) {
-      const int pe = pt0 + (tid >> 3);
-      s.b0 = pe < c1 ? *reinterpret_cast<const V8*>(inm + (size_t)pe * 64 + 8 * (tid & 7)) : zero8;
+      s.b0 = *reinterpret_cast<const V8*>(inm + (size_t)pa * 256 + 8 * cc);
+      s.b1 = *reinterpret_cast<const V8*>(inm + (size_t)pb * 256 + 8 * cc);
+      s.d0 = dalp[want_alpha ? pa : 0];
+      s.d1 = dalp[want_alpha ? pb : 0];
+    } else {
+      const int pe = min(pt0 + ((tid >> 3) & 31), P - 1);
+      s.b0 = *reinterpret_cast<const V8*>(inm + (size_t)pe * 64 + 8 * (tid & 7));
     }
   };
   auto commit = [&](const WStage<BF>& s, int pt0, int buf) {
     T* st = lds + buf * WL_STAGE;
-    *reinterpret_cast<V8*>(st + rr * WL_PITCH + 8 * cc) = s.a0;
-    *reinterpret_cast<V8*>(st + (rr + 16) * WL_PITCH + 8 * cc) = s.a1;
+    const bool va = pt0 + rr < c1, vb = pt0 + rr + 16 < c1;
+    const V8 a0 = va ? s.a0 : zero8, a1 = vb ? s.a1 : zero8;
+    *reinterpret_cast<V8*>(st + rr * WL_PITCH + 8 * cc) = a0;
+    *reinterpret_cast<V8*>(st + (rr + 16) * WL_PITCH + 8 * cc) = a1;
+    V8 b0 = zero8, b1 = zero8;
     if (KW == 256) {
-      *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 8 * cc) = s.b0;
-      *reinterpret_cast<V8*>(st + WL_TILE + (rr + 16) * WL_PITCH + 8 * cc) = s.b1;
+      b0 = va ? s.b0 : zero8; b1 = vb ? s.b1 : zero8;
+      *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 8 * cc) = b0;
+      *reinterpret_cast<V8*>(st + WL_TILE + (rr + 16) * WL_PITCH + 8 * cc) = b1;
     } else if (tid < 256) {
-      *reinterpret_cast<V8*>(st + WL_TILE + (tid >> 3) * WL_PITCH + 8 * (tid & 7)) = s.b0;
+      b0 = pt0 + (tid >> 3) < c1 ? s.b0 : zero8;
+      *reinterpret_cast<V8*>(st + WL_TILE + (tid >> 3) * WL_PITCH + 8 * (tid & 7)) = b0;
     }
     // fp32 riders on the values in flight
     if (jb.flags & WF_BIAS) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) bias_acc[j] += (float)s.a0[j] + (float)s.a1[j];
+      for (int j = 0; j < 8; ++j) bias_acc[j] += (float)a0[j] + (float)a1[j];
     }
-    if (KW == 256 && (jb.flags & WF_ALPHA)) {
-      const int pa = pt0 + rr, pb = pt0 + rr + 16;
-      const float d0 = pa < c1 ? dalp[pa] : 0.f;
-      const float d1 = pb < c1 ? dalp[pb] : 0.f;
+    if (want_alpha) {
+      const float d0 = va ? s.d0 : 0.f, d1 = vb ? s.d1 : 0.f;
 #pragma unroll
       for (int j = 0; j < 8; ++j)
-        alpha_acc[j] = fmaf(d1, (float)s.b1[j], fmaf(d0, (float)s.b0[j], alpha_acc[j]));
+        alpha_acc[j] = fmaf(d1, (float)b1[j], fmaf(d0, (float)b0[j], alpha_acc[j]));
       if (cc == 0) dal_acc += d0 + d1;
     }
   };
@@ -397,28 +409,27 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLp
     }
   };
 
-  // two register stages in flight ahead of the LDS double buffer
-  WStage<BF> r0, r1;
-  r0.a0 = r0.a1 = r0.b0 = r0.b1 = zero8;
-  r1 = r0;
+  // three register stages (96 KB per CU) in flight ahead of a triple LDS buffer: at the top of
+  // stage s LDS buffer s%3 holds stage s and the register sets hold stages s+1, s+2, s+3
+  WStage<BF> r0, r1, r2;
   issue(r0, c0);
-  if (c0 + WL_PT < c1) issue(r1, c0 + WL_PT);
+  issue(r1, c0 + WL_PT);
+  issue(r2, c0 + 2 * WL_PT);
   commit(r0, c0, 0);
-  if (c0 + 2 * WL_PT < c1) issue(r0, c0 + 2 * WL_PT);
+  issue(r0, c0 + 3 * WL_PT);
   __syncthreads();
-  for (int pt0 = c0; pt0 < c1; pt0 += 2 * WL_PT) {
-    // even stage: LDS buffer 0 holds pt0; r1 holds pt0+32, r0 holds pt0+64
-    if (pt0 + WL_PT < c1) commit(r1, pt0 + WL_PT, 1);
-    if (pt0 + 3 * WL_PT < c1) issue(r1, pt0 + 3 * WL_PT);
-    compute(0);
-    __syncthreads();
-    if (pt0 + WL_PT >= c1) break;
-    // odd stage: buffer 1 holds pt0+32; r0 holds pt0+64, r1 holds pt0+96
-    if (pt0 + 2 * WL_PT < c1) commit(r0, pt0 + 2 * WL_PT, 0);
-    if (pt0 + 4 * WL_PT < c1) issue(r0, pt0 + 4 * WL_PT);
-    compute(1);
-    __syncthreads();
+#define WL_STEP(RN, BUF, BUFN, K)                                   \
+  if (pt0 + ((K) + 1) * WL_PT < c1) commit(RN, pt0 + ((K) + 1) * WL_PT, BUFN); \
+  issue(RN, pt0 + ((K) + 4) * WL_PT);                               \
+  compute(BUF);                                                     \
+  __syncthreads();                                                  \
+  if (pt0 + ((K) + 1) * WL_PT >= c1) break;
+  for (int pt0 = c0;; pt0 += 3 * WL_PT) {
+    WL_STEP(r1, 0, 1, 0)
+    WL_STEP(r2, 1, 2, 1)
+    WL_STEP(r0, 2, 0, 2)
   }
+#undef WL_STEP
 
   // ---- write the partial (loss scale removed) -------------------------------------------
   if (active) {
@@ -466,36 +477,62 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLp
   }
 }
 
-// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c]
+// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c].
+// A thread owns 8 columns (one 16-byte load per point) of every 32nd point, four points in flight:
+// this job is pure load latency, and as the LAST job of the table its workgroups set the kernel's end.
 template <bool BF>
 __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpArgs& a, const WgradLpJob& jb, float* lds,
                                                  int c0, int c1, float* __restrict__ out) {
   typedef typename LP<BF>::T T;
+  typedef typename LP<BF>::V8 V8;
   const int tid = threadIdx.x;
-  const int k = tid & 127, part = tid >> 7;     // 4 point-interleaved parts
-  const T* __restrict__ hv = reinterpret_cast<const T*>(a.acts) + jb.in_off;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  for (int pt = c0 + part; pt < c1; pt += 4) {
-    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
-    const float h = (float)hv[(size_t)pt * 256 + k];
-    s0 = fmaf(g[0], h, s0); s1 = fmaf(g[1], h, s1); s2 = fmaf(g[2], h, s2);
-    b0 += g[0]; b1 += g[1]; b2 += g[2];
+  const int k8 = tid & 15, pl = tid >> 4;        // 16 column groups x 32 point lanes
+  const T* __restrict__ hv = reinterpret_cast<const T*>(a.acts) + jb.in_off + 8 * k8;
+  const int P = a.P;
+  float s[3][8], b[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s[c][j] = 0.f;
+  for (int pt0 = c0 + pl; pt0 < c1; pt0 += 128) {
+    V8 h[4];
+    f32x4 g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pt = min(pt0 + 32 * q, P - 1);
+      h[q] = *reinterpret_cast<const V8*>(hv + (size_t)pt * 256);
+      g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (pt0 + 32 * q < c1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float x = (float)h[q][j];
+          s[0][j] = fmaf(g[q][0], x, s[0][j]); s[1][j] = fmaf(g[q][1], x, s[1][j]);
+          s[2][j] = fmaf(g[q][2], x, s[2][j]);
+        }
+        b[0] += g[q][0]; b[1] += g[q][1]; b[2] += g[q][2];
+      }
+    }
   }
-  float* red = lds;                               // [4][6][128]
-  red[(part * 6 + 0) * 128 + k] = s0; red[(part * 6 + 1) * 128 + k] = s1;
-  red[(part * 6 + 2) * 128 + k] = s2; red[(part * 6 + 3) * 128 + k] = b0;
-  red[(part * 6 + 4) * 128 + k] = b1; red[(part * 6 + 5) * 128 + k] = b2;
+  float* red = lds;                               // [32 point lanes][3][128] + [32][4]
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) red[(pl * 3 + c) * 128 + 8 * k8 + j] = s[c][j];
+  float* redb = red + 32 * 3 * 128;
+  if (k8 == 0) { redb[pl * 4 + 0] = b[0]; redb[pl * 4 + 1] = b[1]; redb[pl * 4 + 2] = b[2]; }
   __syncthreads();
   if (tid < 384) {
-    const int c = tid >> 7;
-    float s = 0.f;
-    for (int p = 0; p < 4; ++p) s += red[(p * 6 + c) * 128 + k];
-    out[jb.w_off + c * 128 + k] = s;
+    float t = 0.f;
+    for (int p = 0; p < 32; ++p) t += red[p * 384 + tid];
+    out[jb.w_off + tid] = t;
   }
   if (tid < 3) {
-    float s = 0.f;
-    for (int p = 0; p < 4; ++p) s += red[(p * 6 + 3 + tid) * 128 + 0];
-    out[jb.b_off + tid] = s;
+    float t = 0.f;
+    for (int p = 0; p < 32; ++p) t += redb[p * 4 + tid];
+    out[jb.b_off + tid] = t;
   }
 }
 
@@ -514,14 +551,6 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs a) {
     wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
   } else {
     wgrad_lp_job<BF, 64>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
-  }
-}
-
-__global__ void wgrad_reduce_lp_kernel(const float* partial, int nchunks, float* grad) {
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < N_PARAM_FLOATS; i += gridDim.x * 256) {
-    float s = 0.f;
-    for (int c = 0; c < nchunks; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
-    grad[i] = s;
   }
 }
 
@@ -611,7 +640,7 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   const int grid_x = build_wgrad_lp_jobs(w, P);
   hipLaunchKernelGGL(mlp_wgrad_lp_kernel<BF>, dim3(grid_x, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(wgrad)")) return e;
-  hipLaunchKernelGGL(wgrad_reduce_lp_kernel, dim3(576), dim3(256), 0, s, partial, grid_x, grad_flat);
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd_lp(reduce)");
 }
 

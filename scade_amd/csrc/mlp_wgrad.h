@@ -94,35 +94,78 @@ inline int build_wgrad_jobs(WgradArgs& w, const float* acts, const float* dz, co
   return (P + chunk - 1) / chunk;
 }
 
-// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c]
+// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c].
+// A thread owns 4 columns (one 16-byte load per point) of every 16th point, four points in
+// flight: this job is pure load latency and, as the LAST job of the table, its workgroups
+// would otherwise set the end of the whole launch.
 __device__ __forceinline__ void wgrad_rgb_job(const WgradArgs& a, const WgradJob& jb, float* lds,
                                               int c0, int c1, float* __restrict__ out) {
   const int tid = threadIdx.x;
-  const int k = tid & 127, part = tid >> 7;     // 4 point-interleaved parts
-  const float* __restrict__ hv = a.acts + jb.in_off;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, b0 = 0.f, b1 = 0.f, b2 = 0.f;
-  for (int pt = c0 + part; pt < c1; pt += 4) {
-    const f32x4 g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
-    const float h = hv[(size_t)pt * 256 + k];
-    s0 = fmaf(g[0], h, s0); s1 = fmaf(g[1], h, s1); s2 = fmaf(g[2], h, s2);
-    b0 += g[0]; b1 += g[1]; b2 += g[2];
+  const int k4 = tid & 31, pl = tid >> 5;       // 32 column groups x 16 point lanes
+  const float* __restrict__ hv = a.acts + jb.in_off + 4 * k4;
+  const int P = a.P;
+  float s[3][4], b[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s[c][j] = 0.f;
+  for (int pt0 = c0 + pl; pt0 < c1; pt0 += 64) {
+    f32x4 h[4], g[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int pt = min(pt0 + 16 * q, P - 1);
+      h[q] = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * 256);
+      g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (pt0 + 16 * q < c1) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          s[0][j] = fmaf(g[q][0], h[q][j], s[0][j]);
+          s[1][j] = fmaf(g[q][1], h[q][j], s[1][j]);
+          s[2][j] = fmaf(g[q][2], h[q][j], s[2][j]);
+        }
+        b[0] += g[q][0]; b[1] += g[q][1]; b[2] += g[q][2];
+      }
+    }
   }
-  float* red = lds;                               // [4][6][128]
-  red[(part * 6 + 0) * 128 + k] = s0; red[(part * 6 + 1) * 128 + k] = s1;
-  red[(part * 6 + 2) * 128 + k] = s2; red[(part * 6 + 3) * 128 + k] = b0;
-  red[(part * 6 + 4) * 128 + k] = b1; red[(part * 6 + 5) * 128 + k] = b2;
+  float* red = lds;                               // [16 point lanes][3][128] + [16][4]
+#pragma unroll
+  for (int c = 0; c < 3; ++c)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) red[(pl * 3 + c) * 128 + 4 * k4 + j] = s[c][j];
+  float* redb = red + 16 * 3 * 128;
+  if (k4 == 0) { redb[pl * 4 + 0] = b[0]; redb[pl * 4 + 1] = b[1]; redb[pl * 4 + 2] = b[2]; }
   __syncthreads();
   if (tid < 384) {
-    const int c = tid >> 7;
-    float s = 0.f;
-    for (int p = 0; p < 4; ++p) s += red[(p * 6 + c) * 128 + k];
-    out[jb.w_off + c * 128 + k] = s;
+    float t = 0.f;
+    for (int p = 0; p < 16; ++p) t += red[p * 384 + tid];
+    out[jb.w_off + tid] = t;
   }
   if (tid < 3) {
-    float s = 0.f;
-    for (int p = 0; p < 4; ++p) s += red[(p * 6 + 3 + tid) * 128 + 0];
-    out[jb.b_off + tid] = s;
+    float t = 0.f;
+    for (int p = 0; p < 16; ++p) t += redb[p * 4 + tid];
+    out[jb.b_off + tid] = t;
   }
 }
+
+// sum of the per-chunk partials: one float4 per thread, four independent accumulators
+__global__ static void wgrad_reduce4_kernel(const float* partial, int nchunks, float* grad) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N_PARAM_FLOATS / 4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(partial) + i;
+  constexpr size_t ST = N_PARAM_FLOATS / 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+    s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+  }
+  for (; c < nchunks; ++c) s0 += p[(size_t)c * ST];
+  reinterpret_cast<f32x4*>(grad)[i] = (s0 + s1) + (s2 + s3);
+}
+static_assert(N_PARAM_FLOATS % 4 == 0, "float4 reduce");
+constexpr int WGRAD_REDUCE_BLOCKS = (N_PARAM_FLOATS / 4 + 255) / 256;
 
 }  // namespace scade

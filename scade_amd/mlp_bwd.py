@@ -20,6 +20,16 @@ def mlp_backward(net, acts, g_out):
         flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
     else:
         raise ValueError("NeRF.train_precision must be one of %s" % (net.TRAIN_PRECISIONS,))
+    sink = getattr(net, "_grad_sink", None)
+    if sink is not None:
+        # FlatParams.attach_grad_sinks(): the 24 .grad tensors are consecutive views of one flat
+        # buffer in PARAM_ORDER, so ONE add replaces autograd's 24 per-tensor accumulations
+        first = net.ordered_params()[0].grad
+        if first is None or first.data_ptr() != sink.data_ptr() or sink.numel() != flat.numel():
+            raise RuntimeError("scade_amd: stale gradient sink (parameters were re-homed after "
+                               "FlatParams.attach_grad_sinks); call it again")
+        sink.add_(flat)
+        return [None] * len(ops.PARAM_ORDER)
     grads, o = [], 0
     for name in ops.PARAM_ORDER:
         shape = ops.PARAM_SHAPES[name]

@@ -55,6 +55,25 @@ class FlatParams:
             p.grad = self.grad[o:o + n].view(p.shape)
             o += n
 
+    def attach_grad_sinks(self, nets):
+        """Give every NeRF whose 24 parameters sit consecutively (in kernel order) in this buffer a
+        direct gradient sink: its fused backward then adds its flat gradient with one kernel
+        instead of handing 24 tensors to autograd's per-tensor accumulation."""
+        from . import ops
+        starts, o = {}, 0
+        for p in self.params:
+            starts[id(p)] = o
+            o += p.numel()
+        for net in nets:
+            ps = net.ordered_params()
+            o0 = starts.get(id(ps[0]))
+            ok = o0 is not None
+            o = o0 if ok else 0
+            for p in ps:
+                ok = ok and starts.get(id(p)) == o
+                o += p.numel()
+            net._grad_sink = self.grad[o0:o0 + ops.N_PARAM_FLOATS] if ok else None
+
     def zero_grad(self):
         self.grad.zero_()
         o = 0

@@ -46,6 +46,7 @@ class Trainer:
         self.depth_scales = torch.ones(n_images, 1, device=dev, requires_grad=True)
         self.depth_shifts = torch.zeros(n_images, 1, device=dev, requires_grad=True)
         self.flat = FlatParams(list(coarse.parameters()) + list(fine.parameters()))
+        self.flat.attach_grad_sinks([coarse, fine])
         self.flat_ss = FlatParams([self.depth_scales, self.depth_shifts])
         self.opt = FusedAdam(self.flat, lr=lrate, betas=(0.9, 0.999))
         self.opt_ss = FusedAdam(self.flat_ss, lr=scaleshift_lr)
