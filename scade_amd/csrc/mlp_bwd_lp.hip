@@ -216,12 +216,12 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
     mb[0] = mw[0]; mb[1] = mw[1];
   };
   // this wave's k-tile pair of dgrad index TT: [kt][NB16][64] V8
-#define WTL(TT, NB) (reinterpret_cast<const V8*>(pt_ + off_wtl(TT)) + kt0 * (NB) * 64)
+#define WTL(TT, NB) (reinterpret_cast<const V8*>(pt_ + CE<off_wtl(TT)>::v) + kt0 * (NB) * 64)
   an.t0 = WTL(8, 8)[lane];
   an.t1 = WTL(8, 8)[8 * 64 + lane];
 
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
-  layer_gemm_lp<BF, 2, 0, 8, false>(acc, an, WTL(8, 8), WTL(7, 16), 16, g, g, lane);
+  layer_gemm_lp<BF, 2, 0, 8, false>(acc, an, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, false, false>(acc, kt0, g, mb, nullptr, dal, lane);
   __syncthreads();
@@ -229,7 +229,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
-  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL(7, 16), WTL(6, 16), 16, g, g, lane);
+  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, true, true>(acc, kt0, g, mb, pk + OFF_WA, dal, lane);
   __syncthreads();
@@ -237,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 
 #define DGRAD_LAYER_L(L)                                                                            \
   load_mask((L)-1);                                                                                 \
-  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, g, g, lane); \
+  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, g, g, lane, nullptr); \
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false>(acc, kt0, g, mb, nullptr, dal, lane);                             \
   __syncthreads();                                                                                  \

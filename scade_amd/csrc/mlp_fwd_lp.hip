@@ -12,6 +12,8 @@
 
 namespace scade {
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
 struct MlpLpArgs {
   const void* packed;     // PACKED_LP_BYTES
   const float* in;        // mode 0: x [P,60];  mode 1: pts [P,3]
@@ -22,36 +24,41 @@ struct MlpLpArgs {
   int P, S, vd_stride;
 };
 
+// acc already holds W x + bias (the bias rode in as the first MFMA's C operand): ReLU, round, store.
 // bits[t] bit (q*4+p)*4+i <-> value (t,q,p,i) > 0: the (feature, point) map the dgrad kernel's
-// output fragment uses too
-template <bool BF, int NT, bool RELU>
-__device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], const float* __restrict__ bias,
-                                               int ntile0, typename LP<BF>::T* x, int lane,
-                                               unsigned long long (&bits)[2]) {
-  typedef typename LP<BF>::T T;
-  typedef typename LP<BF>::V4 V4;
+// output fragment uses too (only computed for the training variant)
+template <bool BF, int NT, bool RELU, bool BITS, int NTN>
+__device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], int ntile0,
+                                               typename LP<BF>::T* x, int lane,
+                                               unsigned long long (&bits)[2], f32x16 (&cb)[2],
+                                               const float* __restrict__ bias_next, int ntile0_next) {
   const int r = lane & 31, hh = lane >> 5;
   bits[0] = bits[1] = 0ull;
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int p = 0; p < LPT; ++p) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f);
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int p = 0; p < LPT; ++p) {
-        V4 v;
+      for (int q = 0; q < 4; ++q) {
+        const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
+        if (RELU && BITS) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          float y = acc[t][p][4 * q + i] + bv[i];
-          if (RELU && y > 0.f) bits[t] |= 1ull << ((q * 4 + p) * 4 + i);
-          if (RELU) y = fmaxf(y, 0.f);
-          v[i] = (T)y;
+          for (int i = 0; i < 4; ++i)
+            if (acc[t][p][4 * q + i] > 0.f) bits[t] |= 1ull << ((q * 4 + p) * 4 + i);
         }
+        u32x2 v;
+        v[0] = pack2<BF, RELU>(acc[t][p][4 * q + 0], acc[t][p][4 * q + 1]);
+        v[1] = pack2<BF, RELU>(acc[t][p][4 * q + 2], acc[t][p][4 * q + 3]);
         const int row = p * 32 + r;
-        *reinterpret_cast<V4*>(x + x_idx(row, f >> 3) + (f & 7)) = v;
+        *reinterpret_cast<u32x2*>(x + x_idx(row, f >> 3) + (f & 7)) = v;
       }
+    // the next layer's bias values are fetched into the registers point tile 0 just vacated; the
+    // rest of this epilogue hides their latency
+    if (p == 0 && NTN > 0) {
+      if (NTN == 2) load_bias16<2>(cb, bias_next, ntile0_next, lane);
+      else load_bias16<1>(reinterpret_cast<f32x16(&)[1]>(cb), bias_next, ntile0_next, lane);
     }
+  }
 }
 
 template <bool BF, int MODE, bool SAVE>
@@ -68,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   const int P = a.P;
   const T* __restrict__ wpk = reinterpret_cast<const T*>(a.packed);
   const float* __restrict__ tail = reinterpret_cast<const float*>(wpk + PACKED_LP_ELEMS);
-#define TAIL(off) (tail + ((off) - OFF_BIAS))
+#define TAIL(off) (tail + (int)CE<(off) - OFF_BIAS>::v)
 
   // ---- prologue: embedding tile [128][64] (57 real channels, zero padded) ------------
   {
@@ -121,17 +128,18 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
 
   f32x16 acc[2][LPT];
+  f32x16 cb[2];           // this lane's bias values of the NEXT layer, loaded one epilogue ahead
   unsigned long long bits[2];
   AFragL<BF> an;
   const int nt0 = wave * 2;
-#define WLBASE(L) (reinterpret_cast<const V8*>(wpk + off_wl(L)) + ((L) == L_VIEWS ? wave : nt0) * kb16(L) * 64)
+#define WLBASE(L) (reinterpret_cast<const V8*>(wpk + CE<off_wl(L)>::v) + ((L) == L_VIEWS ? wave : nt0) * (int)CE<kb16(L) * 64>::v)
 
 #define PTS_LAYER_L(L, LNEXT, KBP)                                                              \
   {                                                                                             \
-    layer_gemm_lp<BF, 2, KBP, kbh16(L), false>(acc, an, WLBASE(L), WLBASE(LNEXT), kb16(LNEXT),  \
-                                               e, x, lane);                                     \
+    layer_gemm_lp<BF, 2, KBP, kbh16(L), false>(acc, an, WLBASE(L), WLBASE(LNEXT), (int)CE<kb16(LNEXT)>::v,  \
+                                               e, x, lane, cb);                                 \
     __syncthreads();                                                                            \
-    layer_store_lp<BF, 2, true>(acc, TAIL(off_b(L)), nt0, x, lane, bits);                       \
+    layer_store_lp<BF, 2, true, SAVE, 2>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
     if (SAVE) {                                                                                 \
       unsigned long long* mw = reinterpret_cast<unsigned long long*>(a.acts + lp_acts_mask_byte(P)) + \
                                (((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid) * 2;          \
@@ -142,7 +150,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
 
   an.t0 = WLBASE(0)[lane];
-  an.t1 = WLBASE(0)[kb16(0) * 64 + lane];
+  an.t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + lane];
+  load_bias16<2>(cb, TAIL(off_b(0)), nt0, lane);
   PTS_LAYER_L(0, 1, 4)
   PTS_LAYER_L(1, 2, 0)
   PTS_LAYER_L(2, 3, 0)
@@ -189,18 +198,18 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
 
   // ---- feature_linear ------------------------------------------------------------------
-  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane);
+  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
   __syncthreads();
-  layer_store_lp<BF, 2, false>(acc, TAIL(off_b(L_FEAT)), nt0, x, lane, bits);
+  layer_store_lp<BF, 2, false, false, 1>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
   __syncthreads();
   if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, W, nullptr, tid);
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av[1][LPT];
-    layer_gemm_lp<BF, 1, 1, 16, true>(av, an, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane);
+    layer_gemm_lp<BF, 1, 1, 16, true>(av, an, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
     __syncthreads();
-    layer_store_lp<BF, 1, true>(av, TAIL(off_b(L_VIEWS)), wave, x, lane, bits);
+    layer_store_lp<BF, 1, true, false, 0>(av, wave, x, lane, bits, cb, nullptr, 0);
     __syncthreads();
     if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, nullptr, tid);
   }

@@ -15,6 +15,10 @@
 
 namespace scade {
 
+// forces compile-time evaluation of the constexpr layout helpers at their use sites (hipcc
+// otherwise emits some of them as real device functions and CALLS them from the kernel)
+template <long V> struct CE { static constexpr long v = V; };
+
 template <bool BF> struct LP;
 template <> struct LP<false> {
   typedef _Float16 T;
@@ -85,24 +89,20 @@ __device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typena
 template <bool BF>
 struct AFragL { typename LP<BF>::V8 t0, t1; };
 
-// acc[t][p] += W[n-tile t] * act[point tile p] over the layer's k-blocks.  The A operand of the
-// NEXT k-block (or the next layer's first) is in flight during the 8 MFMAs of the current one;
-// the four B fragments of the next block are read from LDS under the same MFMAs.
+// acc[t][p] = cinit[t] + W[n-tile t] * act[point tile p] over the layer's k-blocks (cinit == nullptr:
+// zero).  The first k-block is peeled so that the initial value rides in as the MFMA's C operand
+// (the lane's bias vector, or the inline constant 0) instead of 128 v_mov + 128 v_add per layer.
+// The A operand of the NEXT k-block (or the next layer's first) is in flight during the 8 MFMAs of
+// the current one; the four B fragments of the next block are read from LDS under the same MFMAs.
 template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW>
 __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragL<BF>& an,
                                               const typename LP<BF>::V8* __restrict__ wp,
                                               const typename LP<BF>::V8* __restrict__ wp_next, int kb_next,
                                               const typename LP<BF>::T* e, const typename LP<BF>::T* x,
-                                              int lane) {
+                                              int lane, const f32x16* cinit) {
   typedef typename LP<BF>::V8 V8;
   constexpr int KB = KBP + KBH;
   const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int p = 0; p < LPT; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
 
 #define LOAD_BL(KBX, PX, B)                                                         \
   {                                                                                 \
@@ -117,28 +117,97 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragL<BF>
 #define MFMA2(PX, A, B)                                                 \
   acc[0][PX] = LP<BF>::mfma(A.t0, B, acc[0][PX]);                       \
   if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(A.t1, B, acc[NT - 1][PX]);
-
-  V8 b0, b1, b2, b3, c0, c1, c2, c3;
-  LOAD_BL(0, 0, b0) LOAD_BL(0, 1, b1) LOAD_BL(0, 2, b2) LOAD_BL(0, 3, b3)
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
-    const AFragL<BF> a = an;
-    if (kb + 1 < KB) {
-      an.t0 = wp[(kb + 1) * 64 + lane];
-      if (NT > 1) an.t1 = wp[(KB + kb + 1) * 64 + lane];
-    } else {   // last k-block: the next layer's first weights
-      an.t0 = wp_next[lane];
-      an.t1 = wp_next[kb_next * 64 + lane];
-    }
-    const int kn = kb + 1 < KB ? kb + 1 : kb;
-    LOAD_BL(kn, 0, c0) LOAD_BL(kn, 1, c1) LOAD_BL(kn, 2, c2) LOAD_BL(kn, 3, c3)
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA2(0, a, b0) MFMA2(1, a, b1) MFMA2(2, a, b2) MFMA2(3, a, b3)
-    __builtin_amdgcn_sched_barrier(0);
-    b0 = c0; b1 = c1; b2 = c2; b3 = c3;
+#define MFMA2_FIRST(PX, A, B)                                           \
+  acc[0][PX] = LP<BF>::mfma(A.t0, B, c00);                              \
+  if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(A.t1, B, c01);
+#define NEXT_A(KBX)                                                     \
+  if ((KBX) + 1 < KB) {                                                 \
+    an.t0 = wp[((KBX) + 1) * 64 + lane];                                \
+    if (NT > 1) an.t1 = wp[(KB + (KBX) + 1) * 64 + lane];               \
+  } else { /* last k-block: the next layer's first weights */          \
+    an.t0 = wp_next[lane];                                              \
+    an.t1 = wp_next[kb_next * 64 + lane];                               \
   }
+
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const f32x16 c00 = cinit ? cinit[0] : zero16;
+  const f32x16 c01 = cinit ? cinit[NT - 1] : zero16;
+  // register plan: A (weights, L2 latency) is fetched a whole k-block ahead; every B fragment (LDS)
+  // is reloaded IN PLACE for the next block right after the two MFMAs that consume it were issued
+  V8 b0, b1, b2, b3;
+  LOAD_BL(0, 0, b0) LOAD_BL(0, 1, b1) LOAD_BL(0, 2, b2) LOAD_BL(0, 3, b3)
+  {   // peeled k-block 0
+    const AFragL<BF> a = an;
+    NEXT_A(0)
+    const int kn = 1 < KB ? 1 : 0;
+    __builtin_amdgcn_sched_barrier(0);
+    // point tile 0 last: its accumulator can then take over the registers of the initial value
+    MFMA2_FIRST(1, a, b1) LOAD_BL(kn, 1, b1)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA2_FIRST(2, a, b2) LOAD_BL(kn, 2, b2)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA2_FIRST(3, a, b3) LOAD_BL(kn, 3, b3)
+    __builtin_amdgcn_sched_barrier(0);
+    MFMA2_FIRST(0, a, b0) LOAD_BL(kn, 0, b0)
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#define KBLOCK(KBX)                                                    \
+  {                                                                    \
+    const AFragL<BF> a = an;                                           \
+    NEXT_A(KBX)                                                        \
+    const int kn = (KBX) + 1 < KB ? (KBX) + 1 : (KBX);                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    MFMA2(0, a, b0) LOAD_BL(kn, 0, b0)                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    MFMA2(1, a, b1) LOAD_BL(kn, 1, b1)                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    MFMA2(2, a, b2) LOAD_BL(kn, 2, b2)                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+    MFMA2(3, a, b3) LOAD_BL(kn, 3, b3)                                 \
+    __builtin_amdgcn_sched_barrier(0);                                 \
+  }
+  // a real loop over PAIRS of k-blocks (two bodies so the A registers alternate by renaming);
+  // never fully unrolled: ten layers of straight-line k-loops would not fit the instruction cache
+  int kb = 1;
+#pragma unroll 1
+  for (; kb + 1 < KB; kb += 2) {
+    KBLOCK(kb)
+    KBLOCK(kb + 1)
+  }
+  if ((KB - 1) & 1) KBLOCK(kb)
+#undef KBLOCK
 #undef LOAD_BL
 #undef MFMA2
+#undef MFMA2_FIRST
+#undef NEXT_A
+}
+
+// this lane's bias values in accumulator order: cb[t][4q+i] = bias[(ntile0+t)*32 + 8q + 4*(lane>>5) + i]
+template <int NT>
+__device__ __forceinline__ void load_bias16(f32x16 (&cb)[NT], const float* __restrict__ bias, int ntile0,
+                                            int lane) {
+  const int hh = lane >> 5;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(bias + (ntile0 + t) * 32 + 8 * q + 4 * hh);
+      cb[t][4 * q + 0] = v[0]; cb[t][4 * q + 1] = v[1]; cb[t][4 * q + 2] = v[2]; cb[t][4 * q + 3] = v[3];
+    }
+}
+
+// round two fp32 values to T (RNE) and pack them into one dword; with RELU the ReLU is applied to
+// the PACKED pair as a signed 16-bit integer max with 0 (v_pk_max_i16: a negative float, including
+// -0, is a negative int16, a positive float a positive one) - one VALU op per two values.
+// Inline asm: the compiler's own lowering of the same expression converts every scalar separately
+// and merges the halves with v_perm_b32.
+template <bool BF, bool RELU>
+__device__ __forceinline__ unsigned pack2(float y0, float y1) {
+  unsigned w;
+  if (BF) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(y0), "v"(y1));
+  else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(y0), "v"(y1));
+  if (RELU) asm("v_pk_max_i16 %0, %1, 0" : "=v"(w) : "v"(w));
+  return w;
 }
 
 }  // namespace scade
