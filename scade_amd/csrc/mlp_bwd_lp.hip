@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 
   f32x16 acc[2][LPT];
   unsigned long long mb[2] = {0ull, 0ull};
-  AFragL<BF> an;
+  AFrag3<BF> A;
   const int kt0 = wave * 2;
   auto load_mask = [&](int layer) {
     const unsigned long long* mw = masks + (((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid) * 2;
@@ -217,11 +217,16 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   };
   // this wave's k-tile pair of dgrad index TT: [kt][NB16][64] V8
 #define WTL(TT, NB) (reinterpret_cast<const V8*>(pt_ + CE<off_wtl(TT)>::v) + kt0 * (NB) * 64)
-  an.t0 = WTL(8, 8)[lane];
-  an.t1 = WTL(8, 8)[8 * 64 + lane];
+  A.s[0].t0 = WTL(8, 8)[lane];
+  A.s[0].t1 = WTL(8, 8)[8 * 64 + lane];
+  A.s[1].t0 = WTL(8, 8)[64 + lane];
+  A.s[1].t1 = WTL(8, 8)[9 * 64 + lane];
+  // rotation of the A register sets on entry of the n-th gemm of the chain: views (8 k-blocks),
+  // feature (16), then layers 7..1 (16 each)
+#define DROT(N) ((N) == 0 ? 0 : (8 + 16 * ((N)-1)) % 3)
 
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
-  layer_gemm_lp<BF, 2, 0, 8, false>(acc, an, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
+  layer_gemm_lp<BF, 2, 0, 8, false, DROT(0)>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, false, false>(acc, kt0, g, mb, nullptr, dal, lane);
   __syncthreads();
@@ -229,7 +234,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
-  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
+  layer_gemm_lp<BF, 2, 0, 16, false, DROT(1)>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, true, true>(acc, kt0, g, mb, pk + OFF_WA, dal, lane);
   __syncthreads();
@@ -237,7 +242,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 
 #define DGRAD_LAYER_L(L)                                                                            \
   load_mask((L)-1);                                                                                 \
-  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, g, g, lane, nullptr); \
+  layer_gemm_lp<BF, 2, 0, 16, false, DROT(9 - (L))>(acc, A, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, \
+                                                    g, g, lane, nullptr);                           \
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false>(acc, kt0, g, mb, nullptr, dal, lane);                             \
   __syncthreads();                                                                                  \
@@ -251,6 +257,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   DGRAD_LAYER_L(2)
   DGRAD_LAYER_L(1)
 #undef DGRAD_LAYER_L
+#undef DROT
 #undef WTL
 }
 

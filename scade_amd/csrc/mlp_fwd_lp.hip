@@ -12,6 +12,13 @@
 
 namespace scade {
 
+// forward layer order: pts 0..7, feature, views
+constexpr int fwd_rot(int l) {
+  int k = 0;
+  for (int i = 0; i < l; ++i) k += kb16(i);
+  return k % 3;
+}
+
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 struct MlpLpArgs {
@@ -85,28 +92,43 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       const int row = i / 7, c = 57 + (i - row * 7);
       e[e_idx(row, c >> 3) + (c & 7)] = (T)0.f;
     }
-    for (int i = tid; i < LM * 30; i += 256) {
-      const int row = i / 30, rem = i - row * 30;
-      const int c = rem / 10, s = rem - c * 10;
-      const int pt = min(p0 + row, P - 1);
-      float v0, v1 = 0.f;
-      int col0, col1 = -1;
-      if (MODE == 0) {
+    if (MODE == 0) {
+      // x rows already hold gamma(x): copy channel pairs (s==0: raw, s>=1: sin/cos of freq s-1)
+      for (int i = tid; i < LM * 30; i += 256) {
+        const int row = i / 30, rem = i - row * 30;
+        const int c = rem / 10, s = rem - c * 10;
+        const int pt = min(p0 + row, P - 1);
         const float* xr = a.in + (size_t)pt * 60;
-        if (s == 0) { col0 = c; v0 = xr[c]; }
-        else { col0 = 3 + 6 * (s - 1) + c; col1 = col0 + 3; v0 = xr[col0]; v1 = xr[col1]; }
-      } else {
-        const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
-        const float xv = (a.in[(size_t)pt * 3 + c] - ctr) * sc;
-        if (s == 0) { col0 = c; v0 = xv; }
-        else {
-          const float arg = (xv * 3.14159274101257324f) * (float)(1 << (s - 1));
-          sincosf(arg, &v0, &v1);
-          col0 = 3 + 6 * (s - 1) + c; col1 = col0 + 3;
+        if (s == 0) {
+          e[e_idx(row, 0) + c] = (T)xr[c];
+        } else {
+          const int col0 = 3 + 6 * (s - 1) + c, col1 = col0 + 3;
+          e[e_idx(row, col0 >> 3) + (col0 & 7)] = (T)xr[col0];
+          e[e_idx(row, col1 >> 3) + (col1 & 7)] = (T)xr[col1];
         }
       }
-      e[e_idx(row, col0 >> 3) + (col0 & 7)] = (T)v0;
-      if (col1 >= 0) e[e_idx(row, col1 >> 3) + (col1 & 7)] = (T)v1;
+    } else {
+      // one thread per (point, coordinate): all nine octaves from ONE exact range reduction each.
+      // sin(pi x 2^k) = sin(2 pi t) with t = x 2^(k-1) revolutions; the scaling by 2^(k-1) and the
+      // fract are exact in fp32, so the hardware v_sin_f32 / v_cos_f32 (argument in revolutions,
+      // ~1e-6 absolute) sees an exact argument.  The reference rounds x*pi_f32 first (up to 5e-5 rad
+      // off at the top octave); both are far inside the 16-bit rounding of this path.
+      for (int i = tid; i < LM * 3; i += 256) {
+        const int row = i / 3, c = i - row * 3;
+        const int pt = min(p0 + row, P - 1);
+        const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
+        const float xv = (a.in[(size_t)pt * 3 + c] - ctr) * sc;
+        e[e_idx(row, 0) + c] = (T)xv;
+        float t = 0.5f * xv;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          const float fr = __builtin_amdgcn_fractf(t);
+          const int col0 = 3 + 6 * k + c, col1 = col0 + 3;
+          e[e_idx(row, col0 >> 3) + (col0 & 7)] = (T)__builtin_amdgcn_sinf(fr);
+          e[e_idx(row, col1 >> 3) + (col1 & 7)] = (T)__builtin_amdgcn_cosf(fr);
+          t += t;
+        }
+      }
     }
   }
   __syncthreads();
@@ -130,14 +152,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   f32x16 acc[2][LPT];
   f32x16 cb[2];           // this lane's bias values of the NEXT layer, loaded one epilogue ahead
   unsigned long long bits[2];
-  AFragL<BF> an;
+  AFrag3<BF> A;
   const int nt0 = wave * 2;
 #define WLBASE(L) (reinterpret_cast<const V8*>(wpk + CE<off_wl(L)>::v) + ((L) == L_VIEWS ? wave : nt0) * (int)CE<kb16(L) * 64>::v)
 
+  // rotation of the A register sets on entry of layer L = (k-blocks of all earlier layers) % 3
+#define FROT(L) ((int)CE<fwd_rot(L)>::v)
 #define PTS_LAYER_L(L, LNEXT, KBP)                                                              \
   {                                                                                             \
-    layer_gemm_lp<BF, 2, KBP, kbh16(L), false>(acc, an, WLBASE(L), WLBASE(LNEXT), (int)CE<kb16(LNEXT)>::v,  \
-                                               e, x, lane, cb);                                 \
+    layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L)>(acc, A, WLBASE(L), WLBASE(LNEXT),       \
+                                                        (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
     __syncthreads();                                                                            \
     layer_store_lp<BF, 2, true, SAVE, 2>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
     if (SAVE) {                                                                                 \
@@ -149,8 +173,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, L), p0, P, W, nullptr, tid);         \
   }
 
-  an.t0 = WLBASE(0)[lane];
-  an.t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + lane];
+  A.s[0].t0 = WLBASE(0)[lane];
+  A.s[0].t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + lane];
+  A.s[1].t0 = WLBASE(0)[64 + lane];
+  A.s[1].t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + 64 + lane];
   load_bias16<2>(cb, TAIL(off_b(0)), nt0, lane);
   PTS_LAYER_L(0, 1, 4)
   PTS_LAYER_L(1, 2, 0)
@@ -198,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
 
   // ---- feature_linear ------------------------------------------------------------------
-  layer_gemm_lp<BF, 2, 0, 16, false>(acc, an, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+  layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT)>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
   __syncthreads();
   layer_store_lp<BF, 2, false, false, 1>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
   __syncthreads();
@@ -207,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av[1][LPT];
-    layer_gemm_lp<BF, 1, 1, 16, true>(av, an, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+    layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS)>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
     __syncthreads();
     layer_store_lp<BF, 1, true, false, 0>(av, wave, x, lane, bits, cb, nullptr, 0);
     __syncthreads();

@@ -88,14 +88,20 @@ __device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typena
 
 template <bool BF>
 struct AFragL { typename LP<BF>::V8 t0, t1; };
+// three A-fragment register sets: k-block kb of a layer entered with rotation ROT lives in set
+// (ROT + kb) % 3; the sets of blocks kb+1 and kb+2 are in flight while block kb is multiplied
+template <bool BF>
+struct AFrag3 { AFragL<BF> s[3]; };
 
 // acc[t][p] = cinit[t] + W[n-tile t] * act[point tile p] over the layer's k-blocks (cinit == nullptr:
 // zero).  The first k-block is peeled so that the initial value rides in as the MFMA's C operand
 // (the lane's bias vector, or the inline constant 0) instead of 128 v_mov + 128 v_add per layer.
-// The A operand of the NEXT k-block (or the next layer's first) is in flight during the 8 MFMAs of
-// the current one; the four B fragments of the next block are read from LDS under the same MFMAs.
-template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW>
-__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragL<BF>& an,
+// A (weights, L2 latency): fetched TWO k-blocks ahead into the rotating sets of AFrag3 - across the
+// layer boundary too (the last two blocks prefetch blocks 0 and 1 of the next layer; the caller
+// enters the next layer with rotation (ROT + KB) % 3).  B (activations, LDS): every fragment is
+// reloaded in place for the next block right after the two MFMAs that consume it were issued.
+template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT>
+__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFrag3<BF>& A,
                                               const typename LP<BF>::V8* __restrict__ wp,
                                               const typename LP<BF>::V8* __restrict__ wp_next, int kb_next,
                                               const typename LP<BF>::T* e, const typename LP<BF>::T* x,
@@ -114,72 +120,74 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragL<BF>
       B = *reinterpret_cast<const V8*>(x + x_idx((PX)*32 + r, 2 * (kb_ - KBP) + hh)); \
     }                                                                               \
   }
-#define MFMA2(PX, A, B)                                                 \
-  acc[0][PX] = LP<BF>::mfma(A.t0, B, acc[0][PX]);                       \
-  if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(A.t1, B, acc[NT - 1][PX]);
-#define MFMA2_FIRST(PX, A, B)                                           \
-  acc[0][PX] = LP<BF>::mfma(A.t0, B, c00);                              \
-  if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(A.t1, B, c01);
-#define NEXT_A(KBX)                                                     \
-  if ((KBX) + 1 < KB) {                                                 \
-    an.t0 = wp[((KBX) + 1) * 64 + lane];                                \
-    if (NT > 1) an.t1 = wp[(KB + (KBX) + 1) * 64 + lane];               \
-  } else { /* last k-block: the next layer's first weights */          \
-    an.t0 = wp_next[lane];                                              \
-    an.t1 = wp_next[kb_next * 64 + lane];                               \
+#define MFMA2(PX, AS, B)                                                \
+  acc[0][PX] = LP<BF>::mfma(AS.t0, B, acc[0][PX]);                      \
+  if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(AS.t1, B, acc[NT - 1][PX]);
+#define MFMA2_FIRST(PX, AS, B)                                          \
+  acc[0][PX] = LP<BF>::mfma(AS.t0, B, c00);                             \
+  if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(AS.t1, B, c01);
+  // fetch k-block KBX+2 (of this layer, or block 0 / 1 of the next) into set DST
+#define FETCH_A(KBX, DST)                                               \
+  {                                                                     \
+    const int blk_ = (KBX) + 2;                                         \
+    if (blk_ < KB) {                                                    \
+      DST.t0 = wp[blk_ * 64 + lane];                                    \
+      if (NT > 1) DST.t1 = wp[(KB + blk_) * 64 + lane];                 \
+    } else {                                                            \
+      DST.t0 = wp_next[(blk_ - KB) * 64 + lane];                        \
+      DST.t1 = wp_next[(kb_next + blk_ - KB) * 64 + lane];              \
+    }                                                                   \
+  }
+#define KBLOCK(KBX, R)                                                  \
+  {                                                                     \
+    FETCH_A(KBX, A.s[((R) + 2) % 3])                                    \
+    const int kn = (KBX) + 1 < KB ? (KBX) + 1 : (KBX);                  \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    MFMA2(0, A.s[R], b0) LOAD_BL(kn, 0, b0)                             \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    MFMA2(1, A.s[R], b1) LOAD_BL(kn, 1, b1)                             \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    MFMA2(2, A.s[R], b2) LOAD_BL(kn, 2, b2)                             \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    MFMA2(3, A.s[R], b3) LOAD_BL(kn, 3, b3)                             \
+    __builtin_amdgcn_sched_barrier(0);                                  \
   }
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const f32x16 c00 = cinit ? cinit[0] : zero16;
   const f32x16 c01 = cinit ? cinit[NT - 1] : zero16;
-  // register plan: A (weights, L2 latency) is fetched a whole k-block ahead; every B fragment (LDS)
-  // is reloaded IN PLACE for the next block right after the two MFMAs that consume it were issued
   V8 b0, b1, b2, b3;
   LOAD_BL(0, 0, b0) LOAD_BL(0, 1, b1) LOAD_BL(0, 2, b2) LOAD_BL(0, 3, b3)
   {   // peeled k-block 0
-    const AFragL<BF> a = an;
-    NEXT_A(0)
+    FETCH_A(0, A.s[(ROT + 2) % 3])
     const int kn = 1 < KB ? 1 : 0;
     __builtin_amdgcn_sched_barrier(0);
     // point tile 0 last: its accumulator can then take over the registers of the initial value
-    MFMA2_FIRST(1, a, b1) LOAD_BL(kn, 1, b1)
+    MFMA2_FIRST(1, A.s[ROT], b1) LOAD_BL(kn, 1, b1)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA2_FIRST(2, a, b2) LOAD_BL(kn, 2, b2)
+    MFMA2_FIRST(2, A.s[ROT], b2) LOAD_BL(kn, 2, b2)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA2_FIRST(3, a, b3) LOAD_BL(kn, 3, b3)
+    MFMA2_FIRST(3, A.s[ROT], b3) LOAD_BL(kn, 3, b3)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA2_FIRST(0, a, b0) LOAD_BL(kn, 0, b0)
+    MFMA2_FIRST(0, A.s[ROT], b0) LOAD_BL(kn, 0, b0)
     __builtin_amdgcn_sched_barrier(0);
   }
-#define KBLOCK(KBX)                                                    \
-  {                                                                    \
-    const AFragL<BF> a = an;                                           \
-    NEXT_A(KBX)                                                        \
-    const int kn = (KBX) + 1 < KB ? (KBX) + 1 : (KBX);                 \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-    MFMA2(0, a, b0) LOAD_BL(kn, 0, b0)                                 \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-    MFMA2(1, a, b1) LOAD_BL(kn, 1, b1)                                 \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-    MFMA2(2, a, b2) LOAD_BL(kn, 2, b2)                                 \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-    MFMA2(3, a, b3) LOAD_BL(kn, 3, b3)                                 \
-    __builtin_amdgcn_sched_barrier(0);                                 \
-  }
-  // a real loop over PAIRS of k-blocks (two bodies so the A registers alternate by renaming);
-  // never fully unrolled: ten layers of straight-line k-loops would not fit the instruction cache
+  // a real loop over TRIPLES of k-blocks (one body per register set); never fully unrolled: ten
+  // layers of straight-line k-loops would not fit the instruction cache
   int kb = 1;
 #pragma unroll 1
-  for (; kb + 1 < KB; kb += 2) {
-    KBLOCK(kb)
-    KBLOCK(kb + 1)
+  for (; kb + 2 < KB; kb += 3) {
+    KBLOCK(kb, (ROT + 1) % 3)
+    KBLOCK(kb + 1, (ROT + 2) % 3)
+    KBLOCK(kb + 2, ROT)
   }
-  if ((KB - 1) & 1) KBLOCK(kb)
+  if ((KB - 1) % 3 >= 1) KBLOCK(kb, (ROT + 1) % 3)
+  if ((KB - 1) % 3 == 2) KBLOCK(kb + 1, (ROT + 2) % 3)
 #undef KBLOCK
+#undef FETCH_A
 #undef LOAD_BL
 #undef MFMA2
 #undef MFMA2_FIRST
-#undef NEXT_A
 }
 
 // this lane's bias values in accumulator order: cb[t][4q+i] = bias[(ntile0+t)*32 + 8q + 4*(lane>>5) + i]

@@ -72,7 +72,9 @@ def test_lp_points_mode_matches_embedded_mode(dev, prec):
         emb = net(x.to(dev)).reshape(N, Sm, 4)
     assert rel_l2(fused, want) < BOUND[prec]
     assert rel_l2(emb, want) < BOUND[prec]
-    assert rel_l2(fused, emb) < BOUND[prec] / 4      # only the sin/cos rounding differs
+    # the fused mode evaluates sin/cos with the hardware instructions on an exactly reduced argument,
+    # the embedded mode receives the oracle's values: different roundings of the 57 inputs
+    assert rel_l2(fused, emb) < BOUND[prec] / 2
 
 
 def psnr(a, b):
