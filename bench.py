@@ -294,7 +294,8 @@ def main():
                      "launches_timed": k["launches"], "avg_launch_ms": avg_ms,
                      "flops_per_launch": flops_per_launch,
                      "note": "algorithmic 1,174,528 FLOP/point x mean points per launch "
-                             "(coarse 65,536 + fine 196,608 per step), HIP events on the launch stream"},
+                             f"(coarse {args.rays * N_COARSE:,} + fine {args.rays * (N_COARSE + N_FINE):,} per step), "
+                             "HIP events on the launch stream"},
     }
     # secondary: the same test-render work as a 16-chunk image render, chunks pipelined over 2 streams
     big = O.synthetic_rays(args.rays * 16, seed=5000 + rank).to(dev)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""pmc_summary.csv (tools/profile_gpu.sh) -> profiles/rNN_pmc.json: per-kernel means per dispatch.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB  (the gfx950 FETCH_SIZE correction of
+MI355X_MICROARCH.md, HBM / rocprofv3 section); MFMA utilisation = (SQ_VALU_MFMA_BUSY_CYCLES / 1024
+SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); LDS conflict fraction = SQ_LDS_BANK_CONFLICT /
+SQ_LDS_IDX_ACTIVE; L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS)."""
+import collections, csv, json, re, sys
+
+KEYS = [  # (regex on the kernel name, key in the json)
+    (r"mlp_fwd_kernel<1, false>", "mlp_fwd_kernel"), (r"mlp_fwd_kernel<1, true>", "mlp_fwd_kernel_train"),
+    (r"mlp_dgrad_kernel", "mlp_dgrad_kernel"), (r"mlp_wgrad_kernel", "mlp_wgrad_kernel"),
+    (r"mlp_fwd_f16_kernel<1, false>", "mlp_fwd_f16_kernel"), (r"mlp_fwd_f16_kernel<1, true>", "mlp_fwd_f16_kernel_train"),
+    (r"mlp_dgrad_f16_kernel", "mlp_dgrad_f16_kernel"), (r"mlp_wgrad_f16_kernel", "mlp_wgrad_f16_kernel"),
+    (r"mlp_fwd_lp_kernel<true, 1, false>", "mlp_fwd_lp_kernel_bf16"), (r"mlp_fwd_lp_kernel<false, 1, false>", "mlp_fwd_lp_kernel_f16"),
+    (r"mlp_fwd_lp_kernel<true, 1, true>", "mlp_fwd_lp_kernel_bf16_train"),
+    (r"mlp_dgrad_lp_kernel<true>", "mlp_dgrad_lp_kernel_bf16"), (r"mlp_wgrad_lp_kernel<true>", "mlp_wgrad_lp_kernel_bf16"),
+    (r"wgrad_reduce4_kernel", "wgrad_reduce4_kernel"),
+]
+
+
+def main(src, dst):
+    rows = collections.defaultdict(dict)
+    for r in csv.reader(open(src)):
+        if r[0] == "kernel":
+            continue
+        rows[r[0]][r[1]] = float(r[3])
+    out = {}
+    for name, v in rows.items():
+        key = next((k for rx, k in KEYS if re.search(rx, name)), None)
+        if key is None:
+            continue
+        gui, mf = v.get("GRBM_GUI_ACTIVE", 0.0), v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        hit, miss = v.get("TCC_HIT_sum", 0.0), v.get("TCC_MISS_sum", 0.0)
+        out[key] = {
+            "fetch_size_kb": v.get("FETCH_SIZE"), "write_size_kb": v.get("WRITE_SIZE"),
+            "hbm_bytes_per_launch": (2 * v.get("FETCH_SIZE", 0.0) + v.get("WRITE_SIZE", 0.0)) * 1024.0,
+            "mfma_util": (mf / 1024) / (gui / 8) if gui else None,
+            "lds_bank_conflict_frac": v.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(v.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0),
+            "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
+            "wave_wait_any_frac": v.get("SQ_WAIT_ANY", 0.0) / max(v.get("SQ_WAVE_CYCLES", 0.0), 1.0),
+        }
+    json.dump(out, open(dst, "w"), indent=1)
+    for k, v in out.items():
+        print(f"{k:32s} mfma {v['mfma_util']:.3f}  hbm {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  "
+              f"lds-conflict {v['lds_bank_conflict_frac']:.3f}  L2 hit {v['l2_hit_rate']:.3f}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])

@@ -39,6 +39,7 @@ with open(os.path.join(out, "pmc_summary.csv"), "w") as fo:
             fo.write(f"\"{k[:90]}\",{c},{len(v)},{sum(v)/len(v):.6g},{sum(v):.6g}\n")
 print(open(os.path.join(out, "pmc_summary.csv")).read()[:6000])
 PY
+python $ROOT/tools/pmc_to_json.py $OUT/pmc_summary.csv $OUT/pmc.json > $OUT/pmc_derived.txt
 find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*counter_collection.csv" -delete; find $OUT -name "*.db" -delete
 cp $OUT/stats/*/bench_kernel_stats.csv $OUT/kernel_stats.csv 2>/dev/null || cp $OUT/stats/bench_kernel_stats.csv $OUT/kernel_stats.csv
 cp $OUT/stats_train/*/bench_kernel_stats.csv $OUT/kernel_stats_train.csv 2>/dev/null || cp $OUT/stats_train/bench_kernel_stats.csv $OUT/kernel_stats_train.csv
