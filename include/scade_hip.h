@@ -177,6 +177,14 @@ int scade_carve_fwd(const float* pred, const float* hyp, const float* mask, floa
 int scade_carve_bwd(const float* pred, const float* hyp, const float* mask, float threshold,
                     int is_joint, int N, int P, int K, const float* workspace,
                     const float* g_loss, float* g_pred, float* g_hyp, void* stream);
+/* The joint forward in two phases, for a ray-sharded job (run_nerf_helpers.py:115-119 takes the mean
+ * over ALL rays before the min over K): colmean writes workspace[K*P] = mean over this shard's N rays;
+ * the caller combines the shards (all-reduce of N_shard/N_total-weighted means); min takes the min over
+ * K / mean over samples of the combined means and stores the argmin after them, as scade_carve_fwd
+ * does, so scade_carve_bwd(is_joint = 1) can follow with g_loss pre-multiplied by N_shard/N_total. */
+int scade_carve_joint_colmean(const float* pred, const float* hyp, const float* mask, float threshold,
+                              int N, int P, int K, float* workspace, void* stream);
+int scade_carve_joint_min(float* workspace, int P, int K, float* loss, void* stream);
 
 /* ---- photometric loss (helpers:11 img2mse; row mask = run_scade_wild.py:978-986) - */
 int scade_mse_fwd(const float* x, const float* y, const float* row_mask, int n, int c,

@@ -774,6 +774,30 @@ extern "C" int scade_carve_fwd(const float* pred, const float* hyp, const float*
   return scade_check_launch("scade_carve_fwd");
 }
 
+// the two phases of the joint forward as separate entries: a ray-sharded job all-reduces the [K,P]
+// column means between them ("exchange-step exceptions")
+extern "C" int scade_carve_joint_colmean(const float* pred, const float* hyp, const float* mask,
+                                         float threshold, int N, int P, int K, float* workspace,
+                                         void* stream) {
+  SCADE_REQUIRE(pred && hyp && workspace, -1, "scade_carve_joint_colmean: null pointer");
+  SCADE_REQUIRE(N > 0 && P > 0 && K > 0, -2, "scade_carve_joint_colmean: empty problem");
+  CarveArgs a{};
+  a.pred = pred; a.hyp = hyp; a.mask = mask; a.partial = workspace;
+  a.threshold = threshold; a.N = N; a.P = P; a.K = K;
+  hipLaunchKernelGGL(carve_joint_colsum_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_carve_joint_colmean");
+}
+
+extern "C" int scade_carve_joint_min(float* workspace, int P, int K, float* loss, void* stream) {
+  SCADE_REQUIRE(workspace && loss, -1, "scade_carve_joint_min: null pointer");
+  SCADE_REQUIRE(P > 0 && K > 0, -2, "scade_carve_joint_min: empty problem");
+  CarveArgs a{};
+  a.partial = workspace; a.loss = loss; a.P = P; a.K = K;
+  hipLaunchKernelGGL(carve_joint_min_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, a,
+                     reinterpret_cast<int*>(workspace + (size_t)K * P));
+  return scade_check_launch("scade_carve_joint_min");
+}
+
 extern "C" int scade_carve_bwd(const float* pred, const float* hyp, const float* mask,
                                float threshold, int is_joint, int N, int P, int K,
                                const float* workspace, const float* g_loss, float* g_pred,

@@ -554,6 +554,46 @@ class CarveFn(torch.autograd.Function):
         return g_pred, g_hyp.reshape(hyp_shape), None, None, None
 
 
+class CarveJointShardedFn(torch.autograd.Function):
+    """is_joint=True space-carving loss of a RAY-SHARDED batch: the mean over
+    rays runs over all shards BEFORE the min over the K hypotheses, so the [K,P] column means are
+    combined across ranks (parallel.combine_shard_means: one all-reduce of K*P floats) between the two
+    kernel phases.  Every rank returns the GLOBAL loss; the backward yields this shard's part of its
+    gradient times ``world`` so that the trainer's usual sum-all-reduce x 1/world stays correct."""
+
+    @staticmethod
+    def forward(ctx, pred, hyp, mask, threshold, group):
+        from . import parallel
+        check(pred, "space_carving: pred_depth"); check(hyp, "space_carving: target_hypothesis")
+        N, P = pred.shape
+        K = hyp.shape[0]
+        pred_c, hyp_c = _c(pred), _c(hyp.reshape(K, N))
+        mask_c = None if mask is None else _c(check(mask, "space_carving: mask").reshape(N))
+        ws = torch.empty(int(_lib.load().scade_carve_workspace_floats(N, P, K, 1)), device=pred.device,
+                         dtype=torch.float32)
+        loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+        call("scade_carve_joint_colmean", ptr(pred_c), ptr(hyp_c), ptr(mask_c), float(threshold), N, P, K,
+             ptr(ws), stream())
+        share, world = parallel.combine_shard_means(ws[:K * P], N, group)
+        call("scade_carve_joint_min", ptr(ws), P, K, ptr(loss), stream())
+        ctx.save_for_backward(pred_c, hyp_c, mask_c if mask_c is not None else pred.new_empty(0), ws)
+        ctx.cfg = (float(threshold), mask is not None, tuple(hyp.shape), share * world)
+        return loss.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, hyp, mask, ws = ctx.saved_tensors
+        thr, has_mask, hyp_shape, factor = ctx.cfg
+        N, P = pred.shape
+        K = hyp.shape[0]
+        g = _c((g.reshape(1) * factor).to(torch.float32))
+        g_pred = torch.empty_like(pred)
+        g_hyp = torch.empty_like(hyp)
+        call("scade_carve_bwd", ptr(pred), ptr(hyp), ptr(mask if has_mask else None), thr, 1, N, P,
+             K, ptr(ws), ptr(g), ptr(g_pred), ptr(g_hyp), stream())
+        return g_pred, g_hyp.reshape(hyp_shape), None, None, None
+
+
 class MseFn(torch.autograd.Function):
     """img2mse (helpers:11), optional per-row mask (run_scade_wild.py:978-986)."""
 

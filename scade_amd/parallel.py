@@ -99,6 +99,30 @@ class FlatParams:
             dist.broadcast(self.data, src=src, group=group)
 
 
+def combine_shard_means(means: torch.Tensor, n_local: int, group=None):
+    """In place: per-shard means over ``n_local`` rays -> the mean over the rays of ALL shards
+    (one sum-all-reduce of the n_local/N_total-weighted means).  Returns (n_local / N_total, world).
+    Single process: identity, (1.0, 1)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1.0, 1
+    world = dist.get_world_size(group)
+    n = torch.tensor([float(n_local)], device=means.device, dtype=torch.float64)
+    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+    share = float(n_local) / float(n.item())
+    means.mul_(share)
+    dist.all_reduce(means, op=dist.ReduceOp.SUM, group=group)
+    return share, world
+
+
+def shared_uniform(shape, device, generator=None, src: int = 0, group=None) -> torch.Tensor:
+    """One uniform draw shared by all ranks (sample_pdf_joint draws ONE u[S] for the whole batch,
+    helpers:452-453): drawn on ``src`` and broadcast."""
+    u = torch.rand(shape, device=device, generator=generator)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(u, src=src, group=group)
+    return u
+
+
 def staircase_lr(lr0: float, decay_rate: float, decay_step: int, it: int) -> float:
     """train_utils/hyperparameter_update.py:8-13 / run_scade_scannet.py:988-991."""
     return lr0 * (decay_rate ** (it // decay_step))

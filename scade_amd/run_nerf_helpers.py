@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import CarveFn, MseFn, SamplePdfFn
+from .ops import CarveFn, CarveJointShardedFn, MseFn, SamplePdfFn
 
 # ---------------------------------------------------------------------------
 # misc  (helpers:11-14)
@@ -56,9 +56,14 @@ def to16b(x):
 
 
 def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2,
-                               threshold=0.0):
+                               threshold=0.0, sharded=False, group=None):
     """pred_depth [N,P]; target_hypothesis [K,N,1].  The norm runs over a size-1
-    axis, so every ``norm_p`` gives |pred - hyp| (kept for signature parity)."""
+    axis, so every ``norm_p`` gives |pred - hyp| (kept for signature parity).
+
+    ``sharded=True`` (not in the reference, which is single-process): the arguments are this
+    rank's SHARD of a ray-partitioned batch.  Only ``is_joint=True`` needs an exchange (its mean
+    over rays precedes the min over K): the result is then the loss of the whole batch, see
+    ``ops.CarveJointShardedFn``."""
     if target_hypothesis.dim() != 3:
         raise ValueError("compute_space_carving_loss: target_hypothesis must be [K,N,1]")
     if target_hypothesis.shape[-1] != 1:
@@ -67,6 +72,8 @@ def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, ma
             "produced by any SCADE driver and are not implemented")
     if norm_p <= 0:
         raise ValueError("norm_p must be positive")
+    if is_joint and sharded:
+        return CarveJointShardedFn.apply(pred_depth, target_hypothesis, mask, float(threshold), group)
     return CarveFn.apply(pred_depth, target_hypothesis, mask, float(threshold), bool(is_joint))
 
 

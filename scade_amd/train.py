@@ -15,11 +15,12 @@ from __future__ import annotations
 from typing import Optional
 
 import torch
+import torch.distributed as dist
 
 from . import rendering as R
 from . import run_nerf_helpers as H
 from .optim import FusedAdam
-from .parallel import FlatParams, staircase_lr
+from .parallel import FlatParams, shared_uniform, staircase_lr
 
 
 def make_scade_nets(device, seed: Optional[int] = None):
@@ -55,12 +56,18 @@ class Trainer:
                         thr=space_carving_threshold, joint=is_joint, warm=warm_start_nerf,
                         lindisp=lindisp, noise=raw_noise_std)
         self.it = 0
+        # rays are sharded over the ranks of the default process group (one process per GPU)
+        self.sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.flat.broadcast_params(0)
         self.flat_ss.broadcast_params(0)
 
     def forward_loss(self, rays, target_s, target_hyp, img_i=0, mask=None, **render_kw):
         c = self.cfg
         target_h = target_hyp * self.depth_scales[img_i] + self.depth_shifts[img_i]          # :954
+        if c["joint"] and self.sharded:
+            # sample_pdf_joint draws ONE u[S] for the whole batch (helpers:452-453): rank 0's draw
+            render_kw.setdefault("u_coarse", shared_uniform((c["Ni"],), rays.device))
+            render_kw.setdefault("cached_u", shared_uniform((c["Ni"],), rays.device))
         ret = R.render_rays(rays, True, self.coarse, self.query, c["Ns"], N_importance=c["Ni"],
                             network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
                             lindisp=c["lindisp"], is_joint=c["joint"], **render_kw)
@@ -70,7 +77,8 @@ class Trainer:
         carve = None
         if c["w"] > 0. and self.it >= c["warm"]:                                              # :973
             carve = H.compute_space_carving_loss(ret["pred_hyp"], target_h, is_joint=c["joint"],
-                                                 mask=mask, norm_p=c["norm_p"], threshold=c["thr"])
+                                                 mask=mask, norm_p=c["norm_p"], threshold=c["thr"],
+                                                 sharded=self.sharded)
             loss = loss + c["w"] * carve
         img_loss0 = mse(ret["rgb0"], target_s)                                                # :981
         loss = loss + img_loss0

@@ -271,3 +271,29 @@ def test_gen_rays_golden(dev):
     rows_full = ops.gen_rays(Hh, Ww, intr, c2w, near=0.1, far=5.0)["rays"]
     want = O.ray_rows(g["rays_o_full"], g["rays_d_full"], 0.1, 5.0)
     assert_close(rows_full, want, rtol=2e-6, atol=1e-7, what="full rows")
+
+
+def test_space_carving_joint_sharded_entry_single_process(dev):
+    """sharded=True with one process: the two-phase entry (column means | exchange | min) gives
+    the same loss and gradients as the fused joint kernel and the oracle."""
+    g = torch.Generator().manual_seed(21)
+    N, K, P = 37, 7, 128
+    pred = torch.rand(N, P, generator=g) * 4 + 0.5
+    hyp = torch.rand(K, N, 1, generator=g) * 4.9 + 0.1
+    mask = (torch.rand(N, generator=g) > 0.3).float()
+    for m, thr in ((None, 0.0), (mask, 0.05)):
+        po, ho = pred.clone().requires_grad_(True), hyp.clone().requires_grad_(True)
+        want = O.compute_space_carving_loss(po, ho, is_joint=True, mask=m, threshold=thr)
+        want.backward()
+        res = []
+        for sharded in (False, True):
+            p = pred.to(dev).requires_grad_(True)
+            h = hyp.to(dev).requires_grad_(True)
+            l = S.compute_space_carving_loss(p, h, is_joint=True, mask=None if m is None else m.to(dev),
+                                             threshold=thr, sharded=sharded)
+            l.backward()
+            res.append((l.detach().cpu(), p.grad.cpu(), h.grad.cpu()))
+        for l, gp, gh in res:
+            assert_close(l, want.detach(), rtol=1e-5, atol=1e-7, what="joint loss")
+            assert_close(gp, po.grad, rtol=1e-5, atol=1e-9, what="joint d/d pred")
+            assert_close(gh, ho.grad, rtol=1e-5, atol=1e-9, what="joint d/d hyp")

@@ -113,3 +113,79 @@ def test_flatparams_views_and_zero_grad():
     assert ps[0].grad is not None and float(flat.grad.abs().sum()) == 0.0
     flat.data.mul_(0)
     assert float(ps[1].abs().sum()) == 0.0
+
+
+# ---------------------------------------------------------------- is_joint exchange
+class _JointShardedCpu(torch.autograd.Function):
+    """CPU stand-in with the SAME structure as scade_amd.ops.CarveJointShardedFn (kernel phases
+    replaced by torch ops): column means of the shard -> parallel.combine_shard_means -> min over
+    K / mean over samples; backward = this shard's part of the global gradient x world."""
+
+    @staticmethod
+    def forward(ctx, pred, hyp):
+        from scade_amd.parallel import combine_shard_means
+        d = (pred[None] - hyp).abs()                       # [K,n,P]
+        means = d.mean(dim=1)                              # [K,P] over this shard's rays
+        share, world = combine_shard_means(means, pred.shape[0])
+        best, arg = means.min(dim=0)
+        ctx.save_for_backward(pred, hyp, arg)
+        ctx.factor = share * world
+        return best.mean()
+
+    @staticmethod
+    def backward(ctx, g):
+        pred, hyp, arg = ctx.saved_tensors
+        n, P = pred.shape
+        sel = hyp[arg, :, 0].T if hyp.shape[-1] == 1 else None      # [n,P] hypothesis of the argmin
+        sgn = torch.sign(pred - sel)
+        gp = sgn * (g * ctx.factor / (n * P))
+        gh = torch.zeros_like(hyp)
+        gh[:, :, 0].index_put_((arg[None, :].expand(n, P).reshape(-1),
+                                torch.arange(n)[:, None].expand(n, P).reshape(-1)), -gp.reshape(-1),
+                               accumulate=True)
+        return gp, gh
+
+
+def _joint_problem():
+    g = torch.Generator().manual_seed(11)
+    N, K, P = 17, 6, 12                                    # uneven shards: 9 + 8 rays
+    pred = (torch.rand(N, P, generator=g) * 4 + 0.5)
+    hyp = torch.rand(K, N, 1, generator=g) * 4.9 + 0.1
+    return pred, hyp
+
+
+def _joint_worker(rank, world, port, out_dir):
+    from scade_amd.parallel import shared_uniform
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    pred, hyp = _joint_problem()
+    a, b = shard_range(pred.shape[0], rank, world)
+    p = pred[a:b].clone().requires_grad_(True)
+    h = hyp[:, a:b].clone().requires_grad_(True)
+    loss = _JointShardedCpu.apply(p, h)
+    loss.backward()
+    torch.manual_seed(100 + rank)                          # different local streams ...
+    u = shared_uniform((8,), torch.device("cpu"))          # ... one shared draw
+    torch.save((loss.detach(), p.grad, h.grad, u), os.path.join(out_dir, f"j{rank}.pt"))
+    dist.destroy_process_group()
+
+
+def test_joint_space_carving_exchange_matches_single_process(tmp_path):
+    world = 2
+    mp.spawn(_joint_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    outs = [torch.load(os.path.join(tmp_path, f"j{r}.pt")) for r in range(world)]
+    pred, hyp = _joint_problem()
+    p = pred.clone().requires_grad_(True)
+    h = hyp.clone().requires_grad_(True)
+    want = O.compute_space_carving_loss(p, h, is_joint=True)
+    want.backward()
+    for r in range(world):
+        assert abs(float(outs[r][0]) - float(want)) < 1e-6 * abs(float(want)), "every rank holds the GLOBAL loss"
+    # the trainer sums the ranks' gradients and applies 1/world: here pred/hyp shards are disjoint
+    # inputs, so the per-shard gradient x 1/world must equal the matching slice of the full gradient
+    gp = torch.cat([outs[r][1] for r in range(world)], 0) / world
+    gh = torch.cat([outs[r][2] for r in range(world)], 1) / world
+    assert torch.allclose(gp, p.grad, rtol=1e-5, atol=1e-8)
+    assert torch.allclose(gh, h.grad, rtol=1e-5, atol=1e-8)
+    assert torch.equal(outs[0][3], outs[1][3]), "sample_pdf_joint's u must be one draw for all ranks"
