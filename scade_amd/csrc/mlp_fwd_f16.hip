@@ -34,26 +34,43 @@ struct MlpF16Args {
   int P, S, vd_stride;
 };
 
-// returns the lane's ReLU sign bits in the exact kernel's format (mlp_fwd.hip layer_store)
-template <int NT, bool RELU>
-__device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)[NT][2],
-                                                            const f32x16 (&acc1)[NT][2],
-                                                            const float* __restrict__ bias, int ntile0,
-                                                            _Float16* xh, _Float16* xl, int lane) {
-  const int r = lane & 31, hh = lane >> 5;
-  unsigned long long bits = 0ull;
+// this lane's bias values in accumulator order: cb[t][4q+i] = bias[(ntile0+t)*32 + 8q + 4*(lane>>5) + i]
+template <int NT>
+__device__ __forceinline__ void load_bias16_h(f32x16 (&cb)[2], const float* __restrict__ bias, int ntile0,
+                                              int lane) {
+  const int hh = lane >> 5;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
-      const f32x4 bv = *reinterpret_cast<const f32x4*>(bias + f);
+      const f32x4 v = *reinterpret_cast<const f32x4*>(bias + (ntile0 + t) * 32 + 8 * q + 4 * hh);
+      cb[t][4 * q + 0] = v[0]; cb[t][4 * q + 1] = v[1]; cb[t][4 * q + 2] = v[2]; cb[t][4 * q + 3] = v[3];
+    }
+}
+
+// acc0 + acc1/2048 already holds W x + bias (the bias rode in as the first MFMA's C operand).
+// Returns the lane's ReLU sign bits in the exact kernel's format (mlp_fwd.hip layer_store).  After
+// point tile 0 the NEXT layer's bias values are fetched (NTN n-tiles) into the vacated registers.
+template <int NT, bool RELU, int NTN>
+__device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)[NT][2],
+                                                            const f32x16 (&acc1)[NT][2], int ntile0,
+                                                            _Float16* xh, _Float16* xl, int lane,
+                                                            f32x16 (&cb)[2],
+                                                            const float* __restrict__ bias_next,
+                                                            int ntile0_next) {
+  const int r = lane & 31, hh = lane >> 5;
+  unsigned long long bits = 0ull;
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+  for (int p = 0; p < 2; ++p) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
         half4 vh, vl;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]) + bv[i];
+          float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
           if (RELU && x > 0.f) bits |= 1ull << (((t * 4 + q) * 2 + p) * 4 + i);
           if (RELU) x = fmaxf(x, 0.f);
           _Float16 h, l;
@@ -65,7 +82,11 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
         *reinterpret_cast<half4*>(xh + o) = vh;
         *reinterpret_cast<half4*>(xl + o) = vl;
       }
+    if (p == 0 && NTN > 0) {
+      if (NTN == 2) load_bias16_h<2>(cb, bias_next, ntile0_next, lane);
+      else load_bias16_h<1>(cb, bias_next, ntile0_next, lane);
     }
+  }
   return bits;
 }
 
@@ -149,6 +170,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   }
 
   f32x16 acc0[2][2], acc1[2][2];
+  f32x16 cb[2];            // this lane's bias values of the NEXT layer, loaded one epilogue ahead
   AFrag an;
   const int nt0 = wave * 2;
 #define WHBASE(L) (reinterpret_cast<const half8*>(wpk + off_wh(L)) + \
@@ -157,10 +179,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
 #define PTS_LAYER_H(L, LNEXT, KBP)                                                               \
   {                                                                                              \
     layer_gemm_h<2, KBP, kbh16(L), false>(acc0, acc1, an, WHBASE(L), WHBASE(LNEXT), kb16(LNEXT), \
-                                          eh, el, xh, xl, lane);                                 \
+                                          eh, el, xh, xl, lane, cb);                             \
     __syncthreads();                                                                             \
     const unsigned long long bits_ =                                                             \
-        layer_store_h<2, true>(acc0, acc1, TAIL(off_b(L)), nt0, xh, xl, lane);                   \
+        layer_store_h<2, true, 2>(acc0, acc1, nt0, xh, xl, lane, cb, TAIL(off_b(LNEXT)), nt0);   \
     if (SAVE)                                                                                    \
       reinterpret_cast<unsigned long long*>(a.acts + acts_mask_off(P))[                          \
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = bits_;                             \
@@ -172,6 +194,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   an.t0l = WHBASE(0)[64 + lane];
   an.t1h = WHBASE(0)[(kb16(0) * 2 + 0) * 64 + lane];
   an.t1l = WHBASE(0)[(kb16(0) * 2 + 1) * 64 + lane];
+  load_bias16_h<2>(cb, TAIL(off_b(0)), nt0, lane);
   PTS_LAYER_H(0, 1, 4)
   PTS_LAYER_H(1, 2, 0)
   PTS_LAYER_H(2, 3, 0)
@@ -217,18 +240,18 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   }
 
   // ---- feature_linear ------------------------------------------------------------------
-  layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WHBASE(L_FEAT), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane);
+  layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WHBASE(L_FEAT), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane, cb);
   __syncthreads();
-  layer_store_h<2, false>(acc0, acc1, TAIL(off_b(L_FEAT)), nt0, xh, xl, lane);
+  layer_store_h<2, false, 1>(acc0, acc1, nt0, xh, xl, lane, cb, TAIL(off_b(L_VIEWS)), wave);
   __syncthreads();
   if (SAVE) save_tile_h(xh, xl, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, W, nullptr, tid);
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av0[1][2], av1[1][2];
-    layer_gemm_h<1, 1, 16, true>(av0, av1, an, WHBASE(L_VIEWS), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane);
+    layer_gemm_h<1, 1, 16, true>(av0, av1, an, WHBASE(L_VIEWS), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane, cb);
     __syncthreads();
-    layer_store_h<1, true>(av0, av1, TAIL(off_b(L_VIEWS)), wave, xh, xl, lane);
+    layer_store_h<1, true, 0>(av0, av1, wave, xh, xl, lane, cb, nullptr, 0);
     __syncthreads();
     if (SAVE) save_tile_h(xh, xl, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, nullptr, tid);
   }

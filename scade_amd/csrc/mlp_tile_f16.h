@@ -50,15 +50,16 @@ __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc
                                              const half8* __restrict__ wp,
                                              const half8* __restrict__ wp_next, int kb_next,
                                              const _Float16* eh, const _Float16* el,
-                                             const _Float16* xh, const _Float16* xl, int lane) {
+                                             const _Float16* xh, const _Float16* xl, int lane,
+                                             const f32x16* cinit = nullptr) {
+  // acc0 + acc1/2048 = cinit + W x.  The first k-block is peeled so that the initial value (the
+  // lane's bias vector, or nothing) rides in as the C operand of acc0's first MFMA and acc1
+  // starts from the inline constant 0: no zero-fill, no bias add in the epilogue.
   constexpr int KB = KBP + KBH;
   const int r = lane & 31, hh = lane >> 5;
-#pragma unroll
-  for (int t = 0; t < NT; ++t)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { acc0[t][p][i] = 0.f; acc1[t][p][i] = 0.f; }
+  const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const f32x16 c00 = cinit ? cinit[0] : zero16;
+  const f32x16 c01 = cinit ? cinit[NT - 1] : zero16;
 
   // activation fragment (both planes) of point tile p for k-block kb
 #define LOAD_B(KBX, PX, BH, BL)                                                              \
@@ -94,32 +95,70 @@ __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc
   // register plan: A (weights, L2 latency) is fetched a whole k-block ahead; B (LDS) ping-pongs
   // between the two point tiles inside the block: b1 of this block loads under the p=0 MFMAs,
   // b0 of the next block under the p=1 MFMAs.
+#define MFMA6_FIRST(PX, A, VH, VL)                                                             \
+  acc0[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0h, VH, c00, 0, 0, 0);                \
+  acc1[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0h, VL, zero16, 0, 0, 0);             \
+  if (NT > 1) {                                                                                \
+    acc0[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1h, VH, c01, 0, 0, 0);        \
+    acc1[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1h, VL, zero16, 0, 0, 0);     \
+  }                                                                                            \
+  acc1[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0l, VH, acc1[0][PX], 0, 0, 0);        \
+  if (NT > 1)                                                                                  \
+    acc1[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1l, VH, acc1[NT - 1][PX], 0, 0, 0);
   half8 b0h, b0l, b1h, b1l;
   LOAD_B(0, 0, b0h, b0l)
-#pragma unroll 2
-  for (int kb = 0; kb < KB; ++kb) {
+  LOAD_B(0, 1, b1h, b1l)
+  {   // peeled k-block 0 (KB >= 4 everywhere).  Point tile 1 first: tile 0's accumulator can then
+      // take over the registers of the initial value.
     const AFrag a = an;
-    if (kb + 1 < KB) {
-      an.t0h = wp[((kb + 1) * 2 + 0) * 64 + lane];
-      an.t0l = wp[((kb + 1) * 2 + 1) * 64 + lane];
-      if (NT > 1) {
-        an.t1h = wp[((KB + kb + 1) * 2 + 0) * 64 + lane];
-        an.t1l = wp[((KB + kb + 1) * 2 + 1) * 64 + lane];
-      }
-    } else {   // last k-block: the next layer's first weights
-      an.t0h = wp_next[lane];
-      an.t0l = wp_next[64 + lane];
-      an.t1h = wp_next[(kb_next * 2 + 0) * 64 + lane];
-      an.t1l = wp_next[(kb_next * 2 + 1) * 64 + lane];
+    an.t0h = wp[(1 * 2 + 0) * 64 + lane];
+    an.t0l = wp[(1 * 2 + 1) * 64 + lane];
+    if (NT > 1) {
+      an.t1h = wp[((KB + 1) * 2 + 0) * 64 + lane];
+      an.t1l = wp[((KB + 1) * 2 + 1) * 64 + lane];
     }
-    LOAD_B(kb, 1, b1h, b1l)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA6(0, a, b0h, b0l)
+    MFMA6_FIRST(1, a, b1h, b1l)
     __builtin_amdgcn_sched_barrier(0);
-    LOAD_B(kb + 1 < KB ? kb + 1 : kb, 0, b0h, b0l)
+    MFMA6_FIRST(0, a, b0h, b0l)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA6(1, a, b1h, b1l)
+    LOAD_B(1, 0, b0h, b0l)
   }
+#undef MFMA6_FIRST
+#define KBLOCK_H(KBX)                                                   \
+  {                                                                     \
+    const AFrag a = an;                                                 \
+    if ((KBX) + 1 < KB) {                                               \
+      an.t0h = wp[(((KBX) + 1) * 2 + 0) * 64 + lane];                   \
+      an.t0l = wp[(((KBX) + 1) * 2 + 1) * 64 + lane];                   \
+      if (NT > 1) {                                                     \
+        an.t1h = wp[((KB + (KBX) + 1) * 2 + 0) * 64 + lane];            \
+        an.t1l = wp[((KB + (KBX) + 1) * 2 + 1) * 64 + lane];            \
+      }                                                                 \
+    } else { /* last k-block: the next layer's first weights */         \
+      an.t0h = wp_next[lane];                                           \
+      an.t0l = wp_next[64 + lane];                                      \
+      an.t1h = wp_next[(kb_next * 2 + 0) * 64 + lane];                  \
+      an.t1l = wp_next[(kb_next * 2 + 1) * 64 + lane];                  \
+    }                                                                   \
+    LOAD_B(KBX, 1, b1h, b1l)                                            \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    MFMA6(0, a, b0h, b0l)                                               \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    LOAD_B((KBX) + 1 < KB ? (KBX) + 1 : (KBX), 0, b0h, b0l)             \
+    __builtin_amdgcn_sched_barrier(0);                                  \
+    MFMA6(1, a, b1h, b1l)                                               \
+  }
+  // a real loop over PAIRS of k-blocks (the A registers alternate by renaming inside the pair);
+  // never fully unrolled: ten layers of straight-line k-loops would not fit the instruction cache
+  int kb = 1;
+#pragma unroll 1
+  for (; kb + 1 < KB; kb += 2) {
+    KBLOCK_H(kb)
+    KBLOCK_H(kb + 1)
+  }
+  if ((KB - 1) & 1) KBLOCK_H(kb)
+#undef KBLOCK_H
 #undef LOAD_B
 #undef MFMA6
 }

@@ -154,20 +154,46 @@ def test_f16x3_training_many_chunks_and_zero_rows(dev):
 
 
 def test_f16x3_train_step_golden(dev):
-    from test_gpu_train import grad_close, train_step
+    """Full train step in split precision.  The loss is held to the golden value.  The gradients
+    are checked in two ways: (i) STRICT - against the exact fp32 backward kernels evaluated on the
+    very workspace (activations, ReLU sign words, upstream gradient) of this step; (ii) against the
+    oracle's golden gradients norm-wise: a ReLU network's gradient is discontinuous where a
+    pre-activation crosses zero, and two correct forwards that differ by 1e-7 disagree on the sign
+    of a handful of units (2 of 4.2 M sign bits on this batch), each of which moves the gradient of
+    a 32-ray batch by up to a percent."""
+    from scade_amd import ops
+    from test_gpu_train import train_step
     g = load_golden("f6_render")
     pc, pf = f6_params(g)
     coarse, fine, query = build(dev, pc, pf, g["bb_center"], g["bb_scale"])
     coarse.train_precision = fine.train_precision = "f16x3"
     scale = torch.ones(1, device=dev, requires_grad=True)
     shift = torch.zeros(1, device=dev, requires_grad=True)
-    ret, loss = train_step(dev, g, coarse, fine, query, scale, shift)
-    loss.backward()
+    cap = {}
+    orig = ops.mlp_bwd_f16
+
+    def spy(packed, packed_t_f16, acts, g_out, wgrad_f16=True):
+        flat = orig(packed, packed_t_f16, acts, g_out, wgrad_f16)
+        cap[g_out.numel() // 4] = (acts, g_out, flat)
+        return flat
+
+    ops.mlp_bwd_f16 = spy
+    try:
+        ret, loss = train_step(dev, g, coarse, fine, query, scale, shift)
+        loss.backward()
+    finally:
+        ops.mlp_bwd_f16 = orig
     assert_close(loss, g["train/loss"], rtol=1e-4, atol=1e-7, what="loss")
+    for P, net in ((32 * 64, coarse), (32 * 192, fine)):
+        acts, g_out, flat = cap[P]
+        exact = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
+        assert rel_l2(flat, exact) < 2e-5, (P, rel_l2(flat, exact))
+        got = torch.cat([p.grad.reshape(-1) for p in net.ordered_params()])
+        assert torch.equal(got, flat)
     for k, p in coarse.named_parameters():
         want = g[f"grad_coarse/{k}"]
         got = sub(p.grad) if p.grad is not None else torch.zeros_like(want)
         if float(want.abs().max()) == 0.0:
             assert float(got.abs().max()) == 0.0
         else:
-            grad_close(got, want, f"f16x3 grad coarse.{k}", rtol=2e-4, scale_atol=5e-5)
+            assert rel_l2(got, want) < 3e-2, (k, rel_l2(got, want))
