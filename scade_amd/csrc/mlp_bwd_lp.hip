@@ -98,13 +98,14 @@ struct MlpDgradLpArgs {
   int P;
 };
 
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 template <bool BF, bool MASK, bool ADD_ALPHA>
 __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][LPT], int ktile0, typename LP<BF>::T* g,
-                                               const unsigned long long (&bits)[2],
+                                               const unsigned (&bits)[4],
                                                const float* __restrict__ w_a, const float* dal_scaled,
                                                int lane) {
-  typedef typename LP<BF>::T T;
-  typedef typename LP<BF>::V4 V4;
   const int r = lane & 31, hh = lane >> 5;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -116,15 +117,21 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][LPT], int 
 #pragma unroll
       for (int p = 0; p < LPT; ++p) {
         const int row = p * 32 + r;
-        V4 v;
+        float y[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float y = acc[t][p][4 * q + i];
-          if (ADD_ALPHA) y = y + wa[i] * dal_scaled[row];
-          if (MASK) y = ((bits[t] >> ((q * 4 + p) * 4 + i)) & 1ull) ? y : 0.f;
-          v[i] = (T)y;
+          y[i] = acc[t][p][4 * q + i];
+          if (ADD_ALPHA) y[i] = y[i] + wa[i] * dal_scaled[row];
         }
-        *reinterpret_cast<V4*>(g + x_idx(row, f >> 3) + (f & 7)) = v;
+        u32x2 v;
+        v[0] = pack2<BF, false>(y[0], y[1]);
+        v[1] = pack2<BF, false>(y[2], y[3]);
+        if (MASK) {   // sign words (mlp_tile_lp.h): dword d = ((t*4+q)*4+p)*2 + j
+          const int d0 = ((t * 4 + q) * 4 + p) * 2;
+          v[0] = mask_pair(v[0], bits[d0 >> 4], d0 & 15);
+          v[1] = mask_pair(v[1], bits[d0 >> 4], (d0 & 15) + 1);
+        }
+        *reinterpret_cast<u32x2*>(g + x_idx(row, f >> 3) + (f & 7)) = v;
       }
     }
 }
@@ -151,8 +158,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   T* __restrict__ dzT = reinterpret_cast<T*>(a.dz);
   const float* __restrict__ alpha_pre = reinterpret_cast<const float*>(a.acts + lp_acts_alpha_byte(P));
   float* __restrict__ dalpha = reinterpret_cast<float*>(a.dz + lp_dz_dalpha_byte(P));
-  const unsigned long long* __restrict__ masks =
-      reinterpret_cast<const unsigned long long*>(a.acts + lp_acts_mask_byte(P));
+  const u32x4* __restrict__ masks = reinterpret_cast<const u32x4*>(a.acts + lp_acts_mask_byte(P));
   const float S = lp_loss_scale(a.gmax[0]);
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
@@ -208,12 +214,12 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   __syncthreads();
 
   f32x16 acc[2][LPT];
-  unsigned long long mb[2] = {0ull, 0ull};
+  unsigned mb[4] = {0u, 0u, 0u, 0u};
   AFrag3<BF> A;
   const int kt0 = wave * 2;
   auto load_mask = [&](int layer) {
-    const unsigned long long* mw = masks + (((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid) * 2;
-    mb[0] = mw[0]; mb[1] = mw[1];
+    const u32x4 mw = masks[((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid];
+    mb[0] = mw[0]; mb[1] = mw[1]; mb[2] = mw[2]; mb[3] = mw[3];
   };
   // this wave's k-tile pair of dgrad index TT: [kt][NB16][64] V8
 #define WTL(TT, NB) (reinterpret_cast<const V8*>(pt_ + CE<off_wtl(TT)>::v) + kt0 * (NB) * 64)
@@ -230,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   __syncthreads();
   dgrad_store_lp<BF, false, false>(acc, kt0, g, mb, nullptr, dal, lane);
   __syncthreads();
-  save_tile_lp<BF>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, W, fac, tid);
+  save_tile_lp<BF, 256>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, fac, tid);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
@@ -238,7 +244,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   __syncthreads();
   dgrad_store_lp<BF, true, true>(acc, kt0, g, mb, pk + OFF_WA, dal, lane);
   __syncthreads();
-  save_tile_lp<BF>(g, dzT + acts_slot_off(P, 7), p0, P, W, fac, tid);
+  save_tile_lp<BF, 256>(g, dzT + acts_slot_off(P, 7), p0, P, fac, tid);
 
 #define DGRAD_LAYER_L(L)                                                                            \
   load_mask((L)-1);                                                                                 \
@@ -247,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false>(acc, kt0, g, mb, nullptr, dal, lane);                             \
   __syncthreads();                                                                                  \
-  save_tile_lp<BF>(g, dzT + acts_slot_off(P, (L)-1), p0, P, W, fac, tid);
+  save_tile_lp<BF, 256>(g, dzT + acts_slot_off(P, (L)-1), p0, P, fac, tid);
 
   DGRAD_LAYER_L(7)
   DGRAD_LAYER_L(6)

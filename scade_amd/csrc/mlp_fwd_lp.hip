@@ -20,6 +20,7 @@ constexpr int fwd_rot(int l) {
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct MlpLpArgs {
   const void* packed;     // PACKED_LP_BYTES
@@ -37,10 +38,10 @@ struct MlpLpArgs {
 template <bool BF, int NT, bool RELU, bool BITS, int NTN>
 __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], int ntile0,
                                                typename LP<BF>::T* x, int lane,
-                                               unsigned long long (&bits)[2], f32x16 (&cb)[2],
+                                               unsigned (&bits)[4], f32x16 (&cb)[2],
                                                const float* __restrict__ bias_next, int ntile0_next) {
   const int r = lane & 31, hh = lane >> 5;
-  bits[0] = bits[1] = 0ull;
+  bits[0] = bits[1] = bits[2] = bits[3] = 0u;
 #pragma unroll
   for (int p = 0; p < LPT; ++p) {
 #pragma unroll
@@ -48,14 +49,15 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], int
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
-        if (RELU && BITS) {
-#pragma unroll
-          for (int i = 0; i < 4; ++i)
-            if (acc[t][p][4 * q + i] > 0.f) bits[t] |= 1ull << ((q * 4 + p) * 4 + i);
-        }
         u32x2 v;
         v[0] = pack2<BF, RELU>(acc[t][p][4 * q + 0], acc[t][p][4 * q + 1]);
         v[1] = pack2<BF, RELU>(acc[t][p][4 * q + 2], acc[t][p][4 * q + 3]);
+        if (RELU && BITS) {   // sign words (mlp_tile_lp.h): dword d = ((t*4+q)*4+p)*2 + j
+          constexpr int dummy = 0; (void)dummy;
+          const int d0 = ((t * 4 + q) * 4 + p) * 2;
+          bits[d0 >> 4] |= sign_pair(v[0]) << (d0 & 15);
+          bits[d0 >> 4] |= sign_pair(v[1]) << ((d0 & 15) + 1);
+        }
         const int row = p * 32 + r;
         *reinterpret_cast<u32x2*>(x + x_idx(row, f >> 3) + (f & 7)) = v;
       }
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 
   f32x16 acc[2][LPT];
   f32x16 cb[2];           // this lane's bias values of the NEXT layer, loaded one epilogue ahead
-  unsigned long long bits[2];
+  unsigned bits[4];
   AFrag3<BF> A;
   const int nt0 = wave * 2;
 #define WLBASE(L) (reinterpret_cast<const V8*>(wpk + CE<off_wl(L)>::v) + ((L) == L_VIEWS ? wave : nt0) * (int)CE<kb16(L) * 64>::v)
@@ -165,12 +167,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     __syncthreads();                                                                            \
     layer_store_lp<BF, 2, true, SAVE, 2>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
     if (SAVE) {                                                                                 \
-      unsigned long long* mw = reinterpret_cast<unsigned long long*>(a.acts + lp_acts_mask_byte(P)) + \
-                               (((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid) * 2;          \
-      mw[0] = bits[0]; mw[1] = bits[1];                                                         \
+      u32x4 mw_ = {bits[0], bits[1], bits[2], bits[3]};                                         \
+      reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[                                  \
+          ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
     }                                                                                           \
     __syncthreads();                                                                            \
-    if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, L), p0, P, W, nullptr, tid);         \
+    if (SAVE) save_tile_lp<BF, 256>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, tid);         \
   }
 
   A.s[0].t0 = WLBASE(0)[lane];
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   __syncthreads();
   layer_store_lp<BF, 2, false, false, 1>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
   __syncthreads();
-  if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, W, nullptr, tid);
+  if (SAVE) save_tile_lp<BF, 256>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, tid);
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
@@ -237,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     __syncthreads();
     layer_store_lp<BF, 1, true, false, 0>(av, wave, x, lane, bits, cb, nullptr, 0);
     __syncthreads();
-    if (SAVE) save_tile_lp<BF>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, nullptr, tid);
+    if (SAVE) save_tile_lp<BF, 128>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, tid);
   }
 #undef WLBASE
 

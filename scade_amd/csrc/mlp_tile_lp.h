@@ -65,25 +65,57 @@ constexpr long lp_acts_bytes(long P) { return lp_acts_mask_byte(P) + 8L * lp_til
 constexpr long lp_dz_dalpha_byte(long P) { return lp_align((long)N_ACT_SLOTS * P * 256 * 2); }
 constexpr long lp_dz_bytes(long P) { return lp_align(lp_dz_dalpha_byte(P) + P * 4); }
 
-// coalesced copy of the first ncols columns of the LDS tile to dst[P][256] (optional per-row factor)
-template <bool BF>
+// coalesced copy of the first NCOLS columns of the LDS tile to dst[P][256] (optional per-row
+// factor).  Four 16-byte chunks per thread in flight: as a plain loop every iteration exposed the
+// LDS latency in front of its store (16 dependent round trips per layer).
+template <bool BF, int NCOLS>
 __device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typename LP<BF>::T* __restrict__ dst,
-                                             int p0, int P, int ncols, const float* row_fac, int tid) {
+                                             int p0, int P, const float* row_fac, int tid) {
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V8 V8;
-  const int cpr = ncols >> 3;
-  for (int i = tid; i < LM * cpr; i += 256) {
-    const int row = i / cpr, c = i - row * cpr;
-    if (p0 + row < P) {
-      V8 v = *reinterpret_cast<const V8*>(x + x_idx(row, c));
-      if (row_fac) {
-        const float f = row_fac[row];
+  constexpr int CPR = NCOLS >> 3;                     // 16-byte chunks per row
+  constexpr int ITERS = LM * CPR / 256;
+  static_assert(ITERS % 4 == 0, "save_tile_lp: batches of four");
+#pragma unroll 1      // keep the batches apart: merged, their 16 reads + conversions spill
+  for (int it0 = 0; it0 < ITERS; it0 += 4) {
+    V8 v[4];
+    float f[4];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (T)((float)v[j] * f);
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * (it0 + j);
+      const int row = i / CPR, c = i - row * CPR;
+      v[j] = *reinterpret_cast<const V8*>(x + x_idx(row, c));
+      f[j] = row_fac ? row_fac[row] : 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = tid + 256 * (it0 + j);
+      const int row = i / CPR, c = i - row * CPR;
+      if (row_fac) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = (T)((float)v[j][e] * f[j]);
       }
-      *reinterpret_cast<V8*>(dst + (size_t)(p0 + row) * W + 8 * c) = v;
+      if (p0 + row < P) *reinterpret_cast<V8*>(dst + (size_t)(p0 + row) * W + 8 * c) = v[j];
     }
   }
+}
+
+// ReLU sign bits of one layer: 4 x 32-bit words per lane.  The 64 packed dwords a lane produces
+// per layer are numbered d = ((t*4 + q)*4 + p)*2 + j (n-tile t, row group q, point tile p, value
+// pair j); word d >> 4 holds, at bit (d & 15), the sign of the dword's LOW half and at bit
+// 16 + (d & 15) the sign of its HIGH half - so both sides handle two values per instruction:
+//   forward : m = v_pk_min_u16(w, 1) (0/1 per half of the ReLU'd pair);  word |= m << (d & 15)
+//   backward: m = (word >> (d & 15)) & 0x00010001;  w = v_pk_mul_lo_u16(w, m)
+__device__ __forceinline__ unsigned sign_pair(unsigned w_relu) {
+  unsigned m;
+  asm("v_pk_min_u16 %0, %1, %2" : "=v"(m) : "v"(w_relu), "v"(0x00010001u));
+  return m;
+}
+__device__ __forceinline__ unsigned mask_pair(unsigned w, unsigned word, int k) {
+  const unsigned m = (word >> k) & 0x00010001u;
+  unsigned r;
+  asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(m));
+  return r;
 }
 
 template <bool BF>

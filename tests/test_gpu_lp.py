@@ -274,3 +274,36 @@ def test_lp_trainer_descends_like_the_exact_path(dev, prec):
     assert lp[-1] < 0.7 * lp[0], lp
     for a, b in zip(lp, exact):
         assert abs(a - b) <= 0.05 * abs(b), (lp, exact)
+
+
+def test_lp_full_size_properties(dev):
+    """BASELINE size (196,608 points = 1024 rays x 192, 85 weight-gradient chunks): the bf16 forward
+    is blind to a permutation of the points, the backward is deterministic, exactly homogeneous under
+    a power-of-two rescaling of the upstream gradient, and close to the exact fp32 backward."""
+    params = O.nerf_init(2)
+    net = make_net(params, dev)
+    torch.manual_seed(0)
+    P = 1024 * 192
+    pts = torch.rand(P, 3) * 2 - 1
+    vd = torch.nn.functional.normalize(torch.randn(P, 3), dim=-1)
+    x = torch.cat([O.embed(pts, 9), vd], -1).to(dev)
+    G = torch.randn(P, 4, device=dev) * 1e-5
+    perm = torch.randperm(P, device=dev)
+    net.inference_precision = "bf16"
+    with torch.no_grad():
+        a = net(x)
+        b = net(x[perm])
+    assert torch.equal(a[perm], b)
+
+    def grads(prec, Gs):
+        net.train_precision = prec
+        net.zero_grad(set_to_none=True)
+        (net(x) * Gs).sum().backward()
+        return torch.cat([p.grad.reshape(-1) for p in net.parameters()])
+
+    g1, g2, g3 = grads("bf16", G), grads("bf16", G), grads("bf16", G * 2.0 ** -12)
+    assert torch.equal(g1, g2)
+    assert torch.equal(g1, g3 * 2.0 ** 12)
+    exact = grads("f32", G)
+    assert rel_l2(g1, exact) < 0.15, rel_l2(g1, exact)          # bf16 rounding + ReLU sign flips
+    assert rel_l2(grads("f16", G), exact) < 0.06
