@@ -43,16 +43,13 @@ def parse():
 
 
 def make_nets(dev):
-    import scade_amd as S
-    from oracle import scade_oracle as O   # only for the seeded random-init weights + cpu_baseline
-    pc, pf = O.nerf_init(0), O.nerf_init(1)
-
-    def mk(p):
-        net = S.NeRF(D=8, W=256, input_ch=57, output_ch=5, skips=[4], input_ch_views=3,
-                     input_ch_cam=0, use_viewdirs=True)
-        net.load_state_dict(p)
-        return net.to(dev)
-    return pc, pf, mk(pc), mk(pf)
+    """Two random-init (Xavier, seeded) SCADE NeRFs on the device + their parameters as CPU dicts
+    (the weights the cpu_baseline leg renders with)."""
+    from scade_amd.train import make_scade_nets
+    coarse, fine = make_scade_nets(dev, seed=0)
+    pc = {k: v.detach().cpu().clone() for k, v in coarse.state_dict().items()}
+    pf = {k: v.detach().cpu().clone() for k, v in fine.state_dict().items()}
+    return pc, pf, coarse, fine
 
 
 def host_cores():
@@ -162,10 +159,10 @@ def train_region(args, dev, world, rank, barrier, precision="f32"):
     import torch.distributed as dist
     from scade_amd import ops
     from scade_amd.train import Trainer, make_scade_nets
-    from oracle import scade_oracle as O
+    from scade_amd.synthetic import synthetic_rays
     coarse, fine = make_scade_nets(dev, seed=0)
     tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
-    rays = O.synthetic_rays(args.rays, seed=2000 + rank).to(dev)
+    rays = synthetic_rays(args.rays, seed=2000 + rank).to(dev)
     g = torch.Generator(device="cpu").manual_seed(3000 + rank)
     tgt = torch.rand(args.rays, 3, generator=g).to(dev)
     hyp = (torch.rand(args.hyp, args.rays, 1, generator=g) * 4.9 + 0.1).to(dev)
@@ -219,13 +216,13 @@ def main():
 
     import scade_amd as S
     from scade_amd import ops
-    from oracle import scade_oracle as O
+    from scade_amd.synthetic import synthetic_rays
 
     pc, pf, coarse, fine = make_nets(dev)
     e, _ = S.get_embedder(9, 0)
     ed, _ = S.get_embedder(0, 0)
     query = S.make_network_query_fn(e, ed, torch.zeros(3, device=dev), torch.tensor(0.2, device=dev))
-    rays = O.synthetic_rays(args.rays, seed=1000 + rank).to(dev)      # distinct rays per rank
+    rays = synthetic_rays(args.rays, seed=1000 + rank).to(dev)        # distinct rays per rank
 
     def step():
         with torch.no_grad():
@@ -298,7 +295,7 @@ def main():
                              "HIP events on the launch stream"},
     }
     # secondary: the same test-render work as a 16-chunk image render, chunks pipelined over 2 streams
-    big = O.synthetic_rays(args.rays * 16, seed=5000 + rank).to(dev)
+    big = synthetic_rays(args.rays * 16, seed=5000 + rank).to(dev)
     for ns in (() if args.no_image else (1, 2)):
         with torch.no_grad():
             S.batchify_rays(big, args.rays, True, streams=ns, network_fn=coarse, network_query_fn=query,
