@@ -151,13 +151,18 @@ def perturb_z_vals(z_vals, pytest):
 def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples,
                 precomputed_z_samples=None, embedded_cam=None, retraw=False, lindisp=False,
                 perturb=0., N_importance=0, network_fine=None, raw_noise_std=0., verbose=False,
-                pytest=False, is_joint=False, cached_u=None, t_rand=None, u_coarse=None):
+                pytest=False, is_joint=False, cached_u=None, t_rand=None, u_coarse=None,
+                coarse_stream=None):
     """run_scade_scannet.py:581-751 (live branch ``N_importance > 0``).
 
     Extra keyword-only knobs beyond the reference signature: ``t_rand`` [N,N_samples]
     and ``u_coarse`` [N,N_importance] inject the stratified jitter / first sampler
     draw (the reference can only inject the last draw through ``cached_u``); used by
-    the parity tests because device RNG streams cannot match the CPU's."""
+    the parity tests because device RNG streams cannot match the CPU's.  ``coarse_stream`` (a
+    ``torch.cuda.Stream``): run the coarse stage on that side stream.  The forward is unchanged
+    (the fine stage waits for it), but autograd replays every backward node on its forward stream,
+    so in a train step the whole coarse backward chain (composite -> dgrad -> wgrad) runs
+    CONCURRENTLY with the fine chain instead of behind it and fills the tails of its launches."""
     if N_importance <= 0:
         raise NotImplementedError(
             "render_rays: N_importance == 0 is dead code in the reference (raises UnboundLocalError "
@@ -186,10 +191,22 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
                 t_rand = torch.rand(N, N_samples, device=dev)
     else:
         t_rand = None
-    z_vals, pts = ops.ray_points(rays, N_samples, t_rand, lindisp)
-    raw = network_query_fn(pts, viewdirs, embedded_cam, network_fn)
-    rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = raw2outputs(
-        raw, z_vals, rays_d, raw_noise_std, pytest=pytest)
+    def coarse_stage():
+        z, p = ops.ray_points(rays, N_samples, t_rand, lindisp)
+        r = network_query_fn(p, viewdirs, embedded_cam, network_fn)
+        return (z, r) + tuple(raw2outputs(r, z, rays_d, raw_noise_std, pytest=pytest))
+
+    if coarse_stream is None:
+        z_vals, raw, rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = coarse_stage()
+    else:
+        main = torch.cuda.current_stream()
+        coarse_stream.wait_stream(main)
+        with torch.cuda.stream(coarse_stream):
+            outs = coarse_stage()
+        main.wait_stream(coarse_stream)
+        for t in outs:                      # allocated on the side stream, consumed on this one
+            t.record_stream(main)
+        z_vals, raw, rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = outs
     z_vals_0 = z_vals
 
     # ---- importance samples from the coarse pdf, detached (:702-711) ---------

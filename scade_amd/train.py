@@ -12,6 +12,7 @@ Not a port of train_nerf (data loading, logging, checkpoints stay with the calle
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -36,7 +37,8 @@ class Trainer:
     def __init__(self, coarse, fine, bb_center, bb_scale, n_images=1, lrate=5e-4, scaleshift_lr=1e-7,
                  space_carving_weight=0.007, N_samples=64, N_importance=128, lrate_decay_rate=0.1,
                  lrate_decay_step=400000, freeze_ss=400000, norm_p=2, space_carving_threshold=0.0,
-                 is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0, precision="f32"):
+                 is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0, precision="f32",
+                 overlap_coarse=None):
         dev = next(coarse.parameters()).device
         self.coarse, self.fine = coarse, fine
         coarse.train_precision = fine.train_precision = precision      # "f32" (exact) | "f16x3"
@@ -56,6 +58,10 @@ class Trainer:
                         thr=space_carving_threshold, joint=is_joint, warm=warm_start_nerf,
                         lindisp=lindisp, noise=raw_noise_std)
         self.it = 0
+        # coarse stage on a side stream: its backward chain then runs beside the fine one
+        if overlap_coarse is None:
+            overlap_coarse = os.environ.get("SCADE_OVERLAP_COARSE", "1") != "0"
+        self.coarse_stream = torch.cuda.Stream(device=dev) if overlap_coarse and dev.type == "cuda" else None
         # rays are sharded over the ranks of the default process group (one process per GPU)
         self.sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.flat.broadcast_params(0)
@@ -70,7 +76,8 @@ class Trainer:
             render_kw.setdefault("cached_u", shared_uniform((c["Ni"],), rays.device))
         ret = R.render_rays(rays, True, self.coarse, self.query, c["Ns"], N_importance=c["Ni"],
                             network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
-                            lindisp=c["lindisp"], is_joint=c["joint"], **render_kw)
+                            lindisp=c["lindisp"], is_joint=c["joint"], coarse_stream=self.coarse_stream,
+                            **render_kw)
         mse = (lambda a, b: H.img2mse(a, b)) if mask is None else (lambda a, b: H.img2mse_masked(a, b, mask))
         img_loss = mse(ret["rgb_map"], target_s)                                              # :968
         loss = img_loss

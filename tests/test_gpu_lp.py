@@ -85,12 +85,12 @@ def psnr(a, b):
 def test_lp_render_psnr_within_0p05_db(dev, prec):
     """North-star acceptance: PSNR of the render against a ground-truth image within 0.05 dB of
     the reference render's.  Ground truth = exact fp32 render (itself pinned to the oracle by
-    tests/test_gpu_render.py) + noise at ~25 dB, a typical ScanNet test PSNR; 2048 rays so that
+    tests/test_gpu_render.py) + noise at ~25 dB, a typical ScanNet test PSNR; 8192 rays so that
     the estimate is not dominated by the error-noise cross term."""
     g = load_golden("f6_render")
     pc, pf = f6_params(g)
     coarse, fine, query = build(dev, pc, pf, g["bb_center"], g["bb_scale"])
-    rays = torch.cat([g["rays"], O.synthetic_rays(2016, seed=11)], 0).to(dev)
+    rays = torch.cat([g["rays"], O.synthetic_rays(8160, seed=11)], 0).to(dev)
     kw = dict(N_importance=128, network_fine=fine, perturb=0.)
     with torch.no_grad():
         exact = S.render_rays(rays, True, coarse, query, 64, **kw)
@@ -102,6 +102,7 @@ def test_lp_render_psnr_within_0p05_db(dev, prec):
     target = ref_rgb + 0.056 * torch.randn_like(ref_rgb)          # ~25 dB
     p_ref, p_lp = psnr(ref_rgb, target), psnr(lp["rgb_map"].cpu(), target)
     assert 20 < p_ref < 30
+    print(f"PSNR vs 25 dB target: exact {p_ref:.4f} dB, {prec} {p_lp:.4f} dB")
     assert abs(p_lp - p_ref) < 0.05, (p_ref, p_lp)
     # and the render itself stays close to the exact one (coarse maps see identical sample positions)
     assert psnr(lp["rgb0"].cpu(), exact["rgb0"].cpu()) > (50 if prec == "f16" else 35)

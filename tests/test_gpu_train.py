@@ -302,3 +302,28 @@ def test_full_size_backward_properties(dev):
     assert torch.equal(grads(x, G1), g1), "bit-wise deterministic"
     perm = torch.randperm(P, device=dev)
     assert rel_l2(grads(x[perm], G1[perm]), g1) < 2e-6, "permutation invariance"
+
+
+def test_trainer_coarse_stream_overlap_is_bitwise_neutral(dev):
+    """The Trainer runs the coarse stage on a side stream so that its backward chain overlaps the
+    fine one: same kernels, same inputs -> bit-identical losses and parameters after several steps."""
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K = 192, 20
+    rays = O.synthetic_rays(N, seed=5).to(dev)
+    torch.manual_seed(5)
+    tgt = torch.rand(N, 3, device=dev)
+    hyp = torch.rand(K, N, 1, device=dev) * 4.9 + 0.1
+    g = torch.Generator().manual_seed(6)
+    draws = [(torch.rand(N, 64, generator=g).to(dev), torch.rand(N, 128, generator=g).to(dev),
+              torch.rand(N, 128, generator=g).to(dev)) for _ in range(5)]
+    out = {}
+    for overlap in (False, True):
+        coarse, fine = make_scade_nets(dev, seed=0)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, overlap_coarse=overlap)
+        assert (tr.coarse_stream is not None) == overlap
+        losses = [float(tr.step(rays, tgt, hyp, t_rand=a, u_coarse=b, cached_u=c)[0]) for a, b, c in draws]
+        torch.cuda.synchronize()
+        out[overlap] = (losses, tr.flat.data.clone(), tr.flat.grad.clone())
+    assert out[False][0] == out[True][0]
+    assert torch.equal(out[False][1], out[True][1])
+    assert torch.equal(out[False][2], out[True][2])
