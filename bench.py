@@ -308,6 +308,31 @@ def main():
         barrier()
         out.setdefault("image_render_16x1024", {})[f"rays_per_s_per_gpu_{ns}_stream"] = \
             big.shape[0] / (time.perf_counter() - t0)
+    # BASELINE.json configs[1] at its real size: one 468 x 624 ScanNet-like image (292,032 rays,
+    # pinhole fx = fy = 578, identity pose) through render() in
+    # 16,384-ray chunks, rays generated on the device
+    if not args.no_image:
+        Hh, Ww = 468, 624
+        intr = torch.tensor([578.0, 578.0, 312.0, 234.0], device=dev)
+        c2w = torch.eye(4, device=dev)[:3, :4].contiguous()
+        kw = dict(chunk=16384, c2w=c2w, near=0.1, far=5.0, use_viewdirs=True, network_fn=coarse,
+                  network_query_fn=query, N_samples=N_COARSE, N_importance=N_FINE, network_fine=fine, perturb=0.)
+        full = {}
+        for prec in ("f32",) + (() if args.no_fast else ("bf16",)):
+            coarse.inference_precision = fine.inference_precision = prec
+            try:
+                with torch.no_grad():
+                    S.render(Hh, Ww, intr, **kw)
+                    barrier()
+                    t0 = time.perf_counter()
+                    rgb = S.render(Hh, Ww, intr, **kw)[0]
+                    barrier()
+                full[f"ms_per_image_{prec}"] = (time.perf_counter() - t0) * 1e3
+                full[f"rays_per_s_per_gpu_{prec}"] = Hh * Ww / (time.perf_counter() - t0)
+                assert rgb.shape == (Hh, Ww, 3) and bool(torch.isfinite(rgb).all())
+            finally:
+                coarse.inference_precision = fine.inference_precision = "f32"
+        out["full_image_468x624"] = full
     # exact fp32 regions first, the opt-in reduced-precision regions after them (the 16-bit bursts
     # leave the chip in a different power state for a few milliseconds)
     if not args.no_train:
