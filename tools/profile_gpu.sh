@@ -7,6 +7,9 @@ ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+# per-kernel durations and counters are only meaningful when the kernels do not overlap: keep the
+# Trainer's coarse stage on the main stream while profiling
+export SCADE_OVERLAP_COARSE=0
 # the headline region only, so per-kernel averages are those of the timed render steps
 CMD="python $ROOT/bench.py --no-cpu-baseline --no-train --no-image --no-fast --steps 20 --warmup 3"
 TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --steps 10 --warmup 2"   # render + f16x3 + train regions
