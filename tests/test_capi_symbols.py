@@ -49,6 +49,20 @@ def test_argument_errors_do_not_need_a_gpu():
     # empty problems are no-ops, not errors
     assert lib.scade_composite_fwd(None, None, None, 3, None, 0, 64, None, None, None, None, None, None) == 0
     assert lib.scade_mlp_fwd(None, 0, None, None, 0, None, 0, 1, None, None, None) == 0
+    # the reduced-precision entries follow the same conventions
+    assert lib.scade_mlp_fwd_f16(None, 0, None, None, 0, None, 0, 1, None, None, None) == 0
+    assert lib.scade_mlp_fwd_lp(None, 1, 0, None, None, 0, None, 0, 1, None, None, None) == 0
+    rc = lib.scade_mlp_fwd_lp(None, 1, 0, None, None, 0, None, 10, 1, None, None, None)
+    assert rc != 0 and b"scade_mlp_fwd_lp" in lib.scade_last_error()
+    rc = lib.scade_mlp_bwd_lp(None, None, 1, None, None, 10, None, None, None)
+    assert rc != 0 and b"null" in lib.scade_last_error()
+    rc = lib.scade_mlp_bwd_lp(None, None, 1, None, None, 0, None, None, None)
+    assert rc != 0 and b"positive" in lib.scade_last_error()
+    rc = lib.scade_carve_joint_min(None, 128, 20, None, None)
+    assert rc != 0
+    # sizes of the training workspaces (bytes): 16-bit rows are half the fp32 workspace
+    assert lib.scade_mlp_acts_lp_bytes(1024) < 0.55 * 4 * lib.scade_mlp_acts_floats(1024)
+    assert lib.scade_mlp_packed_lp_bytes() < 0.55 * lib.scade_mlp_packed_f16_bytes() < 0.55 * 4.1 * lib.scade_mlp_packed_floats()
 
 
 def test_product_path_refuses_cpu_tensors():
