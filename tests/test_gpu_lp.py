@@ -308,3 +308,44 @@ def test_lp_full_size_properties(dev):
     exact = grads("f32", G)
     assert rel_l2(g1, exact) < 0.15, rel_l2(g1, exact)          # bf16 rounding + ReLU sign flips
     assert rel_l2(grads("f16", G), exact) < 0.06
+
+
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_lp_training_curve_parity(dev, prec):
+    """Loss-curve parity (the acceptance criterion for the config-5 path): a
+    student pair of networks is fitted for 200 optimiser steps to a teacher's render (target colours
+    and depth hypotheses around the teacher's depth) once with the exact fp32 kernels and once in
+    mixed precision, identical draws: the curves stay together and the final PSNRs agree."""
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K, steps = 512, 20, 200
+    rays = O.synthetic_rays(N, seed=21).to(dev)
+    tc, tf = make_scade_nets(dev, seed=100)                          # teacher
+    e, _ = S.get_embedder(9, 0)
+    ed, _ = S.get_embedder(0, 0)
+    query = S.make_network_query_fn(e, ed, torch.zeros(3, device=dev), torch.tensor(0.2, device=dev))
+    with torch.no_grad():
+        t = S.render_rays(rays, True, tc, query, 64, N_importance=128, network_fine=tf, perturb=0.)
+    tgt = t["rgb_map"].clone()
+    g = torch.Generator().manual_seed(22)
+    hyp = (t["depth_map"][None, :, None] + 0.3 * torch.randn(K, N, 1, generator=g).to(dev)).clamp(0.1, 5.0)
+    draws = [(torch.rand(N, 64, generator=g).to(dev), torch.rand(N, 128, generator=g).to(dev),
+              torch.rand(N, 128, generator=g).to(dev)) for _ in range(steps)]
+    curves = {}
+    for p in ("f32", prec):
+        coarse, fine = make_scade_nets(dev, seed=7)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=p)
+        out = []
+        for a, b, c in draws:
+            loss, aux = tr.step(rays, tgt, hyp, t_rand=a, u_coarse=b, cached_u=c)
+            out.append((float(loss), float(aux["img_loss"])))
+        curves[p] = out
+    exact, lp = curves["f32"], curves[prec]
+    psnr_e = -10 * torch.log10(torch.tensor([x[1] for x in exact[-20:]]).mean())
+    psnr_l = -10 * torch.log10(torch.tensor([x[1] for x in lp[-20:]]).mean())
+    print(f"final PSNR (mean of last 20 steps): exact {float(psnr_e):.2f} dB, {prec} {float(psnr_l):.2f} dB; "
+          f"loss {exact[0][0]:.4f} -> {exact[-1][0]:.5f} / {lp[-1][0]:.5f}")
+    assert exact[-1][0] < 0.2 * exact[0][0] and lp[-1][0] < 0.2 * lp[0][0]      # both actually train
+    assert abs(float(psnr_e) - float(psnr_l)) < 0.5
+    mean_e = sum(x[0] for x in exact) / steps
+    mean_l = sum(x[0] for x in lp) / steps
+    assert abs(mean_e - mean_l) < 0.1 * mean_e
