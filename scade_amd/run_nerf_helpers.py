@@ -168,8 +168,17 @@ class NeRF(nn.Module):
                 "use_viewdirs=True) only")
 
     def ordered_params(self):
-        sd = dict(self.named_parameters())
-        return [sd[k] for k in ops.PARAM_ORDER]
+        """The 24 parameters in kernel order.  Cached: the walk over named_parameters() costs ~60 us
+        and this is called several times per step; the cache is keyed on the identity of the first
+        and last Parameter objects, which change if a parameter is ever re-assigned."""
+        first = self.pts_linears[0].weight
+        last = self.rgb_linear.bias if self.use_viewdirs else self.output_linear.bias
+        c = getattr(self, "_ordered_cache", None)
+        if c is None or c[0] is not first or c[1] is not last:
+            sd = dict(self.named_parameters())
+            c = (first, last, [sd[k] for k in ops.PARAM_ORDER])
+            self._ordered_cache = c
+        return c[2]
 
     def packed(self):
         """MFMA-ordered parameter blob, rebuilt whenever a parameter changed in place."""
