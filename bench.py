@@ -194,6 +194,38 @@ def train_region(args, dev, world, rank, barrier, precision="f32"):
             "mlp_bwd_tflops": kb["work"] / (kb["ms"] * 1e-3) / 1e12}
 
 
+def graph_region(args, dev, n_rays, precision):
+    """Secondary measurement (single process): the same train step at ``n_rays`` rays, eager vs
+    captured in one HIP graph (scade_amd/graphs.py).  128 rays = the per-GPU shard of a strongly-
+    scaled 1024-ray batch on 8 GPUs (BASELINE.json configs[3]), where the ~1.7 ms of host work per
+    eager step is the limit."""
+    from scade_amd.graphs import GraphedTrainer
+    from scade_amd.synthetic import synthetic_rays
+    from scade_amd.train import Trainer, make_scade_nets
+    out = {}
+    for mode in ("eager", "graph"):
+        coarse, fine = make_scade_nets(dev, seed=0)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
+        rays = synthetic_rays(n_rays, seed=4000).to(dev)
+        g = torch.Generator(device="cpu").manual_seed(4001)
+        tgt = torch.rand(n_rays, 3, generator=g).to(dev)
+        hyp = (torch.rand(args.hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
+        gt = GraphedTrainer(tr, n_rays, args.hyp) if mode == "graph" else None
+        f = (lambda: gt.step(rays, tgt, hyp)) if gt else (lambda: tr.step(rays, tgt, hyp)[0])
+        for _ in range(max(3, args.warmup)):
+            f()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            loss = f()
+        torch.cuda.synchronize()
+        out[f"ms_per_step_{mode}"] = (time.perf_counter() - t0) / args.steps * 1e3
+        assert bool(torch.isfinite(loss))
+    out["rays"] = n_rays
+    out["precision"] = precision
+    return out
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -345,6 +377,9 @@ def main():
             out["train_step_f16x3"] = train_region(args, dev, world, rank, barrier, precision="f16x3")
             # mixed precision (BASELINE config 5's bf16 MFMA path): 16-bit forward, dgrad and wgrad
             out["train_step_bf16"] = train_region(args, dev, world, rank, barrier, precision="bf16")
+            if world == 1:
+                out["train_step_graph"] = [graph_region(args, dev, 128, "f32"), graph_region(args, dev, 128, "bf16"),
+                                           graph_region(args, dev, args.rays, "bf16")]
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pc, pf, 1024)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]

@@ -210,6 +210,12 @@ int scade_gen_rays(const int* coords, int N, int H, int W, const float* intrinsi
 int scade_adam_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                     float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                     void* stream);
+/* The same update with every per-step quantity on the device (for train steps captured in a HIP
+ * graph): state = float[16] {t, lr0, decay_rate, decay_step, beta1, beta2, eps, grad_scale, ...};
+ * each call first advances t and derives the staircase learning rate (hyperparameter_update.py:8-13)
+ * and the bias corrections on the device, then applies the update. */
+int scade_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
+                        float* state, void* stream);
 
 #ifdef __cplusplus
 }

@@ -63,6 +63,7 @@ SIGNATURES = {
     "scade_gen_rays": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P,
                                 _P, _P, _P, _P]),
     "scade_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, _I, c_float, _P]),
+    "scade_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, _P]),
     "scade_mse_bwd": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
 }
 

@@ -27,5 +27,19 @@ class FusedAdam:
         # move): advance the global epoch so NeRF.packed()/packed_t() re-pack
         ops.PARAM_EPOCH += 1
 
+    def use_device_state(self, decay_rate: float = 1.0, decay_step: int = 0, grad_scale: float = 1.0):
+        """Move step count, staircase learning rate and bias corrections to the device
+        (``step_dev``): no per-step launch argument is left, so a captured graph stays valid."""
+        self.state = torch.zeros(16, device=self.flat.data.device, dtype=torch.float32)
+        self.state[:8] = torch.tensor([float(self.steps), self.lr, decay_rate, float(decay_step), self.betas[0],
+                                       self.betas[1], self.eps, grad_scale], dtype=torch.float32)
+        return self
+
+    def step_dev(self):
+        call("scade_adam_step_dev", ptr(self.flat.data), ptr(self.flat.grad), ptr(self.exp_avg),
+             ptr(self.exp_avg_sq), self.flat.numel, ptr(self.state), stream())
+        self.steps += 1
+        ops.PARAM_EPOCH += 1
+
     def zero_grad(self):
         self.flat.zero_grad()

@@ -327,3 +327,39 @@ def test_trainer_coarse_stream_overlap_is_bitwise_neutral(dev):
     assert out[False][0] == out[True][0]
     assert torch.equal(out[False][1], out[True][1])
     assert torch.equal(out[False][2], out[True][2])
+
+
+def test_graphed_trainer_matches_eager(dev):
+    """The whole train step captured in one HIP graph (scade_amd/graphs.py, device-resident Adam
+    state) reproduces the eager Trainer step for step; replay leaves no per-step host work."""
+    from scade_amd.graphs import GraphedTrainer
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K, steps = 128, 20, 6
+    g = torch.Generator().manual_seed(9)
+    batches = []
+    for i in range(steps):
+        rays = O.synthetic_rays(N, seed=50 + i)
+        batches.append((rays, torch.rand(N, 3, generator=g), torch.rand(K, N, 1, generator=g) * 4.9 + 0.1,
+                        torch.rand(N, 64, generator=g), torch.rand(N, 128, generator=g),
+                        torch.rand(N, 128, generator=g)))
+    res = {}
+    for mode in ("eager", "graph"):
+        coarse, fine = make_scade_nets(dev, seed=3)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, lrate_decay_step=4,
+                     lrate_decay_rate=0.5)          # two-stream backward on: captured as a fork/join
+        gt = GraphedTrainer(tr, N, K, inject_draws=True) if mode == "graph" else None
+        losses = []
+        for rays, tgt, hyp, a, b, c in batches:
+            args = [t.to(dev) for t in (rays, tgt, hyp)]
+            kw = dict(t_rand=a.to(dev), u_coarse=b.to(dev), cached_u=c.to(dev))
+            l = gt.step(*args, **kw) if gt else tr.step(*args, **kw)[0]
+            losses.append(float(l))
+        torch.cuda.synchronize()
+        res[mode] = (losses, tr.flat.data.clone(), tr.flat_ss.data.clone(), tr.it, tr.opt.steps)
+    le, lg = res["eager"][0], res["graph"][0]
+    assert res["eager"][3] == res["graph"][3] == steps and res["graph"][4] == steps
+    for a, b in zip(le, lg):
+        assert abs(a - b) <= 1e-5 * abs(a), (le, lg)
+    assert le[-1] < le[0]
+    assert_close(res["graph"][1], res["eager"][1], rtol=1e-5, atol=1e-7, what="parameters after 6 steps")
+    assert_close(res["graph"][2], res["eager"][2], rtol=1e-6, atol=1e-9, what="scale/shift after 6 steps")
