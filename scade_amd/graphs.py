@@ -4,8 +4,9 @@ The eager step costs ~1.7 ms of host time (about sixty launches plus the autogra
 is the limit once the device work is short: a 128-ray shard of a strongly-scaled batch, or the
 bf16 path at 1024 rays.  Captured, the step is one ``graph.replay()``.
 
-The Trainer's two-stream backward is captured as a fork/join inside the graph.  Single process
-only (the gradient all-reduce is not captured), fixed shapes; everything that
+The Trainer's two-stream backward is captured as a fork/join inside the graph, and so is the RCCL
+all-reduce of the gradient bucket when the rays are sharded over ranks (every rank captures and
+replays the same sequence).  Fixed shapes; everything that
 changes per step lives on the device: inputs in static buffers, Adam's step count / staircase
 learning rate / bias corrections in ``FusedAdam.state``."""
 from __future__ import annotations
@@ -17,10 +18,13 @@ from . import ops
 
 
 class GraphedTrainer:
-    def __init__(self, trainer, n_rays: int, n_hyp: int, inject_draws: bool = False):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise NotImplementedError("GraphedTrainer: single process only")
+    def __init__(self, trainer, n_rays: int, n_hyp: int, inject_draws: bool = False,
+                 force_allreduce: bool = False):
         tr = self.tr = trainer
+        if tr.sharded and tr.cfg["joint"]:
+            raise NotImplementedError("GraphedTrainer: the sharded is_joint exchange reads a host scalar")
+        self.force_allreduce = force_allreduce
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
         dev = tr.flat.data.device
         c = tr.cfg
         self.rays = torch.zeros(n_rays, 11, device=dev)
@@ -30,8 +34,8 @@ class GraphedTrainer:
         if inject_draws:
             self.draws = (torch.zeros(n_rays, c["Ns"], device=dev), torch.zeros(n_rays, c["Ni"], device=dev),
                           torch.zeros(n_rays, c["Ni"], device=dev))
-        tr.opt.use_device_state(c["rate"], c["step"])
-        tr.opt_ss.use_device_state()
+        tr.opt.use_device_state(c["rate"], c["step"], grad_scale=1.0 / world)
+        tr.opt_ss.use_device_state(grad_scale=1.0 / world)
         self.graph = None
         self.loss = None
 
@@ -44,6 +48,8 @@ class GraphedTrainer:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
         loss, _ = tr.forward_loss(self.rays, self.tgt, self.hyp, **kw)
         loss.backward()
+        tr.flat.allreduce_grads(force=self.force_allreduce)       # 1/world lives in the Adam state
+        tr.flat_ss.allreduce_grads(force=self.force_allreduce)
         tr.opt.step_dev()
         if tr.it < tr.cfg["freeze_ss"]:
             tr.opt_ss.step_dev()

@@ -83,13 +83,14 @@ class FlatParams:
                 p.grad = self.grad[o:o + n].view(p.shape)
             o += n
 
-    def allreduce_grads(self, group=None) -> float:
+    def allreduce_grads(self, group=None, force: bool = False) -> float:
         """Sum-all-reduce the gradient bucket; returns the factor the optimizer must apply
-        (1/world) so that equal shards with local-mean losses reproduce the global mean."""
+        (1/world) so that equal shards with local-mean losses reproduce the global mean.
+        ``force``: issue the collective even on a one-rank group (self-tests of the RCCL path)."""
         if not (dist.is_available() and dist.is_initialized()):
             return 1.0
         world = dist.get_world_size(group)
-        if world == 1:
+        if world == 1 and not force:
             return 1.0
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / world

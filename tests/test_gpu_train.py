@@ -363,3 +363,43 @@ def test_graphed_trainer_matches_eager(dev):
     assert le[-1] < le[0]
     assert_close(res["graph"][1], res["eager"][1], rtol=1e-5, atol=1e-7, what="parameters after 6 steps")
     assert_close(res["graph"][2], res["eager"][2], rtol=1e-6, atol=1e-9, what="scale/shift after 6 steps")
+
+
+def test_graphed_trainer_captures_the_rccl_allreduce(dev):
+    """One-rank RCCL group: the gradient all-reduce is issued inside the captured step (forced,
+    since a one-rank trainer would skip it) and the graphed steps still match the eager ones."""
+    import os
+    import torch.distributed as dist
+    from scade_amd.graphs import GraphedTrainer
+    from scade_amd.train import Trainer, make_scade_nets
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29561")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        N, K = 96, 10
+        rays = O.synthetic_rays(N, seed=70).to(dev)
+        torch.manual_seed(70)
+        tgt = torch.rand(N, 3, device=dev)
+        hyp = torch.rand(K, N, 1, device=dev) * 4.9 + 0.1
+        g = torch.Generator().manual_seed(71)
+        draws = [tuple(torch.rand(N, s, generator=g).to(dev) for s in (64, 128, 128)) for _ in range(4)]
+        res = {}
+        for mode in ("eager", "graph"):
+            coarse, fine = make_scade_nets(dev, seed=4)
+            tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1)
+            gt = GraphedTrainer(tr, N, K, inject_draws=True, force_allreduce=True) if mode == "graph" else None
+            ls = []
+            for a, b, c in draws:
+                kw = dict(t_rand=a, u_coarse=b, cached_u=c)
+                ls.append(float(gt.step(rays, tgt, hyp, **kw) if gt else tr.step(rays, tgt, hyp, **kw)[0]))
+            torch.cuda.synchronize()
+            res[mode] = (ls, tr.flat.data.clone())
+        for a, b in zip(res["eager"][0], res["graph"][0]):
+            assert abs(a - b) <= 1e-5 * abs(a)
+        assert_close(res["graph"][1], res["eager"][1], rtol=1e-5, atol=1e-7, what="parameters")
+    finally:
+        if created:
+            dist.destroy_process_group()
