@@ -83,7 +83,7 @@ int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in, const f
  * path"): activations and weights rounded to fp16 (bf16 = 0) or bfloat16
  * (bf16 = 1), one v_mfma_f32_32x32x16_{f16,bf16} per product, fp32 accumulate, fp32 biases, heads and
  * outputs.  Ordinary mixed-precision accuracy (relative ~1e-3 fp16 / ~1e-2 bf16), NOT the 1e-4 parity
- * bar.  packed_lp = scade_mlp_pack_lp(params, bf16), scade_mlp_packed_lp_bytes() bytes (the format is
+ * bar.  The fp16 variant needs |activations|, |weights| < 65504; bfloat16 has fp32's range.  packed_lp = scade_mlp_pack_lp(params, bf16), scade_mlp_packed_lp_bytes() bytes (the format is
  * baked into the pack: pass the same bf16 flag to both).  Same modes and arguments as scade_mlp_fwd;
  * acts (nullable) = training workspace of scade_mlp_acts_lp_bytes(P) bytes: 16-bit activations, the
  * embedding rows, fp32 alpha_pre and the ReLU sign words consumed by scade_mlp_bwd_lp. */
