@@ -203,3 +203,12 @@ def render_images_with_metrics(images, depths, valid_depths, poses, Hh, Ww, intr
         out["depths"].append(extras["depth_map"])
     out["mean"] = {k: float(np.mean(out[k])) for k in ("psnr", "img_loss", "psnr0", "depth_rmse") if out[k]}
     return out
+
+
+def depth_std_map(z_vals, weights, depth_map):
+    """Per-ray standard deviation of the rendered depth, the third panel of the reference's
+    ``render_video`` frames (run_scade_scannet.py:257-258): sqrt(clamp(sum_i w_i (z_i - depth)^2,
+    0, 1)).  A handful of elementwise torch ops on ``render``'s extras (visualisation, not on the
+    kernel path; works on any device)."""
+    var = ((z_vals - depth_map.unsqueeze(-1)).pow(2) * weights).sum(-1)
+    return var.clamp(0.0, 1.0).sqrt()

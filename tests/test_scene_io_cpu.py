@@ -72,3 +72,16 @@ def test_checkpoint_roundtrip_reference_format(tmp_path):
     for a, b in zip(list(c.parameters()) + list(f.parameters()), list(c2.parameters()) + list(f2.parameters())):
         assert torch.equal(a, b)
     assert load_checkpoint(str(tmp_path), "missing") is None
+
+
+def test_depth_std_map_matches_reference_formula():
+    import torch
+    from scade_amd.scene import depth_std_map
+    g = torch.Generator().manual_seed(0)
+    z = torch.rand(5, 7, 192, generator=g).sort(-1)[0] * 5
+    w = torch.rand(5, 7, 192, generator=g)
+    w = w / w.sum(-1, keepdim=True)
+    depth = (w * z).sum(-1)
+    want = ((z - depth.unsqueeze(-1)).pow(2) * w).sum(-1).clamp(0., 1.).sqrt()     # :257-258
+    assert torch.equal(depth_std_map(z, w, depth), want)
+    assert depth_std_map(z, w, depth).shape == (5, 7)
