@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
     if (m > 0.f && m < 3.0e38f) {
       int e;
       frexpf(m, &e);                       // m = f * 2^e, f in [0.5, 1)
-      s = ldexpf(1.f, -4 - e);
+      s = ldexpf(1.f, min(-4 - e, 96));    // denormal gradients: keep the scale finite
     }
     if (sub == 0) {
       if (ok) dz[dz_dalpha_off(P) + pt] = da;
@@ -424,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) 
   if (m > 0.f && m < 3.0e38f) {
     int e;
     frexpf(m, &e);
-    S = ldexpf(1.f, 8 - e);
+    S = ldexpf(1.f, min(8 - e, 96));
   }
   if (jb.flags & WF_RGB) {
     wgrad_rgb_job(a, jb, reinterpret_cast<float*>(ldsw), c0, c1, out);

@@ -82,7 +82,7 @@ __device__ __forceinline__ float lp_loss_scale(float m) {
   if (!(m > 0.f) || !(m < 3.0e38f)) return 1.f;
   int e;
   frexpf(m, &e);
-  return ldexpf(1.f, 6 - e);
+  return ldexpf(1.f, min(6 - e, 96));   // denormal max: keep the scale (and S / s_p) finite
 }
 
 // ---------------------------------------------------------------------------
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
     if (m > 0.f && m < 3.0e38f) {
       int e;
       frexpf(m, &e);
-      s = ldexpf(1.f, -4 - e);
+      s = ldexpf(1.f, min(-4 - e, 96));    // denormal gradients: keep the scale finite
     }
     if (sub == 0) {
       if (ok) dalpha[pt] = da;
