@@ -38,6 +38,7 @@ class GraphedTrainer:
         tr.opt_ss.use_device_state(grad_scale=1.0 / world)
         self.graph = None
         self.loss = None
+        self._captured_ss = None     # whether the captured graph contains the scale/shift update
 
     def _body(self):
         tr = self.tr
@@ -72,6 +73,7 @@ class GraphedTrainer:
             dst.copy_(src)
         tr.opt.steps, tr.opt_ss.steps = steps
         ops.PARAM_EPOCH += 1
+        self._captured_ss = tr.it < tr.cfg["freeze_ss"]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
@@ -87,13 +89,14 @@ class GraphedTrainer:
             self.draws[0].copy_(t_rand)
             self.draws[1].copy_(u_coarse)
             self.draws[2].copy_(cached_u)
-        if self.graph is None:
-            self._capture()
-        self.graph.replay()
         tr = self.tr
+        with_ss = tr.it < tr.cfg["freeze_ss"]
+        if self.graph is None or with_ss != self._captured_ss:
+            self._capture()               # first step, or the scale/shift freeze point (:996) was crossed
+        self.graph.replay()
         tr.it += 1
         tr.opt.steps += 1
-        if tr.it <= tr.cfg["freeze_ss"]:
+        if with_ss:
             tr.opt_ss.steps += 1
         ops.PARAM_EPOCH += 1          # parameters changed behind the module caches' back
         return self.loss

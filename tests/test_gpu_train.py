@@ -346,7 +346,8 @@ def test_graphed_trainer_matches_eager(dev):
     for mode in ("eager", "graph"):
         coarse, fine = make_scade_nets(dev, seed=3)
         tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, lrate_decay_step=4,
-                     lrate_decay_rate=0.5)          # two-stream backward on: captured as a fork/join
+                     lrate_decay_rate=0.5, freeze_ss=3)   # two-stream backward on: captured as a fork/join;
+        #                                                    the scale/shift freeze after 3 steps forces a re-capture
         gt = GraphedTrainer(tr, N, K, inject_draws=True) if mode == "graph" else None
         losses = []
         for rays, tgt, hyp, a, b, c in batches:
