@@ -297,3 +297,71 @@ def test_space_carving_joint_sharded_entry_single_process(dev):
             assert_close(l, want.detach(), rtol=1e-5, atol=1e-7, what="joint loss")
             assert_close(gp, po.grad, rtol=1e-5, atol=1e-9, what="joint d/d pred")
             assert_close(gh, ho.grad, rtol=1e-5, atol=1e-9, what="joint d/d hyp")
+
+
+# ---------------------------------------------------------------- randomized shape sweep
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_per_ray_kernels_random_shapes_forward_and_backward(dev, seed):
+    """Shape sweep (ragged ray counts, sample counts on both sides of the 64-lane wave, sampler
+    bins that are not 63 / 191, hypothesis counts that are not 20 / 40) of the per-ray kernels,
+    forward AND backward, against the oracle and its autograd."""
+    g = torch.Generator().manual_seed(100 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for _ in range(4):
+        N, Sn, Ns, K = ri(1, 70), ri(2, 260), ri(1, 150), ri(1, 45)
+        # --- compositing
+        raw = torch.randn(N, Sn, 4, generator=g)
+        z = torch.sort(torch.rand(N, Sn, generator=g) * 4 + 0.1, -1)[0]
+        d = torch.randn(N, 3, generator=g)
+        ro = raw.clone().requires_grad_(True)
+        wo = O.raw2outputs(ro, z, d)
+        cots = [torch.randn(t.shape, generator=g) for t in wo]
+        sum((a * c).sum() for a, c in zip(wo, cots)).backward()
+        rg = raw.to(dev).requires_grad_(True)
+        got = S.raw2outputs(rg, z.to(dev), d.to(dev))
+        sum((a * c.to(dev)).sum() for a, c in zip(got, cots)).backward()
+        for a, b, n in zip(got, wo, ["rgb", "disp", "acc", "w", "depth"]):
+            assert_close(a, b.detach(), what=f"composite N={N} S={Sn} {n}", **TOL)
+        assert_close(rg.grad, ro.grad, rtol=1e-4, atol=1e-5 * float(ro.grad.abs().max()), what=f"composite grad N={N} S={Sn}")
+        # --- sampler (forward from weights with explicit u, backward w.r.t. the weights)
+        M = max(Sn - 1, 2)
+        bins = torch.sort(torch.rand(N, M, generator=g) * 4 + 0.1, -1)[0]
+        w = torch.rand(N, M - 1, generator=g) ** 4
+        if N > 2:
+            w[0] = 0.0                                           # all-zero row
+            w[1] = 0.0
+            w[1, (M - 1) // 2] = 1.0                             # one-hot row
+        u = torch.rand(N, Ns, generator=g)
+        wo_ = w.clone().requires_grad_(True)
+        so = O.sample_pdf(bins, wo_, u)
+        cot = torch.randn(so.shape, generator=g)
+        (so * cot).sum().backward()
+        wg = w.to(dev).requires_grad_(True)
+        sg, _ = S.sample_pdf_return_u(bins.to(dev), wg, Ns, load_u=u.to(dev))
+        (sg * cot.to(dev)).sum().backward()
+        # from raw weights the two cdfs differ by an ulp (torch.sum's vectorised cascade is not
+        # reproducible), so a u within an ulp of a cdf knot may select the neighbouring bin: allow a
+        # vanishing fraction of such samples (the golden test pins the indices given identical cdf, u)
+        err = (sg.cpu() - so.detach()).abs()
+        bad = err > 2e-5 + 1e-4 * so.detach().abs()
+        assert float(bad.float().mean()) < 1e-3, (N, M, Ns, int(bad.sum()))
+        assert float(err.max()) < 0.5
+        scale = float(wo_.grad.abs().max()) + 1e-30
+        assert rel_l2(wg.grad, wo_.grad) < 2e-3, (N, M, Ns, rel_l2(wg.grad, wo_.grad))   # 1/den^2 amplification
+        # --- merge
+        zb = torch.rand(N, Ns, generator=g) * 5
+        rays = O.synthetic_rays(N, seed=200 + seed, unit_dirs=False)
+        zs, pts = ops.merge_sorted(z.to(dev), zb.to(dev), rays.to(dev))
+        assert torch.equal(zs.cpu(), torch.sort(torch.cat([z, zb], -1), -1)[0])
+        # --- space carving
+        pred = torch.rand(N, Ns, generator=g) * 5
+        hyp = torch.rand(K, N, 1, generator=g) * 4.9 + 0.1
+        po, ho = pred.clone().requires_grad_(True), hyp.clone().requires_grad_(True)
+        lo = O.compute_space_carving_loss(po, ho)
+        lo.backward()
+        pg, hg = pred.to(dev).requires_grad_(True), hyp.to(dev).requires_grad_(True)
+        lg = S.compute_space_carving_loss(pg, hg)
+        lg.backward()
+        assert_close(lg, lo.detach(), rtol=1e-5, atol=1e-7, what=f"carve N={N} P={Ns} K={K}")
+        assert_close(pg.grad, po.grad, rtol=1e-5, atol=1e-9, what="carve d/d pred")
+        assert_close(hg.grad, ho.grad, rtol=1e-5, atol=1e-9, what="carve d/d hyp")
