@@ -100,3 +100,50 @@ class GraphedTrainer:
             tr.opt_ss.steps += 1
         ops.PARAM_EPOCH += 1          # parameters changed behind the module caches' back
         return self.loss
+
+
+class GraphedRender:
+    """``render_rays`` (inference: no_grad, perturb = 0) of a fixed-size ray batch captured in one
+    HIP graph: the ~20 launches of a render step replay with a single call, which is what bounds
+    small batches (interactive rendering, the per-GPU shard of a strongly-scaled batch).  The
+    outputs are static tensors that the next replay overwrites - clone what must survive."""
+
+    def __init__(self, n_rays: int, network_fn, network_query_fn, N_samples: int, N_importance: int,
+                 network_fine, device=None, **render_kw):
+        from . import rendering as R
+        dev = device if device is not None else next(network_fn.parameters()).device
+        self.rays = torch.zeros(n_rays, 11, device=dev)
+        self._call = lambda: R.render_rays(self.rays, True, network_fn, network_query_fn, N_samples,
+                                           N_importance=N_importance, network_fine=network_fine, perturb=0.,
+                                           **render_kw)
+        self._nets = (network_fn, network_fine)
+        self._epoch = None
+        self.graph = None
+        self.out = None
+
+    def _capture(self):
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(2):                      # first-launch setup + weight packs outside the capture
+                self._call()
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph), torch.no_grad():
+            self.out = self._call()
+        self._epoch = self._weights_key()
+
+    def _weights_key(self):
+        return (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for n in self._nets for p in n.parameters())
+
+    def __call__(self, rays):
+        """rays [n_rays, >= 11] -> the dict of render_rays (static tensors)."""
+        if self.graph is None or self._epoch != self._weights_key():
+            # the packed weight blobs are baked into the graph as of capture time: re-capture after
+            # any parameter update
+            self.rays.copy_(rays[:, :11])
+            self._capture()
+        else:
+            self.rays.copy_(rays[:, :11])
+        self.graph.replay()
+        return self.out

@@ -215,3 +215,24 @@ def test_render_rays_ragged_batches(dev):
         empty = S.render_rays(rays[:0].to(dev), True, coarse, query, 64, N_importance=128, network_fine=fine,
                               perturb=0., retraw=True)
     assert empty["rgb_map"].shape == (0, 3) and empty["z_vals"].shape == (0, 192) and empty["raw"].shape == (0, 192, 4)
+
+
+def test_graphed_render_matches_eager_and_follows_weight_updates(dev):
+    from scade_amd.graphs import GraphedRender
+    g = load_golden("f6_render")
+    pc, pf = f6_params(g)
+    coarse, fine, query = build(dev, pc, pf, g["bb_center"], g["bb_scale"])
+    rays_a = g["rays"].to(dev)
+    rays_b = O.synthetic_rays(32, seed=77).to(dev)
+    gr = GraphedRender(32, coarse, query, 64, 128, fine)
+    for rays in (rays_a, rays_b, rays_a):
+        with torch.no_grad():
+            want = S.render_rays(rays, True, coarse, query, 64, N_importance=128, network_fine=fine, perturb=0.)
+        got = gr(rays)
+        for k in want:
+            assert torch.equal(torch.nan_to_num(got[k]), torch.nan_to_num(want[k])), k
+    with torch.no_grad():
+        fine.rgb_linear.bias.add_(0.25)            # parameter update -> the graph must be re-captured
+        want = S.render_rays(rays_b, True, coarse, query, 64, N_importance=128, network_fine=fine, perturb=0.)
+    got = gr(rays_b)
+    assert torch.equal(got["rgb_map"], want["rgb_map"])
