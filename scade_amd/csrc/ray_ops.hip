@@ -420,7 +420,7 @@ __global__ void sample_pdf_bwd_kernel(SamplePdfArgs a) {
 }
 
 // ---------------------------------------------------------------------------
-// merge_sorted: z = sort(cat(z_a[Sa], z_b[Sb])) (stable rank sort) + points
+// merge_sorted: z = sort(cat(z_a[Sa], z_b[Sb])) + points
 // ---------------------------------------------------------------------------
 struct MergeArgs {
   const float* za; const float* zb;
@@ -430,16 +430,36 @@ struct MergeArgs {
   int N, Sa, Sb, ray_stride;
 };
 
-__global__ void merge_sorted_kernel(MergeArgs a) {
+// Bitonic sorting network over the concatenation padded to a power of two with +inf (St = 192 ->
+// 256: 36 stages x 2 pair-exchanges per lane, against 576 compares per element of a rank sort).
+// NaN orders above everything (torch.sort puts NaN last); equal values are interchangeable, so the
+// output equals torch.sort(cat(z_a, z_b)).values bit for bit.
+__device__ __forceinline__ bool z_after(float a, float b) { return a > b || (a != a && b == b); }
+
+__global__ void merge_sorted_kernel(MergeArgs a, int PB) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int wv = threadIdx.x >> 6, lane = lane_id();
   const int ray = blockIdx.x * RAYS_PER_WG + wv;
   if (ray >= a.N) return;
   const int St = a.Sa + a.Sb;
-  float* v = smem + wv * St;
+  float* v = smem + wv * PB;
   for (int i = lane; i < a.Sa; i += 64) v[i] = a.za[(size_t)ray * a.Sa + i];
   for (int i = lane; i < a.Sb; i += 64) v[a.Sa + i] = a.zb[(size_t)ray * a.Sb + i];
+  for (int i = St + lane; i < PB; i += 64) v[i] = INFINITY;
   __builtin_amdgcn_wave_barrier();
+  for (int k = 2; k <= PB; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      // pair index t in [0, PB/2): i = element with bit j clear
+      for (int t = lane; t < (PB >> 1); t += 64) {
+        const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        const int ixj = i | j;
+        const float x = v[i], y = v[ixj];
+        const bool asc = (i & k) == 0;
+        if (asc ? z_after(x, y) : z_after(y, x)) { v[i] = y; v[ixj] = x; }
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
   if (a.pts) {
     const float* r = a.rays + (size_t)ray * a.ray_stride;
@@ -447,14 +467,9 @@ __global__ void merge_sorted_kernel(MergeArgs a) {
   }
   for (int i = lane; i < St; i += 64) {
     const float x = v[i];
-    int rank = 0;
-    for (int j = 0; j < St; ++j) {
-      const float y = v[j];
-      rank += (y < x || (y == x && j < i)) ? 1 : 0;
-    }
-    a.z_out[(size_t)ray * St + rank] = x;
+    a.z_out[(size_t)ray * St + i] = x;
     if (a.pts) {
-      float* p = a.pts + ((size_t)ray * St + rank) * 3;
+      float* p = a.pts + ((size_t)ray * St + i) * 3;
       p[0] = ox + dx * x;
       p[1] = oy + dy * x;
       p[2] = oz + dz * x;
@@ -745,8 +760,10 @@ extern "C" int scade_merge_sorted(const float* z_a, int Sa, const float* z_b, in
   SCADE_REQUIRE(!pts || (rays && ray_stride >= 6), -1, "scade_merge_sorted: pts needs rays");
   SCADE_REQUIRE(Sa >= 0 && Sb >= 0 && Sa + Sb <= 4096, -2, "scade_merge_sorted: Sa+Sb > 4096");
   MergeArgs a{z_a, z_b, rays, z_out, pts, N, Sa, Sb, ray_stride};
-  const size_t lds = (size_t)RAYS_PER_WG * (Sa + Sb) * sizeof(float);
-  hipLaunchKernelGGL(merge_sorted_kernel, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a);
+  int PB = 2;
+  while (PB < Sa + Sb) PB <<= 1;
+  const size_t lds = (size_t)RAYS_PER_WG * PB * sizeof(float);
+  hipLaunchKernelGGL(merge_sorted_kernel, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a, PB);
   return scade_check_launch("scade_merge_sorted");
 }
 
