@@ -430,22 +430,97 @@ struct MergeArgs {
   int N, Sa, Sb, ray_stride;
 };
 
-// Bitonic sorting network over the concatenation padded to a power of two with +inf (St = 192 ->
-// 256: 36 stages x 2 pair-exchanges per lane, against 576 compares per element of a rank sort).
-// NaN orders above everything (torch.sort puts NaN last); equal values are interchangeable, so the
-// output equals torch.sort(cat(z_a, z_b)).values bit for bit.
-__device__ __forceinline__ bool z_after(float a, float b) { return a > b || (a != a && b == b); }
+// Bitonic sorting network over the concatenation padded to a power of two PB with the largest key.  The floats
+// are sorted as order-preserving UNSIGNED KEYS (sign bit set: ~bits, else bits | 0x80000000; NaN
+// canonicalised to the largest key, so it sorts last like torch.sort), which makes a compare-exchange
+// two integer ops (v_min_u32 / v_max_u32) with no branches.  Equal values are interchangeable, so the
+// output equals torch.sort(cat(z_a, z_b)).values bit for bit (NaN payloads and the order of -0 / +0
+// aside).
+__device__ __forceinline__ unsigned z_key(float x) {
+  unsigned u = __float_as_uint(x);
+  u = (x != x) ? 0x7fc00000u : u;
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float z_unkey(unsigned k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+constexpr unsigned Z_KEY_INF = 0xffffffffu;   // padding: after every data key, NaN included
 
-__global__ void merge_sorted_kernel(MergeArgs a, int PB) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
+// PB = 64*R <= 512 (SCADE: 192 -> 256, R = 4): the whole ray lives in REGISTERS, element e = lane +
+// 64 r.  A compare-exchange at distance j < 64 is one __shfl_xor per register, at distance >= 64 it is
+// lane-local; 36 stages of four independent shuffles instead of 36 dependent LDS round trips.
+template <int R>
+__global__ void merge_sorted_reg_kernel(MergeArgs a) {
   const int wv = threadIdx.x >> 6, lane = lane_id();
   const int ray = blockIdx.x * RAYS_PER_WG + wv;
   if (ray >= a.N) return;
   const int St = a.Sa + a.Sb;
-  float* v = smem + wv * PB;
-  for (int i = lane; i < a.Sa; i += 64) v[i] = a.za[(size_t)ray * a.Sa + i];
-  for (int i = lane; i < a.Sb; i += 64) v[a.Sa + i] = a.zb[(size_t)ray * a.Sb + i];
-  for (int i = St + lane; i < PB; i += 64) v[i] = INFINITY;
+  unsigned v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = lane + 64 * r;
+    v[r] = e < a.Sa ? z_key(a.za[(size_t)ray * a.Sa + e])
+                    : (e < St ? z_key(a.zb[(size_t)ray * a.Sb + (e - a.Sa)]) : Z_KEY_INF);
+  }
+#pragma unroll
+  for (int k = 2; k <= 64 * R; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      if (j >= 64) {                                   // partner register, same lane
+        const int dr = j >> 6;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          if ((r & dr) == 0) {
+            const bool asc = ((64 * r) & k) == 0;      // lane bits are below 64 <= j < k
+            const unsigned lo = min(v[r], v[r | dr]), hi = max(v[r], v[r | dr]);
+            v[r] = asc ? lo : hi;
+            v[r | dr] = asc ? hi : lo;
+          }
+        }
+      } else {                                         // partner lane, same register
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+          const unsigned x = v[r];
+          const unsigned y = (unsigned)__shfl_xor((int)x, j, 64);
+          const bool lower = (lane & j) == 0;
+          const bool asc = ((lane + 64 * r) & k) == 0;
+          v[r] = (lower == asc) ? min(x, y) : max(x, y);   // the lower element of an ascending pair keeps the min
+        }
+      }
+    }
+  }
+  float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
+  if (a.pts) {
+    const float* rr = a.rays + (size_t)ray * a.ray_stride;
+    ox = rr[0]; oy = rr[1]; oz = rr[2]; dx = rr[3]; dy = rr[4]; dz = rr[5];
+  }
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = lane + 64 * r;
+    if (e < St) {
+      const float x = z_unkey(v[r]);
+      a.z_out[(size_t)ray * St + e] = x;
+      if (a.pts) {
+        float* p = a.pts + ((size_t)ray * St + e) * 3;
+        p[0] = ox + dx * x;
+        p[1] = oy + dy * x;
+        p[2] = oz + dz * x;
+      }
+    }
+  }
+}
+
+// larger rows: the same network in LDS
+__global__ void merge_sorted_kernel(MergeArgs a, int PB) {
+  extern __shared__ __attribute__((aligned(16))) unsigned smem_u[];
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int ray = blockIdx.x * RAYS_PER_WG + wv;
+  if (ray >= a.N) return;
+  const int St = a.Sa + a.Sb;
+  unsigned* v = smem_u + wv * PB;
+  for (int i = lane; i < a.Sa; i += 64) v[i] = z_key(a.za[(size_t)ray * a.Sa + i]);
+  for (int i = lane; i < a.Sb; i += 64) v[a.Sa + i] = z_key(a.zb[(size_t)ray * a.Sb + i]);
+  for (int i = St + lane; i < PB; i += 64) v[i] = Z_KEY_INF;
   __builtin_amdgcn_wave_barrier();
   for (int k = 2; k <= PB; k <<= 1) {
     for (int j = k >> 1; j > 0; j >>= 1) {
@@ -453,9 +528,11 @@ __global__ void merge_sorted_kernel(MergeArgs a, int PB) {
       for (int t = lane; t < (PB >> 1); t += 64) {
         const int i = ((t & ~(j - 1)) << 1) | (t & (j - 1));
         const int ixj = i | j;
-        const float x = v[i], y = v[ixj];
+        const unsigned x = v[i], y = v[ixj];
         const bool asc = (i & k) == 0;
-        if (asc ? z_after(x, y) : z_after(y, x)) { v[i] = y; v[ixj] = x; }
+        const unsigned lo = min(x, y), hi = max(x, y);
+        v[i] = asc ? lo : hi;
+        v[ixj] = asc ? hi : lo;
       }
       __builtin_amdgcn_wave_barrier();
     }
@@ -466,7 +543,7 @@ __global__ void merge_sorted_kernel(MergeArgs a, int PB) {
     ox = r[0]; oy = r[1]; oz = r[2]; dx = r[3]; dy = r[4]; dz = r[5];
   }
   for (int i = lane; i < St; i += 64) {
-    const float x = v[i];
+    const float x = z_unkey(v[i]);
     a.z_out[(size_t)ray * St + i] = x;
     if (a.pts) {
       float* p = a.pts + ((size_t)ray * St + i) * 3;
@@ -756,14 +833,22 @@ extern "C" int scade_merge_sorted(const float* z_a, int Sa, const float* z_b, in
                                   const float* rays, int ray_stride, int N, float* z_out,
                                   float* pts, void* stream) {
   if (N <= 0 || Sa + Sb == 0) return 0;
-  SCADE_REQUIRE(z_a && z_b && z_out, -1, "scade_merge_sorted: null pointer");
+  SCADE_REQUIRE((z_a || Sa == 0) && (z_b || Sb == 0) && z_out, -1, "scade_merge_sorted: null pointer");
   SCADE_REQUIRE(!pts || (rays && ray_stride >= 6), -1, "scade_merge_sorted: pts needs rays");
   SCADE_REQUIRE(Sa >= 0 && Sb >= 0 && Sa + Sb <= 4096, -2, "scade_merge_sorted: Sa+Sb > 4096");
   MergeArgs a{z_a, z_b, rays, z_out, pts, N, Sa, Sb, ray_stride};
-  int PB = 2;
+  int PB = 64;
   while (PB < Sa + Sb) PB <<= 1;
-  const size_t lds = (size_t)RAYS_PER_WG * PB * sizeof(float);
-  hipLaunchKernelGGL(merge_sorted_kernel, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a, PB);
+  const dim3 grid(grid_rays(N)), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (PB) {
+    case 64: hipLaunchKernelGGL(merge_sorted_reg_kernel<1>, grid, block, 0, s, a); break;
+    case 128: hipLaunchKernelGGL(merge_sorted_reg_kernel<2>, grid, block, 0, s, a); break;
+    case 256: hipLaunchKernelGGL(merge_sorted_reg_kernel<4>, grid, block, 0, s, a); break;
+    case 512: hipLaunchKernelGGL(merge_sorted_reg_kernel<8>, grid, block, 0, s, a); break;
+    default:
+      hipLaunchKernelGGL(merge_sorted_kernel, grid, block, (size_t)RAYS_PER_WG * PB * sizeof(float), s, a, PB);
+  }
   return scade_check_launch("scade_merge_sorted");
 }
 

@@ -365,3 +365,23 @@ def test_per_ray_kernels_random_shapes_forward_and_backward(dev, seed):
         assert_close(lg, lo.detach(), rtol=1e-5, atol=1e-7, what=f"carve N={N} P={Ns} K={K}")
         assert_close(pg.grad, po.grad, rtol=1e-5, atol=1e-9, what="carve d/d pred")
         assert_close(hg.grad, ho.grad, rtol=1e-5, atol=1e-9, what="carve d/d hyp")
+
+
+def test_merge_sorted_sizes_nan_and_unsorted_inputs(dev):
+    """Register network (rows up to 512 keys), LDS network (larger), ties, unsorted first operand,
+    NaN placed last like torch.sort."""
+    g = torch.Generator().manual_seed(12)
+    for N, Sa, Sb in ((5, 1, 1), (9, 7, 5), (33, 64, 128), (17, 64, 0), (4, 100, 156), (3, 200, 312),
+                      (2, 300, 500), (2, 1000, 1500)):
+        za = torch.rand(N, Sa, generator=g) * 5                      # deliberately NOT sorted
+        zb = torch.rand(N, Sb, generator=g) * 5
+        if Sb > 3:
+            zb[0, :3] = za[0, :1]                                    # ties
+            zb[-1, 1] = float("nan")
+        rays = O.synthetic_rays(N, seed=4, unit_dirs=False)
+        want, _ = torch.sort(torch.cat([za, zb], -1), -1)
+        got, pts = ops.merge_sorted(za.to(dev), zb.to(dev), rays.to(dev))
+        assert torch.equal(torch.nan_to_num(got.cpu(), nan=-7.0), torch.nan_to_num(want, nan=-7.0)), (N, Sa, Sb)
+        assert torch.equal(torch.isnan(got.cpu()), torch.isnan(want))
+        wpts = rays[:, None, 0:3] + rays[:, None, 3:6] * want[..., None]
+        assert torch.equal(torch.nan_to_num(pts.cpu()), torch.nan_to_num(wpts))
