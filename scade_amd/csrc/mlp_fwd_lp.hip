@@ -13,10 +13,10 @@
 namespace scade {
 
 // forward layer order: pts 0..7, feature, views
-constexpr int fwd_rot(int l) {
+constexpr int fwd_rot(int l, int ns) {
   int k = 0;
   for (int i = 0; i < l; ++i) k += kb16(i);
-  return k % 3;
+  return k % ns;
 }
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -154,15 +154,18 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   f32x16 acc[2][LPT];
   f32x16 cb[2];           // this lane's bias values of the NEXT layer, loaded one epilogue ahead
   unsigned bits[4];
-  AFrag3<BF> A;
+  // inference: weights fetched three k-blocks ahead; the training variant has no registers left
+  // for a fourth set and stays at two
+  constexpr int NS = SAVE ? 3 : 4;
+  AFragN<BF, NS> A;
   const int nt0 = wave * 2;
 #define WLBASE(L) (reinterpret_cast<const V8*>(wpk + CE<off_wl(L)>::v) + ((L) == L_VIEWS ? wave : nt0) * (int)CE<kb16(L) * 64>::v)
 
   // rotation of the A register sets on entry of layer L = (k-blocks of all earlier layers) % 3
-#define FROT(L) ((int)CE<fwd_rot(L)>::v)
+#define FROT(L) ((int)CE<fwd_rot(L, NS)>::v)
 #define PTS_LAYER_L(L, LNEXT, KBP)                                                              \
   {                                                                                             \
-    layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L)>(acc, A, WLBASE(L), WLBASE(LNEXT),       \
+    layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS>(acc, A, WLBASE(L), WLBASE(LNEXT),   \
                                                         (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
     __syncthreads();                                                                            \
     layer_store_lp<BF, 2, true, SAVE, 2>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
@@ -179,6 +182,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   A.s[0].t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + lane];
   A.s[1].t0 = WLBASE(0)[64 + lane];
   A.s[1].t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + 64 + lane];
+  if constexpr (NS == 4) {
+    A.s[2].t0 = WLBASE(0)[128 + lane];
+    A.s[2].t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + 128 + lane];
+  }
   load_bias16<2>(cb, TAIL(off_b(0)), nt0, lane);
   PTS_LAYER_L(0, 1, 4)
   PTS_LAYER_L(1, 2, 0)
@@ -226,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
 
   // ---- feature_linear ------------------------------------------------------------------
-  layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT)>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+  layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
   __syncthreads();
   layer_store_lp<BF, 2, false, false, 1>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
   __syncthreads();
@@ -235,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av[1][LPT];
-    layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS)>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+    layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
     __syncthreads();
     layer_store_lp<BF, 1, true, false, 0>(av, wave, x, lane, bits, cb, nullptr, 0);
     __syncthreads();

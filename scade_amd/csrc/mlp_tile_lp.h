@@ -120,20 +120,22 @@ __device__ __forceinline__ unsigned mask_pair(unsigned w, unsigned word, int k) 
 
 template <bool BF>
 struct AFragL { typename LP<BF>::V8 t0, t1; };
-// three A-fragment register sets: k-block kb of a layer entered with rotation ROT lives in set
-// (ROT + kb) % 3; the sets of blocks kb+1 and kb+2 are in flight while block kb is multiplied
+// NS rotating A-fragment register sets: k-block kb of a layer entered with rotation ROT lives in set
+// (ROT + kb) % NS; the sets of blocks kb+1 .. kb+NS-1 are in flight while block kb is multiplied
+template <bool BF, int NS>
+struct AFragN { AFragL<BF> s[NS]; };
 template <bool BF>
-struct AFrag3 { AFragL<BF> s[3]; };
+using AFrag3 = AFragN<BF, 3>;
 
 // acc[t][p] = cinit[t] + W[n-tile t] * act[point tile p] over the layer's k-blocks (cinit == nullptr:
 // zero).  The first k-block is peeled so that the initial value rides in as the MFMA's C operand
 // (the lane's bias vector, or the inline constant 0) instead of 128 v_mov + 128 v_add per layer.
-// A (weights, L2 latency): fetched TWO k-blocks ahead into the rotating sets of AFrag3 - across the
-// layer boundary too (the last two blocks prefetch blocks 0 and 1 of the next layer; the caller
-// enters the next layer with rotation (ROT + KB) % 3).  B (activations, LDS): every fragment is
+// A (weights, L2 latency): fetched NS-1 k-blocks ahead into the rotating sets of AFragN - across the
+// layer boundary too (the last NS-1 blocks prefetch blocks 0 .. NS-2 of the next layer; the caller
+// enters the next layer with rotation (ROT + KB) % NS).  B (activations, LDS): every fragment is
 // reloaded in place for the next block right after the two MFMAs that consume it were issued.
-template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT>
-__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFrag3<BF>& A,
+template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT, int NS = 3>
+__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragN<BF, NS>& A,
                                               const typename LP<BF>::V8* __restrict__ wp,
                                               const typename LP<BF>::V8* __restrict__ wp_next, int kb_next,
                                               const typename LP<BF>::T* e, const typename LP<BF>::T* x,
@@ -158,10 +160,10 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFrag3<BF>
 #define MFMA2_FIRST(PX, AS, B)                                          \
   acc[0][PX] = LP<BF>::mfma(AS.t0, B, c00);                             \
   if (NT > 1) acc[NT - 1][PX] = LP<BF>::mfma(AS.t1, B, c01);
-  // fetch k-block KBX+2 (of this layer, or block 0 / 1 of the next) into set DST
+  // fetch k-block KBX+NS-1 (of this layer, or one of the first of the next) into set DST
 #define FETCH_A(KBX, DST)                                               \
   {                                                                     \
-    const int blk_ = (KBX) + 2;                                         \
+    const int blk_ = (KBX) + NS - 1;                                    \
     if (blk_ < KB) {                                                    \
       DST.t0 = wp[blk_ * 64 + lane];                                    \
       if (NT > 1) DST.t1 = wp[(KB + blk_) * 64 + lane];                 \
@@ -172,7 +174,7 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFrag3<BF>
   }
 #define KBLOCK(KBX, R)                                                  \
   {                                                                     \
-    FETCH_A(KBX, A.s[((R) + 2) % 3])                                    \
+    FETCH_A(KBX, A.s[((R) + NS - 1) % NS])                              \
     const int kn = (KBX) + 1 < KB ? (KBX) + 1 : (KBX);                  \
     __builtin_amdgcn_sched_barrier(0);                                  \
     MFMA2(0, A.s[R], b0) LOAD_BL(kn, 0, b0)                             \
@@ -191,7 +193,7 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFrag3<BF>
   V8 b0, b1, b2, b3;
   LOAD_BL(0, 0, b0) LOAD_BL(0, 1, b1) LOAD_BL(0, 2, b2) LOAD_BL(0, 3, b3)
   {   // peeled k-block 0
-    FETCH_A(0, A.s[(ROT + 2) % 3])
+    FETCH_A(0, A.s[(ROT + NS - 1) % NS])
     const int kn = 1 < KB ? 1 : 0;
     __builtin_amdgcn_sched_barrier(0);
     // point tile 0 last: its accumulator can then take over the registers of the initial value
@@ -204,17 +206,31 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFrag3<BF>
     MFMA2_FIRST(0, A.s[ROT], b0) LOAD_BL(kn, 0, b0)
     __builtin_amdgcn_sched_barrier(0);
   }
-  // a real loop over TRIPLES of k-blocks (one body per register set); never fully unrolled: ten
+  // a real loop over groups of NS k-blocks (one body per register set); never fully unrolled: ten
   // layers of straight-line k-loops would not fit the instruction cache
+  static_assert(NS == 3 || NS == 4, "layer_gemm_lp: three or four A sets");
   int kb = 1;
+  if constexpr (NS == 3) {
 #pragma unroll 1
-  for (; kb + 2 < KB; kb += 3) {
-    KBLOCK(kb, (ROT + 1) % 3)
-    KBLOCK(kb + 1, (ROT + 2) % 3)
-    KBLOCK(kb + 2, ROT)
+    for (; kb + 2 < KB; kb += 3) {
+      KBLOCK(kb, (ROT + 1) % 3)
+      KBLOCK(kb + 1, (ROT + 2) % 3)
+      KBLOCK(kb + 2, ROT)
+    }
+    if ((KB - 1) % 3 >= 1) KBLOCK(kb, (ROT + 1) % 3)
+    if ((KB - 1) % 3 == 2) KBLOCK(kb + 1, (ROT + 2) % 3)
+  } else {
+#pragma unroll 1
+    for (; kb + 3 < KB; kb += 4) {
+      KBLOCK(kb, (ROT + 1) % 4)
+      KBLOCK(kb + 1, (ROT + 2) % 4)
+      KBLOCK(kb + 2, (ROT + 3) % 4)
+      KBLOCK(kb + 3, ROT)
+    }
+    if ((KB - 1) % 4 >= 1) KBLOCK(kb, (ROT + 1) % 4)
+    if ((KB - 1) % 4 >= 2) KBLOCK(kb + 1, (ROT + 2) % 4)
+    if ((KB - 1) % 4 == 3) KBLOCK(kb + 2, (ROT + 3) % 4)
   }
-  if ((KB - 1) % 3 >= 1) KBLOCK(kb, (ROT + 1) % 3)
-  if ((KB - 1) % 3 == 2) KBLOCK(kb + 1, (ROT + 2) % 3)
 #undef KBLOCK
 #undef FETCH_A
 #undef LOAD_BL

@@ -305,10 +305,8 @@ def _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs, c2w_stat
 
 def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1.,
            with_5_9=False, use_viewdirs=False, c2w_staticcam=None, rays_depth=None, streams=1, **kwargs):
-    """run_scade_scannet.py:80-155 (ray-row assembly is host plumbing; with_5_9 cropping is not
-    carried over)."""
-    if with_5_9:
-        raise NotImplementedError("render: with_5_9 cropping is a visualisation option outside the hot path")
+    """run_scade_scannet.py:80-155 (ray-row assembly is host plumbing).  ``with_5_9`` keeps the centre
+    columns of a full-image render (:108-115, one third of 16:9, used by render_video)."""
     if c2w is not None and use_viewdirs and c2w_staticcam is None and rays_depth is None:
         # full image: ray rows straight from the generation kernel (no [H,W,3] intermediates)
         rays_flat = ops.gen_rays(H, W, intrinsic, c2w, near=near, far=far)["rays"]
@@ -316,6 +314,12 @@ def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near
     else:
         rays_flat, sh = _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs,
                                        c2w_staticcam, rays_depth)
+    if with_5_9 and c2w is not None:
+        Wc = int(H / 9. * 16. / 3.)
+        Wc -= Wc % 2
+        start = (W - Wc) // 2
+        rays_flat = rays_flat.reshape(H, W, -1)[:, start:start + Wc].reshape(H * Wc, -1).contiguous()
+        sh = (H, Wc, 3)
     all_ret = batchify_rays(rays_flat, chunk, use_viewdirs, streams=streams, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))

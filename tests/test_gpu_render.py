@@ -195,6 +195,26 @@ def test_full_image_eval_loop(dev, tmp_path):
     assert abs(res["psnr"][0] - float(want_psnr)) < 0.05          # north_star: PSNR within 0.05 dB
 
 
+def test_render_with_5_9_is_the_centre_crop(dev):
+    """render(with_5_9=True) (run_scade_scannet.py:108-115): W' = even(int(H/9*16/3)) centre columns;
+    rays are independent, so the crop of the full render is the expected result bit for bit."""
+    Hh, Ww = 18, 24
+    pc, pf = O.nerf_init(0), O.nerf_init(1)
+    coarse, fine, query = build(dev, pc, pf, torch.zeros(3), torch.tensor(0.2))
+    intr = torch.tensor([20.0, 20.0, Ww / 2, Hh / 2], device=dev)
+    c2w = torch.eye(4, device=dev)[:3, :4].contiguous()
+    kw = dict(chunk=128, c2w=c2w, near=0.1, far=5.0, use_viewdirs=True, network_fn=coarse, network_query_fn=query,
+              N_samples=64, N_importance=128, network_fine=fine, perturb=0.)
+    with torch.no_grad():
+        full = S.render(Hh, Ww, intr, **kw)
+        crop = S.render_hyp(Hh, Ww, intr, with_5_9=True, **kw)
+    Wc = int(Hh / 9. * 16. / 3.)
+    Wc -= Wc % 2
+    st = (Ww - Wc) // 2
+    assert crop[0].shape == (Hh, Wc, 3) and crop[3]["pred_hyp"].shape == (Hh, Wc, 128)
+    assert torch.equal(crop[0], full[0][:, st:st + Wc]) and torch.equal(crop[3]["depth_map"], full[3]["depth_map"][:, st:st + Wc])
+
+
 import numpy as np  # noqa: E402
 
 
