@@ -162,7 +162,9 @@ int scade_sample_pdf_bwd(const float* bins, int bins_stride, int bins_are_mids,
                          void* stream);
 
 /* ---- coarse+fine merge (run_scade_scannet.py:713-714) --------------------------- */
-/* z_out[N,Sa+Sb] = sort(cat(z_a, z_b)); pts (nullable) = o + d*z_out from rays rows. */
+/* z_out[N,Sa+Sb] = torch.sort(cat(z_a, z_b)).values (neither input needs to be sorted; NaN last;
+ * -0 before +0); pts (nullable) = o + d*z_out from rays rows.  Sa + Sb <= 4096; an operand with
+ * S == 0 may be a null pointer. */
 int scade_merge_sorted(const float* z_a, int Sa, const float* z_b, int Sb, const float* rays,
                        int ray_stride, int N, float* z_out, float* pts, void* stream);
 
