@@ -168,6 +168,21 @@ int scade_sample_pdf_bwd(const float* bins, int bins_stride, int bins_are_mids,
 int scade_merge_sorted(const float* z_a, int Sa, const float* z_b, int Sb, const float* rays,
                        int ray_stride, int N, float* z_out, float* pts, void* stream);
 
+/* ---- everything between two MLP launches of a ray batch, in one launch ----------------
+ * (run_scade_scannet.py:660-714 for the coarse stage, :720-744 for the fine stage)
+ * raw2outputs(raw[N,S,4], z_vals[N,S], rays_d) -> rgb_map, disp_map, acc_map, weights, depth_map;
+ * samples[N,Si] = sample_pdf(z_mid, weights[:,1:-1], u)  (u as in scade_sample_pdf_fwd; nullable
+ * output), z_std[N] (nullable) = std of the samples; and, when z_out is given (coarse stage),
+ * z_out[N,S+Si] = sort(cat(z_vals, samples)), pts (nullable) = o + d*z_out.  rays: the [N,
+ * ray_stride] rows (o at 0..2, d at 3..5).  Bit-identical to scade_composite_fwd ->
+ * scade_sample_pdf_fwd(bins_are_mids=1) -> scade_merge_sorted on the same inputs: the weights and
+ * the samples stay in LDS instead of making two round trips through HBM.  3 <= S <= 512 (with
+ * z_out: S <= 256 and S+Si <= 512; larger rows: use the three separate entries). */
+int scade_ray_tail(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                   const float* noise, int N, int S, const float* u, int u_stride, int Si,
+                   float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
+                   float* samples, float* z_std, float* z_out, float* pts, void* stream);
+
 /* ---- space-carving loss (helpers:93-128) ---------------------------------------- */
 /* pred[N,P]; hyp[K,N] (the reference's [K,N,1], hypothesis-major); mask[N] nullable;
  * threshold <= 0 disables; is_joint selects helpers:115-119.  workspace holds

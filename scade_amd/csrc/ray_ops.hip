@@ -280,17 +280,17 @@ struct SamplePdfArgs {
 };
 
 // builds cdf[M] and bins[M] in LDS for one ray; returns sum(w+1e-5) as float
-__device__ __forceinline__ float build_cdf(const SamplePdfArgs& a, int ray, int lane, float* cdf,
-                                           float* bins, float* pdf /*optional LDS [M-1]*/) {
-  const int M = a.M;
-  const float* br = a.bins + (size_t)ray * a.bins_stride;
+// br: M bins (or M+1 z values when mids), wr: M-1 weights (or cdf_row: M cdf values); the rows may
+// live in global memory or in LDS
+__device__ __forceinline__ float build_cdf_rows(const float* br, int mids, const float* wr,
+                                                const float* cdf_row, int M, int lane, float* cdf,
+                                                float* bins, float* pdf /*optional LDS [M-1]*/) {
   for (int j = lane; j < M; j += 64)
-    bins[j] = a.bins_are_mids ? 0.5f * (br[j + 1] + br[j]) : br[j];
+    bins[j] = mids ? 0.5f * (br[j + 1] + br[j]) : br[j];
   float total = 0.f;
-  if (a.cdf_in) {
-    for (int j = lane; j < M; j += 64) cdf[j] = a.cdf_in[(size_t)ray * M + j];
+  if (cdf_row) {
+    for (int j = lane; j < M; j += 64) cdf[j] = cdf_row[j];
   } else {
-    const float* wr = a.w + (size_t)ray * a.w_stride;
     double part = 0.0;
     for (int j = lane; j < M - 1; j += 64) part += (double)(wr[j] + 1e-5f);   // helpers:339
     total = (float)wave_sum_d(part);                                          // helpers:340 (sum)
@@ -310,6 +310,13 @@ __device__ __forceinline__ float build_cdf(const SamplePdfArgs& a, int ray, int 
   return total;
 }
 
+__device__ __forceinline__ float build_cdf(const SamplePdfArgs& a, int ray, int lane, float* cdf,
+                                           float* bins, float* pdf /*optional LDS [M-1]*/) {
+  return build_cdf_rows(a.bins + (size_t)ray * a.bins_stride, a.bins_are_mids,
+                        a.w ? a.w + (size_t)ray * a.w_stride : nullptr,
+                        a.cdf_in ? a.cdf_in + (size_t)ray * a.M : nullptr, a.M, lane, cdf, bins, pdf);
+}
+
 // searchsorted(cdf, u, right=True): number of entries <= u
 __device__ __forceinline__ int upper_bound(const float* cdf, int M, float u) {
   int lo = 0, hi = M;
@@ -318,6 +325,17 @@ __device__ __forceinline__ int upper_bound(const float* cdf, int M, float u) {
     if (cdf[mid] <= u) lo = mid + 1; else hi = mid;
   }
   return lo;
+}
+
+__device__ __forceinline__ float inverse_cdf(const float* cdf, const float* bins, int M, float u, int& ind) {
+  ind = upper_bound(cdf, M, u);                                               // helpers:366
+  const int below = max(0, ind - 1), above = min(M - 1, ind);                 // :368-369
+  const float c0 = cdf[below], c1 = cdf[above];
+  float den = c1 - c0;                                                        // :378
+  den = den < 1e-5f ? 1.0f : den;                                             // :379
+  const float t = (u - c0) / den;                                             // :380
+  const float b0 = bins[below], b1 = bins[above];
+  return b0 + t * (b1 - b0);                                                  // :381
 }
 
 __global__ void sample_pdf_fwd_kernel(SamplePdfArgs a) {
@@ -334,15 +352,8 @@ __global__ void sample_pdf_fwd_kernel(SamplePdfArgs a) {
   const float* ur = a.u + (size_t)ray * a.u_stride;
   double s1 = 0.0;
   for (int s = lane; s < S; s += 64) {
-    const float u = ur[s];
-    const int ind = upper_bound(cdf, M, u);                                   // helpers:366
-    const int below = max(0, ind - 1), above = min(M - 1, ind);               // :368-369
-    const float c0 = cdf[below], c1 = cdf[above];
-    float den = c1 - c0;                                                      // :378
-    den = den < 1e-5f ? 1.0f : den;                                           // :379
-    const float t = (u - c0) / den;                                           // :380
-    const float b0 = bins[below], b1 = bins[above];
-    const float smp = b0 + t * (b1 - b0);                                     // :381
+    int ind;
+    const float smp = inverse_cdf(cdf, bins, M, ur[s], ind);
     a.samples[(size_t)ray * S + s] = smp;
     if (a.inds) a.inds[(size_t)ray * S + s] = ind;
     s1 += (double)smp;
@@ -450,18 +461,7 @@ constexpr unsigned Z_KEY_INF = 0xffffffffu;   // padding: after every data key, 
 // 64 r.  A compare-exchange at distance j < 64 is one __shfl_xor per register, at distance >= 64 it is
 // lane-local; 36 stages of four independent shuffles instead of 36 dependent LDS round trips.
 template <int R>
-__global__ void merge_sorted_reg_kernel(MergeArgs a) {
-  const int wv = threadIdx.x >> 6, lane = lane_id();
-  const int ray = blockIdx.x * RAYS_PER_WG + wv;
-  if (ray >= a.N) return;
-  const int St = a.Sa + a.Sb;
-  unsigned v[R];
-#pragma unroll
-  for (int r = 0; r < R; ++r) {
-    const int e = lane + 64 * r;
-    v[r] = e < a.Sa ? z_key(a.za[(size_t)ray * a.Sa + e])
-                    : (e < St ? z_key(a.zb[(size_t)ray * a.Sb + (e - a.Sa)]) : Z_KEY_INF);
-  }
+__device__ __forceinline__ void bitonic_sort_keys(unsigned (&v)[R], int lane) {
 #pragma unroll
   for (int k = 2; k <= 64 * R; k <<= 1) {
 #pragma unroll
@@ -489,9 +489,15 @@ __global__ void merge_sorted_reg_kernel(MergeArgs a) {
       }
     }
   }
+}
+
+// the first St sorted keys -> z_out row (+ o + d*z)
+template <int R>
+__device__ __forceinline__ void store_sorted(const unsigned (&v)[R], int lane, int ray, int St,
+                                             const float* rays, int ray_stride, float* z_out, float* pts) {
   float ox = 0, oy = 0, oz = 0, dx = 0, dy = 0, dz = 0;
-  if (a.pts) {
-    const float* rr = a.rays + (size_t)ray * a.ray_stride;
+  if (pts) {
+    const float* rr = rays + (size_t)ray * ray_stride;
     ox = rr[0]; oy = rr[1]; oz = rr[2]; dx = rr[3]; dy = rr[4]; dz = rr[5];
   }
 #pragma unroll
@@ -499,15 +505,32 @@ __global__ void merge_sorted_reg_kernel(MergeArgs a) {
     const int e = lane + 64 * r;
     if (e < St) {
       const float x = z_unkey(v[r]);
-      a.z_out[(size_t)ray * St + e] = x;
-      if (a.pts) {
-        float* p = a.pts + ((size_t)ray * St + e) * 3;
+      z_out[(size_t)ray * St + e] = x;
+      if (pts) {
+        float* p = pts + ((size_t)ray * St + e) * 3;
         p[0] = ox + dx * x;
         p[1] = oy + dy * x;
         p[2] = oz + dz * x;
       }
     }
   }
+}
+
+template <int R>
+__global__ void merge_sorted_reg_kernel(MergeArgs a) {
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int ray = blockIdx.x * RAYS_PER_WG + wv;
+  if (ray >= a.N) return;
+  const int St = a.Sa + a.Sb;
+  unsigned v[R];
+#pragma unroll
+  for (int r = 0; r < R; ++r) {
+    const int e = lane + 64 * r;
+    v[r] = e < a.Sa ? z_key(a.za[(size_t)ray * a.Sa + e])
+                    : (e < St ? z_key(a.zb[(size_t)ray * a.Sb + (e - a.Sa)]) : Z_KEY_INF);
+  }
+  bitonic_sort_keys<R>(v, lane);
+  store_sorted<R>(v, lane, ray, St, a.rays, a.ray_stride, a.z_out, a.pts);
 }
 
 // larger rows: the same network in LDS
@@ -553,6 +576,99 @@ __global__ void merge_sorted_kernel(MergeArgs a, int PB) {
     }
   }
 }
+
+// ---------------------------------------------------------------------------
+// ray_tail: what follows an MLP launch on a ray, in ONE launch (one wave per ray as everywhere):
+//   R > 0 (coarse stage, run_scade_scannet.py:660-714): raw2outputs -> sample_pdf(z_mid, w[1:-1], u)
+//          -> sort(cat(z, samples)) -> o + d*z : the weights and samples never leave the CU
+//   R = 0 (fine stage, :720-744): raw2outputs -> sample_pdf_return_u (+ std of the samples)
+// Same device functions, same order of operations as the three separate kernels: same bits.
+// ---------------------------------------------------------------------------
+struct TailArgs {
+  CompositeArgs c;       // forward fields; rays_d = rays + 3, d_stride = ray_stride
+  const float* rays;     // [N, ray_stride] o(0..2) d(3..5)
+  const float* u;        // element s of ray n at u[n*u_stride + s]
+  float* samples;        // [N,Si] or null
+  float* z_std;          // [N] or null
+  float* z_out;          // [N,S+Si]  (R > 0)
+  float* pts;            // [N,S+Si,3] or null
+  int ray_stride, u_stride, Si;
+};
+
+template <int NC, int R>
+__device__ __forceinline__ void ray_tail_body(const TailArgs& a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int ray = blockIdx.x * RAYS_PER_WG + wv;
+  if (ray >= a.c.N) return;
+  const int S = a.c.S, M = S - 1, Si = a.Si;
+  float* w = smem + (size_t)wv * (4 * S + Si);   // w[S] | cat[S + Si] = z, samples | cdf[M] | bins[M]
+  float* cat = w + S;
+  float* cdf = cat + S + Si;
+  float* bins = cdf + M;
+
+  SampleState st[NC];
+  double sr, sg, sb, sd, sa;
+  composite_ray<NC>(a.c, ray, lane, st, sr, sg, sb, sd, sa);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = c * 64 + lane;
+    if (i < S) {
+      a.c.weights[(size_t)ray * S + i] = st[c].w;
+      w[i] = st[c].w;
+      cat[i] = st[c].z;
+    }
+  }
+  if (lane == 0) {
+    const float depth = (float)sd, acc = (float)sa;
+    a.c.rgb_map[ray * 3 + 0] = (float)sr;
+    a.c.rgb_map[ray * 3 + 1] = (float)sg;
+    a.c.rgb_map[ray * 3 + 2] = (float)sb;
+    a.c.depth_map[ray] = depth;
+    a.c.acc_map[ray] = acc;
+    const float q = depth / acc;                                      // :559
+    a.c.disp_map[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  build_cdf_rows(cat, 1, w + 1, nullptr, M, lane, cdf, bins, nullptr);   // z_mid, weights[1:-1]
+  const float* ur = a.u + (size_t)ray * a.u_stride;
+  double s1 = 0.0;
+  for (int s = lane; s < Si; s += 64) {
+    int ind;
+    const float smp = inverse_cdf(cdf, bins, M, ur[s], ind);
+    if (a.samples) a.samples[(size_t)ray * Si + s] = smp;
+    cat[S + s] = smp;
+    s1 += (double)smp;
+  }
+  if (a.z_std) {                                   // torch.std(unbiased=False), :744
+    const double mean = wave_sum_d(s1) / (double)Si;
+    double s2 = 0.0;
+    for (int s = lane; s < Si; s += 64) {
+      const double dlt = (double)cat[S + s] - mean;                   // same lane wrote it
+      s2 += dlt * dlt;
+    }
+    s2 = wave_sum_d(s2);
+    if (lane == 0) a.z_std[ray] = (float)sqrt(s2 / (double)Si);
+  }
+  if constexpr (R > 0) {
+    __builtin_amdgcn_wave_barrier();
+    const int St = S + Si;
+    unsigned v[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const int e = lane + 64 * r;
+      v[r] = e < St ? z_key(cat[e]) : Z_KEY_INF;
+    }
+    bitonic_sort_keys<R>(v, lane);
+    store_sorted<R>(v, lane, ray, St, a.rays, a.ray_stride, a.z_out, a.pts);
+  }
+}
+
+template <int NC, int R>
+__global__ void ray_tail_kernel(TailArgs a) { ray_tail_body<NC, R>(a); }
+template <int NC>
+__global__ void ray_tail_kernel0(TailArgs a) { ray_tail_body<NC, 0>(a); }   // one template argument for DISPATCH_NC
 
 // ---------------------------------------------------------------------------
 // space-carving loss
@@ -850,6 +966,51 @@ extern "C" int scade_merge_sorted(const float* z_a, int Sa, const float* z_b, in
       hipLaunchKernelGGL(merge_sorted_kernel, grid, block, (size_t)RAYS_PER_WG * PB * sizeof(float), s, a, PB);
   }
   return scade_check_launch("scade_merge_sorted");
+}
+
+extern "C" int scade_ray_tail(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                              const float* noise, int N, int S, const float* u, int u_stride, int Si,
+                              float* rgb_map, float* disp_map, float* acc_map, float* weights,
+                              float* depth_map, float* samples, float* z_std, float* z_out, float* pts,
+                              void* stream) {
+  if (N <= 0) return 0;
+  SCADE_REQUIRE(raw && z_vals && rays && u && rgb_map && disp_map && acc_map && weights && depth_map, -1,
+                "scade_ray_tail: null pointer");
+  SCADE_REQUIRE(ray_stride >= 6, -2, "scade_ray_tail: ray rows need o and d");
+  SCADE_REQUIRE(S >= 3 && S <= 512 && Si >= 1 && Si <= 1024, -2,
+                "scade_ray_tail: S=%d outside [3,512] or Si=%d outside [1,1024]", S, Si);
+  SCADE_REQUIRE(z_out || samples, -1, "scade_ray_tail: neither z_out nor samples requested");
+  SCADE_REQUIRE(!pts || z_out, -1, "scade_ray_tail: pts needs z_out");
+  TailArgs a{};
+  a.c.raw = raw; a.c.z = z_vals; a.c.rays_d = rays + 3; a.c.noise = noise; a.c.rgb_map = rgb_map;
+  a.c.disp_map = disp_map; a.c.acc_map = acc_map; a.c.weights = weights; a.c.depth_map = depth_map;
+  a.c.N = N; a.c.S = S; a.c.d_stride = ray_stride;
+  a.rays = rays; a.u = u; a.samples = samples; a.z_std = z_std; a.z_out = z_out; a.pts = pts;
+  a.ray_stride = ray_stride; a.u_stride = u_stride; a.Si = Si;
+  const size_t lds = (size_t)RAYS_PER_WG * (4 * S + Si) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid(grid_rays(N)), block(256);
+  if (!z_out) {
+    DISPATCH_NC(ray_tail_kernel0, S, grid, block, lds, s, a);
+  } else {
+    SCADE_REQUIRE(S + Si <= 512 && S <= 256, -2, "scade_ray_tail: merged row S+Si=%d > 512 (or S > 256)", S + Si);
+    int PB = 64;
+    while (PB < S + Si) PB <<= 1;
+    const int nc = (S + 63) / 64;
+    bool launched = false;
+#define TAIL_CASE(NCX, RX)                                                                     \
+    if (nc == NCX && PB == 64 * RX) {                                                          \
+      hipLaunchKernelGGL((ray_tail_kernel<NCX, RX>), grid, block, lds, s, a);                  \
+      launched = true;                                                                         \
+    }
+    TAIL_CASE(1, 1) TAIL_CASE(1, 2) TAIL_CASE(1, 4) TAIL_CASE(1, 8)
+    TAIL_CASE(2, 2) TAIL_CASE(2, 4) TAIL_CASE(2, 8)
+    TAIL_CASE(3, 4) TAIL_CASE(3, 8)
+    TAIL_CASE(4, 4) TAIL_CASE(4, 8)
+#undef TAIL_CASE
+    SCADE_REQUIRE(launched, -2, "scade_ray_tail: no kernel for S=%d, Si=%d", S, Si);
+  }
+  return scade_check_launch("scade_ray_tail");
 }
 
 extern "C" long scade_carve_workspace_floats(int N, int P, int K, int is_joint) {

@@ -444,6 +444,59 @@ def merge_sorted(z_a: Tensor, z_b: Tensor, rays: Optional[Tensor] = None):
     return out, pts
 
 
+def ray_tail_supported(S: int, Si: int, merge: bool) -> bool:
+    """shapes scade_ray_tail has a kernel for (others go through the three separate entries)"""
+    return 3 <= S <= 512 and 1 <= Si <= 1024 and (not merge or (S <= 256 and S + Si <= 512))
+
+
+def ray_tail(raw: Tensor, z_vals: Tensor, rays: Tensor, noise: Optional[Tensor], u: Tensor, n_samples: int,
+             merge: bool, want_pts: bool = True, want_samples: bool = True, want_std: bool = False):
+    """scade_ray_tail: raw2outputs -> sample_pdf(z_mid, weights[1:-1], u) [-> sort-merge -> points].
+    Returns (rgb, disp, acc, weights, depth, samples|None, z_std|None, z_out|None, pts|None)."""
+    check(raw, "ray_tail: raw"); check(z_vals, "ray_tail: z_vals")
+    N, S = z_vals.shape
+    if tuple(raw.shape) != (N, S, 4):
+        raise ValueError(f"ray_tail: raw must be [{N},{S},4], got {tuple(raw.shape)}")
+    raw, z_vals = _c(raw), _c(z_vals)
+    rays, rstride = _rows(rays, "ray_tail: rays")
+    if noise is not None:
+        noise = _c(check(noise, "ray_tail: noise"))
+    u, ustride = _u_arg(u, N, n_samples)
+    dev = raw.device
+    rgb = torch.empty(N, 3, device=dev); disp = torch.empty(N, device=dev)
+    acc = torch.empty(N, device=dev); w = torch.empty(N, S, device=dev); depth = torch.empty(N, device=dev)
+    samples = torch.empty(N, n_samples, device=dev) if (want_samples or not merge) else None
+    std = torch.empty(N, device=dev) if want_std else None
+    z_out = torch.empty(N, S + n_samples, device=dev) if merge else None
+    pts = torch.empty(N, S + n_samples, 3, device=dev) if (merge and want_pts) else None
+    call("scade_ray_tail", ptr(raw), ptr(z_vals), ptr(rays), rstride, ptr(noise), N, S, ptr(u), ustride,
+         n_samples, ptr(rgb), ptr(disp), ptr(acc), ptr(w), ptr(depth), ptr(samples), ptr(std), ptr(z_out),
+         ptr(pts), stream())
+    return rgb, disp, acc, w, depth, samples, std, z_out, pts
+
+
+class CoarseTailFn(torch.autograd.Function):
+    """Coarse stage after the MLP (run_scade_scannet.py:660-714): raw2outputs, the detached importance
+    samples, the sorted merge and the fine points, one launch.  Differentiable w.r.t. raw through the
+    five compositing outputs exactly like CompositeFn; z_vals / pts carry no gradient (:711 detaches)."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays, noise, u, n_samples):
+        rgb, disp, acc, w, depth, _, _, z_out, pts = ray_tail(raw, z_vals, rays, noise, u, n_samples,
+                                                              merge=True, want_samples=False)
+        ctx.save_for_backward(raw, z_vals, rays, noise if noise is not None else raw.new_empty(0))
+        ctx.has_noise = noise is not None
+        ctx.mark_non_differentiable(z_out, pts)
+        return rgb, disp, acc, w, depth, z_out, pts
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, *unused):
+        raw, z_vals, rays, noise = ctx.saved_tensors
+        g_raw = composite_bwd(raw, z_vals, rays[:, 3:6], noise if ctx.has_noise else None,
+                              g_rgb, g_disp, g_acc, g_w, g_depth)
+        return g_raw, None, None, None, None, None
+
+
 def gen_rays(H: int, W: int, intrinsic: Tensor, c2w: Tensor, coords: Optional[Tensor] = None,
              near: float = 0.0, far: float = 1.0, image: Optional[Tensor] = None,
              hyps: Optional[Tensor] = None, corner_px: int = 0, edge_px: int = 0,

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .ops import CompositeFn
+from .ops import CoarseTailFn, CompositeFn
 from .run_nerf_helpers import (Embedder, NeRF, _draw_u, _sample, get_rays)
 
 
@@ -119,17 +119,20 @@ def raw2depth(raw, z_vals, rays_d):
     return depth, std
 
 
+def _raw_noise(raw, raw_noise_std, pytest):
+    """the density noise raw2outputs draws (:545-553), or None"""
+    if not raw_noise_std > 0.:
+        return None
+    shape = raw[..., 3].shape
+    if pytest:
+        np.random.seed(0)
+        return torch.Tensor(np.random.rand(*list(shape)) * raw_noise_std).to(raw.device)
+    return torch.randn(shape, device=raw.device) * raw_noise_std
+
+
 def raw2outputs(raw, z_vals, rays_d, raw_noise_std=0, pytest=False):
     """run_scade_scannet.py:530-562 -> rgb_map, disp_map, acc_map, weights, depth_map."""
-    noise = None
-    if raw_noise_std > 0.:
-        shape = raw[..., 3].shape
-        if pytest:
-            np.random.seed(0)
-            noise = torch.Tensor(np.random.rand(*list(shape)) * raw_noise_std).to(raw.device)
-        else:
-            noise = torch.randn(shape, device=raw.device) * raw_noise_std
-    return CompositeFn.apply(raw, z_vals, rays_d, noise)
+    return CompositeFn.apply(raw, z_vals, rays_d, _raw_noise(raw, raw_noise_std, pytest))
 
 
 def perturb_z_vals(z_vals, pytest):
@@ -152,7 +155,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
                 precomputed_z_samples=None, embedded_cam=None, retraw=False, lindisp=False,
                 perturb=0., N_importance=0, network_fine=None, raw_noise_std=0., verbose=False,
                 pytest=False, is_joint=False, cached_u=None, t_rand=None, u_coarse=None,
-                coarse_stream=None):
+                coarse_stream=None, fuse_tails=True):
     """run_scade_scannet.py:581-751 (live branch ``N_importance > 0``).
 
     Extra keyword-only knobs beyond the reference signature: ``t_rand`` [N,N_samples]
@@ -162,7 +165,9 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     ``torch.cuda.Stream``): run the coarse stage on that side stream.  The forward is unchanged
     (the fine stage waits for it), but autograd replays every backward node on its forward stream,
     so in a train step the whole coarse backward chain (composite -> dgrad -> wgrad) runs
-    CONCURRENTLY with the fine chain instead of behind it and fills the tails of its launches."""
+    CONCURRENTLY with the fine chain instead of behind it and fills the tails of its launches.
+    ``fuse_tails=False`` runs the per-ray work between the MLP launches as the separate
+    raw2outputs / sample_pdf / merge operators (same bits; kept for the parity tests)."""
     if N_importance <= 0:
         raise NotImplementedError(
             "render_rays: N_importance == 0 is dead code in the reference (raises UnboundLocalError "
@@ -191,13 +196,22 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
                 t_rand = torch.rand(N, N_samples, device=dev)
     else:
         t_rand = None
+    # coarse stage = points -> MLP -> [raw2outputs -> detached importance samples (:702-711) -> sorted
+    # merge + fine points (:713-714)]; the bracket is ONE launch (scade_ray_tail) when the row fits its
+    # register sort, three otherwise
+    fused = fuse_tails and ops.ray_tail_supported(N_samples, N_importance, merge=True)
+
     def coarse_stage():
         z, p = ops.ray_points(rays, N_samples, t_rand, lindisp)
         r = network_query_fn(p, viewdirs, embedded_cam, network_fn)
-        return (z, r) + tuple(raw2outputs(r, z, rays_d, raw_noise_std, pytest=pytest))
+        if not fused:
+            return (z, r) + tuple(raw2outputs(r, z, rays_d, raw_noise_std, pytest=pytest))
+        noise = _raw_noise(r, raw_noise_std, pytest)
+        uc = u_coarse if u_coarse is not None else _draw_u(z, N_importance, det, pytest, is_joint)
+        return (z, r) + tuple(CoarseTailFn.apply(r, z, rays, noise, uc, N_importance))
 
     if coarse_stream is None:
-        z_vals, raw, rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = coarse_stage()
+        outs = coarse_stage()
     else:
         main = torch.cuda.current_stream()
         coarse_stream.wait_stream(main)
@@ -206,23 +220,33 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
         main.wait_stream(coarse_stream)
         for t in outs:                      # allocated on the side stream, consumed on this one
             t.record_stream(main)
-        z_vals, raw, rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = outs
-    z_vals_0 = z_vals
+    z_vals_0, raw, rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = outs[:7]
 
-    # ---- importance samples from the coarse pdf, detached (:702-711) ---------
-    uc = u_coarse if u_coarse is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
-    with torch.no_grad():
-        z_samples = _sample(z_vals, weights_0[..., 1:-1], uc, bins_are_mids=True)
-    # ---- merge + fine points (:713-714) --------------------------------------
-    z_vals, pts = ops.merge_sorted(z_vals_0, z_samples, rays)
+    if fused:
+        z_vals, pts = outs[7:]
+    else:
+        # ---- importance samples from the coarse pdf, detached (:702-711) ---------
+        uc = u_coarse if u_coarse is not None else _draw_u(z_vals_0, N_importance, det, pytest, is_joint)
+        with torch.no_grad():
+            z_samples = _sample(z_vals_0, weights_0[..., 1:-1], uc, bins_are_mids=True)
+        # ---- merge + fine points (:713-714) --------------------------------------
+        z_vals, pts = ops.merge_sorted(z_vals_0, z_samples, rays)
     run_fn = network_fn if network_fine is None else network_fine
     raw = network_query_fn(pts, viewdirs, embedded_cam, run_fn)
-    rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(
-        raw, z_vals, rays_d, raw_noise_std, pytest=pytest)
 
-    # ---- depth hypotheses from the fine pdf (:723-730) ------------------------
-    u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
-    pred_depth_hyp, z_std = _sample(z_vals, weights[..., 1:-1], u, bins_are_mids=True, want_std=True)
+    # ---- fine stage: raw2outputs + depth hypotheses from the fine pdf (:720-730); one launch when no
+    # gradient is recorded (training differentiates pred_hyp w.r.t. the weights: separate operators)
+    if (fuse_tails and not (torch.is_grad_enabled() and raw.requires_grad)
+            and ops.ray_tail_supported(z_vals.shape[1], N_importance, merge=False)):
+        noise = _raw_noise(raw, raw_noise_std, pytest)
+        u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
+        rgb_map, disp_map, acc_map, weights, depth_map, pred_depth_hyp, z_std, _, _ = ops.ray_tail(
+            raw, z_vals, rays, noise, u, N_importance, merge=False, want_std=True)
+    else:
+        rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(
+            raw, z_vals, rays_d, raw_noise_std, pytest=pytest)
+        u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
+        pred_depth_hyp, z_std = _sample(z_vals, weights[..., 1:-1], u, bins_are_mids=True, want_std=True)
     if u.dim() == 1 or u.stride(0) == 0:
         u = u.expand(N, N_importance)
 

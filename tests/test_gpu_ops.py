@@ -385,3 +385,34 @@ def test_merge_sorted_sizes_nan_and_unsorted_inputs(dev):
         assert torch.equal(torch.isnan(got.cpu()), torch.isnan(want))
         wpts = rays[:, None, 0:3] + rays[:, None, 3:6] * want[..., None]
         assert torch.equal(torch.nan_to_num(pts.cpu()), torch.nan_to_num(wpts))
+
+
+def test_ray_tail_equals_the_three_operators(dev):
+    """scade_ray_tail (raw2outputs -> sample_pdf on z_mid / weights[1:-1] -> sorted merge -> points in
+    one launch) against the separate entries on the same inputs: every output bit for bit, over ragged
+    sizes, density noise, a shared u row, and a NaN density."""
+    g = torch.Generator().manual_seed(21)
+    for N, S, Si, merge in ((7, 64, 128, True), (5, 3, 1, True), (9, 40, 17, True), (6, 130, 100, True),
+                            (4, 256, 256, True), (3, 192, 128, False), (5, 300, 64, False), (2, 512, 1000, False)):
+        raw = torch.randn(N, S, 4, generator=g)
+        z = torch.sort(torch.rand(N, S, generator=g) * 4.9 + 0.1, -1).values
+        rays = O.synthetic_rays(N, seed=N + S, unit_dirs=False)
+        noise = torch.randn(N, S, generator=g) * 0.3 if S % 2 == 0 else None
+        u = torch.rand(Si, generator=g) if N == 9 else torch.rand(N, Si, generator=g)
+        if N == 6:
+            raw[1, 5, 3] = float("nan")
+        a = [t.to(dev) if t is not None else None for t in (raw, z, rays, noise, u)]
+        assert ops.ray_tail_supported(S, Si, merge)
+        got = ops.ray_tail(a[0], a[1], a[2], a[3], a[4], Si, merge=merge, want_std=True)
+        rgb, disp, acc, w, depth = ops.composite_fwd(a[0], a[1], a[2][:, 3:6], a[3])
+        smp, _, _, std = ops.sample_pdf_fwd(a[1], w[:, 1:-1], a[4], Si, bins_are_mids=True, want_std=True)
+        want = [rgb, disp, acc, w, depth, smp, std]
+        if merge:
+            want += list(ops.merge_sorted(a[1], smp, a[2]))
+        eq = lambda x, y: torch.equal(torch.nan_to_num(x, nan=-7.0), torch.nan_to_num(y, nan=-7.0))
+        for k, (x, y) in enumerate(zip(got, want)):
+            assert eq(x, y), (N, S, Si, merge, k)
+    assert not ops.ray_tail_supported(300, 300, True) and not ops.ray_tail_supported(2, 8, False)
+    with pytest.raises(RuntimeError):
+        ops.ray_tail(torch.zeros(2, 300, 4, device=dev), torch.zeros(2, 300, device=dev),
+                     torch.zeros(2, 11, device=dev), None, torch.zeros(2, 300, device=dev), 300, merge=True)

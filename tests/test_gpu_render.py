@@ -215,6 +215,42 @@ def test_render_with_5_9_is_the_centre_crop(dev):
     assert torch.equal(crop[0], full[0][:, st:st + Wc]) and torch.equal(crop[3]["depth_map"], full[3]["depth_map"][:, st:st + Wc])
 
 
+def test_fused_tails_are_bitwise_neutral(dev):
+    """render_rays with the per-ray work between the MLP launches fused (scade_ray_tail, the default)
+    and as separate operators: every dict entry equal bit for bit, in inference and in a recorded
+    training forward, and the parameter gradients of the 3-term loss equal too."""
+    N = 96
+    pc, pf = O.nerf_init(2), O.nerf_init(3)
+    coarse, fine, query = build(dev, pc, pf, torch.zeros(3), torch.tensor(0.2))
+    rays = O.synthetic_rays(N, seed=77).to(dev)
+    g = torch.Generator().manual_seed(5)
+    t_rand, uc, uf = (torch.rand(N, n, generator=g).to(dev) for n in (64, 128, 128))
+    tgt = torch.rand(N, 3, generator=g).to(dev)
+    hyp = (torch.rand(20, N, 1, generator=g) * 4.9 + 0.1).to(dev)
+    kw = dict(N_importance=128, network_fine=fine, retraw=True)
+    with torch.no_grad():
+        a = S.render_rays(rays, True, coarse, query, 64, perturb=0., **kw)
+        b = S.render_rays(rays, True, coarse, query, 64, perturb=0., fuse_tails=False, **kw)
+    assert set(a) == set(b)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    grads = []
+    for fuse in (True, False):
+        for p in list(coarse.parameters()) + list(fine.parameters()):
+            p.grad = None
+        r = S.render_rays(rays, True, coarse, query, 64, perturb=1., raw_noise_std=0.5, pytest=True,
+                          t_rand=t_rand, u_coarse=uc, cached_u=uf, fuse_tails=fuse, **kw)
+        loss = S.img2mse(r["rgb_map"], tgt) + 0.007 * S.compute_space_carving_loss(r["pred_hyp"], hyp) \
+            + S.img2mse(r["rgb0"], tgt)
+        loss.backward()
+        grads.append(([p.grad.clone() for p in list(coarse.parameters()) + list(fine.parameters())], r, loss))
+    for k in grads[0][1]:
+        assert torch.equal(grads[0][1][k], grads[1][1][k]), k
+    assert torch.equal(grads[0][2], grads[1][2])
+    for x, y in zip(grads[0][0], grads[1][0]):
+        assert torch.equal(x, y)
+
+
 import numpy as np  # noqa: E402
 
 
