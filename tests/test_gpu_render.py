@@ -213,6 +213,14 @@ def test_render_with_5_9_is_the_centre_crop(dev):
     st = (Ww - Wc) // 2
     assert crop[0].shape == (Hh, Wc, 3) and crop[3]["pred_hyp"].shape == (Hh, Wc, 128)
     assert torch.equal(crop[0], full[0][:, st:st + Wc]) and torch.equal(crop[3]["depth_map"], full[3]["depth_map"][:, st:st + Wc])
+    # the explicit-rays forms of render() (:117-121) assemble the same ray rows as the c2w form
+    ro, rd = S.get_rays(Hh, Ww, intr, c2w)
+    kw2 = {k: v for k, v in kw.items() if k != "c2w"}
+    with torch.no_grad():
+        a = S.render(Hh, Ww, intr, rays=torch.stack([ro, rd]), **kw2)
+        b = S.render(Hh, Ww, intr, rays=torch.stack([ro, rd, torch.zeros_like(rd)]), **kw2)
+    assert a[0].shape == (Hh, Ww, 3) and torch.equal(a[0], b[0])
+    assert rel_l2(a[0], full[0]) < 1e-4 and rel_l2(a[3]["depth_map"], full[3]["depth_map"]) < 1e-4
 
 
 def test_fused_tails_are_bitwise_neutral(dev):
