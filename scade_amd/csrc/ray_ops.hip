@@ -686,6 +686,11 @@ struct CarveArgs {
   int N, P, K;
 };
 
+// value of lane `src` (wave-uniform index) for every lane
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+  return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src));
+}
+
 __device__ __forceinline__ float carve_dist(float pred, float h, float m, bool has_mask, float thr) {
   float dd = fabsf(pred - h);                     // norm over a size-1 axis == |.| for any p
   if (has_mask) dd = dd * m;
@@ -701,12 +706,24 @@ __global__ void carve_fwd_kernel(CarveArgs a) {
   const bool hm = a.mask != nullptr;
   const float m = hm ? a.mask[ray] : 1.f;
   double acc = 0.0;
-  for (int s = lane; s < a.P; s += 64) {
-    const float p = a.pred[(size_t)ray * a.P + s];
-    float best = INFINITY;
-    for (int k = 0; k < a.K; ++k)
-      best = fminf(best, carve_dist(p, a.hyp[(size_t)k * a.N + ray], m, hm, a.threshold));
-    acc += (double)best;
+  if (a.K <= 64) {
+    // the ray's K hypotheses in ONE load (lane k holds hyp[k]); v_readlane hands them out
+    const float hreg = lane < a.K ? a.hyp[(size_t)lane * a.N + ray] : 0.f;
+    for (int s = lane; s < a.P; s += 64) {
+      const float p = a.pred[(size_t)ray * a.P + s];
+      float best = INFINITY;
+      for (int k = 0; k < a.K; ++k)
+        best = fminf(best, carve_dist(p, lane_bcast(hreg, k), m, hm, a.threshold));
+      acc += (double)best;
+    }
+  } else {
+    for (int s = lane; s < a.P; s += 64) {
+      const float p = a.pred[(size_t)ray * a.P + s];
+      float best = INFINITY;
+      for (int k = 0; k < a.K; ++k)
+        best = fminf(best, carve_dist(p, a.hyp[(size_t)k * a.N + ray], m, hm, a.threshold));
+      acc += (double)best;
+    }
   }
   acc = wave_sum_d(acc);
   if (lane == 0) a.partial[ray] = (float)(acc / (double)a.P);       // helpers:125 mean over samples
@@ -727,20 +744,22 @@ __global__ void carve_bwd_kernel(CarveArgs a) {
   const float m = hm ? a.mask[ray] : 1.f;
   const float scale = a.g_loss[0] / ((float)a.N * (float)a.P);
   // per-lane accumulators for d/d hyp[k] are reduced per k with wave sums
+  const bool pre = a.K <= 64;        // the ray's hypotheses fit one register: lane k holds hyp[k]
+  const float hreg = (pre && lane < a.K) ? a.hyp[(size_t)lane * a.N + ray] : 0.f;
   for (int k0 = 0; k0 < a.K; k0 += 64) {
     float ghk = 0.f;    // lane l holds gradient of hypothesis k0 + l
     for (int s0 = 0; s0 < a.P; s0 += 64) {
       const int s = s0 + lane;
       float gp = 0.f; int kbest = -1; float sgn = 0.f;
+      const float p = s < a.P ? a.pred[(size_t)ray * a.P + s] : 0.f;
+      float best = INFINITY, hbest = 0.f;
+      for (int k = 0; k < a.K; ++k) {      // all lanes walk the loop (readlane needs a uniform index)
+        const float h = pre ? lane_bcast(hreg, k) : a.hyp[(size_t)k * a.N + ray];
+        const float dd = carve_dist(p, h, m, hm, a.threshold);
+        if (dd < best) { best = dd; kbest = k; hbest = h; }         // first index wins ties (torch.min)
+      }
       if (s < a.P) {
-        const float p = a.pred[(size_t)ray * a.P + s];
-        float best = INFINITY;
-        for (int k = 0; k < a.K; ++k) {
-          const float h = a.hyp[(size_t)k * a.N + ray];
-          const float dd = carve_dist(p, h, m, hm, a.threshold);
-          if (dd < best) { best = dd; kbest = k; }                  // first index wins ties (torch.min)
-        }
-        const float h = a.hyp[(size_t)kbest * a.N + ray];
+        const float h = hbest;
         const float diff = p - h;
         float dd = fabsf(diff);
         if (hm) dd *= m;
@@ -749,11 +768,12 @@ __global__ void carve_bwd_kernel(CarveArgs a) {
         gp = sgn * m * scale;
         if (k0 == 0) a.g_pred[(size_t)ray * a.P + s] = gp;
       }
-      // scatter -gp into the winning hypothesis: lane j collects k == k0 + j
-      for (int j = 0; j < 64 && k0 + j < a.K; ++j) {
-        float contrib = (kbest == k0 + j) ? -gp : 0.f;
-        contrib = wave_sum(contrib);
-        if (lane == j) ghk += contrib;
+      // scatter -gp into the winning hypothesis: lane j (hypothesis k0 + j) walks the 64 samples of
+      // this chunk in order (two v_readlane per sample instead of a 6-step cross-lane sum per hypothesis)
+      for (int l = 0; l < 64; ++l) {
+        const int kb = __builtin_amdgcn_readlane(kbest, l);
+        const float g = lane_bcast(gp, l);
+        if (k0 + lane == kb) ghk -= g;
       }
     }
     if (k0 + lane < a.K) a.g_hyp[(size_t)(k0 + lane) * a.N + ray] = ghk;

@@ -482,6 +482,7 @@ class CoarseTailFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, z_vals, rays, noise, u, n_samples):
+        ctx.set_materialize_grads(False)
         rgb, disp, acc, w, depth, _, _, z_out, pts = ray_tail(raw, z_vals, rays, noise, u, n_samples,
                                                               merge=True, want_samples=False)
         ctx.save_for_backward(raw, z_vals, rays, noise if noise is not None else raw.new_empty(0))
@@ -492,6 +493,8 @@ class CoarseTailFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, *unused):
         raw, z_vals, rays, noise = ctx.saved_tensors
+        if all(g is None for g in (g_rgb, g_disp, g_acc, g_w, g_depth)):
+            return None, None, None, None, None, None
         g_raw = composite_bwd(raw, z_vals, rays[:, 3:6], noise if ctx.has_noise else None,
                               g_rgb, g_disp, g_acc, g_w, g_depth)
         return g_raw, None, None, None, None, None
@@ -540,6 +543,7 @@ class CompositeFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, z_vals, rays_d, noise):
+        ctx.set_materialize_grads(False)     # unused outputs arrive as None, not as zero-filled tensors
         outs = composite_fwd(raw, z_vals, rays_d, noise)
         ctx.save_for_backward(raw, z_vals, rays_d, noise if noise is not None else raw.new_empty(0))
         ctx.has_noise = noise is not None
@@ -548,6 +552,8 @@ class CompositeFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth):
         raw, z_vals, rays_d, noise = ctx.saved_tensors
+        if all(g is None for g in (g_rgb, g_disp, g_acc, g_w, g_depth)):
+            return None, None, None, None
         g_raw = composite_bwd(raw, z_vals, rays_d, noise if ctx.has_noise else None,
                               g_rgb, g_disp, g_acc, g_w, g_depth)
         return g_raw, None, None, None
@@ -558,6 +564,7 @@ class SamplePdfFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, bins, weights, u, bins_are_mids, want_std):
+        ctx.set_materialize_grads(False)
         samples, _, _, std = sample_pdf_fwd(bins, weights, u, u.shape[-1], bins_are_mids,
                                             want_std=want_std)
         ctx.save_for_backward(bins, weights, u)
@@ -570,6 +577,8 @@ class SamplePdfFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_samples, *unused):
         bins, weights, u = ctx.saved_tensors
+        if g_samples is None:
+            return None, None, None, None, None
         g_w = sample_pdf_bwd(bins, weights, u, g_samples, ctx.mids)
         return None, g_w, None, None, None
 
