@@ -96,7 +96,8 @@ int scade_mlp_fwd_lp(const void* packed_lp, int bf16, int mode, const float* in,
 /* Mixed-precision backward of scade_mlp_fwd_lp (same mathematics as scade_mlp_bwd): 16-bit dgrad chain
  * with a per-point power-of-two gradient scale, every layer's dZ stored as 16-bit rows under ONE
  * launch-wide power-of-two loss scale (from max|g_out|, removed exactly from the result), weight
- * gradient on 16-bit MFMAs with fp32 accumulation.  packed = the fp32 forward pack (head weights);
+ * gradient on 16-bit MFMAs with fp32 accumulation.  packed: not read, may be NULL (the fp32 head
+ * weights travel in the tail of packed_t_lp, so a 16-bit training step packs no fp32 blob);
  * packed_t_lp = scade_mlp_pack_t_lp(params, bf16); workspace = scade_mlp_bwd_lp_workspace_bytes(P)
  * bytes; grad_flat[589700] fp32 as in scade_mlp_bwd. */
 long scade_mlp_packed_t_lp_bytes(void);

@@ -29,6 +29,11 @@ constexpr long off_wtl(int t) {
   return o;
 }
 constexpr long PACKED_T_LP_ELEMS = off_wtl(NLAYER_DGRAD) + 2 * 64 * 8;
+// fp32 tail behind the 16-bit planes: the head weights the dgrad kernel multiplies on the VALU
+// (alpha_linear.weight [256] | rgb_linear.weight [3][128]) - so that a 16-bit training step needs no
+// fp32 forward blob at all
+constexpr int TL_WA = 0, TL_WR = 256, PACKED_T_LP_TAIL_FLOATS = 256 + 384;
+constexpr long PACKED_T_LP_BYTES = PACKED_T_LP_ELEMS * 2 + PACKED_T_LP_TAIL_FLOATS * 4;
 
 struct PackTLpArgs {
   const float* p[N_PARAM_TENSORS];
@@ -57,9 +62,13 @@ __global__ void mlp_pack_t_lp_kernel(PackTLpArgs a) {
     const int k = kt * 32 + (lane & 31);
     out[off + i] = (T)Wsrc[(size_t)n * ld + hcol0 + k];
   }
-  if (t == 0)
+  if (t == 0) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 64 * 8; i += gridDim.x * blockDim.x)
       out[off_wtl(NLAYER_DGRAD) + i] = (T)0.f;
+    float* tl = reinterpret_cast<float*>(out + PACKED_T_LP_ELEMS);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PACKED_T_LP_TAIL_FLOATS; i += gridDim.x * blockDim.x)
+      tl[i] = i < TL_WR ? a.p[20][i] : a.p[22][i - TL_WR];
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -89,7 +98,7 @@ __device__ __forceinline__ float lp_loss_scale(float m) {
 // B1: dgrad chain
 // ---------------------------------------------------------------------------
 struct MlpDgradLpArgs {
-  const float* packed;          // fp32 forward pack (rgb / alpha head weights)
+  const float* packed;          // unused (the head weights ride in the tail of packedT)
   const void* packedT;          // transposed 16-bit pack
   const unsigned char* acts;    // lp_acts_bytes(P)
   const float* g_out;           // [P,4]
@@ -152,8 +161,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p0 = blockIdx.x * LM;
   const int P = a.P;
-  const float* __restrict__ pk = a.packed;
   const T* __restrict__ pt_ = reinterpret_cast<const T*>(a.packedT);
+  const float* __restrict__ tl = reinterpret_cast<const float*>(pt_ + PACKED_T_LP_ELEMS);
   const T* __restrict__ actsT = reinterpret_cast<const T*>(a.acts);
   T* __restrict__ dzT = reinterpret_cast<T*>(a.dz);
   const float* __restrict__ alpha_pre = reinterpret_cast<const float*>(a.acts + lp_acts_alpha_byte(P));
@@ -186,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
       dal[row] = da * s;
       fac[row] = S / s;
     }
-    const float* wr = pk + OFF_WR;
+    const float* wr = tl + TL_WR;
     const T* hv = actsT + acts_slot_off(P, SLOT_VIEWS_H);
     T* dzv = dzT + acts_slot_off(P, SLOT_VIEWS_H);
 #pragma unroll
@@ -242,7 +251,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   load_mask(7);
   layer_gemm_lp<BF, 2, 0, 16, false, DROT(1)>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
-  dgrad_store_lp<BF, true, true>(acc, kt0, g, mb, pk + OFF_WA, dal, lane);
+  dgrad_store_lp<BF, true, true>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
   __syncthreads();
   save_tile_lp<BF, 256>(g, dzT + acts_slot_off(P, 7), p0, P, fac, tid);
 
@@ -603,7 +612,7 @@ static int build_wgrad_lp_jobs(WgradLpArgs& w, int P) {
 
 using namespace scade;
 
-extern "C" long scade_mlp_packed_t_lp_bytes(void) { return PACKED_T_LP_ELEMS * 2; }
+extern "C" long scade_mlp_packed_t_lp_bytes(void) { return PACKED_T_LP_BYTES; }
 
 extern "C" long scade_mlp_bwd_lp_workspace_bytes(int P) {
   return lp_dz_bytes(P) + (long)pick_chunks(P) * N_PARAM_FLOATS * 4 + 256;
@@ -660,7 +669,8 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
 extern "C" int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, const void* acts,
                                 const float* g_out, int P, void* workspace, float* grad_flat, void* stream) {
   SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd_lp: P must be positive");
-  SCADE_REQUIRE(packed && packed_t_lp && acts && g_out && workspace && grad_flat, -1,
+  (void)packed;   // not read: the head weights are the fp32 tail of packed_t_lp
+  SCADE_REQUIRE(packed_t_lp && acts && g_out && workspace && grad_flat, -1,
                 "scade_mlp_bwd_lp: null pointer");
   const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts);
   unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);

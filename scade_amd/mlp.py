@@ -21,7 +21,6 @@ class MlpEmbeddedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, train, x, *params):
-        packed = net.packed()
         acts = None
         lp = train and net.train_precision in ("f16", "bf16")
         if train:
@@ -33,7 +32,7 @@ class MlpEmbeddedFn(torch.autograd.Function):
         elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), x, None, None, acts)
         else:
-            out = ops.mlp_fwd_embedded(packed, x, acts)
+            out = ops.mlp_fwd_embedded(net.packed(), x, acts)
         ctx.net, ctx.mode = net, 0
         ctx.save_for_backward(x, acts if acts is not None else x.new_empty(0))
         return out
@@ -51,7 +50,6 @@ class MlpPointsFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, net, train, pts, viewdirs, bb, *params):
-        packed = net.packed()
         acts = None
         lp = train and net.train_precision in ("f16", "bf16")
         if train:
@@ -64,7 +62,7 @@ class MlpPointsFn(torch.autograd.Function):
         elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts)
         else:
-            out = ops.mlp_fwd_points(packed, pts, viewdirs, bb, acts)
+            out = ops.mlp_fwd_points(net.packed(), pts, viewdirs, bb, acts)
         ctx.net, ctx.mode = net, 1
         ctx.save_for_backward(pts, viewdirs, bb, acts if acts is not None else pts.new_empty(0))
         return out

@@ -15,7 +15,7 @@ def mlp_backward(net, acts, g_out):
                                wgrad_f16=net.train_precision == "f16x3")
     elif net.train_precision in ("f16", "bf16"):
         bf16 = net.train_precision == "bf16"
-        flat = ops.mlp_bwd_lp(net.packed(), net.packed_t_lp(bf16), bf16, acts, g_out)
+        flat = ops.mlp_bwd_lp(None, net.packed_t_lp(bf16), bf16, acts, g_out)
     elif net.train_precision == "f32":
         flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
     else:

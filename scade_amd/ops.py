@@ -222,7 +222,7 @@ def mlp_pack_t_lp(params: Sequence[Tensor], bf16: bool) -> Tensor:
     return out
 
 
-def mlp_bwd_lp(packed: Tensor, packed_t_lp: Tensor, bf16: bool, acts: Tensor, g_out: Tensor) -> Tensor:
+def mlp_bwd_lp(packed: Optional[Tensor], packed_t_lp: Tensor, bf16: bool, acts: Tensor, g_out: Tensor) -> Tensor:
     """16-bit dgrad + wgrad (fp32 accumulate, power-of-two loss scaling) -> flat gradient [589700]."""
     g = _c(check(g_out, "mlp_bwd_lp: g_out")).reshape(-1, 4)
     P = g.shape[0]
