@@ -32,19 +32,23 @@ _BB_CACHE = {}
 
 
 def _bb_tensor(bb_center, bb_scale, device):
-    """{cx,cy,cz,scale} as one device tensor (cached per (center, scale) object/version)."""
+    """{cx,cy,cz,scale} as one device tensor, cached per (center, scale) tensor OBJECT and version.
+    The entry keeps both objects alive: an address (or id) can then never come back as a different
+    tensor while its entry exists - a cache keyed on data_ptr alone returned a stale box once an
+    earlier tensor's memory had been re-used."""
     if not torch.is_tensor(bb_center):
         bb_center = torch.as_tensor(bb_center, dtype=torch.float32)
     if not torch.is_tensor(bb_scale):
         bb_scale = torch.as_tensor(bb_scale, dtype=torch.float32)
-    key = (bb_center.data_ptr(), bb_center._version, bb_scale.data_ptr(), bb_scale._version, str(device))
+    key = (id(bb_center), bb_center._version, id(bb_scale), bb_scale._version, str(device))
     hit = _BB_CACHE.get(key)
-    if hit is None:
+    if hit is None or hit[0] is not bb_center or hit[1] is not bb_scale:
         if len(_BB_CACHE) > 64:
             _BB_CACHE.clear()
-        hit = torch.cat([bb_center.reshape(-1)[:3].float(), bb_scale.reshape(-1)[:1].float()]).to(device)
+        bb = torch.cat([bb_center.reshape(-1)[:3].float(), bb_scale.reshape(-1)[:1].float()]).to(device)
+        hit = (bb_center, bb_scale, bb)
         _BB_CACHE[key] = hit
-    return hit
+    return hit[2]
 
 
 def _is_fusable(fn, embed_fn, embeddirs_fn, embedded_cam):

@@ -74,6 +74,14 @@ class Trainer:
             # sample_pdf_joint draws ONE u[S] for the whole batch (helpers:452-453): rank 0's draw
             render_kw.setdefault("u_coarse", shared_uniform((c["Ni"],), rays.device))
             render_kw.setdefault("cached_u", shared_uniform((c["Ni"],), rays.device))
+        elif not c["joint"] and not any(k in render_kw for k in ("t_rand", "u_coarse", "cached_u", "pytest")):
+            # the step's three uniform draws (stratified jitter :564-579, the two sample_pdf draws
+            # helpers:346-361) as ONE generator launch; independent streams either way
+            n, ns, ni = rays.shape[0], c["Ns"], c["Ni"]
+            d = torch.rand(n * (ns + 2 * ni), device=rays.device)
+            render_kw["t_rand"] = d[:n * ns].view(n, ns)
+            render_kw["u_coarse"] = d[n * ns:n * (ns + ni)].view(n, ni)
+            render_kw["cached_u"] = d[n * (ns + ni):].view(n, ni)
         ret = R.render_rays(rays, True, self.coarse, self.query, c["Ns"], N_importance=c["Ni"],
                             network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
                             lindisp=c["lindisp"], is_joint=c["joint"], coarse_stream=self.coarse_stream,

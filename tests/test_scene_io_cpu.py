@@ -85,3 +85,24 @@ def test_depth_std_map_matches_reference_formula():
     want = ((z - depth.unsqueeze(-1)).pow(2) * w).sum(-1).clamp(0., 1.).sqrt()     # :257-258
     assert torch.equal(depth_std_map(z, w, depth), want)
     assert depth_std_map(z, w, depth).shape == (5, 7)
+
+
+def test_bounding_box_cache_never_returns_a_recycled_address():
+    """make_network_query_fn caches {center, scale} as one device tensor per (center, scale) OBJECT.
+    Regression: the cache was once keyed on data_ptr + version, and a new tensor that landed on a freed
+    tensor's address rendered with the old scene's box.  The address re-use is forced here with tensors
+    that alias one numpy buffer (same data_ptr, version 0 every time)."""
+    import numpy as np
+    import torch
+    from scade_amd.rendering import _bb_tensor
+    arr_c, arr_s = np.zeros(3, dtype=np.float32), np.zeros(1, dtype=np.float32)
+    for i in range(5):
+        arr_c[:] = float(i)
+        arr_s[:] = 0.1 * (i + 1)
+        c, s = torch.from_numpy(arr_c), torch.from_numpy(arr_s)
+        bb = _bb_tensor(c, s, "cpu")
+        assert torch.equal(bb, torch.tensor([i, i, i, 0.1 * (i + 1)], dtype=torch.float32)), i
+        assert _bb_tensor(c, s, "cpu") is bb                      # same objects: cached
+        c.add_(1.0)                                               # in-place edit: new version, new box
+        assert torch.equal(_bb_tensor(c, s, "cpu")[:3], c)
+        del c, s, bb
