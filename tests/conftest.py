@@ -15,6 +15,15 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu)")
 
 
+def pytest_collection_modifyitems(config, items):
+    """SCADE_TEST_SHUFFLE=<seed>: run the collected tests in a seeded random order (state leaking
+    between tests - caches, allocator re-use, streams - shows up as an order-dependent failure)."""
+    seed = os.environ.get("SCADE_TEST_SHUFFLE")
+    if seed:
+        import random
+        random.Random(int(seed)).shuffle(items)
+
+
 def load_golden(name):
     """npz fixture -> dict of torch tensors (see tools/make_golden.py)."""
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
