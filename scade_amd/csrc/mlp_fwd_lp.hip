@@ -53,7 +53,6 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], int
         v[0] = pack2<BF, RELU>(acc[t][p][4 * q + 0], acc[t][p][4 * q + 1]);
         v[1] = pack2<BF, RELU>(acc[t][p][4 * q + 2], acc[t][p][4 * q + 3]);
         if (RELU && BITS) {   // sign words (mlp_tile_lp.h): dword d = ((t*4+q)*4+p)*2 + j
-          constexpr int dummy = 0; (void)dummy;
           const int d0 = ((t * 4 + q) * 4 + p) * 2;
           bits[d0 >> 4] |= sign_pair(v[0]) << (d0 & 15);
           bits[d0 >> 4] |= sign_pair(v[1]) << ((d0 & 15) + 1);

@@ -11,7 +11,7 @@ from scade_amd.train import Trainer, make_scade_nets
 from scade_amd.graphs import GraphedTrainer
 from scade_amd.synthetic import synthetic_rays
 dev = torch.device("cuda:0")
-N, K, steps = 512, 20, 3000
+N, K, steps = 512, 20, int(os.environ.get("SOAK_STEPS", "3000"))
 tc, tf = make_scade_nets(dev, seed=100)
 e, _ = S.get_embedder(9, 0); ed, _ = S.get_embedder(0, 0)
 query = S.make_network_query_fn(e, ed, torch.zeros(3, device=dev), torch.tensor(0.2, device=dev))
@@ -19,7 +19,7 @@ pool = synthetic_rays(8192, seed=21).to(dev)
 with torch.no_grad():
     t = S.render_rays(pool, True, tc, query, 64, N_importance=128, network_fine=tf, perturb=0.)
 tgt_all = t["rgb_map"].clone(); depth_all = t["depth_map"].clone()
-for prec in ("f32", "f16x3", "bf16", "f16"):
+for prec in os.environ.get("SOAK_PRECISIONS", "f32,f16x3,bf16,f16").split(","):
     coarse, fine = make_scade_nets(dev, seed=7)
     tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=prec)
     gt = GraphedTrainer(tr, N, K)
@@ -29,7 +29,7 @@ for prec in ("f32", "f16x3", "bf16", "f16"):
         idx = torch.randint(0, 8192, (N,), device=dev, generator=g)
         hyp = (depth_all[idx][None, :, None] + 0.3 * torch.randn(K, N, 1, device=dev, generator=g)).clamp(0.1, 5.0)
         loss = gt.step(pool[idx], tgt_all[idx], hyp)
-        if it % 250 == 249:
+        if it % max(250, steps // 12) == max(250, steps // 12) - 1:
             l = float(loss); hist.append(l)
             if not (l == l) or l > 1e3: bad += 1
     torch.cuda.synchronize()
