@@ -49,7 +49,10 @@ int scade_mlp_pack(const float* const* params, float* packed, void* stream);
  *          per-ray view broadcast  == run_network(...), run_scade_scannet.py:48-63 with
  *          get_embedder(9,0)/get_embedder(0,0), helpers:142-189.
  *  acts (nullable): training workspace of scade_mlp_acts_floats(P) floats receiving every
- *          hidden layer's activations, the embedding and alpha (consumed by scade_mlp_bwd). */
+ *          hidden layer's activations, the embedding, alpha and the ReLU sign words (consumed by
+ *          scade_mlp_bwd; the same layout is written by scade_mlp_fwd_f16).
+ *  Launches with P < 64 * 2 * CUs use 32-point workgroups (twice as many) instead of 64-point ones;
+ *  results per point and the workspace layout do not depend on that choice. */
 int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,
                   int vd_stride, const float* bb, int P, int S, float* out, float* acts,
                   void* stream);

@@ -65,8 +65,8 @@ struct MlpDgradArgs {
 
 // write the wave's [2 k-tiles x 64 points] gradient block in place to LDS: optional
 // alpha-head term, optional ReLU mask from the lane-private sign bits the forward saved
-template <bool MASK, bool ADD_ALPHA>
-__device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][2], int ktile0, float* hbuf,
+template <bool MASK, bool ADD_ALPHA, int PT = 2>
+__device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][PT], int ktile0, float* hbuf,
                                             unsigned long long bits, const float* __restrict__ w_a,
                                             const float* dalpha_lds, int lane) {
   const int r = lane & 31, hh = lane >> 5;
@@ -78,7 +78,7 @@ __device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][2], int ktile
       f32x4 wa = {0.f, 0.f, 0.f, 0.f};
       if (ADD_ALPHA) wa = *reinterpret_cast<const f32x4*>(w_a + f);
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < PT; ++p) {
         const int row = p * 32 + r;
         f32x4 v;
 #pragma unroll
@@ -91,17 +91,19 @@ __device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][2], int ktile
         if (MASK) {
 #pragma unroll
           for (int i = 0; i < 4; ++i)
-            v[i] = ((bits >> (((t * 4 + q) * 2 + p) * 4 + i)) & 1ull) ? v[i] : 0.f;
+            v[i] = ((bits >> (p * 32 + (t * 4 + q) * 4 + i)) & 1ull) ? v[i] : 0.f;
         }
         *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
       }
     }
 }
 
+template <int PT>
 __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
+  constexpr int TM = tile_pts(PT);     // points of this workgroup (shadows the 64-point default)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;
-  float* dal = lds + H_FLOATS;   // d alpha_pre of the tile's 64 points
+  float* dal = lds + h_floats(PT);   // d alpha_pre of the tile's points
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -111,15 +113,14 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
   const float* __restrict__ pt_ = a.packedT;
   const float* __restrict__ acts = a.acts;
   float* __restrict__ dz = a.dz;
-  const unsigned long long* __restrict__ masks =
-      reinterpret_cast<const unsigned long long*>(acts + acts_mask_off(P));
-  auto mask_of = [&](int layer) { return masks[((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid]; };
+  auto mask_of = [&](int layer) { return load_relu_words<PT>(acts, P, layer, tid); };
 
   // ---- heads: d alpha_pre, dZ of the views layer (rgb head + ReLU mask) ----------
   {
+    // (PT == 1: the upper half of the workgroup has no rows)
     const int row = tid >> 2, sub = tid & 3;
     const int pt = p0 + row;
-    const bool ok = pt < P;
+    const bool ok = pt < P && (PT == 2 || row < TM);
     f32x4 g = {0.f, 0.f, 0.f, 0.f};
     if (ok) g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
     if (sub == 0) {
@@ -130,7 +131,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
         da = bx > 20.f ? g[3] : g[3] / (1.f + expf(-bx));
         dz[dz_dalpha_off(P) + pt] = da;
       }
-      dal[row] = da;
+      if (PT == 2 || row < TM) dal[row] = da;
     }
     const float* wr = pk + OFF_WR;
     const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
@@ -149,13 +150,13 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
         const float d = g[0] * w0[j] + g[1] * w1[j] + g[2] * w2[j];
         v[j] = m[j] > 0.f ? d : 0.f;
       }
-      *reinterpret_cast<f32x4*>(hbuf + h_idx(row, chunk)) = v;
+      if (PT == 2 || row < TM) *reinterpret_cast<f32x4*>(hbuf + h_idx(row, chunk)) = v;
       if (ok) *reinterpret_cast<f32x4*>(dzv + (size_t)pt * W + chunk * 4) = v;
     }
   }
   __syncthreads();
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][PT];
   f32x4 an[2];
   const int kt0 = wave * 2;
   // transposed-pack base of this wave for dgrad index T (NB = reduction blocks per k-tile)
@@ -164,29 +165,29 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
   an[1] = WTBASE(8, 16)[16 * 64 + lane];
 
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128) --------
-  layer_gemm<2, 0, 16, EMB_STRIDE>(acc, an, WTBASE(8, 16), WTBASE(7, 32), 32, hbuf, hbuf, lane);
+  layer_gemm<2, 0, 16, EMB_STRIDE, PT>(acc, an, WTBASE(8, 16), WTBASE(7, 32), 32, hbuf, hbuf, lane);
   __syncthreads();
-  dgrad_store<false, false>(acc, kt0, hbuf, 0ull, nullptr, dal, lane);
+  dgrad_store<false, false, PT>(acc, kt0, hbuf, 0ull, nullptr, dal, lane);
   __syncthreads();
-  save_tile(hbuf, dz + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid);
+  save_tile(hbuf, dz + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid, TM);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 -----
   unsigned long long mbits = mask_of(7);
-  layer_gemm<2, 0, 32, EMB_STRIDE>(acc, an, WTBASE(7, 32), WTBASE(6, 32), 32, hbuf, hbuf, lane);
+  layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WTBASE(7, 32), WTBASE(6, 32), 32, hbuf, hbuf, lane);
   __syncthreads();
-  dgrad_store<true, true>(acc, kt0, hbuf, mbits, pk + OFF_WA, dal, lane);
+  dgrad_store<true, true, PT>(acc, kt0, hbuf, mbits, pk + OFF_WA, dal, lane);
   __syncthreads();
-  save_tile(hbuf, dz + acts_slot_off(P, 7), p0, P, W, tid);
+  save_tile(hbuf, dz + acts_slot_off(P, 7), p0, P, W, tid, TM);
 
   // ---- pts layers 7..1: dZ_{l-1} = (W_l^T dZ_l) masked by h_{l-1} > 0 -------------
 #define DGRAD_LAYER(L)                                                                         \
   mbits = mask_of((L)-1);                                                                      \
-  layer_gemm<2, 0, 32, EMB_STRIDE>(acc, an, WTBASE((L)-1, 32), WTBASE((L) > 1 ? (L)-2 : 0, 32), \
+  layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WTBASE((L)-1, 32), WTBASE((L) > 1 ? (L)-2 : 0, 32), \
                                    32, hbuf, hbuf, lane);                                      \
   __syncthreads();                                                                             \
-  dgrad_store<true, false>(acc, kt0, hbuf, mbits, nullptr, dal, lane);                         \
+  dgrad_store<true, false, PT>(acc, kt0, hbuf, mbits, nullptr, dal, lane);                         \
   __syncthreads();                                                                             \
-  save_tile(hbuf, dz + acts_slot_off(P, (L)-1), p0, P, W, tid);
+  save_tile(hbuf, dz + acts_slot_off(P, (L)-1), p0, P, W, tid, TM);
 
   DGRAD_LAYER(7)
   DGRAD_LAYER(6)
@@ -431,6 +432,20 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
   return scade_check_launch("scade_mlp_bwd(reduce)");
 }
 
+template <int PT>
+static int launch_dgrad(const MlpDgradArgs& d, hipStream_t s) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<PT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, mlp_lds_bytes(PT));
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(mlp_dgrad_kernel<PT>, dim3((d.P + tile_pts(PT) - 1) / tile_pts(PT)), dim3(256),
+                     mlp_lds_bytes(PT), s, d);
+  return scade_check_launch("scade_mlp_bwd(dgrad)");
+}
+
 extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const float* acts,
                              const float* g_out, int P, float* workspace, float* grad_flat,
                              void* stream) {
@@ -438,19 +453,12 @@ extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const f
   SCADE_REQUIRE(packed && packed_t && acts && g_out && workspace && grad_flat, -1,
                 "scade_mlp_bwd: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
-    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
-  }
   float* dz = workspace;
   float* partial = workspace + dz_floats(P);
 
   MlpDgradArgs d{packed, packed_t, acts, g_out, dz, P};
-  hipLaunchKernelGGL(mlp_dgrad_kernel, dim3((P + TM - 1) / TM), dim3(256), MLP_LDS_BYTES, s, d);
-  if (int e = scade_check_launch("scade_mlp_bwd(dgrad)")) return e;
+  // same point tiling as the forward that wrote the ReLU words of this workspace
+  if (int e = pick_point_tiles(P) == 1 ? launch_dgrad<1>(d, s) : launch_dgrad<2>(d, s)) return e;
 
   return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
 }

@@ -89,7 +89,7 @@ __device__ __forceinline__ void dgrad_store_h(const f32x16 (&acc0)[2][2], const 
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
           if (ADD_ALPHA) x = x + wa[i] * dal_scaled[row];
-          if (MASK) x = ((bits >> (((t * 4 + q) * 2 + p) * 4 + i)) & 1ull) ? x : 0.f;
+          if (MASK) x = ((bits >> (p * 32 + (t * 4 + q) * 4 + i)) & 1ull) ? x : 0.f;
           _Float16 h, l;
           split2(x, h, l);
           vh[i] = h; vl[i] = l;
@@ -116,9 +116,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   const _Float16* __restrict__ pt_ = a.packedT;
   const float* __restrict__ acts = a.acts;
   float* __restrict__ dz = a.dz;
-  const unsigned long long* __restrict__ masks =
-      reinterpret_cast<const unsigned long long*>(acts + acts_mask_off(P));
-  auto mask_of = [&](int layer) { return masks[((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid]; };
+  auto mask_of = [&](int layer) { return load_relu_words<2>(acts, P, layer, tid); };
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
   {

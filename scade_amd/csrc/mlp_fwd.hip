@@ -48,10 +48,10 @@ __device__ __forceinline__ void load_bias(f32x4 (&bv)[NT][4], const float* __res
       bv[t][q] = *reinterpret_cast<const f32x4*>(bias + (ntile0 + t) * 32 + 8 * q + 4 * hh);
 }
 
-// returns this lane's ReLU sign bits: bit ((t*4+q)*2+p)*4+i <-> value (t,q,p,i) > 0, the
+// returns this lane's ReLU sign bits: bit p*32+(t*4+q)*4+i <-> value (t,q,p,i) > 0, the
 // same (t,q,p,i) -> (feature, point) map the dgrad kernel uses for its output fragment
-template <int NT, bool RELU>
-__device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT][2],
+template <int NT, bool RELU, int PT = 2>
+__device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT][PT],
                                                           const f32x4 (&bias)[NT][4], int ntile0,
                                                           float* hbuf, int lane) {
   const int r = lane & 31, hh = lane >> 5;
@@ -63,13 +63,13 @@ __device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT
       const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
       const f32x4 bv = bias[t][q];
 #pragma unroll
-      for (int p = 0; p < 2; ++p) {
+      for (int p = 0; p < PT; ++p) {
         f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float x = acc[t][p][4 * q + i] + bv[i];
           v[i] = RELU ? fmaxf(x, 0.f) : x;
-          if (RELU && x > 0.f) bits |= 1ull << (((t * 4 + q) * 2 + p) * 4 + i);
+          if (RELU && x > 0.f) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
         }
         const int row = p * 32 + r;
         *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
@@ -78,11 +78,12 @@ __device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT
   return bits;
 }
 
-template <int MODE, bool SAVE>
+template <int MODE, bool SAVE, int PT>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
+  constexpr int TM = tile_pts(PT);     // points of this workgroup (shadows the 64-point default)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;
-  float* ebuf = lds + H_FLOATS;
+  float* ebuf = lds + h_floats(PT);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -143,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
   }
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][PT];
   f32x4 an[2], bias[2][4];
   const int nt0 = wave * 2;
   // weight base of this wave for MFMA layer L (views layer: one n-tile per wave)
@@ -153,15 +154,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 #define PTS_LAYER(L, LNEXT, KBP, PRE)                                                              \
   {                                                                                                \
     load_bias<2>(bias, pk + off_b(L), nt0, lane);                                                  \
-    layer_gemm<2, KBP, kb_h(L), EMB_STRIDE>(acc, an, WBASE(L), WBASE(LNEXT), kb_total(LNEXT), PRE, \
-                                            hbuf, lane);                                           \
+    layer_gemm<2, KBP, kb_h(L), EMB_STRIDE, PT>(acc, an, WBASE(L), WBASE(LNEXT), kb_total(LNEXT),  \
+                                                PRE, hbuf, lane);                                  \
     __syncthreads();                                                                               \
-    const unsigned long long bits_ = layer_store<2, true>(acc, bias, nt0, hbuf, lane);             \
-    if (SAVE)                                                                                      \
-      reinterpret_cast<unsigned long long*>(a.acts + acts_mask_off(P))[                            \
-          ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = bits_;                               \
+    const unsigned long long bits_ = layer_store<2, true, PT>(acc, bias, nt0, hbuf, lane);         \
+    if (SAVE) store_relu_words<PT>(a.acts, P, L, tid, bits_);                                      \
     __syncthreads();                                                                               \
-    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, L), p0, P, W, tid);                          \
+    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, L), p0, P, W, tid, TM);                      \
   }
 
   an[0] = WBASE(0)[lane];
@@ -179,8 +178,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int pt = min(p0 + row, P - 1);
     float v = 0.f;
     if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
-    ebuf[row * VIEW_PAD + c] = v;
-    ebuf[row * VIEW_PAD + 4 + c] = 0.f;
+    if (PT == 2 || row < TM) {
+      ebuf[row * VIEW_PAD + c] = v;
+      ebuf[row * VIEW_PAD + 4 + c] = 0.f;
+    }
   }
   // (visibility of the view pad is covered by the barriers of layers 6/7)
 
@@ -189,9 +190,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 #undef PTS_LAYER
 
   // ---------------- alpha head: 256 -> 1 on the VALU -------------------------
+  // (PT == 1: the upper half of the workgroup repeats rows 0..31 and does not store)
+  const bool head_store = PT == 2 || tid < 128;
   float alpha;
   {
-    const int row = tid >> 2, sub = tid & 3;
+    const int row = PT == 2 ? tid >> 2 : (tid >> 2) & 31, sub = tid & 3;
     const float* wa = pk + OFF_WA;
     float s = 0.f;
 #pragma unroll
@@ -205,34 +208,34 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     s += __shfl_xor(s, 1, 64);
     s += __shfl_xor(s, 2, 64);
     alpha = s + pk[OFF_BA];
-    if (SAVE && sub == 0 && p0 + row < P) a.acts[acts_alpha_off(P) + p0 + row] = alpha;
+    if (SAVE && sub == 0 && head_store && p0 + row < P) a.acts[acts_alpha_off(P) + p0 + row] = alpha;
   }
 
   // ---------------- feature_linear: 256 -> 256, no activation ----------------
   load_bias<2>(bias, pk + off_b(L_FEAT), nt0, lane);
-  layer_gemm<2, 0, 32, EMB_STRIDE>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
+  layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
   __syncthreads();
-  layer_store<2, false>(acc, bias, nt0, hbuf, lane);
+  layer_store<2, false, PT>(acc, bias, nt0, hbuf, lane);
   __syncthreads();
-  if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid);
+  if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid, TM);
 
   // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
   {
-    f32x16 accv[1][2];
+    f32x16 accv[1][PT];
     f32x4 biasv[1][4];
     load_bias<1>(biasv, pk + off_b(L_VIEWS), wave, lane);
     // (an[1] is unused by the one-tile views layer; the trailing prefetch re-reads block 0)
-    layer_gemm<1, 1, 32, VIEW_PAD>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
+    layer_gemm<1, 1, 32, VIEW_PAD, PT>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
     __syncthreads();
-    layer_store<1, true>(accv, biasv, wave, hbuf, lane);
+    layer_store<1, true, PT>(accv, biasv, wave, hbuf, lane);
     __syncthreads();
-    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, tid);
+    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, tid, TM);
   }
 
 #undef WBASE
   // ---------------- rgb head 128 -> 3, softplus(alpha, beta=10) --------------
   {
-    const int row = tid >> 2, sub = tid & 3;
+    const int row = PT == 2 ? tid >> 2 : (tid >> 2) & 31, sub = tid & 3;
     const float* wr = pk + OFF_WR;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f;
 #pragma unroll
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
     s1 += __shfl_xor(s1, 1, 64); s1 += __shfl_xor(s1, 2, 64);
     s2 += __shfl_xor(s2, 1, 64); s2 += __shfl_xor(s2, 2, 64);
-    if (sub == 0 && p0 + row < P) {
+    if (sub == 0 && head_store && p0 + row < P) {
       // F.softplus(alpha, beta=10): x if 10x > 20 else log1p(exp(10x))/10
       const float bx = alpha * 10.f;
       const float sp = bx > 20.f ? alpha : log1pf(expf(bx)) / 10.f;
@@ -333,19 +336,23 @@ extern "C" int scade_mlp_pack(const float* const* params, float* packed, void* s
   return scade_check_launch("scade_mlp_pack");
 }
 
-template <int MODE, bool SAVE>
-static int launch_fwd(const MlpFwdArgs& a, hipStream_t s) {
+template <int MODE, bool SAVE, int PT>
+static int launch_fwd_pt(const MlpFwdArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = mlp_fwd_kernel<MODE, SAVE>;
+  auto kern = mlp_fwd_kernel<MODE, SAVE, PT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, MLP_LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, mlp_lds_bytes(PT));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  const int grid = (a.P + TM - 1) / TM;
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), MLP_LDS_BYTES, s, a);
+  const int grid = (a.P + tile_pts(PT) - 1) / tile_pts(PT);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), mlp_lds_bytes(PT), s, a);
   return scade_check_launch("scade_mlp_fwd");
+}
+template <int MODE, bool SAVE>
+static int launch_fwd(const MlpFwdArgs& a, hipStream_t s) {
+  return pick_point_tiles(a.P) == 1 ? launch_fwd_pt<MODE, SAVE, 1>(a, s) : launch_fwd_pt<MODE, SAVE, 2>(a, s);
 }
 
 extern "C" int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,

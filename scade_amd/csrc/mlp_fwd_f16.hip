@@ -71,7 +71,7 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
-          if (RELU && x > 0.f) bits |= 1ull << (((t * 4 + q) * 2 + p) * 4 + i);
+          if (RELU && x > 0.f) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
           if (RELU) x = fmaxf(x, 0.f);
           _Float16 h, l;
           split2(x, h, l);
@@ -183,9 +183,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     __syncthreads();                                                                             \
     const unsigned long long bits_ =                                                             \
         layer_store_h<2, true, 2>(acc0, acc1, nt0, xh, xl, lane, cb, TAIL(off_b(LNEXT)), nt0);   \
-    if (SAVE)                                                                                    \
-      reinterpret_cast<unsigned long long*>(a.acts + acts_mask_off(P))[                          \
-          ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = bits_;                             \
+    if (SAVE) store_relu_words<2>(a.acts, P, L, tid, bits_);                                     \
     __syncthreads();                                                                             \
     if (SAVE) save_tile_h(xh, xl, a.acts + acts_slot_off(P, L), p0, P, W, nullptr, tid);         \
   }

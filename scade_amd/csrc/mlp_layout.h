@@ -8,6 +8,7 @@
 // v_mfma_f32_32x32x2_f32 (k index of MFMA step j, lane half h  <->  channel
 // kb*8 + 4h + j; the activation operand uses the same map).
 #pragma once
+#include <hip/hip_runtime.h>
 
 namespace scade {
 
@@ -84,5 +85,49 @@ constexpr long dz_floats(long P) { return dz_dalpha_off(P) + P; }
 // 22,23  : rgb_linear.{weight,bias}
 constexpr int N_PARAM_TENSORS = 24;
 constexpr int N_PARAM_FLOATS = 589700;
+
+// compute units of the current device (256 on MI355X); 256 when no device is visible (CPU-side
+// size queries in the build container)
+inline int device_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+      n = v;
+    else
+      n = 256;
+  }
+  return n;
+}
+
+// ReLU sign words of the fp32-layout workspace: ONE 32-bit word per (pts layer, 32-point tile, thread
+// of the workgroup that owns the tile), bit (t*4 + q)*4 + i <-> value (n-tile t, row group q, i) of that
+// point tile in the thread's accumulator fragment.  Indexed by POINT TILE, not by workgroup, so the
+// producers and consumers of a workspace may tile the points differently (64-point workgroups carry two
+// words per thread - in registers the u64 `p*32 + (t*4+q)*4 + i` - 32-point workgroups one).
+constexpr long relu_word_tiles(long P) { return 2 * ((P + 63) / 64); }
+template <int PT>
+__device__ __forceinline__ void store_relu_words(float* acts, long P, int layer, int tid,
+                                                 unsigned long long bits) {
+  unsigned* w = reinterpret_cast<unsigned*>(acts + acts_mask_off(P)) +
+                ((size_t)layer * relu_word_tiles(P) + (size_t)blockIdx.x * PT) * 256 + tid;
+  w[0] = (unsigned)bits;
+  if (PT > 1) w[256] = (unsigned)(bits >> 32);
+}
+template <int PT>
+__device__ __forceinline__ unsigned long long load_relu_words(const float* acts, long P, int layer, int tid) {
+  const unsigned* w = reinterpret_cast<const unsigned*>(acts + acts_mask_off(P)) +
+                      ((size_t)layer * relu_word_tiles(P) + (size_t)blockIdx.x * PT) * 256 + tid;
+  unsigned long long b = w[0];
+  if (PT > 1) b |= (unsigned long long)w[256] << 32;
+  return b;
+}
+
+// Point tiles (of 32) per workgroup of the exact forward / dgrad kernels for a launch over P points:
+// two (64 points, the throughput shape) unless the launch would not even give every CU its two
+// workgroups - then one, which doubles the workgroups of a small batch (BASELINE configs[3]: 128 rays
+// per GPU).  (The ReLU words are indexed by point tile, so forward and dgrad need not even agree.)
+inline int pick_point_tiles(long P) { return (P + 63) / 64 < 2L * device_cus() ? 1 : 2; }
 
 }  // namespace scade

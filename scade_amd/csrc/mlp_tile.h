@@ -11,6 +11,11 @@ constexpr int EMB_STRIDE = 60;                 // floats; 240 B rows -> conflict
 constexpr int EMB_FLOATS = TM * EMB_STRIDE + 4;  // 3840 + one zeroed 16-byte pad: the last
                                                 // row's k-block 7 reads columns 60..63
 constexpr int MLP_LDS_BYTES = (H_FLOATS + EMB_FLOATS) * 4;  // 80912
+// the same tile with PT point tiles of 32 (PT = 2 above; PT = 1: the small-batch variant, twice the
+// workgroups for launches that would otherwise leave CUs idle)
+constexpr int tile_pts(int PT) { return 32 * PT; }
+constexpr int h_floats(int PT) { return 32 * PT * W; }
+constexpr int mlp_lds_bytes(int PT) { return (h_floats(PT) + 32 * PT * EMB_STRIDE + 4) * 4; }
 
 // float index of 16-byte chunk `chunk` of row `row` in the swizzled h tile
 __device__ __forceinline__ int h_idx(int row, int chunk) {
@@ -26,8 +31,8 @@ __device__ __forceinline__ int h_idx(int row, int chunk) {
 //   pre     : LDS region for the first KBP k-blocks (row stride PRE_STRIDE floats)
 //   hbuf    : swizzled h tile for the remaining KBH k-blocks
 // ---------------------------------------------------------------------------
-template <int NT, int KBP, int KBH, int PRE_STRIDE>
-__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], f32x4 (&an)[2],
+template <int NT, int KBP, int KBH, int PRE_STRIDE, int PT = 2>
+__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2],
                                            const f32x4* __restrict__ wp,
                                            const f32x4* __restrict__ wp_next, int kb_next,
                                            const float* pre, const float* hbuf, int lane) {
@@ -36,19 +41,19 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], f32x4 (&an)[2],
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int p = 0; p < 2; ++p)
+    for (int p = 0; p < PT; ++p)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
 
-  auto load_b = [&](int kb, f32x4& b0, f32x4& b1) {
+  auto load_b = [&](int kb, f32x4& b0, f32x4& b1) {   // b1: rows 32.. (PT == 2 only)
     if (KBP > 0 && kb < KBP) {
       const float* q = pre + r * PRE_STRIDE + (2 * kb + hh) * 4;
       b0 = *reinterpret_cast<const f32x4*>(q);
-      b1 = *reinterpret_cast<const f32x4*>(q + 32 * PRE_STRIDE);
+      if (PT > 1) b1 = *reinterpret_cast<const f32x4*>(q + 32 * PRE_STRIDE);
     } else {
       const float* q = hbuf + h_idx(r, 2 * (kb - KBP) + hh);
       b0 = *reinterpret_cast<const f32x4*>(q);
-      b1 = *reinterpret_cast<const f32x4*>(q + 32 * W);
+      if (PT > 1) b1 = *reinterpret_cast<const f32x4*>(q + 32 * W);
     }
   };
   auto mfma_block = [&](const f32x4 (&a)[2], const f32x4 (&b)[2]) {
@@ -57,7 +62,7 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], f32x4 (&an)[2],
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int p = 0; p < 2; ++p)
+        for (int p = 0; p < PT; ++p)
           acc[t][p] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[t][j], b[p][j], acc[t][p], 0, 0, 0);
   };
 
@@ -68,7 +73,8 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], f32x4 (&an)[2],
   for (int kb = 0; kb < KB - 1; ++kb) {
     f32x4 a[2], b[2];
     a[0] = an[0]; a[1] = an[1];
-    b[0] = bn[0]; b[1] = bn[1];
+    b[0] = bn[0];
+    if (PT > 1) b[1] = bn[1];
 #pragma unroll
     for (int t = 0; t < NT; ++t) an[t] = wp[(t * KB + kb + 1) * 64 + lane];
     load_b(kb + 1, bn[0], bn[1]);
@@ -80,7 +86,8 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], f32x4 (&an)[2],
   {  // last k-block: prefetch the next layer's first weights instead
     f32x4 a[2], b[2];
     a[0] = an[0]; a[1] = an[1];
-    b[0] = bn[0]; b[1] = bn[1];
+    b[0] = bn[0];
+    if (PT > 1) b[1] = bn[1];
     an[0] = wp_next[lane];
     an[1] = wp_next[kb_next * 64 + lane];
     __builtin_amdgcn_sched_barrier(0);
@@ -90,9 +97,9 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][2], f32x4 (&an)[2],
 
 // coalesced copy of the h tile (first ncols columns) to dst[P][256] (full 1-KiB rows)
 __device__ __forceinline__ void save_tile(const float* hbuf, float* __restrict__ dst, int p0, int P,
-                                          int ncols, int tid) {
+                                          int ncols, int tid, int tm = TM) {
   const int chunks_per_row = ncols >> 2;
-  for (int i = tid; i < TM * chunks_per_row; i += 256) {
+  for (int i = tid; i < tm * chunks_per_row; i += 256) {
     const int row = i / chunks_per_row, c = i - row * chunks_per_row;
     if (p0 + row < P)
       *reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c) =

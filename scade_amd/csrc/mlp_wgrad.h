@@ -53,21 +53,6 @@ inline void param_offsets(int off[N_PARAM_TENSORS + 1]) {
   off[i] = o;
 }
 
-// compute units of the current device (256 on MI355X); 256 when no device is visible (CPU-side
-// size queries in the build container)
-inline int device_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-  }
-  return n;
-}
-
 // Chunks of points per weight-gradient launch.  Every weight-gradient workgroup owns a whole CU
 // (LDS) and the nine 256x256 jobs dominate, so the chunk count is chosen as the largest one for
 // which 9 x chunks fits k "rounds" of one workgroup per CU with chunks near 2400 points (85 chunks

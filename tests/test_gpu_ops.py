@@ -416,3 +416,28 @@ def test_ray_tail_equals_the_three_operators(dev):
     with pytest.raises(RuntimeError):
         ops.ray_tail(torch.zeros(2, 300, 4, device=dev), torch.zeros(2, 300, device=dev),
                      torch.zeros(2, 11, device=dev), None, torch.zeros(2, 300, device=dev), 300, merge=True)
+
+
+def test_mlp_point_tilings_agree(dev):
+    """The exact forward / dgrad kernels run 64-point workgroups, or 32-point ones when the launch is too
+    small to fill the chip (pick_point_tiles: P < 32768 on a 256-CU part).  The golden fixtures pin the
+    small launches; this ties the large ones to them: per-point outputs are bit-identical across the two
+    tilings (same k order), gradients agree to summation order."""
+    net = make_net(O.nerf_init(3), dev)
+    g = torch.Generator().manual_seed(9)
+    P, Ps = 40000, 3000
+    x = torch.cat([O.embed(torch.rand(P, 3, generator=g) * 2 - 1, 9),
+                   torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)], -1).to(dev)
+    with torch.no_grad():
+        big, small = net(x), net(x[:Ps])
+    assert torch.equal(big[:Ps], small)
+    G = torch.zeros(P, 4)
+    G[:Ps] = torch.randn(Ps, 4, generator=g) * 1e-3
+    G = G.to(dev)
+    grads = []
+    for xs, gs in ((x, G), (x[:Ps], G[:Ps])):
+        for p in net.parameters():
+            p.grad = None
+        net(xs).backward(gs)
+        grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]))
+    assert rel_l2(grads[0], grads[1]) < 1e-5
