@@ -397,10 +397,18 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(pc, pf, 1024)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
-    if rank == 0:
-        print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    # the JSON line is the LAST line of stdout: RCCL prints its version banner through C stdio, which
+    # a pipe buffers until exit - flush it out first
+    sys.stdout.flush()
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+    if rank == 0:
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":
