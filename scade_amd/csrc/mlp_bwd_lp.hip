@@ -110,8 +110,8 @@ struct MlpDgradLpArgs {
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-template <bool BF, bool MASK, bool ADD_ALPHA>
-__device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][LPT], int ktile0, typename LP<BF>::T* g,
+template <bool BF, bool MASK, bool ADD_ALPHA, int NPT = LPT>
+__device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][NPT], int ktile0, typename LP<BF>::T* g,
                                                const unsigned (&bits)[4],
                                                const float* __restrict__ w_a, const float* dal_scaled,
                                                int lane) {
@@ -124,7 +124,7 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][LPT], int 
       f32x4 wa = {0.f, 0.f, 0.f, 0.f};
       if (ADD_ALPHA) wa = *reinterpret_cast<const f32x4*>(w_a + f);
 #pragma unroll
-      for (int p = 0; p < LPT; ++p) {
+      for (int p = 0; p < NPT; ++p) {
         const int row = p * 32 + r;
         float y[4];
 #pragma unroll
@@ -145,10 +145,11 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][LPT], int 
     }
 }
 
-constexpr int DGRAD_LP_LDS_BYTES = LXPLANE * 2 + 2 * LM * 4;
+constexpr int dgrad_lp_lds_bytes(int NPT) { return 32 * NPT * W * 2 + 2 * 32 * NPT * 4; }
 
-template <bool BF>
+template <bool BF, int NPT>
 __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) {
+  constexpr int LM = 32 * NPT, LPT = NPT, LXPLANE = LM * W;   // this workgroup's tile (shadow the 128-point default)
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V4 V4;
   typedef typename LP<BF>::V8 V8;
@@ -241,28 +242,28 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 #define DROT(N) ((N) == 0 ? 0 : (8 + 16 * ((N)-1)) % 3)
 
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
-  layer_gemm_lp<BF, 2, 0, 8, false, DROT(0)>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
+  layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), 3, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
-  dgrad_store_lp<BF, false, false>(acc, kt0, g, mb, nullptr, dal, lane);
+  dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
   __syncthreads();
-  save_tile_lp<BF, 256>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, fac, tid);
+  save_tile_lp<BF, 256, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, fac, tid);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
-  layer_gemm_lp<BF, 2, 0, 16, false, DROT(1)>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
+  layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), 3, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
-  dgrad_store_lp<BF, true, true>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
+  dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
   __syncthreads();
-  save_tile_lp<BF, 256>(g, dzT + acts_slot_off(P, 7), p0, P, fac, tid);
+  save_tile_lp<BF, 256, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, fac, tid);
 
 #define DGRAD_LAYER_L(L)                                                                            \
   load_mask((L)-1);                                                                                 \
-  layer_gemm_lp<BF, 2, 0, 16, false, DROT(9 - (L))>(acc, A, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, \
+  layer_gemm_lp<BF, 2, 0, 16, false, DROT(9 - (L)), 3, NPT>(acc, A, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, \
                                                     g, g, lane, nullptr);                           \
   __syncthreads();                                                                                  \
-  dgrad_store_lp<BF, true, false>(acc, kt0, g, mb, nullptr, dal, lane);                             \
+  dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
   __syncthreads();                                                                                  \
-  save_tile_lp<BF, 256>(g, dzT + acts_slot_off(P, (L)-1), p0, P, fac, tid);
+  save_tile_lp<BF, 256, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, fac, tid);
 
   DGRAD_LAYER_L(7)
   DGRAD_LAYER_L(6)
@@ -636,8 +637,11 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
                          int P, unsigned char* ws, float* grad_flat, hipStream_t s) {
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, DGRAD_LP_LDS_BYTES);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, dgrad_lp_lds_bytes(4));
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 2>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, dgrad_lp_lds_bytes(2));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_lp_kernel<BF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LP_LDS_BYTES);
@@ -654,7 +658,11 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(256), 0, s, g_out, ng, gmax);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(gmax)")) return e;
   MlpDgradLpArgs d{packed, packed_t, acts, g_out, dz, reinterpret_cast<const float*>(gmax), P};
-  hipLaunchKernelGGL(mlp_dgrad_lp_kernel<BF>, dim3((P + LM - 1) / LM), dim3(256), DGRAD_LP_LDS_BYTES, s, d);
+  // same point tiling as the forward that wrote the sign words of this workspace
+  if (lp_pick_point_tiles(P) == 2)
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2>), dim3((P + 63) / 64), dim3(256), dgrad_lp_lds_bytes(2), s, d);
+  else
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4>), dim3((P + LM - 1) / LM), dim3(256), dgrad_lp_lds_bytes(4), s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(dgrad)")) return e;
   WgradLpArgs w{};
   w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial;

@@ -35,15 +35,15 @@ struct MlpLpArgs {
 // acc already holds W x + bias (the bias rode in as the first MFMA's C operand): ReLU, round, store.
 // bits[t] bit (q*4+p)*4+i <-> value (t,q,p,i) > 0: the (feature, point) map the dgrad kernel's
 // output fragment uses too (only computed for the training variant)
-template <bool BF, int NT, bool RELU, bool BITS, int NTN>
-__device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], int ntile0,
+template <bool BF, int NT, bool RELU, bool BITS, int NTN, int NPT = LPT>
+__device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][NPT], int ntile0,
                                                typename LP<BF>::T* x, int lane,
                                                unsigned (&bits)[4], f32x16 (&cb)[2],
                                                const float* __restrict__ bias_next, int ntile0_next) {
   const int r = lane & 31, hh = lane >> 5;
   bits[0] = bits[1] = bits[2] = bits[3] = 0u;
 #pragma unroll
-  for (int p = 0; p < LPT; ++p) {
+  for (int p = 0; p < NPT; ++p) {
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -69,8 +69,9 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][LPT], int
   }
 }
 
-template <bool BF, int MODE, bool SAVE>
+template <bool BF, int MODE, bool SAVE, int NPT>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
+  constexpr int LM = 32 * NPT, LPT = NPT, LXPLANE = LM * W;   // this workgroup's tile (shadow the 128-point default)
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V8 V8;
   extern __shared__ __attribute__((aligned(16))) unsigned short lds16[];
@@ -164,17 +165,17 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 #define FROT(L) ((int)CE<fwd_rot(L, NS)>::v)
 #define PTS_LAYER_L(L, LNEXT, KBP)                                                              \
   {                                                                                             \
-    layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS>(acc, A, WLBASE(L), WLBASE(LNEXT),   \
+    layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS, NPT>(acc, A, WLBASE(L), WLBASE(LNEXT),   \
                                                         (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
     __syncthreads();                                                                            \
-    layer_store_lp<BF, 2, true, SAVE, 2>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
+    layer_store_lp<BF, 2, true, SAVE, 2, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
     if (SAVE) {                                                                                 \
       u32x4 mw_ = {bits[0], bits[1], bits[2], bits[3]};                                         \
       reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[                                  \
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
     }                                                                                           \
     __syncthreads();                                                                            \
-    if (SAVE) save_tile_lp<BF, 256>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, tid);         \
+    if (SAVE) save_tile_lp<BF, 256, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, tid);         \
   }
 
   A.s[0].t0 = WLBASE(0)[lane];
@@ -232,20 +233,20 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
 
   // ---- feature_linear ------------------------------------------------------------------
-  layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+  layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS, NPT>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
   __syncthreads();
-  layer_store_lp<BF, 2, false, false, 1>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
+  layer_store_lp<BF, 2, false, false, 1, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
   __syncthreads();
-  if (SAVE) save_tile_lp<BF, 256>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, tid);
+  if (SAVE) save_tile_lp<BF, 256, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, tid);
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av[1][LPT];
-    layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+    layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
     __syncthreads();
-    layer_store_lp<BF, 1, true, false, 0>(av, wave, x, lane, bits, cb, nullptr, 0);
+    layer_store_lp<BF, 1, true, false, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
     __syncthreads();
-    if (SAVE) save_tile_lp<BF, 128>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, tid);
+    if (SAVE) save_tile_lp<BF, 128, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, tid);
   }
 #undef WLBASE
 
@@ -356,18 +357,23 @@ extern "C" int scade_mlp_pack_lp(const float* const* params, void* packed, int b
   return scade_check_launch("scade_mlp_pack_lp");
 }
 
-template <bool BF, int MODE, bool SAVE>
-static int launch_lp(const MlpLpArgs& a, hipStream_t s) {
+template <bool BF, int MODE, bool SAVE, int NPT>
+static int launch_lp_pt(const MlpLpArgs& a, hipStream_t s) {
   static bool attr_set = false;
-  auto kern = mlp_fwd_lp_kernel<BF, MODE, SAVE>;
+  auto kern = mlp_fwd_lp_kernel<BF, MODE, SAVE, NPT>;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LP_LDS_BYTES);
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, lp_lds_bytes(NPT));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_fwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
     attr_set = true;
   }
-  hipLaunchKernelGGL(kern, dim3((a.P + LM - 1) / LM), dim3(256), LP_LDS_BYTES, s, a);
+  hipLaunchKernelGGL(kern, dim3((a.P + 32 * NPT - 1) / (32 * NPT)), dim3(256), lp_lds_bytes(NPT), s, a);
   return scade_check_launch("scade_mlp_fwd_lp");
+}
+template <bool BF, int MODE, bool SAVE>
+static int launch_lp(const MlpLpArgs& a, hipStream_t s) {
+  return lp_pick_point_tiles(a.P) == 2 ? launch_lp_pt<BF, MODE, SAVE, 2>(a, s)
+                                       : launch_lp_pt<BF, MODE, SAVE, 4>(a, s);
 }
 
 extern "C" int scade_mlp_fwd_lp(const void* packed_lp, int bf16, int mode, const float* in,

@@ -42,6 +42,12 @@ constexpr int LPT = LM / 32;                 // point tiles
 constexpr int LXPLANE = LM * W;              // elements of the activation tile
 constexpr int LEPLANE = LM * 64;             // elements of the embedding tile
 constexpr int LP_LDS_BYTES = (LXPLANE + LEPLANE) * 2;   // 81920
+// the same tile with NPT point tiles (NPT = 4 above; NPT = 2: the small-batch variant - twice the
+// workgroups for launches that would leave most CUs idle)
+constexpr int lp_lds_bytes(int NPT) { return 32 * NPT * (W + 64) * 2; }
+// point tiles per workgroup for a launch over P points (forward and dgrad of a step agree: the sign
+// words are indexed by workgroup)
+inline int lp_pick_point_tiles(long P) { return (P + LM - 1) / LM < device_cus() ? 2 : 4; }
 
 // packed blob: per layer [ntile][kb][64 lanes][8 elements]  (counted in 16-bit elements)
 constexpr long wl_elems(int l) { return (long)n_out(l) / 32 * kb16(l) * 64 * 8; }
@@ -60,7 +66,7 @@ constexpr long lp_align(long b) { return (b + 255) / 256 * 256; }
 constexpr long lp_tiles(long P) { return (P + LM - 1) / LM; }
 constexpr long lp_acts_alpha_byte(long P) { return lp_align((acts_emb_off(P) + P * 64) * 2); }
 constexpr long lp_acts_mask_byte(long P) { return lp_align(lp_acts_alpha_byte(P) + P * 4); }
-constexpr long lp_acts_bytes(long P) { return lp_acts_mask_byte(P) + 8L * lp_tiles(P) * 256 * 16; }
+constexpr long lp_acts_bytes(long P) { return lp_acts_mask_byte(P) + 8L * ((P + 63) / 64) * 256 * 16; }   // sized for 64-point workgroups
 // dz: slots [10][P][256] T, every row multiplied by the launch-wide power of two S | d alpha_pre [P] fp32
 constexpr long lp_dz_dalpha_byte(long P) { return lp_align((long)N_ACT_SLOTS * P * 256 * 2); }
 constexpr long lp_dz_bytes(long P) { return lp_align(lp_dz_dalpha_byte(P) + P * 4); }
@@ -68,13 +74,13 @@ constexpr long lp_dz_bytes(long P) { return lp_align(lp_dz_dalpha_byte(P) + P * 
 // coalesced copy of the first NCOLS columns of the LDS tile to dst[P][256] (optional per-row
 // factor).  Four 16-byte chunks per thread in flight: as a plain loop every iteration exposed the
 // LDS latency in front of its store (16 dependent round trips per layer).
-template <bool BF, int NCOLS>
+template <bool BF, int NCOLS, int NPT = LPT>
 __device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typename LP<BF>::T* __restrict__ dst,
                                              int p0, int P, const float* row_fac, int tid) {
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V8 V8;
   constexpr int CPR = NCOLS >> 3;                     // 16-byte chunks per row
-  constexpr int ITERS = LM * CPR / 256;
+  constexpr int ITERS = 32 * NPT * CPR / 256;
   static_assert(ITERS % 4 == 0, "save_tile_lp: batches of four");
 #pragma unroll 1      // keep the batches apart: merged, their 16 reads + conversions spill
   for (int it0 = 0; it0 < ITERS; it0 += 4) {
@@ -134,8 +140,8 @@ using AFrag3 = AFragN<BF, 3>;
 // layer boundary too (the last NS-1 blocks prefetch blocks 0 .. NS-2 of the next layer; the caller
 // enters the next layer with rotation (ROT + KB) % NS).  B (activations, LDS): every fragment is
 // reloaded in place for the next block right after the two MFMAs that consume it were issued.
-template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT, int NS = 3>
-__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragN<BF, NS>& A,
+template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT, int NS = 3, int NPT = LPT>
+__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF, NS>& A,
                                               const typename LP<BF>::V8* __restrict__ wp,
                                               const typename LP<BF>::V8* __restrict__ wp_next, int kb_next,
                                               const typename LP<BF>::T* e, const typename LP<BF>::T* x,
@@ -181,17 +187,20 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragN<BF,
     __builtin_amdgcn_sched_barrier(0);                                  \
     MFMA2(1, A.s[R], b1) LOAD_BL(kn, 1, b1)                             \
     __builtin_amdgcn_sched_barrier(0);                                  \
-    MFMA2(2, A.s[R], b2) LOAD_BL(kn, 2, b2)                             \
-    __builtin_amdgcn_sched_barrier(0);                                  \
-    MFMA2(3, A.s[R], b3) LOAD_BL(kn, 3, b3)                             \
-    __builtin_amdgcn_sched_barrier(0);                                  \
+    if constexpr (NPT > 2) {                                            \
+      MFMA2(2, A.s[R], b2) LOAD_BL(kn, 2, b2)                           \
+      __builtin_amdgcn_sched_barrier(0);                                \
+      MFMA2(3, A.s[R], b3) LOAD_BL(kn, 3, b3)                           \
+      __builtin_amdgcn_sched_barrier(0);                                \
+    }                                                                   \
   }
 
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   const f32x16 c00 = cinit ? cinit[0] : zero16;
   const f32x16 c01 = cinit ? cinit[NT - 1] : zero16;
   V8 b0, b1, b2, b3;
-  LOAD_BL(0, 0, b0) LOAD_BL(0, 1, b1) LOAD_BL(0, 2, b2) LOAD_BL(0, 3, b3)
+  LOAD_BL(0, 0, b0) LOAD_BL(0, 1, b1)
+  if constexpr (NPT > 2) { LOAD_BL(0, 2, b2) LOAD_BL(0, 3, b3) }
   {   // peeled k-block 0
     FETCH_A(0, A.s[(ROT + NS - 1) % NS])
     const int kn = 1 < KB ? 1 : 0;
@@ -199,10 +208,12 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][LPT], AFragN<BF,
     // point tile 0 last: its accumulator can then take over the registers of the initial value
     MFMA2_FIRST(1, A.s[ROT], b1) LOAD_BL(kn, 1, b1)
     __builtin_amdgcn_sched_barrier(0);
-    MFMA2_FIRST(2, A.s[ROT], b2) LOAD_BL(kn, 2, b2)
-    __builtin_amdgcn_sched_barrier(0);
-    MFMA2_FIRST(3, A.s[ROT], b3) LOAD_BL(kn, 3, b3)
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (NPT > 2) {
+      MFMA2_FIRST(2, A.s[ROT], b2) LOAD_BL(kn, 2, b2)
+      __builtin_amdgcn_sched_barrier(0);
+      MFMA2_FIRST(3, A.s[ROT], b3) LOAD_BL(kn, 3, b3)
+      __builtin_amdgcn_sched_barrier(0);
+    }
     MFMA2_FIRST(0, A.s[ROT], b0) LOAD_BL(kn, 0, b0)
     __builtin_amdgcn_sched_barrier(0);
   }

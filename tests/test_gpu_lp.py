@@ -52,6 +52,36 @@ def test_lp_ragged_sizes_and_row_independence(dev, prec):
 
 
 @pytest.mark.parametrize("prec", ["f16", "bf16"])
+def test_lp_point_tilings_agree(dev, prec):
+    """The 16-bit forward / dgrad run 128-point workgroups, or 64-point ones when the launch has fewer
+    than one workgroup per CU (lp_pick_point_tiles: P < 32768 on a 256-CU part).  The golden fixtures
+    pin the small launches; per-point outputs of a large launch are bit-identical to them (same k
+    order, same roundings), and the training gradients agree to summation order."""
+    net = make_net(O.nerf_init(4), dev)
+    net.inference_precision = prec
+    g = torch.Generator().manual_seed(13)
+    P, Ps = 40000, 3000
+    x = torch.cat([O.embed(torch.rand(P, 3, generator=g) * 2 - 1, 9),
+                   torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)], -1).to(dev)
+    with torch.no_grad():
+        big, small = net(x), net(x[:Ps])
+    assert torch.equal(big[:Ps], small)
+    net.train_precision = prec
+    G = torch.zeros(P, 4)
+    G[:Ps] = torch.randn(Ps, 4, generator=g) * 1e-3
+    G = G.to(dev)
+    grads = []
+    for xs, gs in ((x, G), (x[:Ps], G[:Ps])):
+        for p in net.parameters():
+            p.grad = None
+        out = net(xs)
+        out.backward(gs)
+        grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]))
+    # same rounded activations and dZ rows in both launches; only the chunking of the point sum differs
+    assert rel_l2(grads[0], grads[1]) < 1e-4
+
+
+@pytest.mark.parametrize("prec", ["f16", "bf16"])
 def test_lp_points_mode_matches_embedded_mode(dev, prec):
     params = O.nerf_init(3)
     net = make_net(params, dev)
