@@ -7,14 +7,18 @@ SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); LDS conflict fraction = SQ_LDS_BANK_CONFLIC
 SQ_LDS_IDX_ACTIVE; L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS)."""
 import collections, csv, json, re, sys
 
-KEYS = [  # (regex on the kernel name, key in the json)
-    (r"mlp_fwd_kernel<1, false>", "mlp_fwd_kernel"), (r"mlp_fwd_kernel<1, true>", "mlp_fwd_kernel_train"),
-    (r"mlp_dgrad_kernel", "mlp_dgrad_kernel"), (r"mlp_wgrad_kernel", "mlp_wgrad_kernel"),
+KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-size workgroup variants
+    (r"mlp_fwd_kernel<1, false, 2>", "mlp_fwd_kernel"), (r"mlp_fwd_kernel<1, true, 2>", "mlp_fwd_kernel_train"),
+    (r"mlp_fwd_kernel<1, false, 1>", "mlp_fwd_kernel_small"), (r"mlp_fwd_kernel<1, true, 1>", "mlp_fwd_kernel_train_small"),
+    (r"mlp_dgrad_kernel<2>", "mlp_dgrad_kernel"), (r"mlp_dgrad_kernel<1>", "mlp_dgrad_kernel_small"),
+    (r"mlp_wgrad_kernel", "mlp_wgrad_kernel"),
     (r"mlp_fwd_f16_kernel<1, false>", "mlp_fwd_f16_kernel"), (r"mlp_fwd_f16_kernel<1, true>", "mlp_fwd_f16_kernel_train"),
     (r"mlp_dgrad_f16_kernel", "mlp_dgrad_f16_kernel"), (r"mlp_wgrad_f16_kernel", "mlp_wgrad_f16_kernel"),
-    (r"mlp_fwd_lp_kernel<true, 1, false>", "mlp_fwd_lp_kernel_bf16"), (r"mlp_fwd_lp_kernel<false, 1, false>", "mlp_fwd_lp_kernel_f16"),
-    (r"mlp_fwd_lp_kernel<true, 1, true>", "mlp_fwd_lp_kernel_bf16_train"),
-    (r"mlp_dgrad_lp_kernel<true>", "mlp_dgrad_lp_kernel_bf16"), (r"mlp_wgrad_lp_kernel<true>", "mlp_wgrad_lp_kernel_bf16"),
+    (r"mlp_fwd_lp_kernel<true, 1, false, 4>", "mlp_fwd_lp_kernel_bf16"), (r"mlp_fwd_lp_kernel<false, 1, false, 4>", "mlp_fwd_lp_kernel_f16"),
+    (r"mlp_fwd_lp_kernel<true, 1, true, 4>", "mlp_fwd_lp_kernel_bf16_train"),
+    (r"mlp_fwd_lp_kernel<true, 1, true, 2>", "mlp_fwd_lp_kernel_bf16_train_small"),
+    (r"mlp_dgrad_lp_kernel<true, 4>", "mlp_dgrad_lp_kernel_bf16"), (r"mlp_dgrad_lp_kernel<true, 2>", "mlp_dgrad_lp_kernel_bf16_small"),
+    (r"mlp_wgrad_lp_kernel<true>", "mlp_wgrad_lp_kernel_bf16"),
     (r"wgrad_reduce4_kernel", "wgrad_reduce4_kernel"),
 ]
 

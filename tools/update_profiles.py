@@ -1,0 +1,72 @@
+#!/usr/bin/env python3
+"""Copy the outputs of tools/profile_gpu.sh <tag> (gpurun_out/prof_<tag>/) and an un-profiled bench line
+into profiles/ and regenerate the reading table at the end of profiles/README.md.
+Usage: python tools/update_profiles.py r01 gpurun_out/bench_final.json"""
+import csv, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, bench = sys.argv[1], sys.argv[2]
+src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles")
+for a, b in (("kernel_stats.csv", "render_kernel_stats.csv"), ("kernel_stats_train.csv", "train_kernel_stats.csv"),
+             ("bench_line_under_rocprof.json", "render_bench_line_under_rocprof.json"),
+             ("bench_line_train_under_rocprof.json", "train_bench_line_under_rocprof.json"),
+             ("pmc_summary.csv", "pmc_summary.csv"), ("pmc.json", "pmc.json")):
+    shutil.copy(os.path.join(src, a), os.path.join(dst, f"{tag}_{b}"))
+line = [l for l in open(os.path.join(ROOT, bench)).read().splitlines() if l.startswith('{"metric')][-1]
+open(os.path.join(dst, f"{tag}_bench_line.json"), "w").write(line + "\n")
+
+pm = json.load(open(os.path.join(dst, f"{tag}_pmc.json")))
+d = json.loads(line)
+dr = json.load(open(os.path.join(dst, f"{tag}_render_bench_line_under_rocprof.json")))
+st = {r["Name"]: r for r in csv.DictReader(open(os.path.join(dst, f"{tag}_render_kernel_stats.csv")))}
+fw = next(v for k, v in st.items() if "mlp_fwd_kernel<1, false, 2>" in k)
+avg = float(fw["AverageNs"]) / 1e6
+notes = {
+    "mlp_fwd_kernel": f"headline render kernel; algorithmic HBM ~ 6.1 MB, the 2.4 MB weight blob is fetched once per XCD L2; "
+                      f"rocprofv3 average {avg:.4f} ms over {fw['Calls']} launches vs HIP events {dr['roofline']['avg_launch_ms']:.4f} ms "
+                      f"over the timed ones in the same run; {dr['roofline']['frac']:.3f} of the 157.3 TFLOP/s peak by timing",
+    "mlp_fwd_kernel_train": "exact training forward (fp32 activation rows + one 32-bit ReLU word per lane, layer and point tile written)",
+    "mlp_dgrad_kernel": "dZ rows written",
+    "mlp_fwd_kernel_train_small": "32-point workgroups (the 128-ray launches of the graph region)",
+    "mlp_dgrad_kernel_small": "32-point workgroups",
+    "mlp_wgrad_kernel": "dZ and activations streamed once per layer; includes the low-MFMA embedding and rgb-head jobs",
+    "wgrad_reduce4_kernel": "sums the per-chunk partials",
+    "mlp_fwd_f16_kernel": "opt-in f16x3 render kernel (3 f16 MFMAs per fp32-class product)",
+    "mlp_fwd_f16_kernel_train": "f16x3 training forward, bound by the fp32 activation rows it writes",
+    "mlp_dgrad_f16_kernel": "",
+    "mlp_wgrad_f16_kernel": "HBM-bound (~3 TB/s)",
+    "mlp_fwd_lp_kernel_bf16": "opt-in bf16 render kernel (config 5); a quarter of its LDS cycles are the 2-way conflict of the "
+                              "`ds_write_b64` epilogue (8-byte stores against 16-byte swizzle chunks)",
+    "mlp_fwd_lp_kernel_f16": "same kernel, fp16 operands",
+    "mlp_fwd_lp_kernel_bf16_train": "bf16 training forward: 16-bit activation rows",
+    "mlp_dgrad_lp_kernel_bf16": "16-bit dZ rows",
+    "mlp_fwd_lp_kernel_bf16_train_small": "64-point workgroups (128-ray launches)",
+    "mlp_dgrad_lp_kernel_bf16_small": "64-point workgroups",
+    "mlp_wgrad_lp_kernel_bf16": "HBM-bound by design (1 KB per point-layer); 16-bit rows + fp32 partials",
+}
+rows = []
+for k in notes:
+    if k not in pm:
+        continue
+    v = pm[k]
+    hb = v["hbm_bytes_per_launch"]
+    hbs = f"{hb / 1e9:.2f} GB" if hb >= 1e9 else f"{hb / 1e6:.1f} MB"
+    rows.append(f"| `{k}` | {100 * v['mfma_util']:.1f} % | {hbs} | {100 * v['lds_bank_conflict_frac']:.1f} % | {notes[k]} |")
+table = f"""Round-1 reading (final build of the round; `{tag}_pmc.json`).  Every figure is a MEAN PER LAUNCH over
+all launches of that kernel in the profiled command - the coarse (65,536-point) and fine
+(196,608-point) pass of every 1024-ray step and, for the training kernels, the 128-ray launches of the
+graph region (wgrad; their forward / dgrad run the half-size workgroup variants, listed as `_small`) - so
+the byte counts are not those of one particular launch size.
+
+| kernel | MFMA busy | HBM bytes / launch | LDS conflict cycles | note |
+|---|---|---|---|---|
+""" + "\n".join(rows) + f"""
+
+Un-profiled bench line of the same build (`{tag}_bench_line.json`): {d['value']:.0f} rays/s, {d['ms_per_step']:.3f} ms/step,
+`roofline.achieved` {d['roofline']['achieved']:.1f} TFLOP/s (frac {d['roofline']['frac']:.4f}), CPU baseline {d['cpu_baseline']['value']:.0f} rays/s on {d['cpu_baseline']['cores']} cores.
+"""
+p = os.path.join(dst, "README.md")
+s = open(p).read()
+s = s[:s.index("Round-1 reading")] + table
+open(p, "w").write(s)
+print(table[-400:])
