@@ -62,6 +62,12 @@ the byte counts are not those of one particular launch size.
 |---|---|---|---|---|
 """ + "\n".join(rows) + f"""
 
+Effective clocks (GRBM_GUI_ACTIVE / 8 XCDs / rocprofv3 average duration, same profiled command): the exact
+fp32 kernels run at 2.29-2.35 GHz of the 2.4 GHz the 157.3 TFLOP/s peak assumes (the headline kernel's
+0.888 of peak is 0.92 of what its own clock allows); the 16-bit kernels are power-limited to ~2.05 GHz
+(`mlp_fwd_lp_kernel`) and 1.84 GHz (`mlp_fwd_f16_kernel`), i.e. their fractions of the 2.5 PFLOP/s
+peak understate the pipe utilisation by 15-25 %.
+
 Un-profiled bench line of the same build (`{tag}_bench_line.json`): {d['value']:.0f} rays/s, {d['ms_per_step']:.3f} ms/step,
 `roofline.achieved` {d['roofline']['achieved']:.1f} TFLOP/s (frac {d['roofline']['frac']:.4f}), CPU baseline {d['cpu_baseline']['value']:.0f} rays/s on {d['cpu_baseline']['cores']} cores.
 """
