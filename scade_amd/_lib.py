@@ -110,6 +110,15 @@ def stream():
     return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+def check_current_device(t: torch.Tensor, what: str) -> None:
+    """Kernels are enqueued on the CURRENT device's current stream: a tensor that lives on another
+    GPU of the process would be dereferenced on the wrong device.  Checked once per operator entry."""
+    if t.is_cuda and t.device.index != torch.cuda.current_device():
+        raise RuntimeError(f"{what}: tensor is on {t.device} but the current device is "
+                           f"cuda:{torch.cuda.current_device()}; select it first "
+                           "(torch.cuda.set_device / `with torch.cuda.device(...)`)")
+
+
 def call(name: str, *args) -> None:
     rc = getattr(load(), name)(*args)
     if rc != 0:

@@ -11,7 +11,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import call, check, ptr, stream
+from ._lib import call, check, check_current_device, ptr, stream
 
 Tensor = torch.Tensor
 

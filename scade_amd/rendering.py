@@ -179,6 +179,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     if not use_viewdirs:
         raise NotImplementedError("render_rays: SCADE always renders with use_viewdirs=True")
     ops.check(ray_batch, "render_rays: ray_batch")
+    ops.check_current_device(ray_batch, "render_rays: ray_batch")
     if ray_batch.dim() != 2 or ray_batch.shape[1] < 11:
         raise ValueError("render_rays: ray_batch must be [N, >=11] = o,d,near,far,viewdir")
     rays = ray_batch if ray_batch.stride(1) == 1 else ray_batch.contiguous()

@@ -256,6 +256,7 @@ class NeRF(nn.Module):
         """x [P, 60] = [gamma(pts) | viewdir] -> [P,4] (helpers:223-247)."""
         from .mlp import MlpEmbeddedFn
         self._require_supported()
+        ops.check_current_device(x, "NeRF.forward: x")
         ps = self.ordered_params()
         train = torch.is_grad_enabled() and any(p.requires_grad for p in ps)
         if self._fast(train):

@@ -441,3 +441,20 @@ def test_mlp_point_tilings_agree(dev):
         net(xs).backward(gs)
         grads.append(torch.cat([p.grad.reshape(-1) for p in net.parameters()]))
     assert rel_l2(grads[0], grads[1]) < 1e-5
+
+
+def test_wrong_current_device_fails_loudly(dev):
+    """Kernels go to the current device's stream; an operator entry given a tensor of ANOTHER device
+    raises instead of dereferencing it on the wrong GPU (one GPU here: checked through the guard)."""
+    from scade_amd._lib import check_current_device
+    t = torch.zeros(4, device=dev)
+    check_current_device(t, "x")                          # same device: fine
+    real = torch.cuda.current_device
+    torch.cuda.current_device = lambda: 3                 # pretend another device is current
+    try:
+        with pytest.raises(RuntimeError, match="current device"):
+            check_current_device(t, "x")
+        with pytest.raises(RuntimeError, match="current device"):
+            S.render_rays(torch.zeros(2, 11, device=dev), True, None, None, 64, N_importance=128)
+    finally:
+        torch.cuda.current_device = real
