@@ -890,7 +890,8 @@ struct Dummy {};
       case 3: hipLaunchKernelGGL(KERN<3>, __VA_ARGS__); break;                               \
       case 4: hipLaunchKernelGGL(KERN<4>, __VA_ARGS__); break;                               \
       case 5: case 6: hipLaunchKernelGGL(KERN<6>, __VA_ARGS__); break;                       \
-      default: hipLaunchKernelGGL(KERN<8>, __VA_ARGS__); break;                              \
+      case 7: case 8: hipLaunchKernelGGL(KERN<8>, __VA_ARGS__); break;                       \
+      default: hipLaunchKernelGGL(KERN<16>, __VA_ARGS__); break;                             \
     }                                                                                        \
   } while (0)
 
@@ -901,7 +902,7 @@ extern "C" int scade_composite_fwd(const float* raw, const float* z_vals, const 
   if (N <= 0) return 0;
   SCADE_REQUIRE(raw && z_vals && rays_d && rgb_map && disp_map && acc_map && weights && depth_map, -1,
                 "scade_composite_fwd: null pointer");
-  SCADE_REQUIRE(S >= 1 && S <= 512, -2, "scade_composite_fwd: S=%d outside [1,512]", S);
+  SCADE_REQUIRE(S >= 1 && S <= 1024, -2, "scade_composite_fwd: S=%d outside [1,1024]", S);
   CompositeArgs a{};
   a.raw = raw; a.z = z_vals; a.rays_d = rays_d; a.noise = noise; a.rgb_map = rgb_map;
   a.disp_map = disp_map; a.acc_map = acc_map; a.weights = weights; a.depth_map = depth_map;
@@ -917,7 +918,7 @@ extern "C" int scade_composite_bwd(const float* raw, const float* z_vals, const 
                                    void* stream) {
   if (N <= 0) return 0;
   SCADE_REQUIRE(raw && z_vals && rays_d && g_raw, -1, "scade_composite_bwd: null pointer");
-  SCADE_REQUIRE(S >= 1 && S <= 512, -2, "scade_composite_bwd: S=%d outside [1,512]", S);
+  SCADE_REQUIRE(S >= 1 && S <= 1024, -2, "scade_composite_bwd: S=%d outside [1,1024]", S);
   CompositeArgs a{};
   a.raw = raw; a.z = z_vals; a.rays_d = rays_d; a.noise = noise;
   a.g_rgb = g_rgb; a.g_disp = g_disp; a.g_acc = g_acc; a.g_w = g_weights; a.g_depth = g_depth;

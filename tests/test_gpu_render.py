@@ -4,6 +4,7 @@ import pytest
 import torch
 
 import scade_amd as S
+from scade_amd import ops
 from conftest import assert_close, load_golden, rel_l2
 from oracle import scade_oracle as O
 from test_oracle_golden import f6_params
@@ -118,6 +119,57 @@ def test_render_rays_vs_oracle_seeded(dev):
                             perturb=0., retraw=True)
         check_ret(ret, want, "seeded")
         stagewise(dev, want, rays, fine, query, want["u"])
+
+
+@pytest.mark.parametrize("ns,ni", [(16, 32), (48, 200), (100, 37), (200, 320)])
+def test_render_rays_other_sample_counts_vs_oracle(dev, ns, ni):
+    """N_samples / N_importance other than SCADE's 64 / 128 (rows that are not multiples of the wave,
+    the register sort at 64 / 256 / 512 keys, and (200, 320): a merged row of 520 keys, beyond the fused
+    tail kernel, through the separate operators), jittered, with lindisp on one case.  Coarse stage:
+    element-wise on identical inputs.  Every later stage: element-wise on the ORACLE's intermediates
+    (the resampling is ill-conditioned - one flipped cdf bin moves a sample by a bin width - so the
+    end-to-end tensors are only held to a PSNR / loose norm bar, as in check_ret)."""
+    N = 24
+    rays = O.synthetic_rays(N, seed=30 + ns)
+    pc, pf = O.nerf_init(5), O.nerf_init(6)
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+    g = torch.Generator().manual_seed(ns * 1000 + ni)
+    t_rand, uc, uf = torch.rand(N, ns, generator=g), torch.rand(N, ni, generator=g), torch.rand(N, ni, generator=g)
+    lindisp = ns == 48
+    with torch.no_grad():
+        want = O.render_rays(rays, pc, pf, bbc, bbs, n_samples=ns, n_importance=ni, t_rand=t_rand,
+                             u_coarse=uc, u_fine=uf, lindisp=lindisp, retraw=True)
+    coarse, fine, query = build(dev, pc, pf, bbc, bbs)
+    rd = rays.to(dev)
+    with torch.no_grad():
+        ret = S.render_rays(rd, True, coarse, query, ns, N_importance=ni, network_fine=fine,
+                            perturb=1., lindisp=lindisp, t_rand=t_rand.to(dev), u_coarse=uc.to(dev),
+                            cached_u=uf.to(dev))
+        assert ret["z_vals"].shape == (N, ns + ni) and ret["pred_hyp"].shape == (N, ni)
+        for k in ("rgb0", "depth0", "weights0", "z_vals0"):
+            assert_close(ret[k], want[k], rtol=1e-4, atol=2e-6, what=k)
+        # coarse tail on the oracle's coarse weights: merged z (and its points) element-wise
+        z0, w0 = want["z_vals0"].to(dev), want["weights0"].to(dev)
+        smp = S.sample_pdf_return_u(.5 * (z0[..., 1:] + z0[..., :-1]), w0[..., 1:-1], ni, load_u=uc.to(dev))[0]
+        zm, _ = ops.merge_sorted(z0, smp, rd)
+        assert_close(zm, want["z_vals"], rtol=1e-4, atol=1e-5, what="z_vals | ref coarse weights")
+        # fine stage on the oracle's z_vals / raw / weights
+        z = want["z_vals"].to(dev)
+        pts = rd[:, None, 0:3] + rd[:, None, 3:6] * z[..., None]
+        raw = query(pts, rd[:, 8:11], torch.empty(0, device=dev), fine)
+        assert_close(raw, want["raw"], rtol=1e-4, atol=2e-5, what="fine raw | ref z_vals")
+        if ops.ray_tail_supported(ns + ni, ni, merge=False):
+            outs = ops.ray_tail(want["raw"].to(dev), z, rd, None, uf.to(dev), ni, merge=False, want_std=True)
+        else:                                           # 520 samples per ray: the separate operator
+            outs = S.raw2outputs(want["raw"].to(dev), z, rd[:, 3:6])
+        for o, n in zip(outs[:5], ["rgb_map", "disp_map", "acc_map", "weights", "depth_map"]):
+            assert_close(o, want[n], rtol=1e-4, atol=1e-6, what=f"{n} | ref raw")
+        hyp = S.sample_pdf_return_u(.5 * (z[..., 1:] + z[..., :-1]), want["weights"].to(dev)[..., 1:-1], ni,
+                                    load_u=uf.to(dev))[0]
+        assert_close(hyp, want["pred_hyp"], rtol=1e-4, atol=1e-5, what="pred_hyp | ref weights")
+    psnr = -10 * torch.log10(torch.mean((ret["rgb_map"].cpu() - want["rgb_map"]) ** 2) + 1e-30)
+    assert psnr > 60, psnr
+    assert rel_l2(ret["rgb_map"], want["rgb_map"]) < 1e-3 and rel_l2(ret["depth_map"], want["depth_map"]) < 1e-3
 
 
 def test_render_rays_full_size_properties(dev):
