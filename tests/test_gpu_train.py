@@ -404,3 +404,39 @@ def test_graphed_trainer_captures_the_rccl_allreduce(dev):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("ns,ni", [(16, 32), (200, 320)])
+def test_train_step_other_sample_counts_vs_oracle_autograd(dev, ns, ni):
+    """Forward + backward of the three-term loss at sample counts other than 64 / 128 (compositing at 1
+    and 9 wave-chunks per ray, the fused and the separate per-ray tails) against autograd through the
+    oracle: loss to 1e-4; coarse-net gradients - identical inputs all the way - to 1e-3 norm-wise;
+    fine-net gradients behind the resampling norm-wise like test_train_step_golden."""
+    N, K = 24, 5
+    rays = O.synthetic_rays(N, seed=70 + ns)
+    g = torch.Generator().manual_seed(ns + ni)
+    t_rand, uc, uf = torch.rand(N, ns, generator=g), torch.rand(N, ni, generator=g), torch.rand(N, ni, generator=g)
+    tgt = torch.rand(N, 3, generator=g)
+    hyp = torch.rand(K, N, 1, generator=g) * 4.9 + 0.1
+    pc = {k: v.clone().requires_grad_(True) for k, v in O.nerf_init(7).items()}
+    pf = {k: v.clone().requires_grad_(True) for k, v in O.nerf_init(8).items()}
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+    w = O.render_rays(rays, pc, pf, bbc, bbs, n_samples=ns, n_importance=ni, t_rand=t_rand, u_coarse=uc, u_fine=uf)
+    want = O.img2mse(w["rgb_map"], tgt) + 0.007 * O.compute_space_carving_loss(w["pred_hyp"], hyp) \
+        + O.img2mse(w["rgb0"], tgt)
+    want.backward()
+    coarse, fine, query = build(dev, {k: v.detach() for k, v in pc.items()}, {k: v.detach() for k, v in pf.items()},
+                                bbc, bbs)
+    r = S.render_rays(rays.to(dev), True, coarse, query, ns, N_importance=ni, network_fine=fine, perturb=1.,
+                      t_rand=t_rand.to(dev), u_coarse=uc.to(dev), cached_u=uf.to(dev))
+    loss = S.img2mse(r["rgb_map"], tgt.to(dev)) + 0.007 * S.compute_space_carving_loss(r["pred_hyp"], hyp.to(dev)) \
+        + S.img2mse(r["rgb0"], tgt.to(dev))
+    loss.backward()
+    assert_close(loss, want.detach(), rtol=2e-4, atol=1e-7, what="loss")
+    cat = lambda ps: torch.cat([p.grad.reshape(-1).cpu() for p in ps])
+    gc, gf = cat(coarse.parameters()), cat(fine.parameters())
+    wc = torch.cat([pc[k].grad.reshape(-1) for k, _ in coarse.named_parameters()])
+    wf = torch.cat([pf[k].grad.reshape(-1) for k, _ in fine.named_parameters()])
+    assert torch.isfinite(gc).all() and torch.isfinite(gf).all()
+    assert rel_l2(gc, wc) < 1e-3, rel_l2(gc, wc)
+    assert rel_l2(gf, wf) < 5e-2, rel_l2(gf, wf)
