@@ -313,6 +313,7 @@ constexpr int WL_PITCH = 288;                      // elements per LDS row: 256 
                                                    // rows of a transposing read land 16 banks apart)
 constexpr int WL_TILE = WL_PT * WL_PITCH;          // elements per operand tile
 constexpr int WL_STAGE = 2 * WL_TILE;              // dZ tile + input tile
+constexpr int LP_CHUNK_PTS = 3500;   // mlp_wgrad.h pick_chunks: fewer, longer chunks (fp32 partial traffic)
 constexpr int WGRAD_LP_LDS_BYTES = 3 * WL_STAGE * 2;   // triple buffered: 110592
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -581,7 +582,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs a) {
 static int build_wgrad_lp_jobs(WgradLpArgs& w, int P) {
   int off[N_PARAM_TENSORS + 1];
   param_offsets(off);
-  const int nchunks = pick_chunks(P);
+  const int nchunks = pick_chunks(P, LP_CHUNK_PTS);
   int chunk = (P + nchunks - 1) / nchunks;
   chunk = (chunk + WL_PT - 1) / WL_PT * WL_PT;
   w.chunk = chunk;
@@ -616,7 +617,7 @@ using namespace scade;
 extern "C" long scade_mlp_packed_t_lp_bytes(void) { return PACKED_T_LP_BYTES; }
 
 extern "C" long scade_mlp_bwd_lp_workspace_bytes(int P) {
-  return lp_dz_bytes(P) + (long)pick_chunks(P) * N_PARAM_FLOATS * 4 + 256;
+  return lp_dz_bytes(P) + (long)pick_chunks(P, LP_CHUNK_PTS) * N_PARAM_FLOATS * 4 + 256;
 }
 
 extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp, int bf16, void* stream) {
@@ -650,7 +651,7 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   }
   unsigned char* dz = ws;
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
-  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)pick_chunks(P) * N_PARAM_FLOATS);
+  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)pick_chunks(P, LP_CHUNK_PTS) * N_PARAM_FLOATS);
   hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
   SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
   const long ng = 4L * P;

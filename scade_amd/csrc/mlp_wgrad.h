@@ -59,10 +59,12 @@ inline void param_offsets(int off[N_PARAM_TENSORS + 1]) {
 // for the fine pass of a 1024-ray batch, 28 for the coarse pass), never shorter than 512 points.
 // Measured against the former fixed 1536-point chunks: neutral for the MFMA-bound exact kernel
 // (the small jobs fill the tail either way), -4 % for the HBM-bound 16-bit kernel, whose fp32
-// per-chunk partials are a fifth of its traffic.
-inline int pick_chunks(int P) {
+// per-chunk partials are a fifth of its traffic - which is why that kernel asks for longer chunks still
+// (target_pts = LP_CHUNK_PTS = 3500: 56 chunks instead of 85 for the fine pass, bf16 train step -2.5 %;
+// the same choice costs the exact kernel 0.5 %).
+inline int pick_chunks(int P, int target_pts = 2400) {
   const int ncu = device_cus();
-  long k = (9L * P + (long)ncu * 2400 - 1) / ((long)ncu * 2400);
+  long k = (9L * P + (long)ncu * target_pts - 1) / ((long)ncu * target_pts);
   if (k < 1) k = 1;
   long n = ncu * k / 9;
   const long nmax = P / 512 > 1 ? P / 512 : 1;
