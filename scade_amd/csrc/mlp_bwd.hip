@@ -243,7 +243,7 @@ __device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJo
       const int i = tid + 512 * j, row = i >> 6, c4 = i & 63;
       const int pt = pt0 + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pt < c1) v = *reinterpret_cast<const f32x4*>(dzm + (size_t)pt * 256 + c4 * 4);
+      if (pt < c1) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dzm + (size_t)pt * 256 + c4 * 4));   // read once
       pa[j] = v;
     }
 #pragma unroll
@@ -252,7 +252,7 @@ __device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJo
       const int row = KW == 256 ? (i >> 6) : (i >> 4), c4 = KW == 256 ? (i & 63) : (i & 15);
       const int pt = pt0 + row;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pt < c1) v = *reinterpret_cast<const f32x4*>(inm + (size_t)pt * jb.in_stride + c4 * 4);
+      if (pt < c1) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(inm + (size_t)pt * jb.in_stride + c4 * 4));
       pb[j] = v;
     }
   };

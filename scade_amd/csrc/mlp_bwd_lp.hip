@@ -377,11 +377,11 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLp
   const bool want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
   auto issue = [&](WStage<BF>& s, int pt0) {
     const int pa = min(pt0 + rr, P - 1), pb = min(pt0 + rr + 16, P - 1);
-    s.a0 = *reinterpret_cast<const V8*>(dzm + (size_t)pa * 256 + 8 * cc);
-    s.a1 = *reinterpret_cast<const V8*>(dzm + (size_t)pb * 256 + 8 * cc);
+    s.a0 = __builtin_nontemporal_load(reinterpret_cast<const V8*>(dzm + (size_t)pa * 256 + 8 * cc));   // read once
+    s.a1 = __builtin_nontemporal_load(reinterpret_cast<const V8*>(dzm + (size_t)pb * 256 + 8 * cc));
     if (KW == 256) {
-      s.b0 = *reinterpret_cast<const V8*>(inm + (size_t)pa * 256 + 8 * cc);
-      s.b1 = *reinterpret_cast<const V8*>(inm + (size_t)pb * 256 + 8 * cc);
+      s.b0 = __builtin_nontemporal_load(reinterpret_cast<const V8*>(inm + (size_t)pa * 256 + 8 * cc));
+      s.b1 = __builtin_nontemporal_load(reinterpret_cast<const V8*>(inm + (size_t)pb * 256 + 8 * cc));
       s.d0 = dalp[want_alpha ? pa : 0];
       s.d1 = dalp[want_alpha ? pb : 0];
     } else {

@@ -101,9 +101,9 @@ __device__ __forceinline__ void save_tile(const float* hbuf, float* __restrict__
   const int chunks_per_row = ncols >> 2;
   for (int i = tid; i < tm * chunks_per_row; i += 256) {
     const int row = i / chunks_per_row, c = i - row * chunks_per_row;
-    if (p0 + row < P)
-      *reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c) =
-          *reinterpret_cast<const f32x4*>(hbuf + h_idx(row, c));
+    if (p0 + row < P)   // streamed once, read by a later kernel: non-temporal
+      __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(hbuf + h_idx(row, c)),
+                                  reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c));
   }
 }
 

@@ -181,8 +181,8 @@ __device__ __forceinline__ void save_tile_h(const _Float16* xh, const _Float16* 
         o1[j] = ((float)vh[4 + j] + (float)vl[4 + j] * LINV) * sc;
       }
       float* o = dst + (size_t)(p0 + row) * W + 8 * c;
-      *reinterpret_cast<f32x4*>(o) = o0;
-      *reinterpret_cast<f32x4*>(o + 4) = o1;
+      __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(o));       // streamed once: non-temporal
+      __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(o + 4));
     }
   }
 }

@@ -101,7 +101,7 @@ __device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typena
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[j][e] = (T)((float)v[j][e] * f[j]);
       }
-      if (p0 + row < P) *reinterpret_cast<V8*>(dst + (size_t)(p0 + row) * W + 8 * c) = v[j];
+      if (p0 + row < P) __builtin_nontemporal_store(v[j], reinterpret_cast<V8*>(dst + (size_t)(p0 + row) * W + 8 * c));
     }
   }
 }
