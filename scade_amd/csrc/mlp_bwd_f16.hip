@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   _Float16* gl = ldsh + XPLANE;
   float* dal = reinterpret_cast<float*>(ldsh + 2 * XPLANE);   // [64] d alpha_pre * scale
   float* inv_s = dal + 64;                                    // [64] 1/scale of the point
+  float* wmx = inv_s + 64;                                    // [4] per-wave max |g_out|
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,11 +143,12 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
       dal[row] = da * s;
       inv_s[row] = 1.f / s;
     }
-    {   // launch-wide max for the weight-gradient kernel's dZ scale: one atomic per wave
+    {   // launch-wide max for the weight-gradient kernel's dZ scale: one atomic per WORKGROUP (after the
+        // barrier below; 12,000 per-wave atomics on one address were a serial tail of the launch)
       float wm = (m < 3.0e38f) ? m : 0.f;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) wm = fmaxf(wm, __shfl_xor(wm, o, 64));
-      if (lane == 0 && wm > 0.f) atomicMax(a.gmax, __float_as_uint(wm));
+      if (lane == 0) wmx[wave] = wm;
     }
     const float* wr = pk + OFF_WR;
     const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
@@ -176,6 +178,10 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
     }
   }
   __syncthreads();
+  if (tid == 0) {
+    const float wm = fmaxf(fmaxf(wmx[0], wmx[1]), fmaxf(wmx[2], wmx[3]));
+    if (wm > 0.f) atomicMax(a.gmax, __float_as_uint(wm));
+  }
 
   f32x16 acc0[2][2], acc1[2][2];
   AFrag an;
@@ -222,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
 #undef WT16
 }
 
-constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4;
+constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4 + 16;   // + the four waves' gradient maxima
 
 // ---------------------------------------------------------------------------
 // B2': split-precision weight gradient.  dW[n][k] = sum_points dZ[p][n] * In[p][k] contracts
