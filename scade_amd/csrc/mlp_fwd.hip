@@ -128,18 +128,23 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
   }
   __syncthreads();
-  if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0   (coalesced 256-B rows)
+  if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0   (coalesced 256-B rows, 16-byte chunks)
     float* eo = a.acts + acts_emb_off(P);
-    for (int i = tid; i < TM * 64; i += 256) {
-      const int row = i >> 6, c = i & 63;
+    for (int i = tid; i < TM * 16; i += 256) {
+      const int row = i >> 4, c4 = i & 15;
       const int pt = p0 + row;
       if (pt < P) {
-        float v = 0.f;
-        if (c < EMB) v = ebuf[row * EMB_STRIDE + c];
-        else if (c >= 60 && c < 63)
-          v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + (c - 60)]
-                        : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + (c - 60)];
-        eo[(size_t)pt * 64 + c] = v;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c4 < 15) {
+          v = *reinterpret_cast<const f32x4*>(ebuf + row * EMB_STRIDE + 4 * c4);
+          if (c4 == 14) { v[1] = 0.f; v[2] = 0.f; v[3] = 0.f; }       // tile columns 57..59: padding / view dir
+        } else {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            v[c] = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c]
+                             : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(eo + (size_t)pt * 64 + 4 * c4));
       }
     }
   }

@@ -135,18 +135,20 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
   __syncthreads();
   T* actsT = reinterpret_cast<T*>(a.acts);
-  if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0
+  if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0 - one 16-byte chunk per item
     T* eo = actsT + acts_emb_off(P);
-    for (int i = tid; i < LM * 64; i += 256) {
-      const int row = i >> 6, c = i & 63;
+    for (int i = tid; i < LM * 8; i += 256) {
+      const int row = i >> 3, ch = i & 7;
       const int pt = p0 + row;
       if (pt < P) {
-        T v = (T)0.f;
-        if (c < EMB) v = e[e_idx(row, c >> 3) + (c & 7)];
-        else if (c >= 60 && c < 63)
-          v = (T)(MODE == 0 ? a.in[(size_t)pt * 60 + 57 + (c - 60)]
-                            : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + (c - 60)]);
-        eo[(size_t)pt * 64 + c] = v;
+        V8 v = *reinterpret_cast<const V8*>(e + e_idx(row, ch));   // columns 57..63 of the tile are zero
+        if (ch == 7) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c)
+            v[4 + c] = (T)(MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c]
+                                     : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c]);
+        }
+        __builtin_nontemporal_store(v, reinterpret_cast<V8*>(eo + (size_t)pt * 64 + 8 * ch));
       }
     }
   }
