@@ -2,7 +2,7 @@
 """Copy the outputs of tools/profile_gpu.sh <tag> (gpurun_out/prof_<tag>/) and an un-profiled bench line
 into profiles/ and regenerate the reading table at the end of profiles/README.md.
 Usage: python tools/update_profiles.py r01 gpurun_out/bench_final.json"""
-import csv, json, os, shutil, sys
+import csv, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, bench = sys.argv[1], sys.argv[2]
@@ -74,5 +74,9 @@ Un-profiled bench line of the same build (`{tag}_bench_line.json`): {d['value']:
 p = os.path.join(dst, "README.md")
 s = open(p).read()
 s = s[:s.index("Round-1 reading")] + table
+ev = dr["roofline"]["avg_launch_ms"]
+s = re.sub(r"average \*\*[\d.]+ ms\*\*, [\d.]+ % of GPU time", f"average **{avg:.4f} ms**, {float(fw['Percentage']):.1f} % of GPU time", s)
+s = re.sub(r"over the 40 timed launches: \*\*[\d.]+ ms\*\* \(agrees within [\d.]+ %",
+           f"over the 40 timed launches: **{ev:.4f} ms** (agrees within {abs(avg / ev - 1) * 100:.1f} %", s)
 open(p, "w").write(s)
 print(table[-400:])
