@@ -2,9 +2,9 @@
 """Headline benchmark: rays/s of the SCADE per-ray render path (64 coarse + 128 fine
 samples) on N MI355X, one process per GPU.
 
-  python bench.py --gpus 1 --steps 20 --warmup 3
+  python bench.py --gpus N --steps 20 --warmup 3        (N > 1: spawns its own N ranks, one per GPU)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W
+         --master-port P bench.py --gpus N --steps K --warmup W      (the same ranks, launched for it)
 
 A "step" is one render_rays pass (run_scade_scannet.py:581-751, perturb=0, no_grad; the
 test-render configuration BASELINE.json quotes the metric on) over a batch of 1024
@@ -15,7 +15,10 @@ Prints ONE JSON line on rank 0.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
+import threading
 import time
 
 import torch
@@ -24,6 +27,8 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 chip peak
+LP_MFMA_PEAK_TFLOPS = 2500.0           # dense bf16 / f16 MFMA peak
+HBM_PEAK_GBS = 8000.0                  # HBM3E
 FLOP_PER_POINT = 2 * 587264            # SURVEY.md section 8(d), unpadded
 N_COARSE, N_FINE = 64, 128
 
@@ -39,7 +44,31 @@ def parse():
     ap.add_argument("--no-fast", action="store_true", help="skip the secondary split-precision (f16x3) measurement")
     ap.add_argument("--no-image", action="store_true", help="skip the secondary 16-chunk image-render measurement")
     ap.add_argument("--hyp", type=int, default=20, help="depth hypotheses per ray (train step)")
+    ap.add_argument("--no-rayops", action="store_true", help="skip the per-ray kernels' GB/s table")
+    ap.add_argument("--secondary-budget", type=float, default=420.0,
+                    help="seconds the secondary regions may take in total before the line is printed without the rest")
     return ap.parse_args()
+
+
+def spawn_ranks(args):
+    """`python bench.py --gpus N` as a plain command: re-exec as N ranks (one process per GPU) through
+    torch.distributed.run on 127.0.0.1 - the launch line the driver itself uses.  Rank 0 of the child
+    job prints the JSON line on the inherited stdout."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} HIP device(s)")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // max(1, args.gpus))))
+    env["SCADE_BENCH_SPAWNED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
 
 
 def make_nets(dev):
@@ -65,11 +94,13 @@ def host_cores():
     return max(1, n)
 
 
-def cpu_baseline(pc, pf, n_rays):
+def cpu_baseline(pc, pf, n_rays, n_hyp):
     """The reference path (CPU restatement, verified bit-exact against the imported
-    reference) timed on this box's host cores: render_rays forward, no_grad, perturb=0.
-    Bounded: a 128-ray probe picks the best thread count among a few candidates, then
-    the 1024-ray batch is timed (best of <= 3) within a ~30 s budget."""
+    reference) timed on this box's host cores: (i) render_rays forward,
+    no_grad, perturb=0 - the headline's workload; (ii) the train step - render_rays(perturb=1) +
+    3-term loss with K hypotheses + backward through autograd.  Bounded: a 128-ray probe picks the
+    best thread count among a few candidates, then the 1024-ray batch is timed, 1 warm-up + best of
+    <= 5, each leg inside its own ~20 s budget."""
     from oracle import scade_oracle as O
     avail = host_cores()
     bbc, bbs = torch.zeros(3), torch.tensor(0.2)
@@ -87,20 +118,50 @@ def cpu_baseline(pc, pf, n_rays):
                 best_thr, best_rate = c, r
         torch.set_num_threads(best_thr)
         rays = O.synthetic_rays(n_rays, seed=0)
-        best = float("inf")
-        deadline = time.time() + 25.0
+        best, runs = float("inf"), 0
+        deadline = time.time() + 20.0
         O.render_rays(rays, pc, pf, bbc, bbs)                  # warm-up
-        for _ in range(3):
+        for _ in range(5):
             t0 = time.perf_counter()
             O.render_rays(rays, pc, pf, bbc, bbs)
             best = min(best, time.perf_counter() - t0)
+            runs += 1
             if time.time() > deadline:
                 break
+    # train step: forward with jitter + loss + backward (the optimizer update is negligible beside it)
+    g = torch.Generator().manual_seed(1)
+    tgt = torch.rand(n_rays, 3, generator=g)
+    hyp = torch.rand(n_hyp, n_rays, 1, generator=g) * 4.9 + 0.1
+    t_rand = torch.rand(n_rays, N_COARSE, generator=g)
+    u1, u2 = torch.rand(n_rays, N_FINE, generator=g), torch.rand(n_rays, N_FINE, generator=g)
+    qc = {k: v.clone().requires_grad_(True) for k, v in pc.items()}
+    qf = {k: v.clone().requires_grad_(True) for k, v in pf.items()}
+
+    def train_once():
+        for q in (qc, qf):
+            for v in q.values():
+                v.grad = None
+        ret = O.render_rays(rays, qc, qf, bbc, bbs, t_rand=t_rand, u_coarse=u1, u_fine=u2)
+        O.train_loss(ret, tgt, hyp)[0].backward()
+
+    train_once()                                               # warm-up
+    tbest, truns = float("inf"), 0
+    deadline = time.time() + 20.0
+    for _ in range(5):
+        t0 = time.perf_counter()
+        train_once()
+        tbest = min(tbest, time.perf_counter() - t0)
+        truns += 1
+        if time.time() > deadline:
+            break
     return {"value": n_rays / best, "unit": "rays/s", "cores": best_thr, "kind": "port",
             "host_cores_available": avail,
             "sample": f"render_rays forward (no_grad, perturb=0) on {n_rays} synthetic rays x (64+128) "
-                      f"samples, best of <=3 after 1 warm-up, torch {torch.__version__} CPU, "
-                      f"{best_thr} threads (best of {cands} on a 128-ray probe)"}
+                      f"samples, best of {runs} after 1 warm-up, torch {torch.__version__} CPU, "
+                      f"{best_thr} threads (best of {cands} on a 128-ray probe)",
+            "train_step": {"value": n_rays / tbest, "unit": "rays/s", "cores": best_thr,
+                           "sample": f"render_rays(perturb=1) + mse + 0.007 carve(K={n_hyp}) + mse0 + backward on "
+                                     f"{n_rays} rays, best of {truns} after 1 warm-up (no optimizer update)"}}
 
 
 F16X3_EFFECTIVE_PEAK_TFLOPS = 2500.0 / 3.0   # dense f16 MFMA peak / 3 MFMAs per fp32-class product
@@ -152,28 +213,45 @@ def fast_region(args, dev, world, barrier, step, coarse, fine, precision="f16x3"
                          "avg_launch_ms": k["ms"] / k["launches"]}}
 
 
-def train_region(args, dev, world, rank, barrier, precision="f32"):
+TRAIN_PEAKS = {"f32": (FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"), "f16x3": (F16X3_EFFECTIVE_PEAK_TFLOPS, "f16 MFMA / 3"),
+               "bf16": (LP_MFMA_PEAK_TFLOPS, "bf16 MFMA"), "f16": (LP_MFMA_PEAK_TFLOPS, "f16 MFMA")}
+
+
+def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=None, allreduce="single",
+                 graphed=False, scaling="weak"):
     """Secondary measurement (BASELINE.json configs[2]/[3]): full train step = render_rays
-    (perturb=1) + mse + 0.007*space-carving(K hypotheses) + mse0, backward, ONE RCCL
-    all-reduce of the flat gradient bucket (world > 1), fused Adam.  1024 rays per GPU."""
+    (perturb=1) + mse + 0.007*space-carving(K hypotheses) + mse0, backward, the RCCL sum-all-reduce of
+    the ONE flat gradient bucket (world > 1; "overlap": in two pieces, the coarse network's behind the
+    coarse backward chain), fused Adam.  ``rays_per_gpu`` rays on every rank; ``graphed``: the whole
+    step (collective included) replayed as one HIP graph."""
     import torch.distributed as dist
     from scade_amd import ops
+    from scade_amd.graphs import GraphedTrainer
     from scade_amd.train import Trainer, make_scade_nets
     from scade_amd.synthetic import synthetic_rays
+    n = rays_per_gpu or args.rays
     coarse, fine = make_scade_nets(dev, seed=0)
-    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
-    rays = synthetic_rays(args.rays, seed=2000 + rank).to(dev)
+    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision,
+                 allreduce=allreduce)
+    tr.force_allreduce = dist.is_initialized() and world == 1      # one-rank RCCL self-test of the exchange
+    rays = synthetic_rays(n, seed=2000 + rank).to(dev)
     g = torch.Generator(device="cpu").manual_seed(3000 + rank)
-    tgt = torch.rand(args.rays, 3, generator=g).to(dev)
-    hyp = (torch.rand(args.hyp, args.rays, 1, generator=g) * 4.9 + 0.1).to(dev)
-    for _ in range(max(2, args.warmup)):
-        tr.step(rays, tgt, hyp)
+    tgt = torch.rand(n, 3, generator=g).to(dev)
+    hyp = (torch.rand(args.hyp, n, 1, generator=g) * 4.9 + 0.1).to(dev)
+    if graphed:
+        gt = GraphedTrainer(tr, n, args.hyp)
+        one = lambda: gt.step(rays, tgt, hyp)
+    else:
+        one = lambda: tr.step(rays, tgt, hyp)[0]
+    for _ in range(max(3, args.warmup)):
+        one()
     barrier()
     timer = ops.KernelTimer()
-    ops.KERNEL_TIMER = timer
+    if not graphed:
+        ops.KERNEL_TIMER = timer
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, _ = tr.step(rays, tgt, hyp)
+        loss = one()
     barrier()
     elapsed = time.perf_counter() - t0
     ops.KERNEL_TIMER = None
@@ -182,16 +260,100 @@ def train_region(args, dev, world, rank, barrier, precision="f32"):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ks = timer.summary()
-    kb = ks["mlp_bwd"]
-    flops = 3.0 * args.rays * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT   # fwd + dgrad + wgrad
-    return {"value": args.rays * world * args.steps / elapsed, "unit": "rays/s", "precision": precision,
-            "ms_per_step": elapsed / args.steps * 1e3, "rays_per_gpu": args.rays, "hypotheses": args.hyp,
-            "collective": (f"RCCL all-reduce(sum, fp32) of {tr.flat.numel + tr.flat_ss.numel} floats per step"
-                           if world > 1 else "none (1 GPU)"),
-            "whole_step_tflops_per_gpu": flops / (elapsed / args.steps) / 1e12,
-            "whole_step_frac_of_fp32_mfma_peak": flops / (elapsed / args.steps) / 1e12 / FP32_MFMA_PEAK_TFLOPS,
-            "mlp_bwd_tflops": kb["work"] / (kb["ms"] * 1e-3) / 1e12}
+    flops = 3.0 * n * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT   # fwd + dgrad + wgrad
+    peak, peak_name = TRAIN_PEAKS[precision]
+    tfl = flops / (elapsed / args.steps) / 1e12
+    out = {"value": n * world * args.steps / elapsed, "unit": "rays/s", "precision": precision,
+           "ms_per_step": elapsed / args.steps * 1e3, "rays_per_gpu": n, "global_rays": n * world,
+           "scaling": scaling, "hypotheses": args.hyp, "graphed": graphed,
+           "collective": (f"RCCL all-reduce(sum, fp32) of ONE bucket of {tr.bucket.numel} floats per step over "
+                          f"{world} ranks, mode={allreduce}" if world > 1 else "none (1 GPU)"),
+           "rccl_ranks": world if world > 1 else 0,
+           "whole_step_tflops_per_gpu": tfl,
+           "whole_step_frac_of_peak": tfl / peak, "peak": f"{peak:.1f} TFLOP/s ({peak_name})"}
+    if not graphed:
+        kb = timer.summary()["mlp_bwd"]
+        out["mlp_bwd_tflops"] = kb["work"] / (kb["ms"] * 1e-3) / 1e12
+    return out
+
+
+def rayops_region(dev, n_rays=16384, n_hyp=20, iters=20):
+    """The per-ray kernels ("HBM/latency-bound, reported as GB/s vs 8 TB/s") at
+    the 16,384-ray chunk of a full-image render: HIP-event time per launch and ALGORITHMIC bytes = every
+    input tensor read once + every output written once (a stride-0 broadcast input counts once)."""
+    from scade_amd import ops
+    from scade_amd.synthetic import synthetic_rays
+    g = torch.Generator().manual_seed(9)
+    rays = synthetic_rays(n_rays, seed=9).to(dev)
+    S0, Si = N_COARSE, N_FINE
+    S1 = S0 + Si
+    raw0 = torch.randn(n_rays, S0, 4, generator=g).to(dev)
+    raw1 = torch.randn(n_rays, S1, 4, generator=g).to(dev)
+    u = torch.rand(n_rays, Si, generator=g).to(dev)
+    hyp = (torch.rand(n_hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
+    tgt = torch.rand(n_rays, 3, generator=g).to(dev)
+    z0, _ = ops.ray_points(rays, S0, None, False)
+    tail0 = ops.ray_tail(raw0, z0, rays, None, u, Si, merge=True, want_samples=False)
+    z1 = tail0[7]
+    tail1 = ops.ray_tail(raw1, z1, rays, None, u, Si, merge=False, want_std=True)
+    w1, pred = tail1[3], tail1[5]
+    gw = torch.randn(n_rays, S1, generator=g).to(dev)
+    g3, g1 = torch.randn(n_rays, 3, generator=g).to(dev), torch.randn(n_rays, generator=g).to(dev)
+
+    def nbytes(ts):
+        tot = 0
+        for t in ts:
+            if t is None:
+                continue
+            tot += (t.untyped_storage().nbytes() if any(st == 0 for st in t.stride()) and t.numel() > 1
+                    else t.numel() * t.element_size())
+        return tot
+
+    table = {}
+
+    def timed(name, fn, ins):
+        outs = fn()
+        outs = [o for o in (outs if isinstance(outs, (tuple, list)) else [outs]) if torch.is_tensor(o)]
+        for _ in range(3):
+            fn()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) / iters * 1e3
+        by = nbytes(ins) + nbytes(outs)
+        gbs = by / (us * 1e-6) / 1e9
+        table[name] = {"us": round(us, 2), "bytes_per_ray": round(by / n_rays, 1), "GBps": round(gbs, 1),
+                       "frac_of_8TBps": round(gbs / HBM_PEAK_GBS, 4)}
+
+    rows = rays[:, :8]
+    timed("ray_points(S=64)", lambda: ops.ray_points(rays, S0, None, False), [rows])
+    timed("ray_tail coarse: composite+sample_pdf+merge+points (64 -> 192)",
+          lambda: ops.ray_tail(raw0, z0, rays, None, u, Si, merge=True, want_samples=False), [raw0, z0, rows, u])
+    timed("ray_tail fine: composite+sample_pdf+z_std (S=192)",
+          lambda: ops.ray_tail(raw1, z1, rays, None, u, Si, merge=False, want_std=True), [raw1, z1, rows, u])
+    timed("composite_fwd(S=192)", lambda: ops.composite_fwd(raw1, z1, rays[:, 3:6]), [raw1, z1, rays[:, 3:6]])
+    timed("composite_bwd(S=192)", lambda: ops.composite_bwd(raw1, z1, rays[:, 3:6], None, g3, None, None, gw, None),
+          [raw1, z1, rays[:, 3:6], g3, gw])
+    timed("sample_pdf_fwd(M=191,S=128)",
+          lambda: ops.sample_pdf_fwd(z1, w1[:, 1:-1], u, Si, bins_are_mids=True)[0], [z1, w1, u])
+    timed("sample_pdf_bwd(M=191,S=128)", lambda: ops.sample_pdf_bwd(z1, w1[:, 1:-1], u, u, True), [z1, w1, u, u])
+    timed("merge_sorted(64+128)+points", lambda: ops.merge_sorted(z0, pred, rays), [z0, pred, rows])
+    pr = pred.detach().requires_grad_(True)
+    hy = hyp.detach().requires_grad_(True)
+
+    def carve_fb():
+        pr.grad = hy.grad = None
+        ops.CarveFn.apply(pr, hy, None, 0.0, False).backward()
+        return pr.grad, hy.grad
+    with torch.no_grad():
+        timed(f"carve_fwd(K={n_hyp},P=128)", lambda: ops.CarveFn.apply(pred, hyp, None, 0.0, False), [pred, hyp])
+    timed(f"carve fwd+bwd (K={n_hyp},P=128, 2 launches + autograd)", carve_fb, [pred, hyp, pred, hyp])
+    with torch.no_grad():
+        timed("mse_fwd", lambda: ops.MseFn.apply(g3, tgt, None), [g3, tgt])
+    return {"rays": n_rays, "note": "algorithmic bytes / HIP-event time per launch; peak 8 TB/s", "kernels": table}
 
 
 def graph_region(args, dev, n_rays, precision):
@@ -231,14 +393,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
     assert torch.cuda.is_available(), "bench.py needs an MI355X"
+    if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or os.environ.get("SCADE_BENCH_FORCE_SPAWN") == "1"):
+        spawn_ranks(args)                       # does not return
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("SCADE_BENCH_FORCE_DIST") == "1"   # the latter: 1-GPU RCCL self-test
+    # a one-rank RCCL group is the 1-GPU self-test of the collective path (SCADE_BENCH_FORCE_SPAWN=1
+    # re-execs through torch.distributed.run first, SCADE_BENCH_FORCE_DIST=1 stays in this process)
+    use_dist = world > 1 or os.environ.get("SCADE_BENCH_FORCE_DIST") == "1" or \
+        os.environ.get("SCADE_BENCH_SPAWNED") == "1"
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -324,7 +489,10 @@ def main():
                      "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
                      "traffic_unit": "HBM bytes per launch (2*FETCH_SIZE+WRITE_SIZE, rocprofv3 --pmc)",
-                     "traffic_source": traffic_src, "mfma_util_pmc": pmc_util,
+                     "traffic_source": (f"static: read from the committed profiles/{traffic_src} (separate rocprofv3 "
+                                        "--pmc passes of this command), not measured in this run"
+                                        if traffic_src else None),
+                     "mfma_util_pmc": pmc_util,
                      "launches_timed": k["launches"], "avg_launch_ms": avg_ms,
                      "flops_per_launch": flops_per_launch,
                      "note": "algorithmic 1,174,528 FLOP/point x mean points per launch "
@@ -370,45 +538,88 @@ def main():
             finally:
                 coarse.inference_precision = fine.inference_precision = "f32"
         out["full_image_468x624"] = full
-    # exact fp32 regions first, the opt-in reduced-precision regions after them (the 16-bit bursts
-    # leave the chip in a different power state for a few milliseconds)
+    # ---- secondary regions.  They never cost the headline: a failure is recorded in its place, and a
+    # watchdog prints the line with what has been measured if they overrun their budget (a hung
+    # collective must not turn a measured headline into an empty record).
+    state = {"region": None, "done": False}
+    deadline = time.time() + args.secondary_budget
+
+    def emit():
+        sys.stdout.flush()
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)      # RCCL's banner goes through C stdio: flush it out first
+        except Exception:
+            pass
+        if rank == 0:
+            print(json.dumps(out), flush=True)   # the JSON line is the LAST line of stdout
+
+    def watchdog():
+        while not state["done"]:
+            time.sleep(1.0)
+            if time.time() > deadline and not state["done"]:
+                out["watchdog"] = (f"secondary regions exceeded {args.secondary_budget:.0f} s in "
+                                   f"{state['region']!r}; line printed without the rest")
+                emit()
+                os._exit(0)
+
+    threading.Thread(target=watchdog, daemon=True).start()
+
     def guarded(key, fn, *a, **k):
-        """secondary regions never cost the headline line: a failure is recorded in its place"""
+        state["region"] = key
         try:
             out[key] = fn(*a, **k)
         except Exception as exc:   # noqa: BLE001 - reported, not swallowed
             out[key] = {"error": f"{type(exc).__name__}: {exc}"}
             print(f"bench.py: secondary region {key} failed: {exc!r}", file=sys.stderr)
 
+    # exact fp32 regions first, the opt-in reduced-precision regions after them (the 16-bit bursts
+    # leave the chip in a different power state for a few milliseconds)
+    tr_args = (args, dev, world, rank, barrier)
     if not args.no_train:
-        guarded("train_step", train_region, args, dev, world, rank, barrier)
+        guarded("train_step", train_region, *tr_args)
+        if use_dist:
+            guarded("train_step_overlap", train_region, *tr_args, allreduce="overlap")
+        if world > 1 and args.rays % world == 0:
+            # BASELINE.json configs[3]: ONE 1024-ray batch sharded over the ranks, step replayed as a graph
+            guarded("train_step_strong_graph", train_region, *tr_args, rays_per_gpu=args.rays // world,
+                    graphed=True, scaling="strong")
+    if not args.no_rayops and rank == 0:
+        guarded("per_ray_kernels_16384", rayops_region, dev, 16384, args.hyp)
+    if use_dist:
+        barrier()
     if not args.no_fast:
         for prec in ("f16x3", "bf16", "f16"):
             guarded("fast_path_" + prec, fast_region, args, dev, world, barrier, step, coarse, fine, prec)
         if not args.no_train:
             # forward + dgrad + wgrad on the split-precision kernels
-            guarded("train_step_f16x3", train_region, args, dev, world, rank, barrier, precision="f16x3")
+            guarded("train_step_f16x3", train_region, *tr_args, precision="f16x3")
             # mixed precision (BASELINE config 5's bf16 MFMA path): 16-bit forward, dgrad and wgrad
-            guarded("train_step_bf16", train_region, args, dev, world, rank, barrier, precision="bf16")
+            guarded("train_step_bf16", train_region, *tr_args, precision="bf16")
+            if use_dist:
+                guarded("train_step_bf16_overlap", train_region, *tr_args, precision="bf16", allreduce="overlap")
+                guarded("train_step_bf16_graph", train_region, *tr_args, precision="bf16", graphed=True)
+            if world > 1 and args.rays % world == 0:
+                guarded("train_step_bf16_strong_graph", train_region, *tr_args, precision="bf16",
+                        rays_per_gpu=args.rays // world, graphed=True, scaling="strong")
             if world == 1:
                 guarded("train_step_graph", lambda: [graph_region(args, dev, 128, "f32"),
                                                      graph_region(args, dev, 128, "bf16"),
                                                      graph_region(args, dev, args.rays, "bf16")])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(pc, pf, 1024)
+        state["region"] = "cpu_baseline"
+        out["cpu_baseline"] = cpu_baseline(pc, pf, 1024, args.hyp)
         out["gpu_over_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        if isinstance(out.get("train_step"), dict) and "value" in out["train_step"]:
+            out["gpu_over_cpu_train_step"] = out["train_step"]["value"] / out["cpu_baseline"]["train_step"]["value"]
     if use_dist:
+        out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
+                       "version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+        state["region"] = "destroy_process_group"
+        barrier()
         dist.destroy_process_group()
-    # the JSON line is the LAST line of stdout: RCCL prints its version banner through C stdio, which
-    # a pipe buffers until exit - flush it out first
-    sys.stdout.flush()
-    try:
-        import ctypes
-        ctypes.CDLL(None).fflush(None)
-    except Exception:
-        pass
-    if rank == 0:
-        print(json.dumps(out), flush=True)
+    state["done"] = True
+    emit()
 
 
 if __name__ == "__main__":

@@ -20,6 +20,16 @@ int scade_check_launch(const char* what);
     }                                         \
   } while (0)
 
+// hipFuncSetAttribute applies to the CURRENT device only: the launchers keep one "done" bit per device
+// ordinal, so a process that drives several GPUs sets the large-LDS attribute on each of them
+static inline int scade_current_device() {
+  int dv = 0;
+  (void)hipGetDevice(&dv);
+  return dv & 63;
+}
+static inline bool scade_attr_needed(unsigned long long mask) { return !((mask >> scade_current_device()) & 1ull); }
+static inline void scade_attr_done(unsigned long long& mask) { mask |= 1ull << scade_current_device(); }
+
 // wgrad + reduce launcher shared by the backward variants (mlp_bwd.hip)
 int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
                        float* grad_flat, hipStream_t s);

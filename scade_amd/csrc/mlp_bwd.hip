@@ -416,12 +416,12 @@ extern "C" long scade_mlp_bwd_workspace_floats(int P) {
 // wgrad + reduce (shared by the exact and the split-precision backward)
 int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
                        float* grad_flat, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device ordinal
+  if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    scade_attr_done(attr_set);
   }
   WgradArgs w{};
   const int grid_x = build_wgrad_jobs(w, acts, dz, g_out, partial, P, WG_PT);
@@ -434,12 +434,12 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
 
 template <int PT>
 static int launch_dgrad(const MlpDgradArgs& d, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device ordinal
+  if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<PT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, mlp_lds_bytes(PT));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    scade_attr_done(attr_set);
   }
   hipLaunchKernelGGL(mlp_dgrad_kernel<PT>, dim3((d.P + tile_pts(PT) - 1) / tile_pts(PT)), dim3(256),
                      mlp_lds_bytes(PT), s, d);

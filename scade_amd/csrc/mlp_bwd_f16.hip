@@ -464,12 +464,12 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   SCADE_REQUIRE(packed && packed_t_f16 && acts && g_out && workspace && grad_flat, -1,
                 "scade_mlp_bwd_f16: null pointer");
   hipStream_t s = (hipStream_t)stream;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device ordinal
+  if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_f16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DGRAD_F16_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    scade_attr_done(attr_set);
   }
   float* dz = workspace;
   float* partial = workspace + dz_floats(P);

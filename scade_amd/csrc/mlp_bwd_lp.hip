@@ -649,8 +649,8 @@ extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp
 template <bool BF>
 static int launch_bwd_lp(const float* packed, const void* packed_t, const unsigned char* acts, const float* g_out,
                          int P, unsigned char* ws, float* grad_flat, hipStream_t s) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static unsigned long long attr_set = 0;   // one bit per device ordinal
+  if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, dgrad_lp_lds_bytes(4));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -660,7 +660,7 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
     e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_lp_kernel<BF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LP_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    scade_attr_done(attr_set);
   }
   unsigned char* dz = ws;
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));

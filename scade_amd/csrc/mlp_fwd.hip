@@ -343,13 +343,13 @@ extern "C" int scade_mlp_pack(const float* const* params, float* packed, void* s
 
 template <int MODE, bool SAVE, int PT>
 static int launch_fwd_pt(const MlpFwdArgs& a, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // one bit per device ordinal
   auto kern = mlp_fwd_kernel<MODE, SAVE, PT>;
-  if (!attr_set) {
+  if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, mlp_lds_bytes(PT));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_fwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    scade_attr_done(attr_set);
   }
   const int grid = (a.P + tile_pts(PT) - 1) / tile_pts(PT);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(256), mlp_lds_bytes(PT), s, a);

@@ -362,13 +362,13 @@ extern "C" int scade_mlp_pack_f16(const float* const* params, void* packed, void
 
 template <int MODE, bool SAVE>
 static int launch_f16(const MlpF16Args& a, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // one bit per device ordinal
   auto kern = mlp_fwd_f16_kernel<MODE, SAVE>;
-  if (!attr_set) {
+  if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, F16_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_fwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    scade_attr_done(attr_set);
   }
   hipLaunchKernelGGL(kern, dim3((a.P + HM - 1) / HM), dim3(256), F16_LDS_BYTES, s, a);
   return scade_check_launch("scade_mlp_fwd_f16");

@@ -361,13 +361,13 @@ extern "C" int scade_mlp_pack_lp(const float* const* params, void* packed, int b
 
 template <bool BF, int MODE, bool SAVE, int NPT>
 static int launch_lp_pt(const MlpLpArgs& a, hipStream_t s) {
-  static bool attr_set = false;
+  static unsigned long long attr_set = 0;   // one bit per device ordinal
   auto kern = mlp_fwd_lp_kernel<BF, MODE, SAVE, NPT>;
-  if (!attr_set) {
+  if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lp_lds_bytes(NPT));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_fwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    attr_set = true;
+    scade_attr_done(attr_set);
   }
   hipLaunchKernelGGL(kern, dim3((a.P + 32 * NPT - 1) / (32 * NPT)), dim3(256), lp_lds_bytes(NPT), s, a);
   return scade_check_launch("scade_mlp_fwd_lp");

@@ -23,12 +23,14 @@ __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict_
 // is a launch argument, so one captured graph stays valid for every iteration.
 //   [0] t (steps taken)  [1] lr0  [2] decay_rate  [3] decay_step  [4] beta1  [5] beta2  [6] eps
 //   [7] grad_scale  [8] lr of this step  [9] 1 - beta1^t  [10] sqrt(1 - beta2^t)
+//   [11] iteration offset (resumed runs whose optimizer state was not restored)
 __global__ void adam_tick_kernel(float* st) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     const float t = st[0] + 1.0f;
     st[0] = t;
-    // staircase decay on the iteration index it = t - 1 (train_utils/hyperparameter_update.py:8-13)
-    const double it = (double)t - 1.0;
+    // staircase decay on the reference's loop index i, which counts from 1 (run_scade_scannet.py:899-900,
+    // :988; train_utils/hyperparameter_update.py:8-13): i = t + offset
+    const double it = (double)t + (double)st[11];
     const double k = st[3] > 0.f ? floor(it / (double)st[3]) : 0.0;
     st[8] = (float)((double)st[1] * pow((double)st[2], k));
     st[9] = (float)(1.0 - pow((double)st[4], (double)t));

@@ -18,49 +18,59 @@ from . import ops
 
 
 class GraphedTrainer:
+    """``n_total``: rays of the whole (all-rank) batch when the shards are uneven (default: equal
+    shards, n_rays x world); it fixes this rank's loss weight n_rays / n_total at capture time.
+    ``with_mask``: keep a static mask buffer [n_rays] and pass ``mask=`` to every step."""
+
     def __init__(self, trainer, n_rays: int, n_hyp: int, inject_draws: bool = False,
-                 force_allreduce: bool = False):
+                 force_allreduce: bool = False, n_total=None, with_mask: bool = False):
         tr = self.tr = trainer
-        if tr.sharded and tr.cfg["joint"]:
-            raise NotImplementedError("GraphedTrainer: the sharded is_joint exchange reads a host scalar")
-        self.force_allreduce = force_allreduce
+        tr.force_allreduce = tr.force_allreduce or force_allreduce
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        dev = tr.flat.data.device
+        self.n_total = n_total if n_total is not None else n_rays * world
+        dev = tr.bucket.data.device
         c = tr.cfg
         self.rays = torch.zeros(n_rays, 11, device=dev)
         self.tgt = torch.zeros(n_rays, 3, device=dev)
         self.hyp = torch.zeros(n_hyp, n_rays, 1, device=dev)
+        # which image's scale / shift the batch belongs to (:951-954): a device index, so that the
+        # captured graph gathers (and updates) the right row every step
+        self.img_i = torch.zeros(1, device=dev, dtype=torch.long)
+        self.mask = torch.ones(n_rays, device=dev) if with_mask else None
         self.draws = None
         if inject_draws:
             self.draws = (torch.zeros(n_rays, c["Ns"], device=dev), torch.zeros(n_rays, c["Ni"], device=dev),
                           torch.zeros(n_rays, c["Ni"], device=dev))
-        tr.opt.use_device_state(c["rate"], c["step"], grad_scale=1.0 / world)
-        tr.opt_ss.use_device_state(grad_scale=1.0 / world)
+        tr.opt.use_device_state(c["rate"], c["step"])
+        tr.opt_ss.use_device_state()
         self.graph = None
         self.loss = None
-        self._captured_ss = None     # whether the captured graph contains the scale/shift update
+        self._captured = None     # (scale/shift update in the graph?, carving term in the graph?)
 
     def _body(self):
         tr = self.tr
-        tr.opt.zero_grad()
-        tr.opt_ss.zero_grad()
+        tr.bucket.zero_grad()
         kw = {}
         if self.draws is not None:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
-        loss, _ = tr.forward_loss(self.rays, self.tgt, self.hyp, **kw)
+        loss, _ = tr.forward_loss(self.rays, self.tgt, self.hyp, img_i=self.img_i, mask=self.mask,
+                                  n_total=self.n_total, **kw)
         loss.backward()
-        tr.flat.allreduce_grads(force=self.force_allreduce)       # 1/world lives in the Adam state
-        tr.flat_ss.allreduce_grads(force=self.force_allreduce)
+        tr.reduce_grads()
         tr.opt.step_dev()
-        if tr.it < tr.cfg["freeze_ss"]:
+        if tr.scaleshift_active():
             tr.opt_ss.step_dev()
         return loss.detach()
+
+    def _state(self):
+        tr = self.tr
+        return (tr.bucket.data, tr.opt.exp_avg, tr.opt.exp_avg_sq, tr.opt.state,
+                tr.opt_ss.exp_avg, tr.opt_ss.exp_avg_sq, tr.opt_ss.state)
 
     def _capture(self):
         tr = self.tr
         # warm-up (first-call attribute setup, allocator) on a side stream, then roll the state back
-        keep = [t.clone() for t in (tr.flat.data, tr.opt.exp_avg, tr.opt.exp_avg_sq, tr.opt.state,
-                                    tr.flat_ss.data, tr.opt_ss.exp_avg, tr.opt_ss.exp_avg_sq, tr.opt_ss.state)]
+        keep = [t.clone() for t in self._state()]
         steps = (tr.opt.steps, tr.opt_ss.steps)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
@@ -68,31 +78,40 @@ class GraphedTrainer:
             for _ in range(2):
                 self._body()
         torch.cuda.current_stream().wait_stream(side)
-        for dst, src in zip((tr.flat.data, tr.opt.exp_avg, tr.opt.exp_avg_sq, tr.opt.state,
-                             tr.flat_ss.data, tr.opt_ss.exp_avg, tr.opt_ss.exp_avg_sq, tr.opt_ss.state), keep):
+        for dst, src in zip(self._state(), keep):
             dst.copy_(src)
         tr.opt.steps, tr.opt_ss.steps = steps
         ops.PARAM_EPOCH += 1
-        self._captured_ss = tr.it < tr.cfg["freeze_ss"]
+        self._captured = (tr.scaleshift_active(), tr.carving_active())
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.loss = self._body()
         # the capture itself executed nothing; undo its host-side bookkeeping
         tr.opt.steps, tr.opt_ss.steps = steps
 
-    def step(self, rays, target_s, target_hyp, t_rand=None, u_coarse=None, cached_u=None):
+    def step(self, rays, target_s, target_hyp, t_rand=None, u_coarse=None, cached_u=None, img_i=0, mask=None):
         """One optimisation step; returns the loss tensor of the step (a static buffer)."""
+        tr = self.tr
         self.rays.copy_(rays)
         self.tgt.copy_(target_s)
         self.hyp.copy_(target_hyp)
+        if torch.is_tensor(img_i):
+            self.img_i.copy_(img_i.reshape(1))
+        else:
+            if not 0 <= int(img_i) < tr.n_images:
+                raise IndexError(f"GraphedTrainer.step: img_i {img_i} outside [0, {tr.n_images})")
+            self.img_i.fill_(int(img_i))
+        if (mask is None) != (self.mask is None):
+            raise ValueError("GraphedTrainer.step: pass mask= exactly when built with with_mask=True")
+        if mask is not None:
+            self.mask.copy_(mask)
         if self.draws is not None:
             self.draws[0].copy_(t_rand)
             self.draws[1].copy_(u_coarse)
             self.draws[2].copy_(cached_u)
-        tr = self.tr
-        with_ss = tr.it < tr.cfg["freeze_ss"]
-        if self.graph is None or with_ss != self._captured_ss:
-            self._capture()               # first step, or the scale/shift freeze point (:996) was crossed
+        with_ss = tr.scaleshift_active()
+        if self.graph is None or (with_ss, tr.carving_active()) != self._captured:
+            self._capture()      # first step, or the warm-start (:973) / scale-shift freeze point (:996) was crossed
         self.graph.replay()
         tr.it += 1
         tr.opt.steps += 1

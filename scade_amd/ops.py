@@ -621,10 +621,10 @@ class CarveJointShardedFn(torch.autograd.Function):
     rays runs over all shards BEFORE the min over the K hypotheses, so the [K,P] column means are
     combined across ranks (parallel.combine_shard_means: one all-reduce of K*P floats) between the two
     kernel phases.  Every rank returns the GLOBAL loss; the backward yields this shard's part of its
-    gradient times ``world`` so that the trainer's usual sum-all-reduce x 1/world stays correct."""
+    gradient, so the SUM over ranks (the trainer's gradient all-reduce) is the gradient of the loss."""
 
     @staticmethod
-    def forward(ctx, pred, hyp, mask, threshold, group):
+    def forward(ctx, pred, hyp, mask, threshold, group, n_total=None):
         from . import parallel
         check(pred, "space_carving: pred_depth"); check(hyp, "space_carving: target_hypothesis")
         N, P = pred.shape
@@ -636,10 +636,11 @@ class CarveJointShardedFn(torch.autograd.Function):
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
         call("scade_carve_joint_colmean", ptr(pred_c), ptr(hyp_c), ptr(mask_c), float(threshold), N, P, K,
              ptr(ws), stream())
-        share, world = parallel.combine_shard_means(ws[:K * P], N, group)
+        share, _ = parallel.combine_shard_means(ws[:K * P], N, group, n_total)
         call("scade_carve_joint_min", ptr(ws), P, K, ptr(loss), stream())
         ctx.save_for_backward(pred_c, hyp_c, mask_c if mask_c is not None else pred.new_empty(0), ws)
-        ctx.cfg = (float(threshold), mask is not None, tuple(hyp.shape), share * world)
+        # the kernel's backward divides by this shard's N; the global mean divides by N_total
+        ctx.cfg = (float(threshold), mask is not None, tuple(hyp.shape), share)
         return loss.reshape(())
 
     @staticmethod
@@ -653,7 +654,7 @@ class CarveJointShardedFn(torch.autograd.Function):
         g_hyp = torch.empty_like(hyp)
         call("scade_carve_bwd", ptr(pred), ptr(hyp), ptr(mask if has_mask else None), thr, 1, N, P,
              K, ptr(ws), ptr(g), ptr(g_pred), ptr(g_hyp), stream())
-        return g_pred, g_hyp.reshape(hyp_shape), None, None, None
+        return g_pred, g_hyp.reshape(hyp_shape), None, None, None, None
 
 
 class MseFn(torch.autograd.Function):

@@ -27,12 +27,16 @@ class FusedAdam:
         # move): advance the global epoch so NeRF.packed()/packed_t() re-pack
         ops.PARAM_EPOCH += 1
 
-    def use_device_state(self, decay_rate: float = 1.0, decay_step: int = 0, grad_scale: float = 1.0):
+    def use_device_state(self, decay_rate: float = 1.0, decay_step: int = 0, grad_scale: float = 1.0,
+                         iter_offset: int = 0):
         """Move step count, staircase learning rate and bias corrections to the device
-        (``step_dev``): no per-step launch argument is left, so a captured graph stays valid."""
+        (``step_dev``): no per-step launch argument is left, so a captured graph stays valid.
+        The staircase runs on the reference's loop index i = steps taken so far + 1 + ``iter_offset``
+        (run_scade_scannet.py:899-900, :988)."""
         self.state = torch.zeros(16, device=self.flat.data.device, dtype=torch.float32)
         self.state[:8] = torch.tensor([float(self.steps), self.lr, decay_rate, float(decay_step), self.betas[0],
                                        self.betas[1], self.eps, grad_scale], dtype=torch.float32)
+        self.state[11] = float(iter_offset)
         return self
 
     def step_dev(self):

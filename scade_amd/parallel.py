@@ -83,9 +83,17 @@ class FlatParams:
                 p.grad = self.grad[o:o + n].view(p.shape)
             o += n
 
+    def segment(self, start: int, numel: int) -> "FlatSegment":
+        """A contiguous slice of the bucket with the (data, grad, numel, zero_grad) surface FusedAdam
+        needs: several optimizers (different learning rates) then share ONE gradient bucket and ONE
+        all-reduce."""
+        return FlatSegment(self, start, numel)
+
     def allreduce_grads(self, group=None, force: bool = False) -> float:
         """Sum-all-reduce the gradient bucket; returns the factor the optimizer must apply
         (1/world) so that equal shards with local-mean losses reproduce the global mean.
+        (``Trainer`` weights every rank's loss by n_local/N_total instead and applies no factor, which
+        is also right for uneven shards.)
         ``force``: issue the collective even on a one-rank group (self-tests of the RCCL path)."""
         if not (dist.is_available() and dist.is_initialized()):
             return 1.0
@@ -95,21 +103,77 @@ class FlatParams:
         dist.all_reduce(self.grad, op=dist.ReduceOp.SUM, group=group)
         return 1.0 / world
 
+    def allreduce_grads_async(self, pieces, group=None, force: bool = False):
+        """Sum-all-reduce the bucket as several contiguous pieces ``[(start, numel, stream | None)]``,
+        each issued asynchronously behind the work already enqueued on ITS stream (None = the current
+        one): a piece whose producer chain ends early starts its collective while the other chains
+        still compute.  Returns the work handles (``wait_all`` makes the current stream wait)."""
+        if not (dist.is_available() and dist.is_initialized()):
+            return []
+        if dist.get_world_size(group) == 1 and not force:
+            return []
+        works = []
+        for start, numel, st in pieces:
+            if numel <= 0:
+                continue
+            g = self.grad[start:start + numel]
+            if st is not None and g.is_cuda:
+                with torch.cuda.stream(st):
+                    works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+            else:
+                works.append(dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group, async_op=True))
+        return works
+
+    @staticmethod
+    def wait_all(works):
+        for w in works:
+            w.wait()
+
     def broadcast_params(self, src: int = 0, group=None):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
             dist.broadcast(self.data, src=src, group=group)
 
 
-def combine_shard_means(means: torch.Tensor, n_local: int, group=None):
+class FlatSegment:
+    """View of ``FlatParams`` rows [start, start+numel): what one FusedAdam updates."""
+
+    def __init__(self, parent: FlatParams, start: int, numel: int):
+        if start < 0 or numel <= 0 or start + numel > parent.numel:
+            raise ValueError("FlatSegment: range outside the bucket")
+        self.parent, self.start, self.numel = parent, start, numel
+        self.data = parent.data[start:start + numel]
+        self.grad = parent.grad[start:start + numel]
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+
+def batch_share(n_local: int, n_total: Optional[int] = None, group=None) -> float:
+    """Weight of this rank's shard in a mean over the GLOBAL batch: n_local / N_total.  With the
+    share folded into every rank's loss, a plain sum-all-reduce of the gradients is the gradient of
+    the global mean for even AND uneven shards.  ``n_total=None`` assumes equal shards (1/world)
+    and costs no communication."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return 1.0
+    if n_total is None:
+        return 1.0 / dist.get_world_size(group)
+    return float(n_local) / float(n_total)
+
+
+def combine_shard_means(means: torch.Tensor, n_local: int, group=None, n_total: Optional[int] = None):
     """In place: per-shard means over ``n_local`` rays -> the mean over the rays of ALL shards
     (one sum-all-reduce of the n_local/N_total-weighted means).  Returns (n_local / N_total, world).
-    Single process: identity, (1.0, 1)."""
+    Single process: identity, (1.0, 1).  ``n_total`` (the global ray count, known to whoever
+    sharded the batch) saves the extra all-reduce + host read that finds it, which also makes the
+    exchange capturable in a HIP graph."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return 1.0, 1
     world = dist.get_world_size(group)
-    n = torch.tensor([float(n_local)], device=means.device, dtype=torch.float64)
-    dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
-    share = float(n_local) / float(n.item())
+    if n_total is None:
+        n = torch.tensor([float(n_local)], device=means.device, dtype=torch.float64)
+        dist.all_reduce(n, op=dist.ReduceOp.SUM, group=group)
+        n_total = float(n.item())
+    share = float(n_local) / float(n_total)
     means.mul_(share)
     dist.all_reduce(means, op=dist.ReduceOp.SUM, group=group)
     return share, world
@@ -125,5 +189,6 @@ def shared_uniform(shape, device, generator=None, src: int = 0, group=None) -> t
 
 
 def staircase_lr(lr0: float, decay_rate: float, decay_step: int, it: int) -> float:
-    """train_utils/hyperparameter_update.py:8-13 / run_scade_scannet.py:988-991."""
+    """train_utils/hyperparameter_update.py:8-13 / run_scade_scannet.py:988-991; ``it`` is the
+    reference's loop index i, which counts from 1 (:899-900: start = global_step + 1)."""
     return lr0 * (decay_rate ** (it // decay_step))

@@ -212,7 +212,9 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
         if not fused:
             return (z, r) + tuple(raw2outputs(r, z, rays_d, raw_noise_std, pytest=pytest))
         noise = _raw_noise(r, raw_noise_std, pytest)
-        uc = u_coarse if u_coarse is not None else _draw_u(z, N_importance, det, pytest, is_joint)
+        # the coarse importance sampler is ALWAYS the per-ray sample_pdf (:705); only the last
+        # sampler honours is_joint (:726-730)
+        uc = u_coarse if u_coarse is not None else _draw_u(z, N_importance, det, pytest, False)
         return (z, r) + tuple(CoarseTailFn.apply(r, z, rays, noise, uc, N_importance))
 
     if coarse_stream is None:
@@ -231,7 +233,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
         z_vals, pts = outs[7:]
     else:
         # ---- importance samples from the coarse pdf, detached (:702-711) ---------
-        uc = u_coarse if u_coarse is not None else _draw_u(z_vals_0, N_importance, det, pytest, is_joint)
+        uc = u_coarse if u_coarse is not None else _draw_u(z_vals_0, N_importance, det, pytest, False)
         with torch.no_grad():
             z_samples = _sample(z_vals_0, weights_0[..., 1:-1], uc, bins_are_mids=True)
         # ---- merge + fine points (:713-714) --------------------------------------
@@ -288,13 +290,20 @@ def batchify_rays(rays_flat, chunk=1024 * 32, use_viewdirs=False, streams=1, **k
     if streams > 1 and not torch.is_grad_enabled() and rays_flat.shape[0] > chunk:
         cur = torch.cuda.current_stream(rays_flat.device)
         side = _side_streams(rays_flat.device, streams)
+        # the lazily re-packed weight blobs are rebuilt by whichever launch first sees a changed
+        # parameter: do that HERE, on the stream every side stream waits for, or chunk 1 could read a
+        # blob that chunk 0's stream is still rewriting
+        for net in (kwargs.get("network_fn"), kwargs.get("network_fine")):
+            net = net.module if isinstance(net, torch.nn.DataParallel) else net
+            if isinstance(net, NeRF):
+                net.warm_packs()
         for st in side:
             st.wait_stream(cur)
         for n, i in enumerate(range(0, rays_flat.shape[0], chunk)):
             with torch.cuda.stream(side[n % streams]):
                 ret = render_rays(rays_flat[i:i + chunk], use_viewdirs, **kwargs)
             for k in ret:
-                ret[k].record_stream(side[n % streams])
+                ret[k].record_stream(cur)       # allocated on the side stream, consumed by cat() on cur
                 all_ret.setdefault(k, []).append(ret[k])
         for st in side:
             cur.wait_stream(st)

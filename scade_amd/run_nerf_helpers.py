@@ -56,14 +56,15 @@ def to16b(x):
 
 
 def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2,
-                               threshold=0.0, sharded=False, group=None):
+                               threshold=0.0, sharded=False, group=None, n_total=None):
     """pred_depth [N,P]; target_hypothesis [K,N,1].  The norm runs over a size-1
     axis, so every ``norm_p`` gives |pred - hyp| (kept for signature parity).
 
     ``sharded=True`` (not in the reference, which is single-process): the arguments are this
     rank's SHARD of a ray-partitioned batch.  Only ``is_joint=True`` needs an exchange (its mean
     over rays precedes the min over K): the result is then the loss of the whole batch, see
-    ``ops.CarveJointShardedFn``."""
+    ``ops.CarveJointShardedFn`` (``n_total`` = rays of all shards, None = found with one extra
+    all-reduce)."""
     if target_hypothesis.dim() != 3:
         raise ValueError("compute_space_carving_loss: target_hypothesis must be [K,N,1]")
     if target_hypothesis.shape[-1] != 1:
@@ -73,7 +74,7 @@ def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, ma
     if norm_p <= 0:
         raise ValueError("norm_p must be positive")
     if is_joint and sharded:
-        return CarveJointShardedFn.apply(pred_depth, target_hypothesis, mask, float(threshold), group)
+        return CarveJointShardedFn.apply(pred_depth, target_hypothesis, mask, float(threshold), group, n_total)
     return CarveFn.apply(pred_depth, target_hypothesis, mask, float(threshold), bool(is_joint))
 
 
@@ -237,6 +238,16 @@ class NeRF(nn.Module):
             self._packed_t_lp = ops.mlp_pack_t_lp(ps, bf16)
             self._packed_t_lp_key = key
         return self._packed_t_lp
+
+    def warm_packs(self):
+        """Bring the weight pack of the current inference precision up to date on the CURRENT stream
+        (callers that fan work out over several streams do this before forking)."""
+        if self.inference_precision == "f16x3":
+            self.packed_f16()
+        elif self.inference_precision in ("f16", "bf16"):
+            self.packed_lp(self.inference_precision == "bf16")
+        else:
+            self.packed()
 
     INFERENCE_PRECISIONS = ("f32", "f16x3", "f16", "bf16")
     TRAIN_PRECISIONS = ("f32", "f16x3", "f16x3-dgrad", "f16", "bf16")

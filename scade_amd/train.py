@@ -21,7 +21,7 @@ import torch.distributed as dist
 from . import rendering as R
 from . import run_nerf_helpers as H
 from .optim import FusedAdam
-from .parallel import FlatParams, shared_uniform, staircase_lr
+from .parallel import FlatParams, batch_share, shared_uniform, staircase_lr
 
 
 def make_scade_nets(device, seed: Optional[int] = None):
@@ -34,82 +34,147 @@ def make_scade_nets(device, seed: Optional[int] = None):
 
 
 class Trainer:
+    """``mask_mode``: which loss terms a ``mask`` passed to ``step`` multiplies - "scannet"
+    (run_scade_scannet.py:968-983: the space-carving loss only) or "wild" (run_scade_wild.py:977-1008:
+    both photometric terms as well).  ``allreduce``: "single" = ONE sum-all-reduce of the whole
+    gradient bucket per step; "overlap" = the same bucket in two pieces, the
+    coarse network's issued behind the coarse backward chain on ITS stream so that it runs while the
+    (three times longer) fine chain still computes."""
+
     def __init__(self, coarse, fine, bb_center, bb_scale, n_images=1, lrate=5e-4, scaleshift_lr=1e-7,
                  space_carving_weight=0.007, N_samples=64, N_importance=128, lrate_decay_rate=0.1,
                  lrate_decay_step=400000, freeze_ss=400000, norm_p=2, space_carving_threshold=0.0,
                  is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0, precision="f32",
-                 overlap_coarse=None):
+                 overlap_coarse=None, mask_mode="scannet", allreduce=None, start_iter=0):
         dev = next(coarse.parameters()).device
+        if mask_mode not in ("scannet", "wild"):
+            raise ValueError('Trainer: mask_mode must be "scannet" or "wild"')
         self.coarse, self.fine = coarse, fine
         coarse.train_precision = fine.train_precision = precision      # "f32" (exact) | "f16x3"
         embed_fn, _ = H.get_embedder(9, 0)
         embeddirs_fn, _ = H.get_embedder(0, 0)
         self.query = R.make_network_query_fn(embed_fn, embeddirs_fn, bb_center.to(dev), bb_scale.to(dev))
         # DEPTH_SCALES / DEPTH_SHIFTS, one per training image (:878-888)
+        self.n_images = n_images
         self.depth_scales = torch.ones(n_images, 1, device=dev, requires_grad=True)
         self.depth_shifts = torch.zeros(n_images, 1, device=dev, requires_grad=True)
-        self.flat = FlatParams(list(coarse.parameters()) + list(fine.parameters()))
-        self.flat.attach_grad_sinks([coarse, fine])
-        self.flat_ss = FlatParams([self.depth_scales, self.depth_shifts])
+        # ONE gradient bucket: [coarse | fine | scales | shifts] = 2 x 589,700 + 2 n_images floats
+        # (SURVEY section 8e); the two optimizers (different learning rates) update segments of it
+        self.bucket = FlatParams(list(coarse.parameters()) + list(fine.parameters())
+                                 + [self.depth_scales, self.depth_shifts])
+        self.bucket.attach_grad_sinks([coarse, fine])
+        self.n_net = sum(p.numel() for p in coarse.parameters()) + sum(p.numel() for p in fine.parameters())
+        self.n_coarse = sum(p.numel() for p in coarse.parameters())
+        self.flat = self.bucket.segment(0, self.n_net)
+        self.flat_ss = self.bucket.segment(self.n_net, 2 * n_images)
         self.opt = FusedAdam(self.flat, lr=lrate, betas=(0.9, 0.999))
         self.opt_ss = FusedAdam(self.flat_ss, lr=scaleshift_lr)
         self.cfg = dict(lrate=lrate, rate=lrate_decay_rate, step=lrate_decay_step, w=space_carving_weight,
                         Ns=N_samples, Ni=N_importance, freeze_ss=freeze_ss, norm_p=norm_p,
                         thr=space_carving_threshold, joint=is_joint, warm=warm_start_nerf,
-                        lindisp=lindisp, noise=raw_noise_std)
-        self.it = 0
+                        lindisp=lindisp, noise=raw_noise_std, mask_mode=mask_mode)
+        # ``it`` = optimisation steps taken; the reference's loop index of the NEXT step is it + 1
+        # (:899-900: i runs from global_step + 1)
+        self.it = start_iter
         # coarse stage on a side stream: its backward chain then runs beside the fine one
         if overlap_coarse is None:
             overlap_coarse = os.environ.get("SCADE_OVERLAP_COARSE", "1") != "0"
         self.coarse_stream = torch.cuda.Stream(device=dev) if overlap_coarse and dev.type == "cuda" else None
         # rays are sharded over the ranks of the default process group (one process per GPU)
         self.sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        self.flat.broadcast_params(0)
-        self.flat_ss.broadcast_params(0)
+        if allreduce is None:
+            allreduce = os.environ.get("SCADE_ALLREDUCE", "single")
+        if allreduce not in ("single", "overlap"):
+            raise ValueError('Trainer: allreduce must be "single" or "overlap"')
+        self.allreduce = allreduce
+        self.force_allreduce = False        # self-tests: issue the collective on a one-rank group too
+        self.bucket.broadcast_params(0)
 
-    def forward_loss(self, rays, target_s, target_hyp, img_i=0, mask=None, **render_kw):
+    # -- reference loop predicates on i = it + 1 ------------------------------------------------
+    def carving_active(self):
+        return self.cfg["w"] > 0. and (self.it + 1) > self.cfg["warm"]                        # :973
+
+    def scaleshift_active(self):
+        return (self.it + 1) < self.cfg["freeze_ss"]                                          # :996
+
+    def forward_loss(self, rays, target_s, target_hyp, img_i=0, mask=None, n_total=None, **render_kw):
+        """-> (loss, aux).  ``loss`` is this rank's term of the GLOBAL-batch loss: every mean over rays
+        is weighted by n_local / N_total (``n_total`` = rays of all ranks; None = equal shards), so the
+        sum over ranks is the single-process loss and the sum-all-reduced gradient its gradient."""
         c = self.cfg
-        target_h = target_hyp * self.depth_scales[img_i] + self.depth_shifts[img_i]          # :954
+        if torch.is_tensor(img_i):
+            # device index (GraphedTrainer keeps it in a static buffer): gather, no host read
+            scale, shift = self.depth_scales.index_select(0, img_i.reshape(1)), \
+                self.depth_shifts.index_select(0, img_i.reshape(1))
+            target_h = target_hyp * scale.reshape(()) + shift.reshape(())
+        else:
+            target_h = target_hyp * self.depth_scales[img_i] + self.depth_shifts[img_i]      # :954
+        share = batch_share(rays.shape[0], n_total) if self.sharded else 1.0
         if c["joint"] and self.sharded:
-            # sample_pdf_joint draws ONE u[S] for the whole batch (helpers:452-453): rank 0's draw
-            render_kw.setdefault("u_coarse", shared_uniform((c["Ni"],), rays.device))
+            # the LAST sampler (sample_pdf_joint_return_u, :728) draws ONE u[S] for the whole batch
+            # (helpers:498-513): rank 0's draw.  The coarse importance sampler stays per ray (:705).
             render_kw.setdefault("cached_u", shared_uniform((c["Ni"],), rays.device))
-        elif not c["joint"] and not any(k in render_kw for k in ("t_rand", "u_coarse", "cached_u", "pytest")):
-            # the step's three uniform draws (stratified jitter :564-579, the two sample_pdf draws
+        if not any(k in render_kw for k in ("t_rand", "u_coarse", "pytest")):
+            # the step's uniform draws (stratified jitter :564-579, the sample_pdf draws
             # helpers:346-361) as ONE generator launch; independent streams either way
             n, ns, ni = rays.shape[0], c["Ns"], c["Ni"]
-            d = torch.rand(n * (ns + 2 * ni), device=rays.device)
+            need_u = "cached_u" not in render_kw and not c["joint"]
+            d = torch.rand(n * (ns + ni + (ni if need_u else 0)), device=rays.device)
             render_kw["t_rand"] = d[:n * ns].view(n, ns)
             render_kw["u_coarse"] = d[n * ns:n * (ns + ni)].view(n, ni)
-            render_kw["cached_u"] = d[n * (ns + ni):].view(n, ni)
+            if need_u:
+                render_kw["cached_u"] = d[n * (ns + ni):].view(n, ni)
         ret = R.render_rays(rays, True, self.coarse, self.query, c["Ns"], N_importance=c["Ni"],
                             network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
                             lindisp=c["lindisp"], is_joint=c["joint"], coarse_stream=self.coarse_stream,
                             **render_kw)
-        mse = (lambda a, b: H.img2mse(a, b)) if mask is None else (lambda a, b: H.img2mse_masked(a, b, mask))
+        mse_mask = mask if c["mask_mode"] == "wild" else None
+        mse = (lambda a, b: H.img2mse(a, b)) if mse_mask is None else \
+            (lambda a, b: H.img2mse_masked(a, b, mse_mask))
         img_loss = mse(ret["rgb_map"], target_s)                                              # :968
         loss = img_loss
         carve = None
-        if c["w"] > 0. and self.it >= c["warm"]:                                              # :973
+        global_terms = None
+        if self.carving_active():                                                             # :973
             carve = H.compute_space_carving_loss(ret["pred_hyp"], target_h, is_joint=c["joint"],
                                                  mask=mask, norm_p=c["norm_p"], threshold=c["thr"],
-                                                 sharded=self.sharded)
-            loss = loss + c["w"] * carve
+                                                 sharded=self.sharded, n_total=n_total)
+            if c["joint"] and self.sharded:
+                global_terms = c["w"] * carve      # already the loss of the WHOLE batch on every rank
+            else:
+                loss = loss + c["w"] * carve
         img_loss0 = mse(ret["rgb0"], target_s)                                                # :981
         loss = loss + img_loss0
-        return loss, dict(img_loss=img_loss, carve=carve, img_loss0=img_loss0, ret=ret)
+        if share != 1.0:
+            loss = loss * share
+        if global_terms is not None:
+            loss = loss + global_terms
+        return loss, dict(img_loss=img_loss, carve=carve, img_loss0=img_loss0, ret=ret, share=share)
 
-    def step(self, rays, target_s, target_hyp, img_i=0, mask=None, **render_kw):
-        """One optimisation step on this rank's shard; returns the (local) loss tensor."""
-        self.opt.zero_grad()
-        self.opt_ss.zero_grad()
-        loss, aux = self.forward_loss(rays, target_s, target_hyp, img_i, mask, **render_kw)
+    def reduce_grads(self):
+        """The step's gradient exchange: RCCL sum-all-reduce of the bucket over the ranks' shards."""
+        if not (self.sharded or self.force_allreduce):
+            return
+        if self.allreduce == "overlap" and self.coarse_stream is not None:
+            b = self.bucket
+            works = b.allreduce_grads_async(
+                [(0, self.n_coarse, self.coarse_stream),                 # behind the coarse backward chain
+                 (self.n_coarse, b.numel - self.n_coarse, None)],        # fine | scales | shifts
+                force=self.force_allreduce)
+            b.wait_all(works)
+        else:
+            self.bucket.allreduce_grads(force=self.force_allreduce)
+
+    def step(self, rays, target_s, target_hyp, img_i=0, mask=None, n_total=None, **render_kw):
+        """One optimisation step on this rank's shard; returns (this rank's term of the global loss,
+        aux).  ``n_total``: rays of the whole batch when the shards are uneven."""
+        self.bucket.zero_grad()
+        loss, aux = self.forward_loss(rays, target_s, target_hyp, img_i, mask, n_total, **render_kw)
         loss.backward()                                                                       # :985
-        gs = self.flat.allreduce_grads()
-        gs_ss = self.flat_ss.allreduce_grads()
-        lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it)     # :988-991
-        self.opt.step(grad_scale=gs, lr=lr)                                                   # :993
-        if self.it < self.cfg["freeze_ss"]:                                                   # :996-997
-            self.opt_ss.step(grad_scale=gs_ss)
+        self.reduce_grads()
+        lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it + 1)  # :988-991
+        self.opt.step(lr=lr)                                                                  # :993
+        if self.scaleshift_active():                                                          # :996-997
+            self.opt_ss.step()
         self.it += 1
         return loss.detach(), aux

@@ -331,7 +331,9 @@ def test_trainer_coarse_stream_overlap_is_bitwise_neutral(dev):
 
 def test_graphed_trainer_matches_eager(dev):
     """The whole train step captured in one HIP graph (scade_amd/graphs.py, device-resident Adam
-    state) reproduces the eager Trainer step for step; replay leaves no per-step host work."""
+    state) reproduces the eager Trainer step for step; replay leaves no per-step host work.  Three
+    training images: the graph must gather and update the scale/shift row of each step's img_i
+    (run_scade_scannet.py:951-954), and apply the step's mask (wild variant: MSE terms too)."""
     from scade_amd.graphs import GraphedTrainer
     from scade_amd.train import Trainer, make_scade_nets
     N, K, steps = 128, 20, 6
@@ -341,22 +343,23 @@ def test_graphed_trainer_matches_eager(dev):
         rays = O.synthetic_rays(N, seed=50 + i)
         batches.append((rays, torch.rand(N, 3, generator=g), torch.rand(K, N, 1, generator=g) * 4.9 + 0.1,
                         torch.rand(N, 64, generator=g), torch.rand(N, 128, generator=g),
-                        torch.rand(N, 128, generator=g)))
+                        torch.rand(N, 128, generator=g), (torch.rand(N, generator=g) > 0.25).float()))
     res = {}
     for mode in ("eager", "graph"):
         coarse, fine = make_scade_nets(dev, seed=3)
-        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, lrate_decay_step=4,
-                     lrate_decay_rate=0.5, freeze_ss=3)   # two-stream backward on: captured as a fork/join;
-        #                                                    the scale/shift freeze after 3 steps forces a re-capture
-        gt = GraphedTrainer(tr, N, K, inject_draws=True) if mode == "graph" else None
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3, lrate_decay_step=4,
+                     lrate_decay_rate=0.5, freeze_ss=5, scaleshift_lr=1e-3, mask_mode="wild")
+        # two-stream backward on: captured as a fork/join; the scale/shift freeze (i < 5: four updates)
+        # forces a re-capture
+        gt = GraphedTrainer(tr, N, K, inject_draws=True, with_mask=True) if mode == "graph" else None
         losses = []
-        for rays, tgt, hyp, a, b, c in batches:
+        for i, (rays, tgt, hyp, a, b, c, m) in enumerate(batches):
             args = [t.to(dev) for t in (rays, tgt, hyp)]
-            kw = dict(t_rand=a.to(dev), u_coarse=b.to(dev), cached_u=c.to(dev))
+            kw = dict(t_rand=a.to(dev), u_coarse=b.to(dev), cached_u=c.to(dev), img_i=i % 3, mask=m.to(dev))
             l = gt.step(*args, **kw) if gt else tr.step(*args, **kw)[0]
             losses.append(float(l))
         torch.cuda.synchronize()
-        res[mode] = (losses, tr.flat.data.clone(), tr.flat_ss.data.clone(), tr.it, tr.opt.steps)
+        res[mode] = (losses, tr.flat.data.clone(), tr.flat_ss.data.clone(), tr.it, tr.opt.steps, tr.opt_ss.steps)
     le, lg = res["eager"][0], res["graph"][0]
     assert res["eager"][3] == res["graph"][3] == steps and res["graph"][4] == steps
     for a, b in zip(le, lg):
@@ -364,11 +367,16 @@ def test_graphed_trainer_matches_eager(dev):
     assert le[-1] < le[0]
     assert_close(res["graph"][1], res["eager"][1], rtol=1e-5, atol=1e-7, what="parameters after 6 steps")
     assert_close(res["graph"][2], res["eager"][2], rtol=1e-6, atol=1e-9, what="scale/shift after 6 steps")
+    ss = res["graph"][2].cpu()
+    assert bool((ss[:3] != 1).all()) and bool((ss[3:] != 0).all()), "every image's scale and shift row was trained"
+    assert res["graph"][5] == 4, "scale/shift optimizer stops at the freeze point i < freeze_ss (:996)"
 
 
 def test_graphed_trainer_captures_the_rccl_allreduce(dev):
-    """One-rank RCCL group: the gradient all-reduce is issued inside the captured step (forced,
-    since a one-rank trainer would skip it) and the graphed steps still match the eager ones."""
+    """One-rank RCCL group: the gradient all-reduce (the single bucket, and the two-piece overlapped
+    form with the coarse piece issued behind the coarse stream) is issued inside the captured step
+    (forced, since a one-rank trainer would skip it) and the graphed steps still match the eager ones;
+    the per-image scale/shift row follows img_i inside the graph."""
     import os
     import torch.distributed as dist
     from scade_amd.graphs import GraphedTrainer
@@ -388,19 +396,24 @@ def test_graphed_trainer_captures_the_rccl_allreduce(dev):
         g = torch.Generator().manual_seed(71)
         draws = [tuple(torch.rand(N, s, generator=g).to(dev) for s in (64, 128, 128)) for _ in range(4)]
         res = {}
-        for mode in ("eager", "graph"):
+        # (name, graphed, allreduce mode, collective forced on the one-rank group)
+        modes = [("eager", False, "single", False), ("graph", True, "single", True),
+                 ("graph_overlap", True, "overlap", True), ("eager_overlap", False, "overlap", True)]
+        for mode, graphed, ar, force in modes:
             coarse, fine = make_scade_nets(dev, seed=4)
-            tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1)
-            gt = GraphedTrainer(tr, N, K, inject_draws=True, force_allreduce=True) if mode == "graph" else None
+            tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=2, allreduce=ar)
+            tr.force_allreduce = force
+            gt = GraphedTrainer(tr, N, K, inject_draws=True, force_allreduce=force) if graphed else None
             ls = []
-            for a, b, c in draws:
-                kw = dict(t_rand=a, u_coarse=b, cached_u=c)
+            for i, (a, b, c) in enumerate(draws):
+                kw = dict(t_rand=a, u_coarse=b, cached_u=c, img_i=i % 2)
                 ls.append(float(gt.step(rays, tgt, hyp, **kw) if gt else tr.step(rays, tgt, hyp, **kw)[0]))
             torch.cuda.synchronize()
-            res[mode] = (ls, tr.flat.data.clone())
-        for a, b in zip(res["eager"][0], res["graph"][0]):
-            assert abs(a - b) <= 1e-5 * abs(a)
-        assert_close(res["graph"][1], res["eager"][1], rtol=1e-5, atol=1e-7, what="parameters")
+            res[mode] = (ls, tr.bucket.data.clone())
+        for mode in ("graph", "graph_overlap", "eager_overlap"):
+            for a, b in zip(res["eager"][0], res[mode][0]):
+                assert abs(a - b) <= 1e-5 * abs(a), mode
+            assert_close(res[mode][1], res["eager"][1], rtol=1e-5, atol=1e-7, what=f"parameters ({mode})")
     finally:
         if created:
             dist.destroy_process_group()

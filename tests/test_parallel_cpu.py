@@ -11,7 +11,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import scade_oracle as O
-from scade_amd.parallel import FlatParams, shard_batch, shard_range, staircase_lr
+from scade_amd.parallel import FlatParams, batch_share, shard_batch, shard_range, staircase_lr
 
 
 def test_shard_range_covers_everything():
@@ -25,7 +25,8 @@ def test_shard_range_covers_everything():
 
 
 def test_staircase_lr():
-    assert staircase_lr(5e-4, 0.1, 400000, 0) == 5e-4
+    # the argument is the reference's loop index i (counts from 1; Trainer passes it + 1)
+    assert staircase_lr(5e-4, 0.1, 400000, 1) == 5e-4
     assert staircase_lr(5e-4, 0.1, 400000, 399999) == 5e-4
     assert abs(staircase_lr(5e-4, 0.1, 400000, 400000) - 5e-5) < 1e-12
 
@@ -38,8 +39,8 @@ def _free_port():
     return p
 
 
-def _problem():
-    N, K = 16, 5
+def _problem(N=16):
+    K = 5
     rays = O.synthetic_rays(N, seed=3)
     g = torch.Generator().manual_seed(4)
     tgt = torch.rand(N, 3, generator=g)
@@ -64,39 +65,67 @@ def _params():
     return tensors, dict(zip(pc.keys(), tensors[:n])), dict(zip(pf.keys(), tensors[n:2 * n])), tensors[-2], tensors[-1]
 
 
-def _worker(rank, world, port, out_dir):
+def _worker(rank, world, port, out_dir, n_rays, pieces):
+    """One rank of the Trainer's exchange: ONE bucket [coarse | fine | scale | shift], every loss
+    term weighted by n_local / N_total, sum-all-reduce (whole, or in two async pieces), no 1/world."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     torch.set_num_threads(2)
-    rays, tgt, hyp, t_rand, u = _problem()
+    rays, tgt, hyp, t_rand, u = _problem(n_rays)
     tensors, pc, pf, scale, shift = _params()
-    flat = FlatParams(tensors)
+    flat = FlatParams(tensors)                                        # the networks AND scale/shift
     flat.broadcast_params(0)
     flat.zero_grad()
     a, b = shard_range(rays.shape[0], rank, world)
     r, t, h = shard_batch(rays, tgt, hyp, rank, world)
-    loss = _loss(pc, pf, scale, shift, r, t, h, t_rand[a:b], u[a:b])
+    share = batch_share(b - a, n_rays)
+    assert abs(share - (b - a) / n_rays) < 1e-12
+    loss = _loss(pc, pf, scale, shift, r, t, h, t_rand[a:b], u[a:b]) * share
     loss.backward()
     assert tensors[0].grad.data_ptr() == flat.grad.data_ptr()       # accumulated in place
-    gscale = flat.allreduce_grads()
-    assert gscale == 1.0 / world
-    torch.save((flat.grad * gscale).clone(), os.path.join(out_dir, f"g{rank}.pt"))
+    if pieces:
+        n_c = sum(v.numel() for v in pc.values())
+        works = flat.allreduce_grads_async([(0, n_c, None), (n_c, flat.numel - n_c, None)])
+        assert len(works) == 2
+        flat.wait_all(works)
+    else:
+        assert flat.allreduce_grads() == 1.0 / world                  # legacy factor, unused here
+    torch.save((flat.grad.clone(), loss.detach()), os.path.join(out_dir, f"g{rank}.pt"))
     dist.destroy_process_group()
 
 
-def test_sharded_gradients_match_single_process(tmp_path):
+@pytest.mark.parametrize("n_rays,pieces", [(16, False), (17, False), (17, True)])
+def test_sharded_gradients_match_single_process(tmp_path, n_rays, pieces):
+    """8 + 8 and 9 + 8 rays: the summed share-weighted gradients are the single-process ones."""
     world = 2
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    g0 = torch.load(os.path.join(tmp_path, "g0.pt"))
-    g1 = torch.load(os.path.join(tmp_path, "g1.pt"))
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_rays, pieces), nprocs=world, join=True)
+    g0, l0 = torch.load(os.path.join(tmp_path, "g0.pt"))
+    g1, l1 = torch.load(os.path.join(tmp_path, "g1.pt"))
     assert torch.equal(g0, g1), "all ranks must hold identical reduced gradients"
-    rays, tgt, hyp, t_rand, u = _problem()
+    rays, tgt, hyp, t_rand, u = _problem(n_rays)
     tensors, pc, pf, scale, shift = _params()
-    _loss(pc, pf, scale, shift, rays, tgt, hyp, t_rand, u).backward()
+    want = _loss(pc, pf, scale, shift, rays, tgt, hyp, t_rand, u)
+    want.backward()
     ref = torch.cat([t.grad.reshape(-1) if t.grad is not None else torch.zeros(t.numel()) for t in tensors])
     err = (g0 - ref).norm() / ref.norm()
     assert err < 1e-5, f"sharded vs single-process gradient rel-L2 {err:.3e}"
+    assert float(ref[-2:].abs().min()) > 0, "scale / shift gradients ride in the same bucket"
+    assert abs(float(l0 + l1) - float(want)) < 1e-5 * abs(float(want)), "rank terms sum to the global loss"
+
+
+def test_flat_segments_share_the_bucket():
+    ps = [torch.nn.Parameter(torch.randn(6)), torch.nn.Parameter(torch.randn(2, 1)), torch.nn.Parameter(torch.randn(2, 1))]
+    flat = FlatParams(ps)
+    nets, ss = flat.segment(0, 6), flat.segment(6, 4)
+    (ps[0].sum() + 3 * ps[1].sum() + 5 * ps[2].sum()).backward()
+    assert torch.equal(nets.grad, torch.ones(6)) and torch.equal(ss.grad, torch.tensor([3., 3., 5., 5.]))
+    ss.data.zero_()
+    assert float(ps[1].abs().sum() + ps[2].abs().sum()) == 0.0 and nets.data.data_ptr() == flat.data.data_ptr()
+    ss.zero_grad()
+    assert float(flat.grad[6:].abs().sum()) == 0.0 and float(flat.grad[:6].sum()) == 6.0
+    with pytest.raises(ValueError):
+        flat.segment(8, 4)
 
 
 def test_flatparams_views_and_zero_grad():
@@ -119,17 +148,17 @@ def test_flatparams_views_and_zero_grad():
 class _JointShardedCpu(torch.autograd.Function):
     """CPU stand-in with the SAME structure as scade_amd.ops.CarveJointShardedFn (kernel phases
     replaced by torch ops): column means of the shard -> parallel.combine_shard_means -> min over
-    K / mean over samples; backward = this shard's part of the global gradient x world."""
+    K / mean over samples; backward = this shard's part of the global gradient."""
 
     @staticmethod
     def forward(ctx, pred, hyp):
         from scade_amd.parallel import combine_shard_means
         d = (pred[None] - hyp).abs()                       # [K,n,P]
         means = d.mean(dim=1)                              # [K,P] over this shard's rays
-        share, world = combine_shard_means(means, pred.shape[0])
+        share, world = combine_shard_means(means, pred.shape[0], n_total=_joint_problem()[0].shape[0])
         best, arg = means.min(dim=0)
         ctx.save_for_backward(pred, hyp, arg)
-        ctx.factor = share * world
+        ctx.factor = share
         return best.mean()
 
     @staticmethod
@@ -182,10 +211,10 @@ def test_joint_space_carving_exchange_matches_single_process(tmp_path):
     want.backward()
     for r in range(world):
         assert abs(float(outs[r][0]) - float(want)) < 1e-6 * abs(float(want)), "every rank holds the GLOBAL loss"
-    # the trainer sums the ranks' gradients and applies 1/world: here pred/hyp shards are disjoint
-    # inputs, so the per-shard gradient x 1/world must equal the matching slice of the full gradient
-    gp = torch.cat([outs[r][1] for r in range(world)], 0) / world
-    gh = torch.cat([outs[r][2] for r in range(world)], 1) / world
+    # the trainer SUMS the ranks' gradients: here pred/hyp shards are disjoint inputs, so the
+    # per-shard gradient must equal the matching slice of the full gradient
+    gp = torch.cat([outs[r][1] for r in range(world)], 0)
+    gh = torch.cat([outs[r][2] for r in range(world)], 1)
     assert torch.allclose(gp, p.grad, rtol=1e-5, atol=1e-8)
     assert torch.allclose(gh, h.grad, rtol=1e-5, atol=1e-8)
     assert torch.equal(outs[0][3], outs[1][3]), "sample_pdf_joint's u must be one draw for all ranks"
