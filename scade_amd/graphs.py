@@ -53,14 +53,14 @@ class GraphedTrainer:
         kw = {}
         if self.draws is not None:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
-        loss, _ = tr.forward_loss(self.rays, self.tgt, self.hyp, img_i=self.img_i, mask=self.mask,
-                                  n_total=self.n_total, **kw)
+        loss, aux = tr.forward_loss(self.rays, self.tgt, self.hyp, img_i=self.img_i, mask=self.mask,
+                                    n_total=self.n_total, **kw)
         loss.backward()
         tr.reduce_grads()
         tr.opt.step_dev()
         if tr.scaleshift_active():
             tr.opt_ss.step_dev()
-        return loss.detach()
+        return aux["loss_report"]
 
     def _state(self):
         tr = self.tr

@@ -147,9 +147,15 @@ class Trainer:
         loss = loss + img_loss0
         if share != 1.0:
             loss = loss * share
+        report = loss.detach()
         if global_terms is not None:
+            # a term that is already the whole batch's loss on every rank: full weight in the backward
+            # (each rank's backward yields its shard's part), its share in the reported value so that
+            # the ranks' reports still sum to the global loss
             loss = loss + global_terms
-        return loss, dict(img_loss=img_loss, carve=carve, img_loss0=img_loss0, ret=ret, share=share)
+            report = report + share * global_terms.detach()
+        return loss, dict(img_loss=img_loss, carve=carve, img_loss0=img_loss0, ret=ret, share=share,
+                          loss_report=report)
 
     def reduce_grads(self):
         """The step's gradient exchange: RCCL sum-all-reduce of the bucket over the ranks' shards."""
@@ -177,4 +183,4 @@ class Trainer:
         if self.scaleshift_active():                                                          # :996-997
             self.opt_ss.step()
         self.it += 1
-        return loss.detach(), aux
+        return aux["loss_report"], aux
