@@ -72,7 +72,7 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
           if (RELU && x > 0.f) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
-          if (RELU) x = fmaxf(x, 0.f);
+          if (RELU) x = x < 0.f ? 0.f : x;     // NaN-propagating relu (torch.relu semantics)
           _Float16 h, l;
           split2(x, h, l);
           vh[i] = h; vl[i] = l;

@@ -69,6 +69,8 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][NPT], int
   }
 }
 
+__device__ __forceinline__ bool lp_nonfinite(float v) { return !(fabsf(v) <= 3.4028234664e38f); }   // NaN or +-inf
+
 template <bool BF, int MODE, bool SAVE, int NPT>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   constexpr int LM = 32 * NPT, LPT = NPT, LXPLANE = LM * W;   // this workgroup's tile (shadow the 128-point default)
@@ -280,6 +282,27 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
         const float bx = al * 10.f;
         const float sp = bx > 20.f ? al : log1pf(expf(bx)) / 10.f;
         f32x4 o = {s0 + br[0], s1 + br[1], s2 + br[2], sp};
+        // The packed 16-bit ReLU (v_pk_max_i16) does not carry NaN the way torch.relu does, so a
+        // poisoned point is decided from its INPUTS: a non-finite coordinate makes the reference's
+        // whole output row NaN (sin(inf) = NaN feeds every feature), a non-finite view direction its
+        // colour.  The reference's isnan/isinf scan (run_scade_scannet.py:747-749) then still sees it.
+        const size_t pt = (size_t)(p0 + row);
+        bool badp = false, badv = false;
+        if (MODE == 1) {
+          const float* q = a.in + pt * 3;
+          const float* vd = a.viewdirs + (pt / a.S) * a.vd_stride;
+          badp = lp_nonfinite(q[0]) | lp_nonfinite(q[1]) | lp_nonfinite(q[2]);
+          badv = lp_nonfinite(vd[0]) | lp_nonfinite(vd[1]) | lp_nonfinite(vd[2]);
+        } else {
+          const float* q = a.in + pt * 60;
+          for (int c = 0; c < 57; ++c) badp |= lp_nonfinite(q[c]);
+          badv = lp_nonfinite(q[57]) | lp_nonfinite(q[58]) | lp_nonfinite(q[59]);
+        }
+        if (badp | badv) {
+          const float qn = __builtin_nanf("");
+          o[0] = o[1] = o[2] = qn;
+          if (badp) o[3] = qn;
+        }
         *reinterpret_cast<f32x4*>(a.out + (size_t)(p0 + row) * 4) = o;
       }
     }

@@ -152,7 +152,7 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, int ray, i
       const f32x4 rv = rawr[i];
       float sig = rv[3];
       if (a.noise) sig = sig + a.noise[(size_t)ray * S + i];
-      const float sp = fmaxf(sig, 0.f);
+      const float sp = sig < 0.f ? 0.f : sig;   // relu that propagates NaN like F.relu (:512)
       const float alpha = 1.0f - expf(-sp * dist);                   // :512
       const float x = (1.0f - alpha) + 1e-10f;                       // :520
       xd = (double)x;

@@ -1,0 +1,130 @@
+"""BASELINE.json configs[4] at ITS shape - in-the-wild batches of 4096 rays, K = 40 depth
+hypotheses, the bf16 MFMA path (run_scade_wild.py --N_rand 4096 --num_hypothesis 40) - and the
+NaN semantics of a poisoned ray (the failures run_scade_scannet.py:747-749 exists to print)."""
+import pytest
+import torch
+
+import scade_amd as S
+from conftest import assert_close, rel_l2
+from oracle import scade_oracle as O
+from test_gpu_render import build
+
+pytestmark = pytest.mark.gpu
+
+N5, K5 = 4096, 40
+
+
+def _psnr(a, b):
+    return float(-10 * torch.log10(torch.mean((a.double().cpu() - b.double().cpu()) ** 2) + 1e-30))
+
+
+def test_config5_render_4096_rays_bf16(dev):
+    rays = O.synthetic_rays(N5, seed=55)
+    pc, pf = O.nerf_init(56), O.nerf_init(57)
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+    coarse, fine, query = build(dev, pc, pf, bbc, bbs)
+    coarse.inference_precision = fine.inference_precision = "bf16"
+    kw = dict(N_importance=128, network_fine=fine, perturb=0., retraw=True)
+    with torch.no_grad():
+        ret = S.render_rays(rays.to(dev), True, coarse, query, 64, **kw)
+        part = S.render_rays(rays[:256].to(dev), True, coarse, query, 64, **kw)
+        want = O.render_rays(rays[:256], pc, pf, bbc, bbs, retraw=True)          # exact fp32 reference, slice
+    # ---- size-independent properties at the full shape
+    for k, v in ret.items():
+        assert torch.isfinite(v).all() or k == "disp_map", k
+    z = ret["z_vals"]
+    assert z.shape == (N5, 192) and bool((z[:, 1:] >= z[:, :-1]).all()), "z_vals sorted"
+    assert float(z.min()) >= 0.1 - 1e-6 and float(z.max()) <= 5.0 + 1e-5
+    w = ret["weights"]
+    assert float(w.min()) >= 0 and float(w.max()) <= 1 + 1e-6
+    assert_close(ret["acc_map"], w.sum(-1), rtol=1e-5, atol=1e-6, what="acc = sum w")
+    assert float(ret["acc_map"].max()) <= 1 + 1e-5
+    assert_close(ret["depth_map"], (w * z).sum(-1), rtol=1e-4, atol=1e-5, what="depth = sum w z")
+    ph = ret["pred_hyp"]
+    assert ph.shape == (N5, 128) and bool((ph[:, 1:] >= ph[:, :-1] - 1e-6).all()), "det u -> monotone hypotheses"
+    assert float(ph.min()) >= 0.1 - 1e-6 and float(ph.max()) <= 5.0 + 1e-5
+    assert float(ret["rgb_map"].min()) >= 0 and float(ret["rgb_map"].max()) <= 1 + 1e-5
+    # ---- rays are independent units: the first 256 rows do not depend on the other 3840
+    for k in part:
+        assert torch.equal(torch.nan_to_num(part[k]), torch.nan_to_num(ret[k][:256])), k
+    # ---- against the exact reference on the slice: bf16 operand rounding, PSNR-class agreement
+    assert torch.equal(part["z_vals0"].cpu(), want["z_vals0"])
+    assert _psnr(part["rgb0"], want["rgb0"]) > 35 and _psnr(part["rgb_map"], want["rgb_map"]) > 30
+    assert rel_l2(part["depth0"], want["depth0"]) < 2e-2 and rel_l2(part["depth_map"], want["depth_map"]) < 5e-2
+
+
+def test_config5_train_step_4096_rays_k40_bf16(dev):
+    """One Trainer.step at the config-5 shape (wild variant: mask on all three loss terms) against the
+    exact fp32 loss of the oracle on a 256-ray slice with the same draws; gradients finite; a second
+    step lowers the loss on the same batch."""
+    from scade_amd.train import Trainer
+    from test_gpu_ops import make_net
+    g = torch.Generator().manual_seed(58)
+    rays = O.synthetic_rays(N5, seed=59)
+    tgt = torch.rand(N5, 3, generator=g) * 0.3 + 0.35
+    hyp = torch.rand(K5, N5, 1, generator=g) * 4.9 + 0.1
+    mask = (torch.rand(N5, generator=g) > 0.1).float()
+    draws = dict(t_rand=torch.rand(N5, 64, generator=g), u_coarse=torch.rand(N5, 128, generator=g),
+                 cached_u=torch.rand(N5, 128, generator=g))
+    pc, pf = O.nerf_init(60), O.nerf_init(61)
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+    tr = Trainer(make_net(pc, dev), make_net(pf, dev), bbc, bbs, n_images=1, precision="bf16", mask_mode="wild",
+                 scaleshift_lr=1e-5)
+    dd = {k: v.to(dev) for k, v in draws.items()}
+    loss, aux = tr.step(rays.to(dev), tgt.to(dev), hyp.to(dev), mask=mask.to(dev), **dd)
+    assert torch.isfinite(tr.bucket.grad).all() and float(tr.bucket.grad.abs().max()) > 0
+    assert float(tr.flat_ss.grad.abs().min()) > 0, "scale and shift both receive gradient (:954)"
+    ret = aux["ret"]
+    assert ret["pred_hyp"].shape == (N5, 128) and torch.isfinite(ret["pred_hyp"]).all()
+    # slice loss with the reference's arithmetic (fp32 oracle, wild masking run_scade_wild.py:977-1008)
+    sl = slice(0, 256)
+    w = O.render_rays(rays[sl], pc, pf, bbc, bbs, t_rand=draws["t_rand"][sl], u_coarse=draws["u_coarse"][sl],
+                      u_fine=draws["cached_u"][sl])
+    m = mask[sl]
+    want = {"img": torch.mean((w["rgb_map"] - tgt[sl]) ** 2 * m[:, None]),
+            "img0": torch.mean((w["rgb0"] - tgt[sl]) ** 2 * m[:, None]),
+            "carve": O.compute_space_carving_loss(w["pred_hyp"], hyp[:, sl], mask=m)}
+    r = {k: v[sl] for k, v in ret.items()}
+    got = {"img": S.img2mse_masked(r["rgb_map"].detach(), tgt[sl].to(dev), m.to(dev)),
+           "img0": S.img2mse_masked(r["rgb0"].detach(), tgt[sl].to(dev), m.to(dev)),
+           "carve": S.compute_space_carving_loss(r["pred_hyp"].detach().contiguous(), hyp[:, sl].to(dev).contiguous(),
+                                                 mask=m.to(dev))}
+    for k in want:
+        assert abs(float(got[k]) - float(want[k])) <= 2e-2 * abs(float(want[k])), (k, float(got[k]), float(want[k]))
+    psnr_gap = abs(float(S.mse2psnr(got["img"])) - float(O.mse2psnr(want["img"])))
+    assert psnr_gap < 0.05, f"PSNR(bf16) vs PSNR(reference fp32) on the slice: {psnr_gap:.4f} dB"
+    # the same batch again: Adam moved the parameters downhill
+    loss2, _ = tr.step(rays.to(dev), tgt.to(dev), hyp.to(dev), mask=mask.to(dev), **dd)
+    assert float(loss2) < float(loss)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16"])
+def test_poisoned_rays_show_the_references_nan_pattern(dev, prec):
+    """Rays with a NaN origin / an Inf direction / a NaN view direction through render_rays: every
+    output of those rays is NaN exactly where the reference's is (torch.relu propagates NaN; a
+    v_max_f32 ReLU would have returned finite garbage), and the other rays are untouched."""
+    N = 48
+    rays = O.synthetic_rays(N, seed=66)
+    rays[5, 0] = float("nan")            # origin
+    rays[17, 4] = float("inf")           # direction
+    rays[30, 9] = float("nan")           # view direction only: colour is poisoned, density is not
+    pc, pf = O.nerf_init(67), O.nerf_init(68)
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+    with torch.no_grad():
+        want = O.render_rays(rays, pc, pf, bbc, bbs, retraw=True)
+    coarse, fine, query = build(dev, pc, pf, bbc, bbs)
+    coarse.inference_precision = fine.inference_precision = prec
+    with torch.no_grad():
+        ret = S.render_rays(rays.to(dev), True, coarse, query, 64, N_importance=128, network_fine=fine,
+                            perturb=0., retraw=True)
+    clean = torch.ones(N, dtype=torch.bool)
+    clean[[5, 17, 30]] = False
+    for k in want:
+        a, b = ret[k].cpu(), want[k]
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), f"{k}: NaN pattern differs from the reference"
+        assert torch.isfinite(a[clean]).all() or k == "disp_map", k
+    assert torch.isnan(want["rgb_map"][[5, 17, 30]]).all() and torch.isnan(want["raw"][5]).all()
+    assert torch.isfinite(want["weights"][30]).all(), "a poisoned view direction leaves the density alone"
+    if prec == "f32":
+        for k in ("rgb0", "depth0", "weights0"):
+            assert_close(ret[k][clean], want[k][clean], rtol=1e-4, atol=1e-6, what=k)
