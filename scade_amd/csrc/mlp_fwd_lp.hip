@@ -214,12 +214,29 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 #undef PTS_LAYER_L
 
   // ---- alpha head on the VALU (fp32 weights) ------------------------------------------
+  // The packed 16-bit ReLU (v_pk_max_i16) does not carry NaN the way torch.relu does, so a poisoned
+  // point is decided from its INPUTS: a non-finite coordinate makes the reference's whole output row
+  // NaN (sin(inf) = NaN feeds every feature), a non-finite view direction its colour.  The
+  // reference's isnan/isinf scan (run_scade_scannet.py:747-749) then still sees it.  The six input
+  // floats are fetched here so that their latency hides under the alpha dot products.
   float alpha[LM / 64];
+  int badf[LM / 64];
   {
     const float* wa = TAIL(OFF_WA);
 #pragma unroll
     for (int rb = 0; rb < LM / 64; ++rb) {
       const int row = rb * 64 + (tid >> 2), sub = tid & 3;
+      const size_t ptc = (size_t)min(p0 + row, P - 1);
+      float q0, q1, q2, v0, v1, v2;
+      if (MODE == 1) {
+        const float* q = a.in + ptc * 3;
+        const float* vd = a.viewdirs + (ptc / a.S) * a.vd_stride;
+        q0 = q[0]; q1 = q[1]; q2 = q[2]; v0 = vd[0]; v1 = vd[1]; v2 = vd[2];
+      } else {
+        // x rows hold gamma(x) = [x, sin, cos, ...]: a non-finite coordinate shows in the raw columns
+        const float* q = a.in + ptc * 60;
+        q0 = q[0]; q1 = q[1]; q2 = q[2]; v0 = q[57]; v1 = q[58]; v2 = q[59];
+      }
       float s = 0.f;
 #pragma unroll
       for (int i = 0; i < 8; ++i) {
@@ -231,6 +248,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       alpha[rb] = s + TAIL(OFF_BA)[0];
+      const bool badp = lp_nonfinite(q0) | lp_nonfinite(q1) | lp_nonfinite(q2);
+      badf[rb] = badp | lp_nonfinite(v0) | lp_nonfinite(v1) | lp_nonfinite(v2);
+      if (badp) alpha[rb] = __builtin_nanf("");
       if (SAVE && sub == 0 && p0 + row < P)
         reinterpret_cast<float*>(a.acts + lp_acts_alpha_byte(P))[p0 + row] = alpha[rb];
     }
@@ -282,26 +302,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
         const float bx = al * 10.f;
         const float sp = bx > 20.f ? al : log1pf(expf(bx)) / 10.f;
         f32x4 o = {s0 + br[0], s1 + br[1], s2 + br[2], sp};
-        // The packed 16-bit ReLU (v_pk_max_i16) does not carry NaN the way torch.relu does, so a
-        // poisoned point is decided from its INPUTS: a non-finite coordinate makes the reference's
-        // whole output row NaN (sin(inf) = NaN feeds every feature), a non-finite view direction its
-        // colour.  The reference's isnan/isinf scan (run_scade_scannet.py:747-749) then still sees it.
-        const size_t pt = (size_t)(p0 + row);
-        bool badp = false, badv = false;
-        if (MODE == 1) {
-          const float* q = a.in + pt * 3;
-          const float* vd = a.viewdirs + (pt / a.S) * a.vd_stride;
-          badp = lp_nonfinite(q[0]) | lp_nonfinite(q[1]) | lp_nonfinite(q[2]);
-          badv = lp_nonfinite(vd[0]) | lp_nonfinite(vd[1]) | lp_nonfinite(vd[2]);
-        } else {
-          const float* q = a.in + pt * 60;
-          for (int c = 0; c < 57; ++c) badp |= lp_nonfinite(q[c]);
-          badv = lp_nonfinite(q[57]) | lp_nonfinite(q[58]) | lp_nonfinite(q[59]);
-        }
-        if (badp | badv) {
+        if (badf[rb]) {       // poisoned inputs (see the alpha head): colour NaN; density already is
           const float qn = __builtin_nanf("");
           o[0] = o[1] = o[2] = qn;
-          if (badp) o[3] = qn;
         }
         *reinterpret_cast<f32x4*>(a.out + (size_t)(p0 + row) * 4) = o;
       }

@@ -163,8 +163,11 @@ def test_train_step_gradient_error_against_fp64_is_the_references_own(dev):
     _dump("train_step_grads_256rays_K20", table)
     # a single gradient tensor's max/percentile is dominated by a handful of near-knot samples;
     # bound the norm-wise error of every tensor and both statistics of the whole networks
+    # (a scalar - depth scale / shift, a 1-element bias - has ONE error draw, not a statistic: its
+    # bound is C x the reference's or 5e-3, whichever is larger)
+    small = {k for k in table if not k.startswith("_") and g64[k].numel() < 16}
     bad = [(k, r["hip_rel_l2"], r["oracle32_rel_l2"]) for k, r in table.items()
-           if r["hip_rel_l2"] > C_BOUND * r["oracle32_rel_l2"] + 2e-7]
+           if r["hip_rel_l2"] > max(C_BOUND * r["oracle32_rel_l2"] + 2e-7, 5e-3 if k in small else 0.0)]
     assert not bad, "HIP gradients farther from fp64 than C x the reference's fp32: %s" % bad
     for k in ("_all_coarse", "_all_fine"):
         assert table[k]["hip_p999"] <= C_BOUND * table[k]["oracle32_p999"] + 2e-7, (k, table[k])
