@@ -70,8 +70,9 @@ __device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT
           float x = acc[t][p][4 * q + i] + bv[i];
           // relu that PROPAGATES NaN like torch.relu (v_max_f32 would return 0 for a NaN input and
           // hide a poisoned point from the reference's isnan/isinf scan, run_scade_scannet.py:747-749)
-          v[i] = RELU ? (x < 0.f ? 0.f : x) : x;
-          if (RELU && x > 0.f) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
+          const bool off = x <= 0.f;             // one compare serves the value and the sign bit
+          v[i] = RELU ? (off ? 0.f : x) : x;
+          if (RELU && !off) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
         }
         const int row = p * 32 + r;
         *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
