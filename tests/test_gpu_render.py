@@ -36,7 +36,14 @@ def check_ret(ret, want, tag):
     amplifies a 1e-7 shift of a point ~800x, so two correct fp32 implementations
     (e.g. two BLAS builds of the reference itself) differ there element-wise.  The
     fine stage is held to the element-wise bar separately, on identical inputs, by
-    ``stagewise`` below."""
+    ``stagewise`` below.
+
+    MEASURED (tests/test_gpu_parity64.py -> profiles/r02_parity.json, 512 rays): against an fp64
+    evaluation of the same algorithm the REFERENCE's own fp32 arithmetic is off by rel-L2 2e-4
+    (rgb_map), 6e-4 (depth_map), 5e-5 (z_vals), 5e-3 (weights), 1.4e-3 (pred_hyp), 6e-3 (raw); the
+    HIP path is off by the same amounts (ratio 1.0-1.2) and HIP-vs-reference is of that size too.
+    The bounds below therefore sit AT the fp32 noise floor of the problem for this fixture's 32
+    rays, not above an achievable tighter bar."""
     assert set(want) <= set(ret)
     for k in COARSE_KEYS:
         atol = 1e-5 * float(torch.nan_to_num(want[k]).abs().max()) + 1e-7

@@ -109,7 +109,10 @@ def test_train_step_golden(dev):
         else:
             grad_close(got, want, f"grad coarse.{k}", rtol=2e-4, scale_atol=5e-5)
     # fine net sits behind the ill-conditioned resampling (see test_gpu_render.check_ret):
-    # norm-wise here, element-wise in test_fine_net_gradients_on_reference_z below
+    # norm-wise here, element-wise in test_fine_net_gradients_on_reference_z below.  Measured
+    # (profiles/r02_parity.json, 256 rays): the reference's OWN fp32 gradients are rel-L2 1e-3...6e-3
+    # (pts layers), 1.6e-2 (alpha weight), 1.1e-1 (alpha bias) away from the fp64 answer and the HIP
+    # path's are the same distance away, so 2e-2 on this 32-ray fixture is the noise floor
     worst = 0.0
     for k, p in fine.named_parameters():
         want = g[f"grad_fine/{k}"]
