@@ -16,7 +16,7 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libscade_hip.so")
-SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_fwd_f16.hip", "mlp_bwd_f16.hip", "mlp_fwd_lp.hip",
+SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_wgrad2.hip", "mlp_fwd_f16.hip", "mlp_bwd_f16.hip", "mlp_fwd_lp.hip",
            "mlp_bwd_lp.hip", "ray_ops.hip", "optim.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]

@@ -200,192 +200,6 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
 #undef WTBASE
 }
 
-// ---------------------------------------------------------------------------
-// B2: wgrad
-// ---------------------------------------------------------------------------
-constexpr int WG_PT = 32;                    // points per LDS stage
-constexpr int WGRAD_LDS_BYTES = (2 * (2 * WG_PT * 256) + 2 * 64 + 2 * WG_PT * 4) * 4;  // double-buffered
-
-template <int KW>
-__device__ __forceinline__ void wgrad_mfma_job(const WgradArgs& a, const WgradJob& jb, float* lds,
-                                               int c0, int c1, float* __restrict__ out) {
-  constexpr int NKT = KW == 256 ? 4 : 1;          // k-tiles of 32 per wave
-  constexpr int B_F4_PER_THR = KW == 256 ? 4 : 1; // float4 staged per thread for the B tile
-  // two stage buffers: As[32][256] | Bs[32][KW], then dal[2][64], vws[2][128]
-  constexpr int STAGE_FLOATS = 2 * WG_PT * 256;
-  float* dal_base = lds + 2 * STAGE_FLOATS;
-  float* vws_base = dal_base + 2 * 64;
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  const int n0 = (wave >> 1) * 64;
-  const int k0 = (wave & 1) * (KW / 2);
-  const bool active = n0 < jb.n_rows;
-  const int P = a.P;
-  const float* __restrict__ dzm = a.dz + jb.dz_off;
-  const float* __restrict__ inm = a.acts + jb.in_off;
-
-  f32x16 acc[2][NKT];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < NKT; ++u)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-  float bias_acc = 0.f, alpha_acc = 0.f, dal_acc = 0.f;
-  float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
-
-  f32x4 pa[4], pb[B_F4_PER_THR];
-  auto issue = [&](int pt0) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = tid + 512 * j, row = i >> 6, c4 = i & 63;
-      const int pt = pt0 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pt < c1) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(dzm + (size_t)pt * 256 + c4 * 4));   // read once
-      pa[j] = v;
-    }
-#pragma unroll
-    for (int j = 0; j < B_F4_PER_THR; ++j) {
-      const int i = tid + 512 * j;
-      const int row = KW == 256 ? (i >> 6) : (i >> 4), c4 = KW == 256 ? (i & 63) : (i & 15);
-      const int pt = pt0 + row;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (pt < c1) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(inm + (size_t)pt * jb.in_stride + c4 * 4));
-      pb[j] = v;
-    }
-  };
-  auto commit = [&](int pt0, int buf) {
-    float* As = lds + buf * STAGE_FLOATS;
-    float* Bs = As + WG_PT * 256;
-    float* dal = dal_base + buf * 64;
-    float* vws = vws_base + buf * 128;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) reinterpret_cast<f32x4*>(As)[tid + 512 * j] = pa[j];
-#pragma unroll
-    for (int j = 0; j < B_F4_PER_THR; ++j) reinterpret_cast<f32x4*>(Bs)[tid + 512 * j] = pb[j];
-    if ((jb.flags & WF_ALPHA) && tid < WG_PT) {
-      const int pt = pt0 + tid;
-      dal[tid] = pt < c1 ? a.dz[dz_dalpha_off(P) + pt] : 0.f;
-    }
-    if ((jb.flags & WF_VIEWCOLS) && tid < WG_PT * 4) {
-      const int row = tid >> 2, c = tid & 3;
-      const int pt = pt0 + row;
-      vws[tid] = (pt < c1 && c < 3) ? a.acts[acts_emb_off(P) + (size_t)pt * 64 + 60 + c] : 0.f;
-    }
-  };
-
-  // software pipeline: stage s+2 in flight to registers, stage s+1 committed to the other
-  // LDS buffer while stage s is multiplied; ONE barrier per stage
-  issue(c0);
-  commit(c0, 0);
-  if (c0 + WG_PT < c1) issue(c0 + WG_PT);
-  __syncthreads();
-  int buf = 0;
-  for (int pt0 = c0; pt0 < c1; pt0 += WG_PT, buf ^= 1) {
-    if (pt0 + WG_PT < c1) commit(pt0 + WG_PT, buf ^ 1);
-    if (pt0 + 2 * WG_PT < c1) issue(pt0 + 2 * WG_PT);
-    const float* As = lds + buf * STAGE_FLOATS;
-    const float* Bs = As + WG_PT * 256;
-    const float* dal = dal_base + buf * 64;
-    const float* vws = vws_base + buf * 128;
-    if (active) {
-      // operands of k-step kk+1 are read from LDS before the 8 MFMAs of k-step kk
-      float avn[2], bvn[NKT];
-      auto lds_frag = [&](int kk) {
-        const int row = 2 * kk + hh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) avn[t] = As[row * 256 + n0 + 32 * t + r];
-#pragma unroll
-        for (int u = 0; u < NKT; ++u) bvn[u] = Bs[row * KW + k0 + 32 * u + r];
-      };
-      lds_frag(0);
-#pragma unroll 8
-      for (int kk = 0; kk < WG_PT / 2; ++kk) {
-        float av[2], bv[NKT];
-#pragma unroll
-        for (int t = 0; t < 2; ++t) av[t] = avn[t];
-#pragma unroll
-        for (int u = 0; u < NKT; ++u) bv[u] = bvn[u];
-        lds_frag((kk + 1) & (WG_PT / 2 - 1));
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int t = 0; t < 2; ++t)
-#pragma unroll
-          for (int u = 0; u < NKT; ++u)
-            acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[t], bv[u], acc[t][u], 0, 0, 0);
-      }
-    }
-    // VALU riders: thread tid < 256 owns column tid
-    if (tid < 256) {
-      if (jb.flags & WF_BIAS) {
-#pragma unroll 8
-        for (int row = 0; row < WG_PT; ++row) bias_acc += As[row * 256 + tid];
-      }
-      if (jb.flags & WF_ALPHA) {
-#pragma unroll 8
-        for (int row = 0; row < WG_PT; ++row) alpha_acc = fmaf(dal[row], Bs[row * KW + tid], alpha_acc);
-        if (tid == 0)
-          for (int row = 0; row < WG_PT; ++row) dal_acc += dal[row];
-      }
-      if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
-#pragma unroll 8
-        for (int row = 0; row < WG_PT; ++row) {
-          const float d = As[row * 256 + tid];
-          vc0 = fmaf(d, vws[row * 4 + 0], vc0);
-          vc1 = fmaf(d, vws[row * 4 + 1], vc1);
-          vc2 = fmaf(d, vws[row * 4 + 2], vc2);
-        }
-      }
-    }
-    __syncthreads();
-  }
-
-  // ---- write the partial ---------------------------------------------------------
-  if (active) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int u = 0; u < NKT; ++u) {
-        const int k = k0 + 32 * u + r;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int n = n0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (n < jb.n_rows && k < jb.kvalid)
-            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k] = acc[t][u][i];
-        }
-      }
-  }
-  if (tid < 256) {
-    if ((jb.flags & WF_BIAS) && tid < jb.n_rows) out[jb.b_off + tid] = bias_acc;
-    if (jb.flags & WF_ALPHA) {
-      out[jb.aux_off + tid] = alpha_acc;
-      if (tid == 0) out[jb.aux_off + 256] = dal_acc;
-    }
-    if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
-      out[jb.w_off + (size_t)tid * jb.ld + 256] = vc0;
-      out[jb.w_off + (size_t)tid * jb.ld + 257] = vc1;
-      out[jb.w_off + (size_t)tid * jb.ld + 258] = vc2;
-    }
-  }
-}
-
-__global__ __launch_bounds__(512, 2) void mlp_wgrad_kernel(WgradArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const WgradJob& jb = a.jobs[blockIdx.y];
-  const int c0 = blockIdx.x * a.chunk;
-  const int c1 = min(a.P, c0 + a.chunk);
-  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
-  if (jb.flags & WF_RGB) {
-    wgrad_rgb_job(a, jb, lds, c0, c1, out);
-  } else if (jb.kw == 256) {
-    wgrad_mfma_job<256>(a, jb, lds, c0, c1, out);
-  } else {
-    wgrad_mfma_job<64>(a, jb, lds, c0, c1, out);
-  }
-}
-
 }  // namespace scade
 
 // ===========================================================================
@@ -407,29 +221,15 @@ extern "C" int scade_mlp_pack_t(const float* const* params, float* packed_t, voi
   return scade_check_launch("scade_mlp_pack_t");
 }
 
-extern "C" int scade_mlp_bwd_chunks(int P) { return pick_chunks(P); }
+namespace scade { int pick_chunks_v2(int P); }   // mlp_wgrad2.hip
+
+// chunk count of the exact weight-gradient kernel (mlp_wgrad2.hip)
+extern "C" int scade_mlp_bwd_chunks(int P) { return pick_chunks_v2(P); }
 
 extern "C" long scade_mlp_bwd_workspace_floats(int P) {
-  return dz_floats(P) + (long)pick_chunks(P) * N_PARAM_FLOATS + 4;   // + launch-wide max slot (f16x3 mode)
-}
-
-// wgrad + reduce (shared by the exact and the split-precision backward)
-int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
-                       float* grad_flat, hipStream_t s) {
-  static unsigned long long attr_set = 0;   // one bit per device ordinal
-  if (scade_attr_needed(attr_set)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LDS_BYTES);
-    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    scade_attr_done(attr_set);
-  }
-  WgradArgs w{};
-  const int grid_x = build_wgrad_jobs(w, acts, dz, g_out, partial, P, WG_PT);
-  const int nj = w.njobs;
-  hipLaunchKernelGGL(mlp_wgrad_kernel, dim3(grid_x, nj), dim3(512), WGRAD_LDS_BYTES, s, w);
-  if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
-  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
-  return scade_check_launch("scade_mlp_bwd(reduce)");
+  // one workspace serves the exact kernel and the split-precision one (which chunks by pick_chunks)
+  const int nc = pick_chunks(P) > pick_chunks_v2(P) ? pick_chunks(P) : pick_chunks_v2(P);
+  return dz_floats(P) + (long)nc * N_PARAM_FLOATS + 4;   // + launch-wide max slot (f16x3 mode)
 }
 
 template <int PT>
