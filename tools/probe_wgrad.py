@@ -10,7 +10,8 @@ from scade_amd.train import make_scade_nets
 dev = torch.device("cuda:0")
 coarse, fine = make_scade_nets(dev, seed=0)
 bb = torch.tensor([0., 0., 0., 0.2], device=dev)
-for N, S in ((1024, 192), (1024, 64), (128, 192)):
+SIZES = [tuple(int(v) for v in a.split("x")) for a in sys.argv[1:]] or [(1024, 192), (1024, 64), (128, 192)]
+for N, S in SIZES:
     P = N * S
     pts = torch.rand(N, S, 3, device=dev) * 2 - 1
     vd = torch.nn.functional.normalize(torch.randn(N, 3, device=dev), dim=-1)
