@@ -23,8 +23,7 @@
 //    local address space: lgkmcnt(0), never vmcnt(0) - the global prefetch stays in flight); every
 //    fragment is read one k-group (32 MFMAs) ahead of its use, also across stages;
 //  * ONE ROUND: the launch has (just under) 2 x CUs workgroups of EQUAL cost, all resident from start to
-//    end - 16 half-layer jobs, the 128-row views layer (whose workgroups also do the rgb head, on
-//    shorter chunks to make up for it) and ONE job for both 57-column embedding blocks (dZ0 | dZ5 against
+//    end - 16 half-layer jobs, the 128-row views layer (with the view-direction columns) and ONE job for both 57-column embedding blocks (dZ0 | dZ5 against
 //    the embedding: 512 x 64 outputs = the MFMA work of a half layer).  Every job has its own chunk
 //    length; the partial-sum slots are reduced per tensor with that job's chunk count.  The two halves
 //    of a layer sit 8 workgroup ids apart = on the same XCD, so the input rows the second one streams
@@ -63,6 +62,7 @@ struct Wgrad2Args {
   float* partial;
   int P;
   int n_big;         // chunks of every half-layer job
+  int dbg;           // knock-out experiments (SCADE_WGRAD_DBG): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads
 };
 
 // float offset of 16-byte chunk lc (0..7 = buffer*4 + point group) of LDS row `row`; rows stored four per
@@ -215,15 +215,16 @@ __device__ __forceinline__ void wgrad2_big_job(const Wgrad2Args& a, const Wgrad2
   Frag f0, f1;
   read_frag(f0, 0, 0);
   int buf = 0;
+  const int dbg = a.dbg;
   for (int pt0 = c0; pt0 < c1; pt0 += W2_PT, buf ^= 1) {
     const bool has_next = pt0 + W2_PT < c1;
-    if (has_next) commit(buf ^ 1);
-    if (pt0 + 2 * W2_PT < c1) issue(pt0 + 2 * W2_PT);
-    read_frag(f1, buf, 1);
+    if (has_next && !(dbg & 2)) commit(buf ^ 1);
+    if (pt0 + 2 * W2_PT < c1 && !(dbg & 1)) issue(pt0 + 2 * W2_PT);
+    if (!(dbg & 8)) read_frag(f1, buf, 1);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(f0);
-    w2_barrier();
-    if (has_next) read_frag(f0, buf ^ 1, 0);
+    if (!(dbg & 4)) w2_barrier();
+    if (has_next && !(dbg & 8)) read_frag(f0, buf ^ 1, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(f1);
   }
@@ -391,15 +392,18 @@ __device__ __forceinline__ void wgrad2_emb_job(const Wgrad2Args& a, const Wgrad2
   out[jb.b_off + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
 }
 
-// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c].  A thread owns 4 columns
-// (one 16-byte load per point) of every 8th point, four points in flight: pure load latency.  Runs at the
-// end of the views workgroup, over that workgroup's points.
-__device__ __forceinline__ void wgrad2_rgb_tail(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0,
-                                                int c1, float* __restrict__ out) {
+// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c] - pure load latency (a
+// thread owns 4 columns of every 8th point, four points in flight), so it is its own small launch of many
+// short workgroups; their partials [n_rgb][388] are summed by the reduce kernel.
+constexpr int W2_RGB_PTS = 384;                   // points per workgroup
+constexpr int W2_RGB_ROW = 388;                   // 3 x 128 weights + 3 bias + pad
+__global__ __launch_bounds__(256) void wgrad2_rgb_kernel(const float* __restrict__ acts, const float* __restrict__ g_out,
+                                                         int P, float* __restrict__ part) {
+  __shared__ float red[8 * 3 * 128 + 8 * 4];
   const int tid = threadIdx.x;
   const int k4 = tid & 31, pl = tid >> 5;       // 32 column groups x 8 point lanes
-  const float* __restrict__ hv = a.acts + acts_slot_off(a.P, SLOT_VIEWS_H) + 4 * k4;
-  const int P = a.P;
+  const int c0 = blockIdx.x * W2_RGB_PTS, c1 = min(P, c0 + W2_RGB_PTS);
+  const float* __restrict__ hv = acts + acts_slot_off(P, SLOT_VIEWS_H) + 4 * k4;
   float s[3][4], b[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -411,7 +415,7 @@ __device__ __forceinline__ void wgrad2_rgb_tail(const Wgrad2Args& a, const Wgrad
     for (int q = 0; q < 4; ++q) {
       const int pt = min(pt0 + 8 * q, P - 1);
       h[q] = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * 256);
-      g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+      g[q] = *reinterpret_cast<const f32x4*>(g_out + (size_t)pt * 4);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -426,8 +430,6 @@ __device__ __forceinline__ void wgrad2_rgb_tail(const Wgrad2Args& a, const Wgrad
       }
     }
   }
-  __syncthreads();                                // the views job's rider reduction has finished with the LDS
-  float* red = lds;                               // [8 point lanes][3][128] + [8][4]
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -435,15 +437,16 @@ __device__ __forceinline__ void wgrad2_rgb_tail(const Wgrad2Args& a, const Wgrad
   float* redb = red + 8 * 3 * 128;
   if (k4 == 0) { redb[pl * 4 + 0] = b[0]; redb[pl * 4 + 1] = b[1]; redb[pl * 4 + 2] = b[2]; }
   __syncthreads();
+  float* out = part + (size_t)blockIdx.x * W2_RGB_ROW;
   for (int i = tid; i < 384; i += 256) {
     float t = 0.f;
     for (int p = 0; p < 8; ++p) t += red[p * 384 + i];
-    out[jb.w_off2 + i] = t;
+    out[i] = t;
   }
   if (tid < 3) {
     float t = 0.f;
     for (int p = 0; p < 8; ++p) t += redb[p * 4 + tid];
-    out[jb.ld2 + tid] = t;
+    out[384 + tid] = t;
   }
 }
 
@@ -469,11 +472,11 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad2_kernel(Wgrad2Args a) {
   const int c1 = min(a.P, c0 + jb.chunk);
   float* out = a.partial + (size_t)chunk_i * N_PARAM_FLOATS;
   if (c0 >= c1) return;
+  if ((a.dbg >> 8) && ((a.dbg >> 8) & 3) != jb.kind + 1) return;      // experiments: only one kind of job
   if (jb.kind == W2_EMB) {
     wgrad2_emb_job(a, jb, lds, c0, c1, out);
   } else if (jb.kind == W2_VIEWS) {
     wgrad2_big_job<WF_BIAS | WF_VIEWCOLS>(a, jb, lds, c0, c1, out);
-    wgrad2_rgb_tail(a, jb, lds, c0, c1, out);
   } else if (jb.flags & WF_ALPHA) {
     wgrad2_big_job<WF_BIAS | WF_ALPHA>(a, jb, lds, c0, c1, out);
   } else {
@@ -488,10 +491,33 @@ struct Reduce2Args {
   int t_off[N_PARAM_TENSORS + 1];
   int t_slots[N_PARAM_TENSORS];
   int slots_emb;
+  int n_rgb;                  // partial rows of the rgb head (wgrad2_rgb_kernel)
+  const float* rgb_part;
 };
 __global__ void wgrad2_reduce_kernel(const float* __restrict__ partial, Reduce2Args ra, float* __restrict__ grad) {
   const int i4 = blockIdx.x * 256 + threadIdx.x;
   if (i4 >= N_PARAM_FLOATS / 4) return;
+  if (4 * i4 + 3 >= ra.t_off[22]) {              // rgb_linear weight [3][128] + bias [3]: the last 387 floats
+    for (int e = 0; e < 4; ++e) {
+      const int i = 4 * i4 + e;
+      if (i < ra.t_off[22]) {                    // (the vector straddles the tensor boundary: alpha bias)
+        float s = 0.f;
+        for (int c = 0; c < ra.t_slots[21]; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
+        grad[i] = s;
+      } else if (i < N_PARAM_FLOATS) {
+        const int k = i - ra.t_off[22];
+        float s0 = 0.f, s1 = 0.f;
+        int c = 0;
+        for (; c + 2 <= ra.n_rgb; c += 2) {
+          s0 += ra.rgb_part[(size_t)c * W2_RGB_ROW + k];
+          s1 += ra.rgb_part[(size_t)(c + 1) * W2_RGB_ROW + k];
+        }
+        if (c < ra.n_rgb) s0 += ra.rgb_part[(size_t)c * W2_RGB_ROW + k];
+        grad[i] = s0 + s1;
+      }
+    }
+    return;
+  }
   auto slots_of = [&](int i) {
     int t = 0;
 #pragma unroll 1
@@ -528,7 +554,7 @@ struct W2Plan { int n_big, n_views, n_emb; };
 static W2Plan w2_plan(int P) {
   static double cv = 0.0, ce = 0.0;
   if (cv == 0.0) {
-    cv = 1.15; ce = 1.10;
+    cv = 1.03; ce = 1.12;
     if (const char* e = getenv("SCADE_WGRAD_COSTS")) {
       double x = 0, y = 0;
       if (sscanf(e, "%lf,%lf", &x, &y) == 2 && x > 0.2 && y > 0.2) { cv = x; ce = y; }
@@ -547,7 +573,13 @@ static W2Plan w2_plan(int P) {
   if (p.n_emb > cap) p.n_emb = cap;
   return p;
 }
-int pick_chunks_v2(int P) {          // partial-sum slots of a launch = the largest chunk count
+int pick_chunks_v2(int P) {          // partial-sum slots of a launch = the largest chunk count, + room for
+  const W2Plan p = w2_plan(P);       // the rgb head's partial rows (whole slots, so callers size by slots only)
+  const int n = p.n_views > p.n_emb ? (p.n_views > p.n_big ? p.n_views : p.n_big) : (p.n_emb > p.n_big ? p.n_emb : p.n_big);
+  const long rgb_floats = (long)((P + W2_RGB_PTS - 1) / W2_RGB_PTS) * W2_RGB_ROW;
+  return n + (int)((rgb_floats + N_PARAM_FLOATS - 1) / N_PARAM_FLOATS);
+}
+static int w2_slots(int P) {
   const W2Plan p = w2_plan(P);
   return p.n_views > p.n_emb ? (p.n_views > p.n_big ? p.n_views : p.n_big) : (p.n_emb > p.n_big ? p.n_emb : p.n_big);
 }
@@ -584,6 +616,7 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
   const int n_big = (P + chunk_big - 1) / chunk_big, n_views = (P + chunk_views - 1) / chunk_views,
             n_emb = (P + chunk_emb - 1) / chunk_emb;
   w.n_big = n_big;
+  if (const char* e = getenv("SCADE_WGRAD_DBG")) w.dbg = atoi(e);
   for (int t = 0; t <= N_PARAM_TENSORS; ++t) ra.t_off[t] = off[t];
   for (int t = 0; t < N_PARAM_TENSORS; ++t) ra.t_slots[t] = n_big;
   for (int li = 0; li < 8; ++li) {           // job 2 li + h: layers 1..7 and feature_linear
@@ -607,8 +640,7 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
     j.kind = W2_VIEWS; j.n_base = 0; j.chunk = chunk_views; j.first_id = 16 * n_big;
     j.dz_off = slot(SLOT_VIEWS_H); j.in_off = slot(SLOT_FEAT);
     j.w_off = off[16]; j.ld = 259; j.kcol0 = 0; j.b_off = off[17]; j.flags = WF_BIAS | WF_VIEWCOLS;
-    j.w_off2 = off[22]; j.ld2 = off[23];     // rgb_linear weight / bias offsets
-    ra.t_slots[16] = ra.t_slots[17] = ra.t_slots[22] = ra.t_slots[23] = n_views;
+    ra.t_slots[16] = ra.t_slots[17] = n_views;
   }
   {                                          // embedding blocks of layers 0 and 5
     Wgrad2Job& j = w.jobs[17];
@@ -619,6 +651,10 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
     ra.slots_emb = n_emb;
   }
   const int grid = 16 * n_big + n_views + n_emb;
+  const int n_rgb = (P + W2_RGB_PTS - 1) / W2_RGB_PTS;
+  float* rgb_part = partial + (size_t)w2_slots(P) * N_PARAM_FLOATS;
+  ra.n_rgb = n_rgb; ra.rgb_part = rgb_part;
+  hipLaunchKernelGGL(wgrad2_rgb_kernel, dim3(n_rgb), dim3(256), 0, s, acts, g_out, P, rgb_part);
   hipLaunchKernelGGL(mlp_wgrad2_kernel, dim3(grid), dim3(256), W2_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
   hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, ra, grad_flat);
