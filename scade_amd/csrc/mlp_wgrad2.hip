@@ -4,77 +4,70 @@
 // The contraction runs over POINTS while both operands sit in HBM point-major, so the MFMA fragments
 // ("k-index = point") are columns of the staged tiles.  Second design of this kernel (the first fed
 // v_mfma_f32_32x32x2_f32 from one ds_read_b32 per operand and k-step, 512-thread workgroups, one per CU,
-// all eight waves in lock step on one barrier per stage: 64 % MFMA-busy, 2.49 ms for 196,608 points):
+// all eight waves in lock step on one barrier per stage):
 //
-//  * workgroup = 4 waves = a 128 x 256 block of output (HALF of a layer's weight gradient) for one chunk
-//    of points; <= 72 KiB of LDS => TWO independent workgroups per CU, so the staging / barrier phase of
-//    one hides under the MFMAs of the other (the forward kernel's recipe);
+//  * workgroup = 4 waves = HALF of a layer's weight gradient (128 output features n x 256 inputs k) for
+//    one chunk of points; 48 KiB of LDS => TWO independent workgroups per CU, so the staging / barrier
+//    phase of one hides under the MFMAs of the other (the forward kernel's recipe);
 //  * tiles are TRANSPOSED on the way into LDS - a thread loads a 4-point x 4-feature block (four
 //    coalesced 16-byte row loads) and writes four ds_write_b128 "feature f: points p..p+3" - so that one
 //    ds_read_b128 is the operand of FOUR MFMA k-steps (lanes 0-31 carry points 8g..8g+3, lanes 32-63
 //    points 8g+4..8g+7 of k-group g; both operands use the same point <-> (k-step, lane half) map, and any
 //    permutation of the contraction index is legal): 6 LDS reads per 32 MFMAs instead of 24;
-//  * LDS image: rows of 32 points = BOTH pipeline buffers of 16 points side by side in one 128-byte row,
-//    16-byte chunk c stored at c ^ key(row): conflict free for the transposed stores (8-lane groups) and
-//    for the fragment reads (the ds_read_b128 lane groups {0-3,12-15,20-27}, ...);
+//  * LDS image: 384 rows (128 dZ features | 256 input features) of 32 points = BOTH pipeline buffers of 16
+//    points side by side in one 128-byte row, 16-byte chunk c stored at c ^ key(row), key = (row ^ row>>2)
+//    & 7 for rows stored four per lane and (row ^ row>>1) & 7 for the dZ rows stored two per lane:
+//    conflict free for the transposed stores (8-lane groups) and for the fragment reads (the
+//    ds_read_b128 lane groups {0-3,12-15,20-27}, ...) - measured SQ_LDS_BANK_CONFLICT = 0;
 //  * bias / alpha-head / view-column riders work on the STAGING REGISTERS (no LDS traffic) and are reduced
 //    over the four waves once per workgroup;
 //  * the barrier sits BETWEEN the two k-groups of a stage and orders LDS only (fences restricted to the
 //    local address space: lgkmcnt(0), never vmcnt(0) - the global prefetch stays in flight); every
-//    fragment is read one k-group (32 MFMAs) ahead of its use, also across stages;
-//  * ONE ROUND: the launch has (just under) 2 x CUs workgroups of EQUAL cost, all resident from start to
-//    end - 16 half-layer jobs, the 128-row views layer (with the view-direction columns) and ONE job for both 57-column embedding blocks (dZ0 | dZ5 against
-//    the embedding: 512 x 64 outputs = the MFMA work of a half layer).  Every job has its own chunk
-//    length; the partial-sum slots are reduced per tensor with that job's chunk count.  The two halves
-//    of a layer sit 8 workgroup ids apart = on the same XCD, so the input rows the second one streams
-//    are the first one's L2 hits.
-#include <stdio.h>
-#include <stdlib.h>
-
+//    fragment is read one k-group (32 MFMAs) ahead of its use, also across stages.
+//
+// Measured (MI355X, 196,608 points, alone on the chip): 1.93 ms against 2.01 ms of the first design, 0.67
+// against 0.80 ms at 65,536 points; knock-outs of this kernel: no global loads -7 %, no LDS stores -1 %,
+// no barrier -1.5 %, no fragment reads -2 %, all four -16 % (= the bare MFMA stream with its prologue /
+// epilogue, 84 % of the pipe's peak).  A ONE-ROUND variant (511 equal-cost workgroups resident from start
+// to end, per-job chunk lengths, both embedding blocks as one 512 x 64 job, halves of a layer on the same
+// XCD for L2 reuse: FETCH_SIZE -17 %) measured 3-7 % SLOWER at every size and was dropped.
 #include "mlp_wgrad.h"
 
 namespace scade {
 
-constexpr int W2_PT = 16;                          // points per pipeline stage (two stages per LDS row)
-constexpr int W2_ROWS_BIG = 128 + 256;             // dZ half | 256 input features
-constexpr int W2_ROWS_EMB = 512 + 64;              // dZ0 | dZ5 | embedding
-constexpr int W2_LDS_BYTES = W2_ROWS_EMB * 32 * 4; // 73,728: two workgroups per CU (160 KiB)
-
-enum { W2_BIG = 0, W2_VIEWS = 1, W2_EMB = 2 };
-constexpr int W2_NJOBS = 18;                       // 16 half layers, views (+ rgb head), embedding blocks
+constexpr int W2_PT = 16;                         // points per pipeline stage (two stages per LDS row)
+constexpr int W2_ROWS = 128 + 256;
+constexpr int W2_LDS_BYTES = W2_ROWS * 32 * 4;    // 49,152
 
 struct Wgrad2Job {
   long dz_off;       // float offset of the dZ matrix (row stride 256) in the dz workspace, n_base included
-  long dz_off2;      // W2_EMB: the second dZ matrix (layer 5)
   long in_off;       // float offset of the input matrix in the acts workspace
-  int kind;
+  int in_stride;     // 256 (activation slot) or 64 (emb)
+  int kw;            // k width of the tile: 256 or 64; 0 = the rgb-head job
   int n_base;        // first output row of this half (0 / 128)
-  int w_off, ld, kcol0, b_off, flags, aux_off;   // as WgradJob
-  int w_off2, ld2;   // W2_EMB: layer 5's weight (columns 0..56);  W2_VIEWS: rgb weight / bias offsets
-  int chunk;         // points per workgroup of this job
-  int first_id;      // first workgroup id of the job (W2_VIEWS / W2_EMB; the half layers are interleaved)
+  int n_rows;        // output rows of the tensor (256 / 128)
+  int w_off, ld, kcol0, kvalid, b_off, flags, aux_off;   // as WgradJob
 };
+constexpr int MAX_WGRAD2_JOBS = 24;
 struct Wgrad2Args {
-  Wgrad2Job jobs[W2_NJOBS];
+  Wgrad2Job jobs[MAX_WGRAD2_JOBS];
   const float* acts;
   const float* dz;
   const float* g_out;
   float* partial;
-  int P;
-  int n_big;         // chunks of every half-layer job
-  int dbg;           // knock-out experiments (SCADE_WGRAD_DBG): 1 no global loads, 2 no LDS stores, 4 no barrier, 8 no fragment reads
+  int P, chunk, njobs;
 };
 
-// float offset of 16-byte chunk lc (0..7 = buffer*4 + point group) of LDS row `row`; rows stored four per
-// lane (4 i + j) use key (row ^ row>>2) & 7, rows stored two per lane (2 i + j) key (row ^ row>>1) & 7;
-// both keys are conflict free for the fragment reads
-__device__ __forceinline__ int w2_off4(int row_abs, int row_local, int lc) {
+// float offset of 16-byte chunk lc (0..7 = buffer*4 + point group) of LDS row `row` (swizzle key from the
+// row index LOCAL to its region, which is what both the stores and the reads use)
+__device__ __forceinline__ int w2_off(int row_abs, int row_local, int lc) {
   return row_abs * 32 + ((lc ^ ((row_local ^ (row_local >> 2)) & 7)) << 2);
 }
-__device__ __forceinline__ int w2_off2(int row, int lc) { return row * 32 + ((lc ^ ((row ^ (row >> 1)) & 7)) << 2); }
-
+// the dZ rows are stored two per lane (rows 2 lane + j), which wants a different key: (row ^ row>>1) & 7
+__device__ __forceinline__ int w2_off_a(int row, int lc) { return row * 32 + ((lc ^ ((row ^ (row >> 1)) & 7)) << 2); }
 // workgroup barrier that orders LDS only: release/acquire fences restricted to the local address space
-// (lgkmcnt(0), no vmcnt(0)), visible to the compiler's own wait counting, pinned against the MFMA groups
+// (lgkmcnt(0), no vmcnt(0) - the global prefetch stays in flight), visible to the compiler's own wait
+// counting, pinned in place against the MFMA groups on either side
 __device__ __forceinline__ void w2_barrier() {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -92,54 +85,51 @@ __device__ __forceinline__ w2_rsrc_t w2_make_rsrc(const float* base, unsigned by
   void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
 }
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 w2_load2(w2_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 2));    // read once: nt
-}
-__device__ __forceinline__ f32x4 w2_load4(w2_rsrc_t r, int voff, int soff) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2));
-}
 
-// ---------------------------------------------------------------------------
-// half layer: 128 (n) x 256 (k); wave = 64 x 128 = 2 x 4 MFMA tiles
-// ---------------------------------------------------------------------------
-template <int FLAGS>
-__device__ __forceinline__ void wgrad2_big_job(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0,
-                                               int c1, float* __restrict__ out) {
+template <int KW, int FLAGS>
+__device__ __forceinline__ void wgrad2_mfma_job(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0,
+                                                int c1, float* __restrict__ out) {
+  constexpr int NKT = KW == 256 ? 4 : 1;          // k-tiles of 32 per wave
   constexpr int flags = FLAGS;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
   const int nsub = (wave >> 1) * 64;              // this wave's 64 output features inside the half
-  const int k0 = (wave & 1) * 128;
+  const int k0 = (wave & 1) * (KW / 2);
   const int P = a.P;
   const int npts = c1 - c0;
+  // dZ rows of this chunk (row stride 1 KiB; n_base is inside dz_off) and input rows (1 KiB or 256 B)
   const w2_rsrc_t ra = w2_make_rsrc(a.dz + jb.dz_off + (size_t)c0 * 256, (unsigned)npts * 1024u);
-  const w2_rsrc_t rb = w2_make_rsrc(a.acts + jb.in_off + (size_t)c0 * 256, (unsigned)npts * 1024u);
+  const w2_rsrc_t rb = w2_make_rsrc(a.acts + jb.in_off + (size_t)c0 * (KW == 256 ? 256 : 64),
+                                    (unsigned)npts * (KW == 256 ? 1024u : 256u));
 
-  f32x16 acc[2][4];
+  f32x16 acc[2][NKT];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < NKT; ++u)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
-  // staging: A block = 4 points x features {2 lane, 2 lane + 1}; B block = 4 points x features 4 lane .. + 3;
-  // points 4 wave + q of the stage
+  // ---- staging: A block = 4 points x features {2 lane, 2 lane + 1}; B block = 4 points x features
+  // 4 lane .. 4 lane + 3 (KW = 64: wave 0 only, 16 column groups x 4 point groups); points 4 wave + q
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   f32x2 pa[4];
   f32x4 pb[4];
   float da[4] = {0.f, 0.f, 0.f, 0.f};             // d alpha_pre of the wave's 4 points (WF_ALPHA)
   float vw[4][3];                                 // view directions of the wave's 4 points (WF_VIEWCOLS)
   float bias_acc[2] = {0.f, 0.f}, alpha_acc[4] = {0.f, 0.f, 0.f, 0.f}, dal_acc = 0.f;
   float vc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  const int va = lane * 8, vb = lane * 16;        // byte offsets inside a row
+  const int b_c4 = KW == 256 ? lane : (lane & 15), b_pg = KW == 256 ? wave : (lane >> 4);
+  const bool b_on = KW == 256 || wave == 0;
 
+  const int va = lane * 8;                                                       // byte offset inside a dZ row
+  const int vb = KW == 256 ? lane * 16 : (4 * b_pg) * 256 + b_c4 * 16;         // inside an input row (+ point group)
   auto issue = [&](int pt0) {
-    const int rel = pt0 - c0 + 4 * wave;          // wave-uniform row index
+    const int rel = pt0 - c0 + 4 * wave;                                           // wave-uniform row index
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-      pa[q] = w2_load2(ra, va, (rel + q) * 1024);
+      pa[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ra, va, (rel + q) * 1024, 2));   // read once: nt
       const int pt = pt0 + 4 * wave + q;
       if (flags & WF_ALPHA) da[q] = pt < c1 ? a.dz[dz_dalpha_off(P) + pt] : 0.f;
       if (flags & WF_VIEWCOLS) {
@@ -147,22 +137,28 @@ __device__ __forceinline__ void wgrad2_big_job(const Wgrad2Args& a, const Wgrad2
         for (int c = 0; c < 3; ++c) vw[q][c] = pt < c1 ? a.acts[acts_emb_off(P) + (size_t)pt * 64 + 60 + c] : 0.f;
       }
     }
+    if (b_on) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) pb[q] = w2_load4(rb, vb, (rel + q) * 1024);
+      for (int q = 0; q < 4; ++q)
+        pb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+            rb, vb, KW == 256 ? (rel + q) * 1024 : (pt0 - c0 + q) * 256, 2));
+    }
   };
   auto commit = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int row = 2 * lane + j;
       const f32x4 v = {pa[0][j], pa[1][j], pa[2][j], pa[3][j]};
-      *reinterpret_cast<f32x4*>(lds + w2_off2(row, 4 * buf + wave)) = v;
+      *reinterpret_cast<f32x4*>(lds + w2_off_a(row, 4 * buf + wave)) = v;
       bias_acc[j] += (pa[0][j] + pa[1][j]) + (pa[2][j] + pa[3][j]);
     }
+    if (b_on) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = 4 * lane + j;
-      const f32x4 v = {pb[0][j], pb[1][j], pb[2][j], pb[3][j]};
-      *reinterpret_cast<f32x4*>(lds + w2_off4(128 + row, row, 4 * buf + wave)) = v;
+      for (int j = 0; j < 4; ++j) {
+        const int row = 4 * b_c4 + j;
+        const f32x4 v = {pb[0][j], pb[1][j], pb[2][j], pb[3][j]};
+        *reinterpret_cast<f32x4*>(lds + w2_off(128 + row, row, 4 * buf + b_pg)) = v;
+      }
     }
     if (flags & WF_ALPHA) {
 #pragma unroll
@@ -182,19 +178,19 @@ __device__ __forceinline__ void wgrad2_big_job(const Wgrad2Args& a, const Wgrad2
     }
   };
 
-  // fragments: one ds_read_b128 = 4 points of this lane half = operand of 4 MFMA k-steps
-  struct Frag { f32x4 a[2]; f32x4 b[4]; };
-  int rowA[2], rowB[4];
+  // ---- fragments: one ds_read_b128 = 4 points of this lane half = operand of 4 MFMA k-steps
+  struct Frag { f32x4 a[2]; f32x4 b[NKT]; };
+  int rowA[2], rowB[NKT];
 #pragma unroll
   for (int t = 0; t < 2; ++t) rowA[t] = nsub + 32 * t + r;
 #pragma unroll
-  for (int u = 0; u < 4; ++u) rowB[u] = k0 + 32 * u + r;
+  for (int u = 0; u < NKT; ++u) rowB[u] = k0 + 32 * u + r;
   auto read_frag = [&](Frag& f, int buf, int g) {
     const int lc = 4 * buf + 2 * g + hh;
 #pragma unroll
-    for (int t = 0; t < 2; ++t) f.a[t] = *reinterpret_cast<const f32x4*>(lds + w2_off2(rowA[t], lc));
+    for (int t = 0; t < 2; ++t) f.a[t] = *reinterpret_cast<const f32x4*>(lds + w2_off_a(rowA[t], lc));
 #pragma unroll
-    for (int u = 0; u < 4; ++u) f.b[u] = *reinterpret_cast<const f32x4*>(lds + w2_off4(128 + rowB[u], rowB[u], lc));
+    for (int u = 0; u < NKT; ++u) f.b[u] = *reinterpret_cast<const f32x4*>(lds + w2_off(128 + rowB[u], rowB[u], lc));
   };
   auto mfma_group = [&](const Frag& f) {
 #pragma unroll
@@ -202,155 +198,12 @@ __device__ __forceinline__ void wgrad2_big_job(const Wgrad2Args& a, const Wgrad2
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < NKT; ++u)
           acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t][j], f.b[u][j], acc[t][u], 0, 0, 0);
   };
 
-  // pipeline: stage s+2 in flight to registers, stage s+1 committed to the other half of the rows while
-  // stage s is multiplied; the barrier between the two k-groups of a stage publishes stage s+1
-  issue(c0);
-  commit(0);
-  if (c0 + W2_PT < c1) issue(c0 + W2_PT);
-  w2_barrier();
-  Frag f0, f1;
-  read_frag(f0, 0, 0);
-  int buf = 0;
-  const int dbg = a.dbg;
-  for (int pt0 = c0; pt0 < c1; pt0 += W2_PT, buf ^= 1) {
-    const bool has_next = pt0 + W2_PT < c1;
-    if (has_next && !(dbg & 2)) commit(buf ^ 1);
-    if (pt0 + 2 * W2_PT < c1 && !(dbg & 1)) issue(pt0 + 2 * W2_PT);
-    if (!(dbg & 8)) read_frag(f1, buf, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(f0);
-    if (!(dbg & 4)) w2_barrier();
-    if (has_next && !(dbg & 8)) read_frag(f0, buf ^ 1, 0);
-    __builtin_amdgcn_sched_barrier(0);
-    mfma_group(f1);
-  }
-
-  // ---- write the partial ---------------------------------------------------------
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int k = k0 + 32 * u + r;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = jb.n_base + nsub + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k] = acc[t][u][i];
-      }
-    }
-  // riders: every wave saw a quarter of the points -> sum the four waves through LDS
-  w2_barrier();                                  // all fragment reads done: the rows are free
-  float* red = lds;                              // [4 waves][128 bias | 256 alpha | 384 view cols | 1]
-  float* rw = red + wave * 772;
-  rw[2 * lane] = bias_acc[0];
-  rw[2 * lane + 1] = bias_acc[1];
-  if (flags & WF_ALPHA) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) rw[128 + 4 * lane + j] = alpha_acc[j];
-    if (lane == 0) rw[768] = dal_acc;
-  }
-  if (flags & WF_VIEWCOLS) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) rw[384 + (2 * lane + j) * 3 + c] = vc[j][c];
-  }
-  w2_barrier();
-  auto sum4 = [&](int i) { return (red[i] + red[772 + i]) + (red[1544 + i] + red[2316 + i]); };
-  if (tid < 128) out[jb.b_off + jb.n_base + tid] = sum4(tid);
-  if (flags & WF_ALPHA) {
-    out[jb.aux_off + tid] = sum4(128 + tid);
-    if (tid == 0) out[jb.aux_off + 256] = sum4(768);
-  }
-  if ((flags & WF_VIEWCOLS) && tid < 128) {
-#pragma unroll
-    for (int c = 0; c < 3; ++c) out[jb.w_off + (size_t)tid * jb.ld + 256 + c] = sum4(384 + tid * 3 + c);
-  }
-}
-
-// ---------------------------------------------------------------------------
-// both embedding blocks: [dZ0 | dZ5] (512 n) x embedding (64 k, 57 valid); wave = 128 x 64 = 4 x 2 tiles.
-// Rows 0..255 -> pts_linears.0.weight [256][57] (+ its bias), rows 256..511 -> pts_linears.5.weight[:, :57]
-// ---------------------------------------------------------------------------
-__device__ __forceinline__ void wgrad2_emb_job(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0, int c1,
-                                               float* __restrict__ out) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  const int nsub = wave * 128;
-  const int npts = c1 - c0;
-  const w2_rsrc_t r0 = w2_make_rsrc(a.dz + jb.dz_off + (size_t)c0 * 256, (unsigned)npts * 1024u);
-  const w2_rsrc_t r5 = w2_make_rsrc(a.dz + jb.dz_off2 + (size_t)c0 * 256, (unsigned)npts * 1024u);
-  const w2_rsrc_t rb = w2_make_rsrc(a.acts + jb.in_off + (size_t)c0 * 64, (unsigned)npts * 256u);
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-#pragma unroll
-    for (int u = 0; u < 2; ++u)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-
-  // staging: A blocks = 4 points x features 4 lane .. + 3 of dZ0 and of dZ5 (points 4 wave + q); B block
-  // (wave 0 only) = 4 points x embedding columns 4 (lane & 15) .. + 3, points 4 (lane >> 4) + q
-  f32x4 p0[4], p5[4], pb[4];
-  float bias_acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int va = lane * 16, vb = (4 * (lane >> 4)) * 256 + (lane & 15) * 16;
-  auto issue = [&](int pt0) {
-    const int rel = pt0 - c0 + 4 * wave;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      p0[q] = w2_load4(r0, va, (rel + q) * 1024);
-      p5[q] = w2_load4(r5, va, (rel + q) * 1024);
-    }
-    if (wave == 0) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) pb[q] = w2_load4(rb, vb, (pt0 - c0 + q) * 256);
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int row = 4 * lane + j;
-      const f32x4 v0 = {p0[0][j], p0[1][j], p0[2][j], p0[3][j]};
-      const f32x4 v5 = {p5[0][j], p5[1][j], p5[2][j], p5[3][j]};
-      *reinterpret_cast<f32x4*>(lds + w2_off4(row, row, 4 * buf + wave)) = v0;
-      *reinterpret_cast<f32x4*>(lds + w2_off4(256 + row, row, 4 * buf + wave)) = v5;
-      bias_acc[j] += (p0[0][j] + p0[1][j]) + (p0[2][j] + p0[3][j]);
-    }
-    if (wave == 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 4 * (lane & 15) + j;
-        const f32x4 v = {pb[0][j], pb[1][j], pb[2][j], pb[3][j]};
-        *reinterpret_cast<f32x4*>(lds + w2_off4(512 + row, row, 4 * buf + (lane >> 4))) = v;
-      }
-    }
-  };
-  struct Frag { f32x4 a[4]; f32x4 b[2]; };
-  auto read_frag = [&](Frag& f, int buf, int g) {
-    const int lc = 4 * buf + 2 * g + hh;
-#pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int row = nsub + 32 * t + r;
-      f.a[t] = *reinterpret_cast<const f32x4*>(lds + w2_off4(row, row & 255, lc));
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) f.b[u] = *reinterpret_cast<const f32x4*>(lds + w2_off4(512 + 32 * u + r, 32 * u + r, lc));
-  };
-  auto mfma_group = [&](const Frag& f) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-#pragma unroll
-        for (int u = 0; u < 2; ++u)
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t][j], f.b[u][j], acc[t][u], 0, 0, 0);
-  };
-
+  // ---- pipeline: stage s+2 in flight to registers, stage s+1 committed to the other half of the rows
+  // while stage s is multiplied; the barrier between the two k-groups of a stage publishes stage s+1
   issue(c0);
   commit(0);
   if (c0 + W2_PT < c1) issue(c0 + W2_PT);
@@ -371,39 +224,58 @@ __device__ __forceinline__ void wgrad2_emb_job(const Wgrad2Args& a, const Wgrad2
     mfma_group(f1);
   }
 
-  // rows 0..255 (waves 0, 1) -> layer 0, rows 256..511 (waves 2, 3) -> layer 5, columns 0..56
-  const int woff = wave < 2 ? jb.w_off : jb.w_off2, ld = wave < 2 ? jb.ld : jb.ld2;
+  // ---- write the partial ---------------------------------------------------------
 #pragma unroll
-  for (int t = 0; t < 4; ++t)
+  for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int k = 32 * u + r;
+    for (int u = 0; u < NKT; ++u) {
+      const int k = k0 + 32 * u + r;
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
-        const int n = (nsub & 255) + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (k < EMB) out[woff + (size_t)n * ld + k] = acc[t][u][i];
+        const int n = jb.n_base + nsub + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (n < jb.n_rows && k < jb.kvalid) out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k] = acc[t][u][i];
       }
     }
-  w2_barrier();
-  float* red = lds;                              // [4 waves][256] bias of layer 0
+  // riders: every wave saw a quarter of the points -> sum the four waves through LDS
+  if (flags & (WF_BIAS | WF_ALPHA | WF_VIEWCOLS)) {
+    w2_barrier();                                  // all fragment reads done: the rows are free
+    float* red = lds;                              // [4 waves][128 bias | 256 alpha | 384 view cols | 1]
+    float* rw = red + wave * 772;
+    rw[2 * lane] = bias_acc[0];
+    rw[2 * lane + 1] = bias_acc[1];
+    if (flags & WF_ALPHA) {
 #pragma unroll
-  for (int j = 0; j < 4; ++j) red[wave * 256 + 4 * lane + j] = bias_acc[j];
-  w2_barrier();
-  out[jb.b_off + tid] = (red[tid] + red[256 + tid]) + (red[512 + tid] + red[768 + tid]);
+      for (int j = 0; j < 4; ++j) rw[128 + 4 * lane + j] = alpha_acc[j];
+      if (lane == 0) rw[768] = dal_acc;
+    }
+    if (flags & WF_VIEWCOLS) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rw[384 + (2 * lane + j) * 3 + c] = vc[j][c];
+    }
+    w2_barrier();
+    auto sum4 = [&](int i) { return (red[i] + red[772 + i]) + (red[1544 + i] + red[2316 + i]); };
+    if ((jb.flags & WF_BIAS) && tid < 128 && jb.n_base + tid < jb.n_rows) out[jb.b_off + jb.n_base + tid] = sum4(tid);
+    if (flags & WF_ALPHA) {
+      out[jb.aux_off + tid] = sum4(128 + tid);
+      if (tid == 0) out[jb.aux_off + 256] = sum4(768);
+    }
+    if ((flags & WF_VIEWCOLS) && tid < 128 && jb.n_base + tid < jb.n_rows) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) out[jb.w_off + (size_t)(jb.n_base + tid) * jb.ld + 256 + c] = sum4(384 + tid * 3 + c);
+    }
+  }
 }
 
-// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c] - pure load latency (a
-// thread owns 4 columns of every 8th point, four points in flight), so it is its own small launch of many
-// short workgroups; their partials [n_rgb][388] are summed by the reduce kernel.
-constexpr int W2_RGB_PTS = 384;                   // points per workgroup
-constexpr int W2_RGB_ROW = 388;                   // 3 x 128 weights + 3 bias + pad
-__global__ __launch_bounds__(256) void wgrad2_rgb_kernel(const float* __restrict__ acts, const float* __restrict__ g_out,
-                                                         int P, float* __restrict__ part) {
-  __shared__ float red[8 * 3 * 128 + 8 * 4];
+// rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c].  A thread owns 4 columns
+// (one 16-byte load per point) of every 8th point, four points in flight: this job is pure load latency.
+__device__ __forceinline__ void wgrad2_rgb_job(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0,
+                                               int c1, float* __restrict__ out) {
   const int tid = threadIdx.x;
   const int k4 = tid & 31, pl = tid >> 5;       // 32 column groups x 8 point lanes
-  const int c0 = blockIdx.x * W2_RGB_PTS, c1 = min(P, c0 + W2_RGB_PTS);
-  const float* __restrict__ hv = acts + acts_slot_off(P, SLOT_VIEWS_H) + 4 * k4;
+  const float* __restrict__ hv = a.acts + jb.in_off + 4 * k4;
+  const int P = a.P;
   float s[3][4], b[3] = {0.f, 0.f, 0.f};
 #pragma unroll
   for (int c = 0; c < 3; ++c)
@@ -415,7 +287,7 @@ __global__ __launch_bounds__(256) void wgrad2_rgb_kernel(const float* __restrict
     for (int q = 0; q < 4; ++q) {
       const int pt = min(pt0 + 8 * q, P - 1);
       h[q] = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * 256);
-      g[q] = *reinterpret_cast<const f32x4*>(g_out + (size_t)pt * 4);
+      g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
     }
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -430,6 +302,7 @@ __global__ __launch_bounds__(256) void wgrad2_rgb_kernel(const float* __restrict
       }
     }
   }
+  float* red = lds;                               // [8 point lanes][3][128] + [8][4]
 #pragma unroll
   for (int c = 0; c < 3; ++c)
 #pragma unroll
@@ -437,156 +310,95 @@ __global__ __launch_bounds__(256) void wgrad2_rgb_kernel(const float* __restrict
   float* redb = red + 8 * 3 * 128;
   if (k4 == 0) { redb[pl * 4 + 0] = b[0]; redb[pl * 4 + 1] = b[1]; redb[pl * 4 + 2] = b[2]; }
   __syncthreads();
-  float* out = part + (size_t)blockIdx.x * W2_RGB_ROW;
   for (int i = tid; i < 384; i += 256) {
     float t = 0.f;
     for (int p = 0; p < 8; ++p) t += red[p * 384 + i];
-    out[i] = t;
+    out[jb.w_off + i] = t;
   }
   if (tid < 3) {
     float t = 0.f;
     for (int p = 0; p < 8; ++p) t += redb[p * 4 + tid];
-    out[384 + tid] = t;
+    out[jb.b_off + tid] = t;
   }
 }
 
 __global__ __launch_bounds__(256, 2) void mlp_wgrad2_kernel(Wgrad2Args a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  // workgroup id -> (job, chunk).  Half layers first: unit u = layer * n_big + chunk, its two halves 8 ids
-  // apart (ids are dealt to the 8 XCDs round robin: same XCD, same L2, started together)
-  const int id = blockIdx.x;
-  const int n_units = 8 * a.n_big;
-  int job, chunk_i;
-  if (id < 2 * n_units) {
-    const int g = id >> 4, wi = id & 15;
-    const int unit = g * 8 + (wi & 7);
-    job = (unit / a.n_big) * 2 + (wi >> 3);
-    chunk_i = unit % a.n_big;
-  } else if (id < a.jobs[17].first_id) {
-    job = 16; chunk_i = id - a.jobs[16].first_id;
+  const Wgrad2Job& jb = a.jobs[blockIdx.y];
+  const int c0 = blockIdx.x * a.chunk;
+  const int c1 = min(a.P, c0 + a.chunk);
+  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
+  if (jb.kw == 0) {
+    wgrad2_rgb_job(a, jb, lds, c0, c1, out);
+  } else if (jb.kw == 256) {
+    if (jb.flags == WF_BIAS) wgrad2_mfma_job<256, WF_BIAS>(a, jb, lds, c0, c1, out);
+    else if (jb.flags == (WF_BIAS | WF_ALPHA)) wgrad2_mfma_job<256, WF_BIAS | WF_ALPHA>(a, jb, lds, c0, c1, out);
+    else wgrad2_mfma_job<256, WF_BIAS | WF_VIEWCOLS>(a, jb, lds, c0, c1, out);
   } else {
-    job = 17; chunk_i = id - a.jobs[17].first_id;
-  }
-  const Wgrad2Job& jb = a.jobs[job];
-  const int c0 = chunk_i * jb.chunk;
-  const int c1 = min(a.P, c0 + jb.chunk);
-  float* out = a.partial + (size_t)chunk_i * N_PARAM_FLOATS;
-  if (c0 >= c1) return;
-  if ((a.dbg >> 8) && ((a.dbg >> 8) & 3) != jb.kind + 1) return;      // experiments: only one kind of job
-  if (jb.kind == W2_EMB) {
-    wgrad2_emb_job(a, jb, lds, c0, c1, out);
-  } else if (jb.kind == W2_VIEWS) {
-    wgrad2_big_job<WF_BIAS | WF_VIEWCOLS>(a, jb, lds, c0, c1, out);
-  } else if (jb.flags & WF_ALPHA) {
-    wgrad2_big_job<WF_BIAS | WF_ALPHA>(a, jb, lds, c0, c1, out);
-  } else {
-    wgrad2_big_job<WF_BIAS>(a, jb, lds, c0, c1, out);
+    wgrad2_mfma_job<64, WF_BIAS>(a, jb, lds, c0, c1, out);     // (the layer-5 block has no bias: b_off checked)
   }
 }
 
-// Sum of the per-chunk partials into the flat gradient.  The jobs chunk the points differently, so every
-// tensor has its own slot count; pts_linears.5.weight is written by two jobs (columns 0..56: embedding
-// job, the rest: its half-layer jobs).  Fixed summation order (deterministic).
-struct Reduce2Args {
-  int t_off[N_PARAM_TENSORS + 1];
-  int t_slots[N_PARAM_TENSORS];
-  int slots_emb;
-  int n_rgb;                  // partial rows of the rgb head (wgrad2_rgb_kernel)
-  const float* rgb_part;
-};
-__global__ void wgrad2_reduce_kernel(const float* __restrict__ partial, Reduce2Args ra, float* __restrict__ grad) {
-  const int i4 = blockIdx.x * 256 + threadIdx.x;
-  if (i4 >= N_PARAM_FLOATS / 4) return;
-  if (4 * i4 + 3 >= ra.t_off[22]) {              // rgb_linear weight [3][128] + bias [3]: the last 387 floats
-    for (int e = 0; e < 4; ++e) {
-      const int i = 4 * i4 + e;
-      if (i < ra.t_off[22]) {                    // (the vector straddles the tensor boundary: alpha bias)
-        float s = 0.f;
-        for (int c = 0; c < ra.t_slots[21]; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
-        grad[i] = s;
-      } else if (i < N_PARAM_FLOATS) {
-        const int k = i - ra.t_off[22];
-        float s0 = 0.f, s1 = 0.f;
-        int c = 0;
-        for (; c + 2 <= ra.n_rgb; c += 2) {
-          s0 += ra.rgb_part[(size_t)c * W2_RGB_ROW + k];
-          s1 += ra.rgb_part[(size_t)(c + 1) * W2_RGB_ROW + k];
-        }
-        if (c < ra.n_rgb) s0 += ra.rgb_part[(size_t)c * W2_RGB_ROW + k];
-        grad[i] = s0 + s1;
-      }
-    }
-    return;
+// Chunks of points per launch.  Two workgroups share a CU; per chunk there are 17 half-layer workgroups of
+// equal length (8 layers x 2 halves + the 128-row views layer) plus five short ones (four embedding
+// columns blocks, the rgb head) worth about 1.5 more.  The chunk count fills k whole "rounds" of the
+// 2 x CUs slots with chunks near `target_pts` points (SCADE_WGRAD_PTS overrides it for experiments).
+static int w2_target_pts() {
+  static int v = 0;
+  if (v == 0) {
+    const char* e = getenv("SCADE_WGRAD_PTS");
+    v = e ? atoi(e) : 0;
+    if (v < 64) v = 2400;
   }
-  auto slots_of = [&](int i) {
-    int t = 0;
-#pragma unroll 1
-    while (i >= ra.t_off[t + 1]) ++t;
-    if (t == 10) return ((i - ra.t_off[10]) % 313) < EMB ? ra.slots_emb : ra.t_slots[10];
-    return ra.t_slots[t];
+  return v;
+}
+int pick_chunks_v2(int P) {
+  const double slots = 2.0 * device_cus(), per_chunk = 18.5;
+  const int target = w2_target_pts();
+  long k = (long)((double)P * per_chunk / (slots * target) + 0.5);
+  if (k < 1) k = 1;
+  long n = (long)(slots * k / per_chunk);
+  const long nmax = P / 256 > 1 ? P / 256 : 1;
+  if (n > nmax) n = nmax;
+  if (n < 1) n = 1;
+  if (n > 1024) n = 1024;
+  return (int)n;
+}
+
+static int build_wgrad2_jobs(Wgrad2Args& w, const float* acts, const float* dz, const float* g_out, float* partial,
+                             int P) {
+  int off[N_PARAM_TENSORS + 1];
+  param_offsets(off);
+  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial; w.P = P;
+  const int nchunks = pick_chunks_v2(P);
+  int chunk = (P + nchunks - 1) / nchunks;
+  chunk = (chunk + W2_PT - 1) / W2_PT * W2_PT;
+  w.chunk = chunk;
+  int nj = 0;
+  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
+  auto add = [&](long dzo, long ino, int ins, int kw, int nbase, int nrows, int woff, int ld, int kcol0, int kvalid,
+                 int boff, int flags, int aux) {
+    Wgrad2Job& j = w.jobs[nj++];
+    j.dz_off = dzo + nbase; j.in_off = ino; j.in_stride = ins; j.kw = kw; j.n_base = nbase; j.n_rows = nrows;
+    j.w_off = woff; j.ld = ld; j.kcol0 = kcol0; j.kvalid = kvalid; j.b_off = boff; j.flags = flags; j.aux_off = aux;
   };
-  const int n_first = slots_of(4 * i4), n_last = slots_of(4 * i4 + 3);
-  constexpr size_t ST = N_PARAM_FLOATS / 4;
-  if (n_first == n_last && slots_of(4 * i4 + 1) == n_first && slots_of(4 * i4 + 2) == n_first) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(partial) + i4;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int c = 0;
-    for (; c + 4 <= n_first; c += 4) {
-      s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
-      s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
-    }
-    for (; c < n_first; ++c) s0 += p[(size_t)c * ST];
-    reinterpret_cast<f32x4*>(grad)[i4] = (s0 + s1) + (s2 + s3);
-  } else {
-    for (int e = 0; e < 4; ++e) {
-      const int i = 4 * i4 + e, n = slots_of(i);
-      float s = 0.f;
-      for (int c = 0; c < n; ++c) s += partial[(size_t)c * N_PARAM_FLOATS + i];
-      grad[i] = s;
-    }
+  // long jobs first, short last (tail filling)
+  for (int l = 1; l <= 7; ++l) {
+    const int ld = l == 5 ? 313 : 256, kc0 = l == 5 ? 57 : 0;
+    for (int h = 0; h < 2; ++h)
+      add(slot(l), slot(l - 1), 256, 256, 128 * h, 256, off[2 * l], ld, kc0, 256, off[2 * l + 1], WF_BIAS, 0);
   }
-}
-
-// Workgroups per job.  All of a launch's workgroups are resident at once (two per CU) and should end
-// together: 16 half-layer jobs of cost 1 per point, the views job (+ rgb head) and the embedding job with
-// their measured relative costs (SCADE_WGRAD_COSTS="views,emb" overrides them for calibration runs).
-struct W2Plan { int n_big, n_views, n_emb; };
-static W2Plan w2_plan(int P) {
-  static double cv = 0.0, ce = 0.0;
-  if (cv == 0.0) {
-    cv = 1.03; ce = 1.12;
-    if (const char* e = getenv("SCADE_WGRAD_COSTS")) {
-      double x = 0, y = 0;
-      if (sscanf(e, "%lf,%lf", &x, &y) == 2 && x > 0.2 && y > 0.2) { cv = x; ce = y; }
-    }
+  for (int h = 0; h < 2; ++h)   // the alpha head rides on ONE half only (it needs the whole input row, not dZ)
+    add(slot(SLOT_FEAT), slot(7), 256, 256, 128 * h, 256, off[18], 256, 0, 256, off[19],
+        WF_BIAS | (h == 0 ? WF_ALPHA : 0), off[20]);
+  add(slot(SLOT_VIEWS_H), slot(SLOT_FEAT), 256, 256, 0, 128, off[16], 259, 0, 256, off[17], WF_BIAS | WF_VIEWCOLS, 0);
+  for (int h = 0; h < 2; ++h) {
+    add(slot(0), acts_emb_off(P), 64, 64, 128 * h, 256, off[0], 57, 0, 57, off[1], WF_BIAS, 0);
+    add(slot(5), acts_emb_off(P), 64, 64, 128 * h, 256, off[10], 313, 0, 57, 0, 0, 0);
   }
-  const int slots = 2 * device_cus();
-  const int cap = P / 64 > 1 ? P / 64 : 1;          // never chunks shorter than 64 points
-  W2Plan p;
-  p.n_big = (int)(slots / (16.0 + cv + ce));
-  if (p.n_big > cap) p.n_big = cap;
-  if (p.n_big < 1) p.n_big = 1;
-  p.n_views = (int)(p.n_big * cv + 0.5);
-  p.n_emb = (int)(p.n_big * ce + 0.5);
-  while (16 * p.n_big + p.n_views + p.n_emb > slots && p.n_views > 1) --p.n_views;
-  if (p.n_views > cap) p.n_views = cap;
-  if (p.n_emb > cap) p.n_emb = cap;
-  return p;
-}
-int pick_chunks_v2(int P) {          // partial-sum slots of a launch = the largest chunk count, + room for
-  const W2Plan p = w2_plan(P);       // the rgb head's partial rows (whole slots, so callers size by slots only)
-  const int n = p.n_views > p.n_emb ? (p.n_views > p.n_big ? p.n_views : p.n_big) : (p.n_emb > p.n_big ? p.n_emb : p.n_big);
-  const long rgb_floats = (long)((P + W2_RGB_PTS - 1) / W2_RGB_PTS) * W2_RGB_ROW;
-  return n + (int)((rgb_floats + N_PARAM_FLOATS - 1) / N_PARAM_FLOATS);
-}
-static int w2_slots(int P) {
-  const W2Plan p = w2_plan(P);
-  return p.n_views > p.n_emb ? (p.n_views > p.n_big ? p.n_views : p.n_big) : (p.n_emb > p.n_big ? p.n_emb : p.n_big);
-}
-
-static int w2_chunk_len(int P, int n) {
-  int chunk = (P + n - 1) / n;
-  return (chunk + W2_PT - 1) / W2_PT * W2_PT;
+  add(0, slot(SLOT_VIEWS_H), 256, 0, 0, 0, off[22], 128, 0, 0, off[23], WF_RGB, 0);
+  w.njobs = nj;
+  return (P + chunk - 1) / chunk;
 }
 
 }  // namespace scade
@@ -603,60 +415,10 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(attr_set);
   }
-  int off[N_PARAM_TENSORS + 1];
-  param_offsets(off);
-  const W2Plan plan = w2_plan(P);
   Wgrad2Args w{};
-  Reduce2Args ra{};
-  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial; w.P = P;
-  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
-  // real chunk counts (the rounded-up chunk length can cover P with fewer workgroups than planned)
-  const int chunk_big = w2_chunk_len(P, plan.n_big), chunk_views = w2_chunk_len(P, plan.n_views),
-            chunk_emb = w2_chunk_len(P, plan.n_emb);
-  const int n_big = (P + chunk_big - 1) / chunk_big, n_views = (P + chunk_views - 1) / chunk_views,
-            n_emb = (P + chunk_emb - 1) / chunk_emb;
-  w.n_big = n_big;
-  if (const char* e = getenv("SCADE_WGRAD_DBG")) w.dbg = atoi(e);
-  for (int t = 0; t <= N_PARAM_TENSORS; ++t) ra.t_off[t] = off[t];
-  for (int t = 0; t < N_PARAM_TENSORS; ++t) ra.t_slots[t] = n_big;
-  for (int li = 0; li < 8; ++li) {           // job 2 li + h: layers 1..7 and feature_linear
-    const int l = li + 1;
-    for (int h = 0; h < 2; ++h) {
-      Wgrad2Job& j = w.jobs[2 * li + h];
-      j.kind = W2_BIG; j.n_base = 128 * h; j.chunk = chunk_big;
-      if (l <= 7) {
-        j.dz_off = slot(l) + 128 * h; j.in_off = slot(l - 1);
-        j.w_off = off[2 * l]; j.ld = l == 5 ? 313 : 256; j.kcol0 = l == 5 ? EMB : 0; j.b_off = off[2 * l + 1];
-        j.flags = WF_BIAS;
-      } else {                               // feature_linear; the alpha head rides on its first half
-        j.dz_off = slot(SLOT_FEAT) + 128 * h; j.in_off = slot(7);
-        j.w_off = off[18]; j.ld = 256; j.kcol0 = 0; j.b_off = off[19];
-        j.flags = WF_BIAS | (h == 0 ? WF_ALPHA : 0); j.aux_off = off[20];
-      }
-    }
-  }
-  {                                          // views layer (128 rows) + view-direction columns + rgb head
-    Wgrad2Job& j = w.jobs[16];
-    j.kind = W2_VIEWS; j.n_base = 0; j.chunk = chunk_views; j.first_id = 16 * n_big;
-    j.dz_off = slot(SLOT_VIEWS_H); j.in_off = slot(SLOT_FEAT);
-    j.w_off = off[16]; j.ld = 259; j.kcol0 = 0; j.b_off = off[17]; j.flags = WF_BIAS | WF_VIEWCOLS;
-    ra.t_slots[16] = ra.t_slots[17] = n_views;
-  }
-  {                                          // embedding blocks of layers 0 and 5
-    Wgrad2Job& j = w.jobs[17];
-    j.kind = W2_EMB; j.chunk = chunk_emb; j.first_id = 16 * n_big + n_views;
-    j.dz_off = slot(0); j.dz_off2 = slot(5); j.in_off = acts_emb_off(P);
-    j.w_off = off[0]; j.ld = EMB; j.b_off = off[1]; j.w_off2 = off[10]; j.ld2 = 313;
-    ra.t_slots[0] = ra.t_slots[1] = n_emb;
-    ra.slots_emb = n_emb;
-  }
-  const int grid = 16 * n_big + n_views + n_emb;
-  const int n_rgb = (P + W2_RGB_PTS - 1) / W2_RGB_PTS;
-  float* rgb_part = partial + (size_t)w2_slots(P) * N_PARAM_FLOATS;
-  ra.n_rgb = n_rgb; ra.rgb_part = rgb_part;
-  hipLaunchKernelGGL(wgrad2_rgb_kernel, dim3(n_rgb), dim3(256), 0, s, acts, g_out, P, rgb_part);
-  hipLaunchKernelGGL(mlp_wgrad2_kernel, dim3(grid), dim3(256), W2_LDS_BYTES, s, w);
+  const int grid_x = build_wgrad2_jobs(w, acts, dz, g_out, partial, P);
+  hipLaunchKernelGGL(mlp_wgrad2_kernel, dim3(grid_x, w.njobs), dim3(256), W2_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
-  hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, ra, grad_flat);
+  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd(reduce)");
 }
