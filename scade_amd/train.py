@@ -76,10 +76,6 @@ class Trainer:
         # ``it`` = optimisation steps taken; the reference's loop index of the NEXT step is it + 1
         # (:899-900: i runs from global_step + 1)
         self.it = start_iter
-        # coarse stage on a side stream: its backward chain then runs beside the fine one
-        if overlap_coarse is None:
-            overlap_coarse = os.environ.get("SCADE_OVERLAP_COARSE", "1") != "0"
-        self.coarse_stream = torch.cuda.Stream(device=dev) if overlap_coarse and dev.type == "cuda" else None
         # rays are sharded over the ranks of the default process group (one process per GPU)
         self.sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if allreduce is None:
@@ -87,6 +83,14 @@ class Trainer:
         if allreduce not in ("single", "overlap"):
             raise ValueError('Trainer: allreduce must be "single" or "overlap"')
         self.allreduce = allreduce
+        # coarse stage on a side stream: its backward chain then runs beside the fine one.  Off by default
+        # since the weight-gradient kernel runs two workgroups per CU (round 2): two kernels sharing the
+        # chip no longer beat the same two back to back (measured 1024 rays: exact 7.66 vs 7.54 ms, bf16
+        # 1.68 vs 1.60 ms; 128 rays: 1.60 vs 1.41 ms of mostly host time; only f16x3 still gains, 4.22 vs
+        # 4.32 ms).  The two-piece overlapped all-reduce needs the side stream and turns it on.
+        if overlap_coarse is None:
+            overlap_coarse = os.environ.get("SCADE_OVERLAP_COARSE", "0") != "0" or allreduce == "overlap"
+        self.coarse_stream = torch.cuda.Stream(device=dev) if overlap_coarse and dev.type == "cuda" else None
         self.force_allreduce = False        # self-tests: issue the collective on a one-rank group too
         self.bucket.broadcast_params(0)
 

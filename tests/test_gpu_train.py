@@ -351,7 +351,7 @@ def test_graphed_trainer_matches_eager(dev):
     for mode in ("eager", "graph"):
         coarse, fine = make_scade_nets(dev, seed=3)
         tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3, lrate_decay_step=4,
-                     lrate_decay_rate=0.5, freeze_ss=5, scaleshift_lr=1e-3, mask_mode="wild")
+                     lrate_decay_rate=0.5, freeze_ss=5, scaleshift_lr=1e-3, mask_mode="wild", overlap_coarse=True)
         # two-stream backward on: captured as a fork/join; the scale/shift freeze (i < 5: four updates)
         # forces a re-capture
         gt = GraphedTrainer(tr, N, K, inject_draws=True, with_mask=True) if mode == "graph" else None
