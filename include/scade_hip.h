@@ -206,6 +206,16 @@ int scade_carve_bwd(const float* pred, const float* hyp, const float* mask, floa
 int scade_carve_joint_colmean(const float* pred, const float* hyp, const float* mask, float threshold,
                               int N, int P, int K, float* workspace, void* stream);
 int scade_carve_joint_min(float* workspace, int P, int K, float* loss, void* stream);
+/* The same entries for hypotheses cached PER SAMPLE, hyp [K,N,P] - the "each quantile here already picked
+ * a hypothesis" branch of compute_space_carving_loss (run_nerf_helpers.py:100-102); g_hyp is [K,N,P].
+ * Workspace sizes and scade_carve_joint_min are shared with the [K,N] entries. */
+int scade_carve_knp_fwd(const float* pred, const float* hyp, const float* mask, float threshold,
+                        int is_joint, int N, int P, int K, float* workspace, float* loss, void* stream);
+int scade_carve_knp_bwd(const float* pred, const float* hyp, const float* mask, float threshold,
+                        int is_joint, int N, int P, int K, const float* workspace, const float* g_loss,
+                        float* g_pred, float* g_hyp, void* stream);
+int scade_carve_knp_joint_colmean(const float* pred, const float* hyp, const float* mask, float threshold,
+                                  int N, int P, int K, float* workspace, void* stream);
 
 /* ---- photometric loss (helpers:11 img2mse; row mask = run_scade_wild.py:978-986) - */
 int scade_mse_fwd(const float* x, const float* y, const float* row_mask, int n, int c,

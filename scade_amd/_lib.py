@@ -60,6 +60,9 @@ SIGNATURES = {
     "scade_carve_bwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "scade_carve_joint_colmean": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _P, _P]),
     "scade_carve_joint_min": (c_int, [_P, _I, _I, _P, _P]),
+    "scade_carve_knp_fwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P]),
+    "scade_carve_knp_bwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
+    "scade_carve_knp_joint_colmean": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _P, _P]),
     "scade_mse_fwd": (c_int, [_P, _P, _P, _I, _I, _P, _P]),
     "scade_gen_rays": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P,
                                 _P, _P, _P, _P]),

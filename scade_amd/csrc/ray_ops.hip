@@ -830,6 +830,90 @@ __global__ void carve_joint_bwd_kernel(CarveArgs a, const int* argmin_in) {
   }
 }
 
+
+// ---- hypotheses cached per sample: target_hypothesis [K,N,P] ("each quantile here already picked a
+// hypothesis", helpers:100-102).  Same reductions as above with hyp indexed (k, ray, sample); a [K,N,P]
+// tensor is streamed once, coalesced along the samples.
+__global__ void carve_knp_fwd_kernel(CarveArgs a) {
+  const int ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  const int lane = lane_id();
+  const bool hm = a.mask != nullptr;
+  const float m = hm ? a.mask[ray] : 1.f;
+  const size_t kstride = (size_t)a.N * a.P;
+  double acc = 0.0;
+  for (int s = lane; s < a.P; s += 64) {
+    const float p = a.pred[(size_t)ray * a.P + s];
+    const float* h = a.hyp + (size_t)ray * a.P + s;
+    float best = INFINITY;
+    for (int k = 0; k < a.K; ++k) best = fminf(best, carve_dist(p, h[k * kstride], m, hm, a.threshold));
+    acc += (double)best;
+  }
+  acc = wave_sum_d(acc);
+  if (lane == 0) a.partial[ray] = (float)(acc / (double)a.P);
+}
+__global__ void carve_knp_bwd_kernel(CarveArgs a) {
+  const int ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  const int lane = lane_id();
+  const bool hm = a.mask != nullptr;
+  const float m = hm ? a.mask[ray] : 1.f;
+  const float scale = a.g_loss[0] / ((float)a.N * (float)a.P);
+  const size_t kstride = (size_t)a.N * a.P;
+  for (int s = lane; s < a.P; s += 64) {
+    const size_t o = (size_t)ray * a.P + s;
+    const float p = a.pred[o];
+    float best = INFINITY, hbest = 0.f;
+    int kbest = 0;
+    for (int k = 0; k < a.K; ++k) {
+      const float h = a.hyp[k * kstride + o];
+      const float dd = carve_dist(p, h, m, hm, a.threshold);
+      if (dd < best) { best = dd; kbest = k; hbest = h; }           // first index wins ties (torch.min)
+    }
+    const float diff = p - hbest;
+    float dd = fabsf(diff);
+    if (hm) dd *= m;
+    const bool dead = a.threshold > 0.f && dd < a.threshold;
+    const float sgn = dead ? 0.f : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+    const float gp = sgn * m * scale;
+    a.g_pred[o] = gp;
+    for (int k = 0; k < a.K; ++k) a.g_hyp[k * kstride + o] = k == kbest ? -gp : 0.f;
+  }
+}
+__global__ void carve_knp_colsum_kernel(CarveArgs a) {
+  const int k = blockIdx.x;
+  const bool hm = a.mask != nullptr;
+  const float* hk = a.hyp + (size_t)k * a.N * a.P;
+  for (int s = threadIdx.x; s < a.P; s += blockDim.x) {
+    double acc = 0.0;
+    for (int r = 0; r < a.N; ++r)
+      acc += (double)carve_dist(a.pred[(size_t)r * a.P + s], hk[(size_t)r * a.P + s], hm ? a.mask[r] : 1.f, hm,
+                                a.threshold);
+    a.partial[(size_t)k * a.P + s] = (float)(acc / (double)a.N);
+  }
+}
+__global__ void carve_knp_joint_bwd_kernel(CarveArgs a, const int* argmin_in) {
+  const int ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  const int lane = lane_id();
+  const bool hm = a.mask != nullptr;
+  const float m = hm ? a.mask[ray] : 1.f;
+  const float scale = a.g_loss[0] / ((float)a.N * (float)a.P);
+  const size_t kstride = (size_t)a.N * a.P;
+  for (int s = lane; s < a.P; s += 64) {
+    const size_t o = (size_t)ray * a.P + s;
+    const int kb = argmin_in[s];
+    const float diff = a.pred[o] - a.hyp[kb * kstride + o];
+    float dd = fabsf(diff);
+    if (hm) dd *= m;
+    const bool dead = a.threshold > 0.f && dd < a.threshold;
+    const float sgn = dead ? 0.f : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
+    const float gp = sgn * m * scale;
+    a.g_pred[o] = gp;
+    for (int k = 0; k < a.K; ++k) a.g_hyp[k * kstride + o] = k == kb ? -gp : 0.f;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // img2mse: mean((x-y)^2), optional per-row mask (run_scade_wild.py:978-986)
 // ---------------------------------------------------------------------------
@@ -1100,6 +1184,58 @@ extern "C" int scade_carve_bwd(const float* pred, const float* hyp, const float*
                        reinterpret_cast<const int*>(workspace + (size_t)K * P));
   }
   return scade_check_launch("scade_carve_bwd");
+}
+
+// ---- the same three entries for hypotheses cached per sample, hyp [K,N,P] (helpers:100-102) ----------
+extern "C" int scade_carve_knp_fwd(const float* pred, const float* hyp, const float* mask, float threshold,
+                                   int is_joint, int N, int P, int K, float* workspace, float* loss,
+                                   void* stream) {
+  SCADE_REQUIRE(pred && hyp && workspace && loss, -1, "scade_carve_knp_fwd: null pointer");
+  SCADE_REQUIRE(N > 0 && P > 0 && K > 0, -2, "scade_carve_knp_fwd: empty problem");
+  CarveArgs a{};
+  a.pred = pred; a.hyp = hyp; a.mask = mask; a.partial = workspace; a.loss = loss;
+  a.threshold = threshold; a.N = N; a.P = P; a.K = K;
+  hipStream_t s = (hipStream_t)stream;
+  if (!is_joint) {
+    hipLaunchKernelGGL(carve_knp_fwd_kernel, dim3(grid_rays(N)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(carve_reduce_kernel, dim3(1), dim3(64), 0, s, workspace, N, loss);
+  } else {
+    hipLaunchKernelGGL(carve_knp_colsum_kernel, dim3(K), dim3(128), 0, s, a);
+    hipLaunchKernelGGL(carve_joint_min_kernel, dim3(1), dim3(64), 0, s, a,
+                       reinterpret_cast<int*>(workspace + (size_t)K * P));
+  }
+  return scade_check_launch("scade_carve_knp_fwd");
+}
+
+extern "C" int scade_carve_knp_joint_colmean(const float* pred, const float* hyp, const float* mask,
+                                             float threshold, int N, int P, int K, float* workspace,
+                                             void* stream) {
+  SCADE_REQUIRE(pred && hyp && workspace, -1, "scade_carve_knp_joint_colmean: null pointer");
+  SCADE_REQUIRE(N > 0 && P > 0 && K > 0, -2, "scade_carve_knp_joint_colmean: empty problem");
+  CarveArgs a{};
+  a.pred = pred; a.hyp = hyp; a.mask = mask; a.partial = workspace;
+  a.threshold = threshold; a.N = N; a.P = P; a.K = K;
+  hipLaunchKernelGGL(carve_knp_colsum_kernel, dim3(K), dim3(128), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_carve_knp_joint_colmean");
+}
+
+extern "C" int scade_carve_knp_bwd(const float* pred, const float* hyp, const float* mask, float threshold,
+                                   int is_joint, int N, int P, int K, const float* workspace,
+                                   const float* g_loss, float* g_pred, float* g_hyp, void* stream) {
+  SCADE_REQUIRE(pred && hyp && g_loss && g_pred && g_hyp, -1, "scade_carve_knp_bwd: null pointer");
+  SCADE_REQUIRE(N > 0 && P > 0 && K > 0, -2, "scade_carve_knp_bwd: empty problem");
+  CarveArgs a{};
+  a.pred = pred; a.hyp = hyp; a.mask = mask; a.g_loss = g_loss; a.g_pred = g_pred; a.g_hyp = g_hyp;
+  a.threshold = threshold; a.N = N; a.P = P; a.K = K;
+  hipStream_t s = (hipStream_t)stream;
+  if (!is_joint) {
+    hipLaunchKernelGGL(carve_knp_bwd_kernel, dim3(grid_rays(N)), dim3(256), 0, s, a);
+  } else {
+    SCADE_REQUIRE(workspace, -1, "scade_carve_knp_bwd: joint mode needs the forward workspace");
+    hipLaunchKernelGGL(carve_knp_joint_bwd_kernel, dim3(grid_rays(N)), dim3(256), 0, s, a,
+                       reinterpret_cast<const int*>(workspace + (size_t)K * P));
+  }
+  return scade_check_launch("scade_carve_knp_bwd");
 }
 
 extern "C" int scade_mse_fwd(const float* x, const float* y, const float* row_mask, int n, int c,

@@ -583,6 +583,14 @@ class SamplePdfFn(torch.autograd.Function):
         return None, g_w, None, None, None
 
 
+def _carve_per_sample(hyp: Tensor, N: int, P: int) -> bool:
+    """target_hypothesis [K,N,1] (one hypothesis per ray, repeated over the samples, helpers:97-99) or
+    [K,N,P] (cached quantiles: a hypothesis per sample, helpers:100-102)."""
+    if hyp.dim() != 3 or hyp.shape[1] != N or hyp.shape[2] not in (1, P):
+        raise ValueError(f"space_carving: target_hypothesis must be [K,{N},1] or [K,{N},{P}], got {tuple(hyp.shape)}")
+    return hyp.shape[2] != 1
+
+
 class CarveFn(torch.autograd.Function):
     """compute_space_carving_loss (helpers:93-128)."""
 
@@ -591,28 +599,29 @@ class CarveFn(torch.autograd.Function):
         check(pred, "space_carving: pred_depth"); check(hyp, "space_carving: target_hypothesis")
         N, P = pred.shape
         K = hyp.shape[0]
-        pred_c, hyp_c = _c(pred), _c(hyp.reshape(K, N))
+        knp = _carve_per_sample(hyp, N, P)          # hypotheses cached per sample [K,N,P] (helpers:100-102)
+        pred_c, hyp_c = _c(pred), _c(hyp.reshape(K, N, P) if knp else hyp.reshape(K, N))
         mask_c = None if mask is None else _c(check(mask, "space_carving: mask").reshape(N))
         nws = int(_lib.load().scade_carve_workspace_floats(N, P, K, int(is_joint)))
         ws = torch.empty(nws, device=pred.device, dtype=torch.float32)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
-        call("scade_carve_fwd", ptr(pred_c), ptr(hyp_c), ptr(mask_c), float(threshold), int(is_joint),
-             N, P, K, ptr(ws), ptr(loss), stream())
+        call("scade_carve_knp_fwd" if knp else "scade_carve_fwd", ptr(pred_c), ptr(hyp_c), ptr(mask_c),
+             float(threshold), int(is_joint), N, P, K, ptr(ws), ptr(loss), stream())
         ctx.save_for_backward(pred_c, hyp_c, mask_c if mask_c is not None else pred.new_empty(0), ws)
-        ctx.cfg = (float(threshold), int(is_joint), mask is not None, tuple(hyp.shape))
+        ctx.cfg = (float(threshold), int(is_joint), mask is not None, tuple(hyp.shape), knp)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         pred, hyp, mask, ws = ctx.saved_tensors
-        thr, joint, has_mask, hyp_shape = ctx.cfg
+        thr, joint, has_mask, hyp_shape, knp = ctx.cfg
         N, P = pred.shape
         K = hyp.shape[0]
         g = _c(g.reshape(1).to(torch.float32))
         g_pred = torch.empty_like(pred)
         g_hyp = torch.empty_like(hyp)
-        call("scade_carve_bwd", ptr(pred), ptr(hyp), ptr(mask if has_mask else None), thr, joint, N, P,
-             K, ptr(ws), ptr(g), ptr(g_pred), ptr(g_hyp), stream())
+        call("scade_carve_knp_bwd" if knp else "scade_carve_bwd", ptr(pred), ptr(hyp),
+             ptr(mask if has_mask else None), thr, joint, N, P, K, ptr(ws), ptr(g), ptr(g_pred), ptr(g_hyp), stream())
         return g_pred, g_hyp.reshape(hyp_shape), None, None, None
 
 
@@ -629,31 +638,32 @@ class CarveJointShardedFn(torch.autograd.Function):
         check(pred, "space_carving: pred_depth"); check(hyp, "space_carving: target_hypothesis")
         N, P = pred.shape
         K = hyp.shape[0]
-        pred_c, hyp_c = _c(pred), _c(hyp.reshape(K, N))
+        knp = _carve_per_sample(hyp, N, P)
+        pred_c, hyp_c = _c(pred), _c(hyp.reshape(K, N, P) if knp else hyp.reshape(K, N))
         mask_c = None if mask is None else _c(check(mask, "space_carving: mask").reshape(N))
         ws = torch.empty(int(_lib.load().scade_carve_workspace_floats(N, P, K, 1)), device=pred.device,
                          dtype=torch.float32)
         loss = torch.empty(1, device=pred.device, dtype=torch.float32)
-        call("scade_carve_joint_colmean", ptr(pred_c), ptr(hyp_c), ptr(mask_c), float(threshold), N, P, K,
-             ptr(ws), stream())
+        call("scade_carve_knp_joint_colmean" if knp else "scade_carve_joint_colmean", ptr(pred_c), ptr(hyp_c),
+             ptr(mask_c), float(threshold), N, P, K, ptr(ws), stream())
         share, _ = parallel.combine_shard_means(ws[:K * P], N, group, n_total)
         call("scade_carve_joint_min", ptr(ws), P, K, ptr(loss), stream())
         ctx.save_for_backward(pred_c, hyp_c, mask_c if mask_c is not None else pred.new_empty(0), ws)
         # the kernel's backward divides by this shard's N; the global mean divides by N_total
-        ctx.cfg = (float(threshold), mask is not None, tuple(hyp.shape), share)
+        ctx.cfg = (float(threshold), mask is not None, tuple(hyp.shape), share, knp)
         return loss.reshape(())
 
     @staticmethod
     def backward(ctx, g):
         pred, hyp, mask, ws = ctx.saved_tensors
-        thr, has_mask, hyp_shape, factor = ctx.cfg
+        thr, has_mask, hyp_shape, factor, knp = ctx.cfg
         N, P = pred.shape
         K = hyp.shape[0]
         g = _c((g.reshape(1) * factor).to(torch.float32))
         g_pred = torch.empty_like(pred)
         g_hyp = torch.empty_like(hyp)
-        call("scade_carve_bwd", ptr(pred), ptr(hyp), ptr(mask if has_mask else None), thr, 1, N, P,
-             K, ptr(ws), ptr(g), ptr(g_pred), ptr(g_hyp), stream())
+        call("scade_carve_knp_bwd" if knp else "scade_carve_bwd", ptr(pred), ptr(hyp),
+             ptr(mask if has_mask else None), thr, 1, N, P, K, ptr(ws), ptr(g), ptr(g_pred), ptr(g_hyp), stream())
         return g_pred, g_hyp.reshape(hyp_shape), None, None, None, None
 
 

@@ -57,8 +57,9 @@ def to16b(x):
 
 def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, mask=None, norm_p=2,
                                threshold=0.0, sharded=False, group=None, n_total=None):
-    """pred_depth [N,P]; target_hypothesis [K,N,1].  The norm runs over a size-1
-    axis, so every ``norm_p`` gives |pred - hyp| (kept for signature parity).
+    """pred_depth [N,P]; target_hypothesis [K,N,1], or [K,N,P] when every sample (quantile) already
+    picked its hypothesis (helpers:100-102).  The norm runs over a size-1 axis, so every ``norm_p``
+    gives |pred - hyp| (kept for signature parity).
 
     ``sharded=True`` (not in the reference, which is single-process): the arguments are this
     rank's SHARD of a ray-partitioned batch.  Only ``is_joint=True`` needs an exchange (its mean
@@ -66,11 +67,7 @@ def compute_space_carving_loss(pred_depth, target_hypothesis, is_joint=False, ma
     ``ops.CarveJointShardedFn`` (``n_total`` = rays of all shards, None = found with one extra
     all-reduce)."""
     if target_hypothesis.dim() != 3:
-        raise ValueError("compute_space_carving_loss: target_hypothesis must be [K,N,1]")
-    if target_hypothesis.shape[-1] != 1:
-        raise NotImplementedError(
-            "compute_space_carving_loss: per-quantile hypotheses [K,N,P] (helpers:100-102) are not "
-            "produced by any SCADE driver and are not implemented")
+        raise ValueError("compute_space_carving_loss: target_hypothesis must be [K,N,1] or [K,N,P]")
     if norm_p <= 0:
         raise ValueError("norm_p must be positive")
     if is_joint and sharded:

@@ -4,9 +4,12 @@ full-image evaluation loop.  File formats follow the reference exactly so its da
 pretrained checkpoints can be consumed unchanged:
 
   load_scene_scannet      data/load_scene.py:243-383 (read_files :16-26, gt depth :72-91)
+  load_scene_processed    data/load_scene.py:386-532 (the in-the-wild scenes of run_scade_wild.py)
   scene_bbox              run_scade_scannet.py:1236-1244
   save/load_checkpoint    run_scade_scannet.py:411-420, :1004-1019
   render_images_with_metrics (PSNR + depth RMSE part)   run_scade_scannet.py:304-394
+  write_images_with_metrics / MeanTracker               run_scade_scannet.py:396-409, train_utils/logging.py:5-34
+  render_video (frame loop; the ffmpeg call only if present)   run_scade_scannet.py:236-264
 
 Images are read with PIL (cv2 / imageio are not part of this image).
 """
@@ -57,6 +60,18 @@ def load_ground_truth_depth(basedir, train_filenames, image_size, depth_scaling_
 def load_scene_scannet(basedir, cimle_dir, num_hypothesis=20, train_json="transforms_train.json",
                        init_scales=False, scales_dir=None, gt_init=False):
     """Same return tuple as the reference (data/load_scene.py:243-383)."""
+    return _load_scene(basedir, cimle_dir, num_hypothesis, train_json, init_scales, scales_dir, gt_init, False)
+
+
+def load_scene_processed(basedir, cimle_dir, num_hypothesis=20, train_json="transforms_train.json",
+                         init_scales=False, scales_dir=None, gt_init=False):
+    """The in-the-wild loader run_scade_wild.py:1261 uses (data/load_scene.py:386-532): the depth
+    map of a frame is ``<depth_file_path stem>.png`` whatever extension the json names (:423), and
+    there are no separate ground-truth depth maps (the 11th / 12th entries of the tuple are None)."""
+    return _load_scene(basedir, cimle_dir, num_hypothesis, train_json, init_scales, scales_dir, gt_init, True)
+
+
+def _load_scene(basedir, cimle_dir, num_hypothesis, train_json, init_scales, scales_dir, gt_init, processed):
     splits = ['train', 'val', 'test', 'video']
     all_imgs, all_depths, all_valid, all_poses, all_intr = [], [], [], [], []
     counts, filenames = [0], []
@@ -75,7 +90,10 @@ def load_scene_scannet(basedir, cimle_dir, num_hypothesis=20, train_json="transf
         imgs, depths, valids, poses, intr = [], [], [], [], []
         for frame in meta['frames']:
             if len(frame['file_path']) != 0 or len(frame['depth_file_path']) != 0:
-                img, depth = read_files(basedir, frame['file_path'], frame['depth_file_path'])
+                depth_file = frame['depth_file_path']
+                if processed:
+                    depth_file = depth_file.split(".")[0] + ".png"
+                img, depth = read_files(basedir, frame['file_path'], depth_file)
                 if depth.ndim == 2:
                     depth = np.expand_dims(depth, -1)
                 valids.append(depth[:, :, 0] > 0.5)
@@ -96,7 +114,8 @@ def load_scene_scannet(basedir, cimle_dir, num_hypothesis=20, train_json="transf
     valid_depths = np.concatenate(all_valid, 0)
     poses = np.concatenate(all_poses, 0)
     intrinsics = np.concatenate(all_intr, 0)
-    gt_depths, gt_valid_depths = load_ground_truth_depth(basedir, filenames, (Hh, Ww), depth_scaling_factor)
+    gt_depths, gt_valid_depths = (None, None) if processed else \
+        load_ground_truth_depth(basedir, filenames, (Hh, Ww), depth_scaling_factor)
 
     leres_dir = os.path.join(basedir, "train", "leres_cimle", cimle_dir)
     hyps = []
@@ -177,32 +196,152 @@ def compute_rmse(prediction, target):
     return torch.sqrt((prediction - target).pow(2).mean())
 
 
+class MeanTracker:
+    """Running means of named metrics (train_utils/logging.py:5-34: add / has / get / as_dict / print)."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.mean_dict, self.total_weight = {}, 0
+
+    def add(self, values, weight=1.):
+        for k, v in values.items():
+            self.mean_dict[k] = (self.mean_dict.get(k, 0) * self.total_weight + v) / (self.total_weight + weight)
+        self.total_weight += weight
+
+    def has(self, key):
+        return key in self.mean_dict
+
+    def get(self, key):
+        return self.mean_dict[key]
+
+    def as_dict(self):
+        return self.mean_dict
+
+    def print(self, f=None):
+        for k, v in self.mean_dict.items():
+            print("{}: {}".format(k, v), file=f) if f is not None else print("{}: {}".format(k, v))
+
+
 @torch.no_grad()
 def render_images_with_metrics(images, depths, valid_depths, poses, Hh, Ww, intrinsics, render_kwargs_test,
                                chunk=1024 * 16, count=None, indices=None) -> Dict[str, object]:
     """The render + PSNR + depth-RMSE part of run_scade_scannet.py:304-394 (SSIM = skimage and
     LPIPS = AlexNet are third-party metrics and stay with the caller).  images [M,H,W,3],
-    depths [M,H,W,1], valid_depths [M,H,W] are device tensors; returns per-image and mean metrics
-    plus the rendered rgb / depth maps."""
+    depths [M,H,W,1], valid_depths [M,H,W] are device tensors; returns per-image and mean metrics,
+    the rendered rgb / depth maps, and under ``"images"`` / ``"mean_metrics"`` the result dict and
+    tracker in the reference's layout (:380-394: channel-first CPU tensors, rgb clamped to [0,1],
+    depths divided by ``far``) that ``write_images_with_metrics`` consumes."""
     idx = list(range(images.shape[0])) if indices is None else list(indices)
     if count is not None:
         idx = idx[:count]
+    far = float(render_kwargs_test.get("far", 1.0))
     out = {"psnr": [], "img_loss": [], "psnr0": [], "depth_rmse": [], "rgbs": [], "depths": []}
+    res = {k: [] for k in ("rgbs", "target_rgbs", "depths", "target_depths", "target_valid_depths", "rgbs0", "depths0")}
+    mean_metrics, mean_depth_metrics = MeanTracker(), MeanTracker()
     for n in idx:
         rgb, _, _, extras = R.render(Hh, Ww, intrinsics[n], chunk=chunk, c2w=poses[n], **render_kwargs_test)
         target = images[n]
         img_loss = H.img2mse(rgb, target)
         out["img_loss"].append(float(img_loss))
         out["psnr"].append(float(H.mse2psnr(img_loss)))
+        metrics = {"img_loss": out["img_loss"][-1], "psnr": out["psnr"][-1]}
         if "rgb0" in extras:
-            out["psnr0"].append(float(H.mse2psnr(H.img2mse(extras["rgb0"], target))))
+            l0 = H.img2mse(extras["rgb0"], target)
+            out["psnr0"].append(float(H.mse2psnr(l0)))
+            metrics.update({"img_loss0": float(l0), "psnr0": out["psnr0"][-1]})
+            res["rgbs0"].append(extras["rgb0"].clamp(0., 1.).permute(2, 0, 1).cpu())
+            res["depths0"].append((extras["depth0"] / far).unsqueeze(0).cpu())
         v = valid_depths[n]
         if bool(v.any()):
-            out["depth_rmse"].append(float(compute_rmse(extras["depth_map"][v], depths[n][:, :, 0][v])))
+            rmse = float(compute_rmse(extras["depth_map"][v], depths[n][:, :, 0][v]))
+            if rmse == rmse:                                           # :347: NaN RMSEs are not tracked
+                out["depth_rmse"].append(rmse)
+                mean_depth_metrics.add({"depth_rmse": rmse})
+        mean_metrics.add(metrics)
         out["rgbs"].append(rgb)
         out["depths"].append(extras["depth_map"])
+        res["rgbs"].append(rgb.clamp(0., 1.).permute(2, 0, 1).cpu())
+        res["target_rgbs"].append(target.permute(2, 0, 1).cpu())
+        res["depths"].append((extras["depth_map"] / far).unsqueeze(0).cpu())
+        res["target_depths"].append((depths[n][:, :, 0] / far).unsqueeze(0).cpu())
+        res["target_valid_depths"].append(v.unsqueeze(0).cpu())
     out["mean"] = {k: float(np.mean(out[k])) for k in ("psnr", "img_loss", "psnr0", "depth_rmse") if out[k]}
+    out["images"] = {k: torch.stack(v, 0) for k, v in res.items() if v}
+    allm = MeanTracker()
+    allm.add({**mean_metrics.as_dict(), **mean_depth_metrics.as_dict()})
+    out["mean_metrics"] = allm
     return out
+
+
+def write_images_with_metrics(images, mean_metrics, far, args=None, with_test_time_optimization=False,
+                              result_dir=None):
+    """run_scade_scannet.py:396-409: ``<n>_rgb.jpg`` (8 bit), ``<n>_d.png`` (16 bit, depth / far) and
+    ``metrics.txt`` under ``ckpt_dir/expname/test_images_[with_optimization_]<scene_id>`` (``args`` as in
+    the reference) or under an explicit ``result_dir``.  ``images`` / ``mean_metrics`` are the
+    ``"images"`` / ``"mean_metrics"`` entries of ``render_images_with_metrics``.  PIL writes the files
+    (the reference's cv2 is not part of this image; RGB order on disk is the same)."""
+    from PIL import Image
+    if result_dir is None:
+        result_dir = os.path.join(args.ckpt_dir, args.expname, "test_images_" +
+                                  ("with_optimization_" if with_test_time_optimization else "") + args.scene_id)
+    os.makedirs(result_dir, exist_ok=True)
+    rgbs = images["rgbs"].permute(0, 2, 3, 1).cpu().numpy()
+    deps = images["depths"].permute(0, 2, 3, 1).cpu().numpy()
+    for n, (rgb, depth) in enumerate(zip(rgbs, deps)):
+        Image.fromarray(H.to8b(rgb)).save(os.path.join(result_dir, f"{n}_rgb.jpg"))
+        Image.fromarray(H.to16b(depth[..., 0])).save(os.path.join(result_dir, f"{n}_d.png"))
+    with open(os.path.join(result_dir, "metrics.txt"), "w") as f:
+        mean_metrics.print(f)
+    mean_metrics.print()
+    return result_dir
+
+
+# anchor colours of the two colormaps render_video paints with (cv2.COLORMAP_TURBO / COLORMAP_VIRIDIS in the
+# reference), sampled at 0, 1/8, ..., 1 and interpolated linearly - a visualisation aid, not a metric
+_TURBO = np.array([[48, 18, 59], [70, 107, 227], [40, 170, 235], [36, 227, 164], [143, 253, 74], [227, 228, 39],
+                   [253, 157, 34], [223, 73, 11], [122, 4, 3]], np.float32)
+_VIRIDIS = np.array([[68, 1, 84], [71, 45, 123], [59, 82, 139], [44, 114, 142], [33, 145, 140], [39, 173, 129],
+                     [92, 200, 99], [170, 220, 50], [253, 231, 37]], np.float32)
+
+
+def _colormap(x01, anchors):
+    t = np.clip(np.asarray(x01, np.float32), 0., 1.) * (len(anchors) - 1)
+    i = np.minimum(t.astype(np.int32), len(anchors) - 2)
+    w = (t - i)[..., None]
+    return (anchors[i] * (1 - w) + anchors[i + 1] * w).astype(np.uint8)
+
+
+@torch.no_grad()
+def render_video(poses, Hh, Ww, intrinsics, filename, render_kwargs_test, out_dir, chunk=1024 * 16, fps=25,
+                 every=3, run_ffmpeg=True):
+    """The frame loop of run_scade_scannet.py:236-264: every third pose rendered 16:9 with the centre
+    third kept (``with_5_9``), frame = rgb | depth / far (turbo) | depth standard deviation (viridis),
+    written as ``video_<filename>/<idx>.jpg``; ffmpeg assembles the mp4 when it is installed.
+    Returns (frame directory, maximal depth seen)."""
+    import shutil
+    import subprocess
+    from PIL import Image
+    video_dir = os.path.join(out_dir, "video_" + filename)
+    if os.path.exists(video_dir):
+        shutil.rmtree(video_dir)
+    os.makedirs(video_dir, exist_ok=True)
+    depth_scale = float(render_kwargs_test["far"])
+    max_depth = 0.0
+    for img_idx in range(0, len(poses), every):
+        rgb, _, _, extras = R.render(Hh, Ww, intrinsics[img_idx], chunk=chunk, c2w=poses[img_idx][:3, :4],
+                                     with_5_9=True, **render_kwargs_test)
+        max_depth = max(max_depth, float(extras["depth_map"].max()))
+        frame = [H.to8b(rgb.cpu().numpy()),
+                 _colormap((extras["depth_map"] / depth_scale).cpu().numpy(), _TURBO),
+                 _colormap(depth_std_map(extras["z_vals"], extras["weights"], extras["depth_map"]).cpu().numpy(),
+                           _VIRIDIS)]
+        Image.fromarray(np.concatenate(frame, 1)).save(os.path.join(video_dir, f"{img_idx}.jpg"))
+    if run_ffmpeg and shutil.which("ffmpeg"):
+        subprocess.call(["ffmpeg", "-y", "-framerate", str(fps), "-i", os.path.join(video_dir, "%d.jpg"), "-c:v",
+                         "libx264", "-profile:v", "high", "-crf", str(fps), os.path.join(out_dir, filename + ".mp4")])
+    return video_dir, max_depth
 
 
 def depth_std_map(z_vals, weights, depth_map):

@@ -231,6 +231,27 @@ def test_carve_golden(dev, K):
         assert_close(h.grad, 1.5 * g[f"{name}/grad_hyp"], rtol=1e-4, atol=1e-8, what=f"{name} dhyp")
 
 
+def test_space_carving_cached_quantile_hypotheses_golden(dev):
+    """target_hypothesis [K,N,P]: every sample already picked its hypothesis (helpers:100-102) - loss and
+    both gradients against the reference, plain and ray-sharded entry."""
+    g = load_golden("f5_carve_knp")
+    mask = g["mask"].to(dev)
+    variants = {"default": {}, "mask": dict(mask=mask), "thr": dict(threshold=0.05),
+                "joint": dict(is_joint=True), "joint_mask_thr": dict(is_joint=True, mask=mask, threshold=0.05),
+                "mask_thr": dict(mask=mask, threshold=0.05)}
+    for name, kw in variants.items():
+        for sharded in ((False, True) if kw.get("is_joint") else (False,)):
+            p = g["pred"].to(dev).requires_grad_(True)
+            h = g["hyp"].to(dev).requires_grad_(True)
+            loss = S.compute_space_carving_loss(p, h, sharded=sharded, **kw)
+            (loss * 1.5).backward()
+            assert_close(loss, g[f"{name}/loss"], rtol=1e-5, atol=1e-7, what=f"carve knp {name}")
+            assert_close(p.grad, 1.5 * g[f"{name}/grad_pred"], rtol=1e-5, atol=1e-9, what=f"knp {name} dpred")
+            assert_close(h.grad, 1.5 * g[f"{name}/grad_hyp"], rtol=1e-5, atol=1e-9, what=f"knp {name} dhyp")
+    with pytest.raises(ValueError):
+        S.compute_space_carving_loss(g["pred"].to(dev), g["hyp"].to(dev)[:, :, :7])
+
+
 def test_mse(dev):
     torch.manual_seed(2)
     x, y, m = torch.rand(100, 3), torch.rand(100, 3), (torch.rand(100) > 0.5).float()

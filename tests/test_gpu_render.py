@@ -1,5 +1,8 @@
 """GPU parity of render_rays end-to-end: golden fixture from the real reference
 (N=32), oracle on seeded inputs, and size-independent properties at the bench size."""
+import os
+
+import numpy as np
 import pytest
 import torch
 
@@ -252,6 +255,23 @@ def test_full_image_eval_loop(dev, tmp_path):
     assert psnr > 80, psnr
     want_psnr = O.mse2psnr(O.img2mse(want["rgb_map"].reshape(Hh, Ww, 3), torch.as_tensor(imgs[0])))
     assert abs(res["psnr"][0] - float(want_psnr)) < 0.05          # north_star: PSNR within 0.05 dB
+    # the reference's result layout (:380-394) and its writers (:396-409, :236-264)
+    from scade_amd.scene import render_video, write_images_with_metrics
+    im = res["images"]
+    assert im["rgbs"].shape == (3, 3, Hh, Ww) and im["depths"].shape == (3, 1, Hh, Ww) and im["rgbs0"].shape == (3, 3, Hh, Ww)
+    assert im["target_valid_depths"].dtype == torch.bool and float(im["rgbs"].max()) <= 1.0
+    assert torch.equal(im["depths"][0, 0], (res["depths"][0] / far).cpu())
+    mm = res["mean_metrics"]
+    assert abs(mm.get("psnr") - res["mean"]["psnr"]) < 1e-4 and mm.has("depth_rmse") and mm.has("psnr0")
+    out_dir = write_images_with_metrics(im, mm, far, result_dir=str(tmp_path / "imgs"))
+    assert len(os.listdir(out_dir)) == 7
+    vdir, max_depth = render_video(t(poses), Hh, Ww, t(intr), "spiral", kw, str(tmp_path), chunk=200, run_ffmpeg=False)
+    Wc = int(Hh / 9. * 16. / 3.)
+    Wc -= Wc % 2
+    from PIL import Image
+    frames = sorted(os.listdir(vdir))
+    assert frames == ["0.jpg"] and 0 < max_depth <= far + 1e-4       # every third of the three poses
+    assert Image.open(os.path.join(vdir, "0.jpg")).size == (3 * Wc, Hh)   # rgb | depth | depth std
 
 
 def test_render_with_5_9_is_the_centre_crop(dev):

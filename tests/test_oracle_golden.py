@@ -109,6 +109,22 @@ def test_carve(K):
         assert_close(h.grad, g[f"{name}/grad_hyp"], what=f"{name} dhyp", **TIGHT)
 
 
+def test_carve_cached_quantile_hypotheses():
+    """target_hypothesis [K,N,P] (helpers:100-102)."""
+    g = load_golden("f5_carve_knp")
+    variants = {"default": {}, "mask": dict(mask=g["mask"]), "thr": dict(threshold=0.05),
+                "joint": dict(is_joint=True), "joint_mask_thr": dict(is_joint=True, mask=g["mask"], threshold=0.05),
+                "mask_thr": dict(mask=g["mask"], threshold=0.05)}
+    for name, kw in variants.items():
+        p = g["pred"].clone().requires_grad_(True)
+        h = g["hyp"].clone().requires_grad_(True)
+        assert h.shape == (20, 16, 128)
+        loss = O.compute_space_carving_loss(p, h, **kw)
+        loss.backward()
+        assert torch.equal(loss.detach(), g[f"{name}/loss"]), name
+        assert torch.equal(p.grad, g[f"{name}/grad_pred"]) and torch.equal(h.grad, g[f"{name}/grad_hyp"]), name
+
+
 def test_perturb():
     g = load_golden("f7_perturb")
     assert_close(O.perturb_z_vals(g["z"], g["t_rand"]), g["out"], what="perturb", **TIGHT)

@@ -54,6 +54,56 @@ def test_load_scene_scannet(tmp_path):
     assert gt_d.shape == (3, Hh, Ww, 1) and not gt_v.any()
 
 
+def test_load_scene_processed(tmp_path):
+    """data/load_scene.py:386-532: depth read from <depth_file_path stem>.png, no ground-truth depth maps."""
+    from scade_amd.scene import load_scene_processed, load_scene_scannet
+    Hh, Ww = write_scene(str(tmp_path))
+    for split in ("train", "test"):                                # the json names another extension (:423)
+        jf = os.path.join(str(tmp_path), f"transforms_{split}.json")
+        meta = json.load(open(jf))
+        for fr in meta["frames"]:
+            fr["depth_file_path"] = fr["depth_file_path"].replace(".png", ".exr")
+        json.dump(meta, open(jf, "w"))
+    out = load_scene_processed(str(tmp_path), "dump", num_hypothesis=3)
+    assert len(out) == 13 and out[10] is None and out[11] is None
+    imgs, depths, valid, poses, H2, W2, intr, near, far, i_split, _, _, hyp = out
+    assert (H2, W2) == (Hh, Ww) and depths.shape == (3, Hh, Ww, 1) and not valid[0, 0, 0] and valid[0, 1, 1]
+    assert hyp.shape == (2, 3, Hh, Ww, 1) and hyp.min() >= near and hyp.max() <= far
+    with pytest.raises(FileNotFoundError):
+        load_scene_scannet(str(tmp_path), "dump", num_hypothesis=3)  # that loader takes the path literally
+    sdir = os.path.join(str(tmp_path), "train", "scale_shift_inits", "s")
+    os.makedirs(sdir)
+    for i in range(2):
+        np.save(os.path.join(sdir, f"{i}_sfminit.npy"), np.array([1.5 + i, -0.25 * i], np.float32))
+    out = load_scene_processed(str(tmp_path), "dump", num_hypothesis=3, init_scales=True, scales_dir="s")
+    assert len(out) == 15 and np.allclose(out[13], [1.5, 2.5]) and np.allclose(out[14], [0.0, -0.25])
+
+
+def test_mean_tracker_and_image_writer(tmp_path):
+    """train_utils/logging.py:5-34 and run_scade_scannet.py:396-409: 8-bit jpg, 16-bit depth png, metrics.txt."""
+    from types import SimpleNamespace
+    from PIL import Image
+    from scade_amd.scene import MeanTracker, write_images_with_metrics
+    mt = MeanTracker()
+    mt.add({"psnr": 20.0, "img_loss": 0.01})
+    mt.add({"psnr": 30.0, "img_loss": 0.03})
+    assert mt.has("psnr") and abs(mt.get("psnr") - 25.0) < 1e-12 and abs(mt.as_dict()["img_loss"] - 0.02) < 1e-12
+    g = torch.Generator().manual_seed(0)
+    images = {"rgbs": torch.rand(2, 3, 6, 8, generator=g), "depths": torch.rand(2, 1, 6, 8, generator=g)}
+    args = SimpleNamespace(ckpt_dir=str(tmp_path), expname="exp", scene_id="scene0758_00")
+    d = write_images_with_metrics(images, mt, 5.0, args)
+    assert d.endswith(os.path.join("exp", "test_images_scene0758_00"))
+    assert sorted(os.listdir(d)) == ["0_d.png", "0_rgb.jpg", "1_d.png", "1_rgb.jpg", "metrics.txt"]
+    dep = np.asarray(Image.open(os.path.join(d, "1_d.png")))
+    assert dep.dtype == np.uint16 and dep.shape == (6, 8)
+    assert np.array_equal(dep, ((2 ** 16 - 1) * images["depths"][1, 0].numpy()).astype(np.uint16))   # to16b, lossless
+    rgb = np.asarray(Image.open(os.path.join(d, "0_rgb.jpg")))
+    assert rgb.shape == (6, 8, 3) and rgb.dtype == np.uint8
+    assert open(os.path.join(d, "metrics.txt")).read().splitlines() == ["psnr: 25.0", "img_loss: 0.02"]
+    d2 = write_images_with_metrics(images, mt, 5.0, args, with_test_time_optimization=True)
+    assert d2.endswith("test_images_with_optimization_scene0758_00")
+
+
 def test_checkpoint_roundtrip_reference_format(tmp_path):
     import scade_amd as S
     from scade_amd.scene import load_checkpoint, restore, save_checkpoint

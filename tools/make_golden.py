@@ -271,6 +271,41 @@ def f5_carve():
         save(f"f5_carve_{K}", **arrs)
 
 
+# ---------------------------------------------------------------- F5b carve, cached-quantile hypotheses
+def f5_carve_knp():
+    """target_hypothesis [K,N,P]: "each quantile here already picked a hypothesis" (helpers:100-102)."""
+    torch.manual_seed(95)
+    K, N, P = 20, 16, 128
+    pred = (torch.rand(N, P) * 4.9 + 0.1)
+    hyp = (torch.rand(K, N, P) * 4.9 + 0.1)
+    hyp[0, 3, :4] = 1.0
+    hyp[1, 3, :4] = 3.0
+    pred[3, :4] = 2.0                        # exact tie between hyp 0 and 1 ...
+    hyp[2:, 3, :4] = 10.0                    # ... all other hyps far away
+    pred[4, 0] = hyp[5, 4, 0]                # exact zero distance
+    mask = (torch.rand(N) > 0.3).float()
+    arrs = dict(pred=pred, hyp=hyp, mask=mask)
+    variants = {"default": dict(), "mask": dict(mask=mask), "thr": dict(threshold=0.05),
+                "joint": dict(is_joint=True), "joint_mask_thr": dict(is_joint=True, mask=mask, threshold=0.05),
+                "mask_thr": dict(mask=mask, threshold=0.05)}
+    for name, kw in variants.items():
+        p = pred.clone().requires_grad_(True)
+        h = hyp.clone().requires_grad_(True)
+        loss = H.compute_space_carving_loss(p, h, **kw)
+        loss.backward()
+        p2 = pred.clone().requires_grad_(True)
+        h2 = hyp.clone().requires_grad_(True)
+        lo = O.compute_space_carving_loss(p2, h2, **kw)
+        lo.backward()
+        same(lo, loss, f"carve_knp.{name}")
+        same(p2.grad, p.grad, f"d carve_knp.{name}/d pred")
+        same(h2.grad, h.grad, f"d carve_knp.{name}/d hyp")
+        arrs[f"{name}/loss"] = loss
+        arrs[f"{name}/grad_pred"] = p.grad
+        arrs[f"{name}/grad_hyp"] = h.grad
+    save("f5_carve_knp", **arrs)
+
+
 # ---------------------------------------------------------------- F7 perturb
 def f7_perturb():
     torch.manual_seed(40)
@@ -413,6 +448,7 @@ if __name__ == "__main__":
     f3_composite()
     f4_sample_pdf()
     f5_carve()
+    f5_carve_knp()
     f7_perturb()
     f6_render()
     print("all fixtures written; oracle pinned bit-exact against the reference on this torch build")
