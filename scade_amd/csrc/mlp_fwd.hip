@@ -37,6 +37,13 @@ struct MlpFwdArgs {
 
 // bias (+ReLU) and in-place write of the wave's [NT*32 features] x [64 points]
 // this lane's 16 bias values per n-tile (issued before the k-loop, consumed in layer_store)
+__device__ __forceinline__ float relu_keep_nan(float x) {
+  const int b = __builtin_bit_cast(int, x);
+  return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+// positive-signed quiet NaN for any NaN (the sign of a propagated NaN is otherwise the input's)
+__device__ __forceinline__ float canon_nan(float x) { return x != x ? __builtin_nanf("") : x; }
+
 template <int NT>
 __device__ __forceinline__ void load_bias(f32x4 (&bv)[NT][4], const float* __restrict__ bias,
                                           int ntile0, int lane) {
@@ -69,10 +76,13 @@ __device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT
         for (int i = 0; i < 4; ++i) {
           float x = acc[t][p][4 * q + i] + bv[i];
           // relu that PROPAGATES NaN like torch.relu (v_max_f32 would return 0 for a NaN input and
-          // hide a poisoned point from the reference's isnan/isinf scan, run_scade_scannet.py:747-749)
-          const bool off = x <= 0.f;             // one compare serves the value and the sign bit
-          v[i] = RELU ? (off ? 0.f : x) : x;
-          if (RELU && !off) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
+          // hide a poisoned point from the reference's isnan/isinf scan, run_scade_scannet.py:747-749):
+          // ONE integer max on the float's bits - negative floats (and -0) are negative integers and
+          // become 0, a positive-signed NaN is a large positive integer and survives.  NaNs enter the
+          // layers positive-signed: the prologue canonicalises the embedding, the hardware's own
+          // default NaN (inf - inf in an MFMA) is +qNaN.
+          v[i] = RELU ? relu_keep_nan(x) : x;
+          if (RELU && x > 0.f) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
         }
         const int row = p * 32 + r;
         *reinterpret_cast<f32x4*>(hbuf + h_idx(row, f >> 2)) = v;
@@ -105,6 +115,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
       const int row = i / 15;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < nvalid) v = src[i];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[c] = canon_nan(v[c]);
       reinterpret_cast<f32x4*>(ebuf)[i] = v;
     }
   } else {
@@ -118,15 +130,15 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
       const float x = (a.in[(size_t)pt * 3 + c] - ctr) * sc;   // run_scade_scannet.py:52
       float* e = ebuf + row * EMB_STRIDE;
       if (s == 0) {
-        e[c] = x;
+        e[c] = canon_nan(x);
         e[57 + c] = 0.f;
       } else {
         // helpers:165  p_fn(x * np.pi * freq): fl32(x*pi_f32) * 2^k (exact)
         const float arg = (x * 3.14159274101257324f) * (float)(1 << (s - 1));
         float sn, cs;
         sincosf(arg, &sn, &cs);
-        e[3 + 6 * (s - 1) + c] = sn;
-        e[6 + 6 * (s - 1) + c] = cs;
+        e[3 + 6 * (s - 1) + c] = canon_nan(sn);
+        e[6 + 6 * (s - 1) + c] = canon_nan(cs);
       }
     }
   }
@@ -187,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     float v = 0.f;
     if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
     if (PT == 2 || row < TM) {
-      ebuf[row * VIEW_PAD + c] = v;
+      ebuf[row * VIEW_PAD + c] = canon_nan(v);
       ebuf[row * VIEW_PAD + 4 + c] = 0.f;
     }
   }
