@@ -43,6 +43,10 @@ __device__ __forceinline__ float relu_keep_nan(float x) {
 }
 // positive-signed quiet NaN for any NaN (the sign of a propagated NaN is otherwise the input's)
 __device__ __forceinline__ float canon_nan(float x) { return x != x ? __builtin_nanf("") : x; }
+// ... and for +-inf: an infinite coordinate makes the reference's whole row NaN (sin(inf) = NaN meets every
+// feature of layer 0) while inf - inf inside an MFMA yields a default NaN of either sign, which the integer
+// relu would not carry reliably - so it enters the layers as +NaN already
+__device__ __forceinline__ float canon_nonfinite(float x) { return fabsf(x) <= 3.4028234664e38f ? x : __builtin_nanf(""); }
 
 template <int NT>
 __device__ __forceinline__ void load_bias(f32x4 (&bv)[NT][4], const float* __restrict__ bias,
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < nvalid) v = src[i];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) v[c] = canon_nan(v[c]);
+      for (int c = 0; c < 4; ++c) v[c] = canon_nonfinite(v[c]);
       reinterpret_cast<f32x4*>(ebuf)[i] = v;
     }
   } else {
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
       const float x = (a.in[(size_t)pt * 3 + c] - ctr) * sc;   // run_scade_scannet.py:52
       float* e = ebuf + row * EMB_STRIDE;
       if (s == 0) {
-        e[c] = canon_nan(x);
+        e[c] = canon_nonfinite(x);
         e[57 + c] = 0.f;
       } else {
         // helpers:165  p_fn(x * np.pi * freq): fl32(x*pi_f32) * 2^k (exact)
@@ -199,7 +203,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     float v = 0.f;
     if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
     if (PT == 2 || row < TM) {
-      ebuf[row * VIEW_PAD + c] = canon_nan(v);
+      ebuf[row * VIEW_PAD + c] = canon_nonfinite(v);
       ebuf[row * VIEW_PAD + 4 + c] = 0.f;
     }
   }
@@ -318,14 +322,14 @@ __global__ void mlp_pack_kernel(PackArgs a) {
       const int kb = blk % KB, nt = blk / KB;
       const int n = nt * 32 + (lane & 31);
       const int src = kmap(l, kb * 8 + 4 * (lane >> 5) + j);
-      a.packed[off + i] = src >= 0 ? Wsrc[(size_t)n * kr + src] : 0.f;
+      a.packed[off + i] = src >= 0 ? canon_nan(Wsrc[(size_t)n * kr + src]) : 0.f;   // NaN weights: positive-signed
     }
   } else {
     const int t0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
     for (int i = t0; i < NLAYER_MFMA * 256; i += stride) {
       const int ll = i >> 8, f = i & 255;
       const int bidx = ll < 8 ? 2 * ll + 1 : (ll == L_FEAT ? 19 : 17);
-      a.packed[OFF_BIAS + i] = (ll == L_VIEWS && f >= 128) ? 0.f : a.p[bidx][f];
+      a.packed[OFF_BIAS + i] = (ll == L_VIEWS && f >= 128) ? 0.f : canon_nan(a.p[bidx][f]);
     }
     for (int i = t0; i < 256; i += stride) a.packed[OFF_WA + i] = a.p[20][i];
     for (int i = t0; i < 4; i += stride) a.packed[OFF_BA + i] = i == 0 ? a.p[21][0] : 0.f;

@@ -108,6 +108,9 @@ def test_poisoned_rays_show_the_references_nan_pattern(dev, prec):
     rays[5, 0] = float("nan")            # origin
     rays[17, 4] = float("inf")           # direction
     rays[30, 9] = float("nan")           # view direction only: colour is poisoned, density is not
+    rays[7, 1] = -float("nan")           # the same with the other sign (the integer relu of the exact kernel and
+    rays[20, 3] = -float("inf")          # the packed 16-bit relu only carry positive-signed NaNs: the kernels
+    rays[33, 10] = -float("nan")         # canonicalise what enters the layers)
     pc, pf = O.nerf_init(67), O.nerf_init(68)
     bbc, bbs = torch.zeros(3), torch.tensor(0.2)
     with torch.no_grad():
@@ -118,7 +121,7 @@ def test_poisoned_rays_show_the_references_nan_pattern(dev, prec):
         ret = S.render_rays(rays.to(dev), True, coarse, query, 64, N_importance=128, network_fine=fine,
                             perturb=0., retraw=True)
     clean = torch.ones(N, dtype=torch.bool)
-    clean[[5, 17, 30]] = False
+    clean[[5, 17, 30, 7, 20, 33]] = False
     for k in want:
         a, b = ret[k].cpu(), want[k]
         assert torch.equal(torch.isnan(a), torch.isnan(b)), f"{k}: NaN pattern differs from the reference"
@@ -128,3 +131,28 @@ def test_poisoned_rays_show_the_references_nan_pattern(dev, prec):
     if prec == "f32":
         for k in ("rgb0", "depth0", "weights0"):
             assert_close(ret[k][clean], want[k][clean], rtol=1e-4, atol=1e-6, what=k)
+
+
+@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("sign", [1.0, -1.0])
+def test_nan_parameters_poison_every_output_like_the_reference(dev, prec, sign):
+    """A NaN (either sign) in a HIDDEN layer's weight or bias - a diverged training run - must surface as
+    NaN in every output, as torch.relu lets it in the reference; a ReLU that returned 0 for NaN would
+    render finite garbage from the layers behind it.  (The opt-in 16-bit path guarantees this for poisoned
+    INPUTS only - test above - and for NaN head parameters, whose arithmetic is fp32; a NaN in a hidden
+    layer's 16-bit weight copy is not guaranteed to survive its packed integer ReLU: INTEGRATION.md.)"""
+    N = 16
+    rays = O.synthetic_rays(N, seed=70)
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+    for key, idx in (("pts_linears.3.weight", (5, 7)), ("pts_linears.6.bias", (100,)), ("views_linears.0.weight", (3, 200))):
+        pc, pf = O.nerf_init(71), O.nerf_init(72)
+        pc[key][idx] = sign * float("nan")
+        with torch.no_grad():
+            want = O.render_rays(rays, pc, pf, bbc, bbs)
+        coarse, fine, query = build(dev, pc, pf, bbc, bbs)
+        coarse.inference_precision = fine.inference_precision = prec
+        with torch.no_grad():
+            ret = S.render_rays(rays.to(dev), True, coarse, query, 64, N_importance=128, network_fine=fine, perturb=0.)
+        for k in ("rgb0", "rgb_map", "weights0", "depth0", "depth_map", "pred_hyp"):
+            assert torch.equal(torch.isnan(ret[k].cpu()), torch.isnan(want[k])), (key, k)
+        assert torch.isnan(want["rgb0"]).all(), key
