@@ -223,6 +223,28 @@ int scade_mse_fwd(const float* x, const float* y, const float* row_mask, int n, 
 int scade_mse_bwd(const float* x, const float* y, const float* row_mask, int n, int c,
                   const float* g_loss, float* g_x, void* stream);
 
+/* ---- the train loop's three-term loss in one forward / one backward entry (run_scade_scannet.py:954,
+ *      :968-983; the wild variant's masked photometric terms run_scade_wild.py:977-1008):
+ *          target_h = hyp * scales[img] + shifts[img]
+ *          loss = mse(rgb, target) + carve_weight * space_carving(pred, target_h) + mse(rgb0, target)
+ *      (non-joint space carving, hyp [K,N]).  img = *img_i_dev when that device pointer is given (graph
+ *      captured steps), else img_i.  mask [N] or NULL multiplies the carving distances, and the squared
+ *      errors too when mse_masked.  carve_on = 0 drops the middle term (warm start, :973).  out_scale
+ *      multiplies the total (a rank's share of a ray-sharded batch).  loss4 = {total, img_loss, carve,
+ *      img_loss0}; workspace [4 N] floats.  The backward writes g_rgb / g_rgb0 [N,3], g_pred [N,P] and ADDS
+ *      the scale / shift gradients into g_scales[img] / g_shifts[img]. */
+int scade_train_loss_fwd(const float* rgb, const float* rgb0, const float* target, const float* pred,
+                         const float* hyp, const float* scales, const float* shifts,
+                         const long long* img_i_dev, int img_i, const float* mask, int mse_masked, int carve_on,
+                         float carve_weight, float threshold, float out_scale, int N, int P, int K,
+                         float* workspace, float* loss4, void* stream);
+int scade_train_loss_bwd(const float* rgb, const float* rgb0, const float* target, const float* pred,
+                         const float* hyp, const float* scales, const float* shifts,
+                         const long long* img_i_dev, int img_i, const float* mask, int mse_masked, int carve_on,
+                         float carve_weight, float threshold, float out_scale, int N, int P, int K,
+                         float* workspace, const float* g_loss, float* g_rgb, float* g_rgb0, float* g_pred,
+                         float* g_scales, float* g_shifts, void* stream);
+
 /* ---- ray generation + training-batch gather (helpers:285-305 get_ray_dirs/get_rays; the ray
  *      rows of render()/render_hyp(), run_scade_scannet.py:122-141; the gathers of
  *      get_ray_batch_from_one_image_hypothesis_idx, :784-821) ------------------------------- */

@@ -64,6 +64,10 @@ SIGNATURES = {
     "scade_carve_knp_bwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "scade_carve_knp_joint_colmean": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _P, _P]),
     "scade_mse_fwd": (c_int, [_P, _P, _P, _I, _I, _P, _P]),
+    "scade_train_loss_fwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, c_float, c_float, c_float,
+                                     _I, _I, _I, _P, _P, _P]),
+    "scade_train_loss_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, c_float, c_float, c_float,
+                                     _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "scade_gen_rays": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P,
                                 _P, _P, _P, _P]),
     "scade_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, _I, c_float, _P]),

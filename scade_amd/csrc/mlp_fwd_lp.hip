@@ -47,18 +47,34 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][NPT], int
 #pragma unroll
     for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
-        u32x2 v;
-        v[0] = pack2<BF, RELU>(acc[t][p][4 * q + 0], acc[t][p][4 * q + 1]);
-        v[1] = pack2<BF, RELU>(acc[t][p][4 * q + 2], acc[t][p][4 * q + 3]);
-        if (RELU && BITS) {   // sign words (mlp_tile_lp.h): dword d = ((t*4+q)*4+p)*2 + j
-          const int d0 = ((t * 4 + q) * 4 + p) * 2;
-          bits[d0 >> 4] |= sign_pair(v[0]) << (d0 & 15);
-          bits[d0 >> 4] |= sign_pair(v[1]) << ((d0 & 15) + 1);
+      for (int m = 0; m < 2; ++m) {       // row groups q = 2m, 2m + 1: two 16-byte chunks of 8 features
+        u32x2 v[2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * m + qq;
+          v[qq][0] = pack2<BF, RELU>(acc[t][p][4 * q + 0], acc[t][p][4 * q + 1]);
+          v[qq][1] = pack2<BF, RELU>(acc[t][p][4 * q + 2], acc[t][p][4 * q + 3]);
+          if (RELU && BITS) {   // sign words (mlp_tile_lp.h): dword d = ((t*4+q)*4+p)*2 + j
+            const int d0 = ((t * 4 + q) * 4 + p) * 2;
+            bits[d0 >> 4] |= sign_pair(v[qq][0]) << (d0 & 15);
+            bits[d0 >> 4] |= sign_pair(v[qq][1]) << ((d0 & 15) + 1);
+          }
+        }
+        // A lane holds features 8q + 4hh .. + 3 of both chunks, i.e. HALF of each 16-byte chunk; as two
+        // ds_write_b64 the 16 rows of a lane group share 8 slots of a 128-byte bank line (2-way conflict,
+        // 26 % of this kernel's LDS cycles in round 1).  v_permlane32_swap trades the halves between lane
+        // r and lane r + 32: the lower lane ends up with ALL of chunk 2m, the upper one with all of chunk
+        // 2m + 1, and each stores one conflict-free ds_write_b128.
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const auto sw = __builtin_amdgcn_permlane32_swap(v[0][j], v[1][j], false, false);
+          w[j] = sw[0];         // lower lanes: own chunk 2m low half;  upper lanes: the lower lane's chunk 2m+1 low half
+          w[2 + j] = sw[1];     // lower lanes: the upper lane's chunk 2m high half;  upper lanes: own chunk 2m+1 high half
         }
         const int row = p * 32 + r;
-        *reinterpret_cast<u32x2*>(x + x_idx(row, f >> 3) + (f & 7)) = v;
+        const int c = (ntile0 + t) * 4 + 2 * m + hh;
+        *reinterpret_cast<u32x4*>(x + x_idx(row, c)) = w;
       }
     // the next layer's bias values are fetched into the registers point tile 0 just vacated; the
     // rest of this epilogue hides their latency

@@ -667,6 +667,74 @@ class CarveJointShardedFn(torch.autograd.Function):
         return g_pred, g_hyp.reshape(hyp_shape), None, None, None, None
 
 
+class TrainLossFn(torch.autograd.Function):
+    """loss = mse(rgb, target) + w * space_carving(pred, hyp * scale[img] + shift[img]) + mse(rgb0, target)
+    (run_scade_scannet.py:954, :968-983) as ONE forward and ONE backward entry (scade_train_loss_*): what the
+    Trainer uses instead of ~25 launches of separate operators.  Returns (total, [img_loss, carve,
+    img_loss0]).  The scale / shift gradients are accumulated straight into ``scales.grad`` /
+    ``shifts.grad`` when those exist (the Trainer's gradient bucket), otherwise returned densely."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb0, target, pred, hyp, scales, shifts, img_i, mask, mse_masked, carve_on,
+                carve_weight, threshold, out_scale):
+        for t, w in ((rgb, "rgb"), (rgb0, "rgb0"), (target, "target"), (pred, "pred_hyp"), (hyp, "hypotheses")):
+            check(t, "train_loss: " + w)
+        N, P = pred.shape
+        K = hyp.shape[0]
+        if tuple(hyp.shape[1:]) not in ((N,), (N, 1)):
+            raise ValueError(f"train_loss: hypotheses must be [K,{N},1], got {tuple(hyp.shape)}")
+        if tuple(rgb.shape) != (N, 3) or tuple(rgb0.shape) != (N, 3) or tuple(target.shape) != (N, 3):
+            raise ValueError("train_loss: rgb, rgb0 and target must be [N,3]")
+        rgb_c, rgb0_c, tgt_c, pred_c, hyp_c = _c(rgb), _c(rgb0), _c(target), _c(pred), _c(hyp.reshape(K, N))
+        sc, sh = _c(scales.detach().reshape(-1)), _c(shifts.detach().reshape(-1))
+        mask_c = None if mask is None else _c(check(mask, "train_loss: mask").reshape(N))
+        idx_t = img_i.reshape(1) if torch.is_tensor(img_i) else None
+        idx = 0 if torch.is_tensor(img_i) else int(img_i)
+        if idx_t is None and not 0 <= idx < sc.numel():
+            raise IndexError(f"train_loss: img_i {idx} outside [0, {sc.numel()})")
+        ws = torch.empty(4 * N, device=pred.device, dtype=torch.float32)
+        loss4 = torch.empty(4, device=pred.device, dtype=torch.float32)
+        call("scade_train_loss_fwd", ptr(rgb_c), ptr(rgb0_c), ptr(tgt_c), ptr(pred_c), ptr(hyp_c), ptr(sc), ptr(sh),
+             ptr(idx_t), idx, ptr(mask_c), int(bool(mse_masked)), int(bool(carve_on)), float(carve_weight),
+             float(threshold), float(out_scale), N, P, K, ptr(ws), ptr(loss4), stream())
+        ctx.save_for_backward(rgb_c, rgb0_c, tgt_c, pred_c, hyp_c, sc, sh,
+                              mask_c if mask_c is not None else pred.new_empty(0),
+                              idx_t if idx_t is not None else pred.new_empty(0, dtype=torch.long), ws)
+        ctx.cfg = (idx, mask is not None, idx_t is not None, int(bool(mse_masked)), int(bool(carve_on)),
+                   float(carve_weight), float(threshold), float(out_scale), tuple(hyp.shape))
+        ctx.ss = (scales, shifts)
+        comps = loss4[1:]
+        ctx.mark_non_differentiable(comps)
+        return loss4[0], comps
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        rgb, rgb0, tgt, pred, hyp, sc, sh, mask, idx_t, ws = ctx.saved_tensors
+        idx, has_mask, has_idx, mse_masked, carve_on, w, thr, out_scale, hyp_shape = ctx.cfg
+        scales, shifts = ctx.ss
+        N, P = pred.shape
+        K = hyp.shape[0]
+        g = _c(g.reshape(1).to(torch.float32))
+        g_rgb, g_rgb0, g_pred = torch.empty_like(rgb), torch.empty_like(rgb0), torch.empty_like(pred)
+
+        def sink(p):     # accumulate straight into an existing contiguous fp32 .grad (the Trainer's bucket view)
+            gr = p.grad
+            return gr if (gr is not None and gr.is_contiguous() and gr.dtype == torch.float32
+                          and gr.numel() == p.numel()) else None
+        gs, gh = sink(scales), sink(shifts)
+        direct = gs is not None and gh is not None
+        if not direct:
+            gs, gh = torch.zeros_like(sc), torch.zeros_like(sh)
+        call("scade_train_loss_bwd", ptr(rgb), ptr(rgb0), ptr(tgt), ptr(pred), ptr(hyp), ptr(sc), ptr(sh),
+             ptr(idx_t if has_idx else None), idx, ptr(mask if has_mask else None), mse_masked, carve_on, w, thr,
+             out_scale, N, P, K, ptr(ws), ptr(g), ptr(g_rgb), ptr(g_rgb0), ptr(g_pred), ptr(gs), ptr(gh), stream())
+        need = ctx.needs_input_grad
+        return (g_rgb if need[0] else None, g_rgb0 if need[1] else None, None, g_pred if need[3] else None, None,
+                None if direct or not need[5] else gs.reshape(scales.shape),
+                None if direct or not need[6] else gh.reshape(shifts.shape),
+                None, None, None, None, None, None, None)
+
+
 class MseFn(torch.autograd.Function):
     """img2mse (helpers:11), optional per-row mask (run_scade_wild.py:978-986)."""
 

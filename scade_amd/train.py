@@ -18,6 +18,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
+from . import ops
 from . import rendering as R
 from . import run_nerf_helpers as H
 from .optim import FusedAdam
@@ -45,7 +46,7 @@ class Trainer:
                  space_carving_weight=0.007, N_samples=64, N_importance=128, lrate_decay_rate=0.1,
                  lrate_decay_step=400000, freeze_ss=400000, norm_p=2, space_carving_threshold=0.0,
                  is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0, precision="f32",
-                 overlap_coarse=None, mask_mode="scannet", allreduce=None, start_iter=0):
+                 overlap_coarse=None, mask_mode="scannet", allreduce=None, start_iter=0, fused_loss=True):
         dev = next(coarse.parameters()).device
         if mask_mode not in ("scannet", "wild"):
             raise ValueError('Trainer: mask_mode must be "scannet" or "wild"')
@@ -93,6 +94,9 @@ class Trainer:
                 or allreduce == "overlap"
         self.coarse_stream = torch.cuda.Stream(device=dev) if overlap_coarse and dev.type == "cuda" else None
         self.force_allreduce = False        # self-tests: issue the collective on a one-rank group too
+        # the three-term loss as one fused operator (ops.TrainLossFn) instead of the separate public
+        # operators (same arithmetic; ``fused_loss=False`` keeps the operator-by-operator path)
+        self.fused_loss = fused_loss
         self.bucket.broadcast_params(0)
 
     # -- reference loop predicates on i = it + 1 ------------------------------------------------
@@ -107,13 +111,6 @@ class Trainer:
         is weighted by n_local / N_total (``n_total`` = rays of all ranks; None = equal shards), so the
         sum over ranks is the single-process loss and the sum-all-reduced gradient its gradient."""
         c = self.cfg
-        if torch.is_tensor(img_i):
-            # device index (GraphedTrainer keeps it in a static buffer): gather, no host read
-            scale, shift = self.depth_scales.index_select(0, img_i.reshape(1)), \
-                self.depth_shifts.index_select(0, img_i.reshape(1))
-            target_h = target_hyp * scale.reshape(()) + shift.reshape(())
-        else:
-            target_h = target_hyp * self.depth_scales[img_i] + self.depth_shifts[img_i]      # :954
         share = batch_share(rays.shape[0], n_total) if self.sharded else 1.0
         if c["joint"] and self.sharded:
             # the LAST sampler (sample_pdf_joint_return_u, :728) draws ONE u[S] for the whole batch
@@ -133,6 +130,23 @@ class Trainer:
                             network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
                             lindisp=c["lindisp"], is_joint=c["joint"], coarse_stream=self.coarse_stream,
                             **render_kw)
+        hyp_per_ray = target_hyp.dim() == 3 and target_hyp.shape[-1] == 1
+        if self.fused_loss and not c["joint"] and hyp_per_ray:
+            # the whole loss (affine map of the hypotheses :954, both photometric terms, the carving term,
+            # their sum :968-983, this rank's share) in one forward / one backward entry
+            loss, comps = ops.TrainLossFn.apply(
+                ret["rgb_map"], ret["rgb0"], target_s, ret["pred_hyp"], target_hyp, self.depth_scales,
+                self.depth_shifts, img_i, mask, c["mask_mode"] == "wild", self.carving_active(), c["w"], c["thr"],
+                share)
+            return loss, dict(img_loss=comps[0], carve=comps[1] if self.carving_active() else None,
+                              img_loss0=comps[2], ret=ret, share=share, loss_report=loss.detach())
+        if torch.is_tensor(img_i):
+            # device index (GraphedTrainer keeps it in a static buffer): gather, no host read
+            scale, shift = self.depth_scales.index_select(0, img_i.reshape(1)), \
+                self.depth_shifts.index_select(0, img_i.reshape(1))
+            target_h = target_hyp * scale.reshape(()) + shift.reshape(())
+        else:
+            target_h = target_hyp * self.depth_scales[img_i] + self.depth_shifts[img_i]      # :954
         mse_mask = mask if c["mask_mode"] == "wild" else None
         mse = (lambda a, b: H.img2mse(a, b)) if mse_mask is None else \
             (lambda a, b: H.img2mse_masked(a, b, mse_mask))

@@ -307,6 +307,50 @@ def test_full_size_backward_properties(dev):
     assert rel_l2(grads(x[perm], G1[perm]), g1) < 2e-6, "permutation invariance"
 
 
+@pytest.mark.parametrize("variant", ["scannet_mask", "wild_mask_thr", "plain_dev_index", "warm_start"])
+def test_fused_train_loss_equals_the_separate_operators(dev, variant):
+    """ops.TrainLossFn (one forward + one backward entry for hyp*scale+shift, both img2mse terms, the
+    space-carving term and their sum, run_scade_scannet.py:954, :968-983) against the operator-by-operator
+    path of the same Trainer: loss terms, every network gradient and the per-image scale / shift rows."""
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K = 96, 20
+    rays = O.synthetic_rays(N, seed=81).to(dev)
+    g = torch.Generator().manual_seed(82)
+    tgt = torch.rand(N, 3, generator=g).to(dev)
+    hyp = (torch.rand(K, N, 1, generator=g) * 4.9 + 0.1).to(dev)
+    mask = (torch.rand(N, generator=g) > 0.3).float().to(dev)
+    draws = dict(t_rand=torch.rand(N, 64, generator=g).to(dev), u_coarse=torch.rand(N, 128, generator=g).to(dev),
+                 cached_u=torch.rand(N, 128, generator=g).to(dev))
+    kw = {"scannet_mask": dict(mask_mode="scannet"), "wild_mask_thr": dict(mask_mode="wild", space_carving_threshold=0.05),
+          "plain_dev_index": dict(), "warm_start": dict(warm_start_nerf=5)}[variant]
+    use_mask = "mask" in variant
+    img_i = torch.tensor([2], device=dev) if variant == "plain_dev_index" else 2
+    res = {}
+    for fused in (True, False):
+        coarse, fine = make_scade_nets(dev, seed=6)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=4, fused_loss=fused, **kw)
+        with torch.no_grad():
+            tr.depth_scales.copy_(torch.tensor([[1.0], [0.9], [1.1], [1.2]]))
+            tr.depth_shifts.copy_(torch.tensor([[0.0], [0.1], [-0.05], [0.2]]))
+        tr.bucket.zero_grad()
+        loss, aux = tr.forward_loss(rays, tgt, hyp, img_i=img_i, mask=mask if use_mask else None, **draws)
+        loss.backward()
+        comps = [float(aux["img_loss"]), float(aux["carve"]) if aux["carve"] is not None else None, float(aux["img_loss0"])]
+        res[fused] = (float(loss), comps, tr.bucket.grad.clone())
+    (lf, cf, gf), (ls, cs, gs) = res[True], res[False]
+    assert abs(lf - ls) <= 1e-6 * abs(ls), (lf, ls)
+    for a, b in zip(cf, cs):
+        assert (a is None) == (b is None) and (a is None or abs(a - b) <= 1e-6 * abs(b)), (cf, cs)
+    n_net = gf.numel() - 8
+    assert rel_l2(gf[:n_net], gs[:n_net]) < 1e-5, rel_l2(gf[:n_net], gs[:n_net])
+    if variant == "warm_start":
+        assert cf[1] is None and float(gf[n_net:].abs().max()) == 0.0      # i = 1 <= warm_start_nerf: no carving term
+    else:
+        assert_close(gf[n_net:], gs[n_net:], rtol=1e-4, atol=1e-9, what="scale / shift gradients")
+        assert float(gf[n_net + 2].abs()) > 0 and float(gf[n_net + 4 + 2].abs()) > 0      # row 2 of each
+        assert float(gf[n_net:].abs().sum()) == float(gf[n_net + 2].abs() + gf[n_net + 6].abs())
+
+
 def test_trainer_coarse_stream_overlap_is_bitwise_neutral(dev):
     """The Trainer runs the coarse stage on a side stream so that its backward chain overlaps the
     fine one: same kernels, same inputs -> bit-identical losses and parameters after several steps."""
