@@ -186,6 +186,13 @@ int scade_ray_tail(const float* raw, const float* z_vals, const float* rays, int
                    const float* noise, int N, int S, const float* u, int u_stride, int Si,
                    float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
                    float* samples, float* z_std, float* z_out, float* pts, void* stream);
+/* Backward of the fine form of scade_ray_tail (z_out = NULL): d loss / d raw [N,S,4] from the gradients of
+ * rgb_map / disp_map / acc_map / weights / depth_map (each may be NULL) and of the drawn samples [N,Si],
+ * one launch = scade_sample_pdf_bwd on weights[1:-1] followed by scade_composite_bwd, bit for bit. */
+int scade_ray_tail_bwd(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                       const float* noise, int N, int S, const float* u, int u_stride, int Si,
+                       const float* g_rgb, const float* g_disp, const float* g_acc, const float* g_weights,
+                       const float* g_depth, const float* g_samples, float* g_raw, void* stream);
 
 /* ---- space-carving loss (helpers:93-128) ---------------------------------------- */
 /* pred[N,P]; hyp[K,N] (the reference's [K,N,1], hypothesis-major); mask[N] nullable;

@@ -55,6 +55,7 @@ SIGNATURES = {
     "scade_sample_pdf_bwd": (c_int, [_P, _I, _I, _P, _I, _P, _I, _P, _I, _I, _I, _P, _P]),
     "scade_merge_sorted": (c_int, [_P, _I, _P, _I, _P, _I, _I, _P, _P, _P]),
     "scade_ray_tail": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "scade_ray_tail_bwd": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "scade_carve_workspace_floats": (c_long, [_I, _I, _I, _I]),
     "scade_carve_fwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P]),
     "scade_carve_bwd": (c_int, [_P, _P, _P, c_float, _I, _I, _I, _I, _P, _P, _P, _P, _P]),

@@ -205,15 +205,12 @@ __global__ void composite_fwd_kernel(CompositeArgs a) {
   }
 }
 
+// backward of one ray given its recomputed forward state; ``gw_inner`` (LDS, or null) holds an extra
+// gradient w.r.t. weights[1 .. S-2] (the fine sampler's, scade_ray_tail_bwd)
 template <int NC>
-__global__ void composite_bwd_kernel(CompositeArgs a) {
-  const int ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
-  if (ray >= a.N) return;
-  const int lane = lane_id();
+__device__ __forceinline__ void composite_bwd_ray(const CompositeArgs& a, int ray, int lane, const SampleState (&st)[NC],
+                                                  double sd, double sa, const float* gw_inner) {
   const int S = a.S;
-  SampleState st[NC];
-  double sr, sg, sb, sd, sa;
-  composite_ray<NC>(a, ray, lane, st, sr, sg, sb, sd, sa);
   const float depth = (float)sd, acc = (float)sa;
   const float gr = a.g_rgb ? a.g_rgb[ray * 3 + 0] : 0.f;
   const float gg = a.g_rgb ? a.g_rgb[ray * 3 + 1] : 0.f;
@@ -241,6 +238,7 @@ __global__ void composite_bwd_kernel(CompositeArgs a) {
     if (valid) {
       G = gr * s.sr + gg * s.sg + gb * s.sb + gdepth * s.z + gacc;
       if (a.g_w) G += a.g_w[(size_t)ray * S + i];
+      if (gw_inner && i >= 1 && i <= S - 2) G += gw_inner[i - 1];
     }
     const double gw = valid ? (double)G * (double)s.w : 0.0;
     const double incl = wave_incl_sum_rev(gw);
@@ -259,6 +257,17 @@ __global__ void composite_bwd_kernel(CompositeArgs a) {
       gout[i] = g;
     }
   }
+}
+
+template <int NC>
+__global__ void composite_bwd_kernel(CompositeArgs a) {
+  const int ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
+  if (ray >= a.N) return;
+  const int lane = lane_id();
+  SampleState st[NC];
+  double sr, sg, sb, sd, sa;
+  composite_ray<NC>(a, ray, lane, st, sr, sg, sb, sd, sa);
+  composite_bwd_ray<NC>(a, ray, lane, st, sd, sa, nullptr);
 }
 
 // ---------------------------------------------------------------------------
@@ -372,23 +381,16 @@ __global__ void sample_pdf_fwd_kernel(SamplePdfArgs a) {
 
 // d samples / d weights  (closed form; matches
 // autograd through the reference op sequence)
-__global__ void sample_pdf_bwd_kernel(SamplePdfArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wv = threadIdx.x >> 6, lane = lane_id();
-  const int ray = blockIdx.x * RAYS_PER_WG + wv;
-  if (ray >= a.N) return;
-  const int M = a.M, S = a.S;
-  float* cdf = smem + wv * 4 * M;
-  float* bins = cdf + M;
-  float* pdf = bins + M;
-  float* dcdf = pdf + M;          // [M] float accumulators (LDS atomics)
-  const float total = build_cdf(a, ray, lane, cdf, bins, pdf);
+// cdf / bins / pdf of the ray are in LDS (build_cdf_rows); dcdf [M] is LDS scratch; writes d samples / d w
+// for the M-1 weights into ``gw_out`` (global row or LDS).  The cdf buffer is reused as scratch.
+__device__ __forceinline__ void sample_pdf_bwd_rows(float* cdf, const float* bins, const float* pdf, float* dcdf,
+                                                    float total, const float* ur, const float* gs_row, int M, int S,
+                                                    int lane, float* gw_out) {
   for (int j = lane; j < M; j += 64) dcdf[j] = 0.f;
   __builtin_amdgcn_wave_barrier();
-  const float* ur = a.u + (size_t)ray * a.u_stride;
   for (int s = lane; s < S; s += 64) {
     const float u = ur[s];
-    const float g = a.g_samples[(size_t)ray * S + s];
+    const float g = gs_row[s];
     const int ind = upper_bound(cdf, M, u);
     const int below = max(0, ind - 1), above = min(M - 1, ind);
     const float c0 = cdf[below], c1 = cdf[above];
@@ -426,8 +428,22 @@ __global__ void sample_pdf_bwd_kernel(SamplePdfArgs a) {
   }
   dot = wave_sum_d(dot);
   __builtin_amdgcn_wave_barrier();
-  for (int i = lane; i < M - 1; i += 64)
-    a.g_w[(size_t)ray * (M - 1) + i] = (float)(((double)cdf[i] - dot) / (double)total);
+  for (int i = lane; i < M - 1; i += 64) gw_out[i] = (float)(((double)cdf[i] - dot) / (double)total);
+}
+
+__global__ void sample_pdf_bwd_kernel(SamplePdfArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int ray = blockIdx.x * RAYS_PER_WG + wv;
+  if (ray >= a.N) return;
+  const int M = a.M, S = a.S;
+  float* cdf = smem + wv * 4 * M;
+  float* bins = cdf + M;
+  float* pdf = bins + M;
+  float* dcdf = pdf + M;          // [M] float accumulators (LDS atomics)
+  const float total = build_cdf(a, ray, lane, cdf, bins, pdf);
+  sample_pdf_bwd_rows(cdf, bins, pdf, dcdf, total, a.u + (size_t)ray * a.u_stride, a.g_samples + (size_t)ray * S, M, S,
+                      lane, a.g_w + (size_t)ray * (M - 1));
 }
 
 // ---------------------------------------------------------------------------
@@ -669,6 +685,45 @@ template <int NC, int R>
 __global__ void ray_tail_kernel(TailArgs a) { ray_tail_body<NC, R>(a); }
 template <int NC>
 __global__ void ray_tail_kernel0(TailArgs a) { ray_tail_body<NC, 0>(a); }   // one template argument for DISPATCH_NC
+
+// Backward of the fine tail (raw2outputs -> sample_pdf(z_mid, weights[1:-1], u)) in ONE launch: the forward
+// of the ray is recomputed (weights, cdf), the sampler's closed-form d samples / d weights goes to LDS and
+// joins the compositing backward as an extra gradient of weights[1 .. S-2].  Same device functions, same
+// operation order as scade_sample_pdf_bwd followed by scade_composite_bwd => same bits.
+struct TailBwdArgs {
+  CompositeArgs c;          // raw, z, rays_d (+stride), noise, g_rgb .. g_depth, g_raw, N, S
+  const float* u;           // [N,Si] (u_stride 0: one shared row)
+  const float* g_samples;   // [N,Si]
+  int u_stride, Si;
+};
+template <int NC>
+__global__ void ray_tail_bwd_kernel(TailBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int ray = blockIdx.x * RAYS_PER_WG + wv;
+  if (ray >= a.c.N) return;
+  const int S = a.c.S, M = S - 1;
+  float* w = smem + (size_t)wv * (6 * S);      // w[S] | cdf[M] | bins[M] | pdf[M] | dcdf[M] | gw_inner[M]
+  float* cdf = w + S;
+  float* bins = cdf + S;
+  float* pdf = bins + S;
+  float* dcdf = pdf + S;
+  float* gwi = dcdf + S;
+  SampleState st[NC];
+  double sr, sg, sb, sd, sa;
+  composite_ray<NC>(a.c, ray, lane, st, sr, sg, sb, sd, sa);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = c * 64 + lane;
+    if (i < S) w[i] = st[c].w;
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float total = build_cdf_rows(a.c.z + (size_t)ray * S, 1, w + 1, nullptr, M, lane, cdf, bins, pdf);
+  sample_pdf_bwd_rows(cdf, bins, pdf, dcdf, total, a.u + (size_t)ray * a.u_stride, a.g_samples + (size_t)ray * a.Si,
+                      M, a.Si, lane, gwi);
+  __builtin_amdgcn_wave_barrier();
+  composite_bwd_ray<NC>(a.c, ray, lane, st, sd, sa, gwi);
+}
 
 // ---------------------------------------------------------------------------
 // space-carving loss
@@ -1116,6 +1171,28 @@ extern "C" int scade_ray_tail(const float* raw, const float* z_vals, const float
     SCADE_REQUIRE(launched, -2, "scade_ray_tail: no kernel for S=%d, Si=%d", S, Si);
   }
   return scade_check_launch("scade_ray_tail");
+}
+
+// Backward of scade_ray_tail's fine form (no merge): d loss / d raw from the gradients of the five
+// compositing outputs and of the drawn samples, one launch (see ray_tail_bwd_kernel).
+extern "C" int scade_ray_tail_bwd(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                                  const float* noise, int N, int S, const float* u, int u_stride, int Si,
+                                  const float* g_rgb, const float* g_disp, const float* g_acc,
+                                  const float* g_weights, const float* g_depth, const float* g_samples,
+                                  float* g_raw, void* stream) {
+  if (N <= 0) return 0;
+  SCADE_REQUIRE(raw && z_vals && rays && u && g_samples && g_raw, -1, "scade_ray_tail_bwd: null pointer");
+  SCADE_REQUIRE(ray_stride >= 6, -2, "scade_ray_tail_bwd: ray rows need o and d");
+  SCADE_REQUIRE(S >= 3 && S <= 512 && Si >= 1 && Si <= 1024, -2,
+                "scade_ray_tail_bwd: S=%d outside [3,512] or Si=%d outside [1,1024]", S, Si);
+  TailBwdArgs a{};
+  a.c.raw = raw; a.c.z = z_vals; a.c.rays_d = rays + 3; a.c.noise = noise; a.c.d_stride = ray_stride;
+  a.c.g_rgb = g_rgb; a.c.g_disp = g_disp; a.c.g_acc = g_acc; a.c.g_w = g_weights; a.c.g_depth = g_depth;
+  a.c.g_raw = g_raw; a.c.N = N; a.c.S = S;
+  a.u = u; a.g_samples = g_samples; a.u_stride = u_stride; a.Si = Si;
+  const size_t lds = (size_t)RAYS_PER_WG * 6 * S * sizeof(float);
+  DISPATCH_NC(ray_tail_bwd_kernel, S, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a);
+  return scade_check_launch("scade_ray_tail_bwd");
 }
 
 extern "C" long scade_carve_workspace_floats(int N, int P, int K, int is_joint) {

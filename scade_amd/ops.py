@@ -500,6 +500,44 @@ class CoarseTailFn(torch.autograd.Function):
         return g_raw, None, None, None, None, None
 
 
+class FineTailFn(torch.autograd.Function):
+    """Fine stage after the MLP when a gradient is recorded (run_scade_scannet.py:720-730): raw2outputs and
+    the depth-hypothesis sampler ``sample_pdf_return_u(z_mid, weights[1:-1], u)`` as ONE forward launch
+    (scade_ray_tail) and ONE backward launch (scade_ray_tail_bwd) instead of two operators forward and
+    two operators + the slice glue backward.  Differentiable w.r.t. raw; z_std carries no gradient."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays, noise, u, n_samples):
+        ctx.set_materialize_grads(False)
+        rgb, disp, acc, w, depth, samples, std, _, _ = ray_tail(raw, z_vals, rays, noise, u, n_samples, merge=False,
+                                                                want_std=True)
+        ctx.save_for_backward(raw, z_vals, rays, noise if noise is not None else raw.new_empty(0), u)
+        ctx.has_noise, ctx.n_samples = noise is not None, n_samples
+        ctx.mark_non_differentiable(std)
+        return rgb, disp, acc, w, depth, samples, std
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_disp, g_acc, g_w, g_depth, g_samples, _g_std):
+        raw, z_vals, rays, noise, u = ctx.saved_tensors
+        gs = [g_rgb, g_disp, g_acc, g_w, g_depth]
+        if g_samples is None:
+            if all(g is None for g in gs):
+                return None, None, None, None, None, None
+            g_raw = composite_bwd(raw, z_vals, rays[:, 3:6], noise if ctx.has_noise else None, *gs)
+            return g_raw, None, None, None, None, None
+        N, S = z_vals.shape
+        raw_c, z_c = _c(raw), _c(z_vals)
+        rays_c, rstride = _rows(rays, "ray_tail.backward: rays")
+        u_c, ustride = _u_arg(u, N, ctx.n_samples)
+        gs = [None if g is None else _c(g) for g in gs]
+        g_samples = _c(g_samples)
+        g_raw = torch.empty(N, S, 4, device=raw.device, dtype=torch.float32)
+        call("scade_ray_tail_bwd", ptr(raw_c), ptr(z_c), ptr(rays_c), rstride, ptr(noise if ctx.has_noise else None),
+             N, S, ptr(u_c), ustride, ctx.n_samples, ptr(gs[0]), ptr(gs[1]), ptr(gs[2]), ptr(gs[3]), ptr(gs[4]),
+             ptr(g_samples), ptr(g_raw), stream())
+        return g_raw, None, None, None, None, None
+
+
 def gen_rays(H: int, W: int, intrinsic: Tensor, c2w: Tensor, coords: Optional[Tensor] = None,
              near: float = 0.0, far: float = 1.0, image: Optional[Tensor] = None,
              hyps: Optional[Tensor] = None, corner_px: int = 0, edge_px: int = 0,

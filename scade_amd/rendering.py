@@ -14,7 +14,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .ops import CoarseTailFn, CompositeFn
+from .ops import CoarseTailFn, CompositeFn, FineTailFn
 from .run_nerf_helpers import (Embedder, NeRF, _draw_u, _sample, get_rays)
 
 
@@ -241,14 +241,19 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     run_fn = network_fn if network_fine is None else network_fine
     raw = network_query_fn(pts, viewdirs, embedded_cam, run_fn)
 
-    # ---- fine stage: raw2outputs + depth hypotheses from the fine pdf (:720-730); one launch when no
-    # gradient is recorded (training differentiates pred_hyp w.r.t. the weights: separate operators)
-    if (fuse_tails and not (torch.is_grad_enabled() and raw.requires_grad)
-            and ops.ray_tail_supported(z_vals.shape[1], N_importance, merge=False)):
+    # ---- fine stage: raw2outputs + depth hypotheses from the fine pdf (:720-730): one launch; when a
+    # gradient is recorded also ONE backward launch (ops.FineTailFn)
+    fusable = fuse_tails and ops.ray_tail_supported(z_vals.shape[1], N_importance, merge=False)
+    if fusable and not (torch.is_grad_enabled() and raw.requires_grad):
         noise = _raw_noise(raw, raw_noise_std, pytest)
         u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
         rgb_map, disp_map, acc_map, weights, depth_map, pred_depth_hyp, z_std, _, _ = ops.ray_tail(
             raw, z_vals, rays, noise, u, N_importance, merge=False, want_std=True)
+    elif fusable:
+        noise = _raw_noise(raw, raw_noise_std, pytest)
+        u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
+        rgb_map, disp_map, acc_map, weights, depth_map, pred_depth_hyp, z_std = FineTailFn.apply(
+            raw, z_vals, rays, noise, u, N_importance)
     else:
         rgb_map, disp_map, acc_map, weights, depth_map = raw2outputs(
             raw, z_vals, rays_d, raw_noise_std, pytest=pytest)

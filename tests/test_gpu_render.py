@@ -321,21 +321,25 @@ def test_fused_tails_are_bitwise_neutral(dev):
     assert set(a) == set(b)
     for k in a:
         assert torch.equal(a[k], b[k]), k
-    grads = []
-    for fuse in (True, False):
-        for p in list(coarse.parameters()) + list(fine.parameters()):
-            p.grad = None
-        r = S.render_rays(rays, True, coarse, query, 64, perturb=1., raw_noise_std=0.5, pytest=True,
-                          t_rand=t_rand, u_coarse=uc, cached_u=uf, fuse_tails=fuse, **kw)
-        loss = S.img2mse(r["rgb_map"], tgt) + 0.007 * S.compute_space_carving_loss(r["pred_hyp"], hyp) \
-            + S.img2mse(r["rgb0"], tgt)
-        loss.backward()
-        grads.append(([p.grad.clone() for p in list(coarse.parameters()) + list(fine.parameters())], r, loss))
-    for k in grads[0][1]:
-        assert torch.equal(grads[0][1][k], grads[1][1][k]), k
-    assert torch.equal(grads[0][2], grads[1][2])
-    for x, y in zip(grads[0][0], grads[1][0]):
-        assert torch.equal(x, y)
+    for every_output in (False, True):
+        grads = []
+        for fuse in (True, False):
+            for p in list(coarse.parameters()) + list(fine.parameters()):
+                p.grad = None
+            r = S.render_rays(rays, True, coarse, query, 64, perturb=1., raw_noise_std=0.5, pytest=True,
+                              t_rand=t_rand, u_coarse=uc, cached_u=uf, fuse_tails=fuse, **kw)
+            loss = S.img2mse(r["rgb_map"], tgt) + 0.007 * S.compute_space_carving_loss(r["pred_hyp"], hyp) \
+                + S.img2mse(r["rgb0"], tgt)
+            if every_output:    # gradients into ALL differentiable outputs of the fused fine tail (scade_ray_tail_bwd)
+                loss = loss + 1e-3 * r["weights"].pow(2).sum() + 1e-3 * r["depth_map"].sum() + 1e-3 * r["acc_map"].sum() \
+                    + 1e-4 * torch.nan_to_num(r["disp_map"], posinf=0.0).clamp(max=50.).sum()
+            loss.backward()
+            grads.append(([p.grad.clone() for p in list(coarse.parameters()) + list(fine.parameters())], r, loss))
+        for k in grads[0][1]:
+            assert torch.equal(grads[0][1][k], grads[1][1][k]), k
+        assert torch.equal(grads[0][2], grads[1][2])
+        for x, y in zip(grads[0][0], grads[1][0]):
+            assert torch.equal(x, y)
 
 
 import numpy as np  # noqa: E402
