@@ -237,8 +237,11 @@ __device__ __forceinline__ void composite_bwd_ray(const CompositeArgs& a, int ra
     float G = 0.f;
     if (valid) {
       G = gr * s.sr + gg * s.sg + gb * s.sb + gdepth * s.z + gacc;
-      if (a.g_w) G += a.g_w[(size_t)ray * S + i];
-      if (gw_inner && i >= 1 && i <= S - 2) G += gw_inner[i - 1];
+      // the gradient of weights is summed first (autograd adds the sampler's slice gradient to the
+      // caller's before compositing sees it), then joins G: same roundings as the separate operators
+      float gws = a.g_w ? a.g_w[(size_t)ray * S + i] : 0.f;
+      if (gw_inner && i >= 1 && i <= S - 2) gws = gws + gw_inner[i - 1];
+      if (a.g_w || gw_inner) G += gws;
     }
     const double gw = valid ? (double)G * (double)s.w : 0.0;
     const double incl = wave_incl_sum_rev(gw);
