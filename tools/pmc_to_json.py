@@ -11,7 +11,11 @@ KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-siz
     (r"mlp_fwd_kernel<1, false, 2>", "mlp_fwd_kernel"), (r"mlp_fwd_kernel<1, true, 2>", "mlp_fwd_kernel_train"),
     (r"mlp_fwd_kernel<1, false, 1>", "mlp_fwd_kernel_small"), (r"mlp_fwd_kernel<1, true, 1>", "mlp_fwd_kernel_train_small"),
     (r"mlp_dgrad_kernel<2>", "mlp_dgrad_kernel"), (r"mlp_dgrad_kernel<1>", "mlp_dgrad_kernel_small"),
-    (r"mlp_wgrad_kernel", "mlp_wgrad_kernel"),
+    (r"mlp_wgrad_kernel", "mlp_wgrad_kernel"), (r"mlp_wgrad2_kernel", "mlp_wgrad2_kernel"),
+    (r"wgrad2_reduce_kernel", "wgrad2_reduce_kernel"), (r"wgrad2_rgb_kernel", "wgrad2_rgb_kernel"),
+    (r"ray_tail_kernel<1, 4>", "ray_tail_coarse"), (r"ray_tail_kernel0<3>", "ray_tail_fine"),
+    (r"ray_tail_bwd_kernel<3>", "ray_tail_bwd_fine"), (r"train_loss_fwd_kernel", "train_loss_fwd"),
+    (r"train_loss_bwd_kernel", "train_loss_bwd"),
     (r"mlp_fwd_f16_kernel<1, false>", "mlp_fwd_f16_kernel"), (r"mlp_fwd_f16_kernel<1, true>", "mlp_fwd_f16_kernel_train"),
     (r"mlp_dgrad_f16_kernel", "mlp_dgrad_f16_kernel"), (r"mlp_wgrad_f16_kernel", "mlp_wgrad_f16_kernel"),
     (r"mlp_fwd_lp_kernel<true, 1, false, 4>", "mlp_fwd_lp_kernel_bf16"), (r"mlp_fwd_lp_kernel<false, 1, false, 4>", "mlp_fwd_lp_kernel_f16"),

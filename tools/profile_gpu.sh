@@ -2,17 +2,18 @@
 # Run ON THE GPU BOX (via gpurun): rocprofv3 per-kernel stats + separate PMC passes of the
 # default bench command.  Usage: tools/profile_gpu.sh <round-tag>   (outputs under gpurun_out/)
 set -u
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations and counters are only meaningful when the kernels do not overlap: keep the
-# Trainer's coarse stage on the main stream while profiling
+# Trainer's coarse stage on the main stream while profiling (the default since round 2; f16x3 would
+# otherwise turn its side stream on)
 export SCADE_OVERLAP_COARSE=0
 # the headline region only, so per-kernel averages are those of the timed render steps
-CMD="python $ROOT/bench.py --no-cpu-baseline --no-train --no-image --no-fast --steps 20 --warmup 3"
-TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --steps 10 --warmup 2"   # render + f16x3 + train regions
+CMD="python $ROOT/bench.py --no-cpu-baseline --no-train --no-image --no-fast --no-rayops --steps 20 --warmup 3"
+TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --no-rayops --steps 10 --warmup 2"   # render + f16x3 + train regions
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- $CMD > $OUT/stats.log 2>&1
 grep -o '^{"metric.*}' $OUT/stats.log | tail -1 > $OUT/bench_line_under_rocprof.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_train -o bench -- $TRAIN_CMD > $OUT/stats_train.log 2>&1
