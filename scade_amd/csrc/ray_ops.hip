@@ -787,11 +787,20 @@ __global__ void carve_fwd_kernel(CarveArgs a) {
   if (lane == 0) a.partial[ray] = (float)(acc / (double)a.P);       // helpers:125 mean over samples
 }
 
-__global__ void carve_reduce_kernel(const float* partial, int n, float* loss) {
+// one workgroup of 1024 threads (a lone wave walking 16,384 partials was 60 us of dependent loads); the
+// 16 wave sums meet in LDS and are added in a fixed order (deterministic)
+__global__ __launch_bounds__(1024) void carve_reduce_kernel(const float* partial, int n, float* loss) {
+  __shared__ double red[16];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n; i += 64) acc += (double)partial[i];
+  for (int i = threadIdx.x; i < n; i += 1024) acc += (double)partial[i];
   acc = wave_sum_d(acc);
-  if (threadIdx.x == 0) loss[0] = (float)(acc / (double)n);         // helpers:126 mean over rays
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    loss[0] = (float)(t / (double)n);         // helpers:126 mean over rays
+  }
 }
 
 __global__ void carve_bwd_kernel(CarveArgs a) {
@@ -975,11 +984,11 @@ __global__ void carve_knp_joint_bwd_kernel(CarveArgs a, const int* argmin_in) {
 // ---------------------------------------------------------------------------
 // img2mse: mean((x-y)^2), optional per-row mask (run_scade_wild.py:978-986)
 // ---------------------------------------------------------------------------
-__global__ void mse_fwd_kernel(const float* x, const float* y, const float* mask, int n, int c,
-                               float* loss) {
-  __shared__ double red[4];
+__global__ __launch_bounds__(1024) void mse_fwd_kernel(const float* x, const float* y, const float* mask, int n, int c,
+                                                       float* loss) {
+  __shared__ double red[16];
   double acc = 0.0;
-  for (int i = threadIdx.x; i < n * c; i += 256) {
+  for (int i = threadIdx.x; i < n * c; i += 1024) {
     const float dlt = x[i] - y[i];
     float sq = dlt * dlt;
     if (mask) sq = sq * mask[i / c];
@@ -988,7 +997,11 @@ __global__ void mse_fwd_kernel(const float* x, const float* y, const float* mask
   acc = wave_sum_d(acc);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  if (threadIdx.x == 0) loss[0] = (float)((red[0] + red[1] + red[2] + red[3]) / (double)(n * c));
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    loss[0] = (float)(t / (double)(n * c));
+  }
 }
 __global__ void mse_bwd_kernel(const float* x, const float* y, const float* mask, int n, int c,
                                const float* g_loss, float* g_x) {
@@ -1213,7 +1226,7 @@ extern "C" int scade_carve_fwd(const float* pred, const float* hyp, const float*
   hipStream_t s = (hipStream_t)stream;
   if (!is_joint) {
     hipLaunchKernelGGL(carve_fwd_kernel, dim3(grid_rays(N)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(carve_reduce_kernel, dim3(1), dim3(64), 0, s, workspace, N, loss);
+    hipLaunchKernelGGL(carve_reduce_kernel, dim3(1), dim3(1024), 0, s, workspace, N, loss);
   } else {
     hipLaunchKernelGGL(carve_joint_colsum_kernel, dim3(K), dim3(128), 0, s, a);
     hipLaunchKernelGGL(carve_joint_min_kernel, dim3(1), dim3(64), 0, s, a,
@@ -1278,7 +1291,7 @@ extern "C" int scade_carve_knp_fwd(const float* pred, const float* hyp, const fl
   hipStream_t s = (hipStream_t)stream;
   if (!is_joint) {
     hipLaunchKernelGGL(carve_knp_fwd_kernel, dim3(grid_rays(N)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(carve_reduce_kernel, dim3(1), dim3(64), 0, s, workspace, N, loss);
+    hipLaunchKernelGGL(carve_reduce_kernel, dim3(1), dim3(1024), 0, s, workspace, N, loss);
   } else {
     hipLaunchKernelGGL(carve_knp_colsum_kernel, dim3(K), dim3(128), 0, s, a);
     hipLaunchKernelGGL(carve_joint_min_kernel, dim3(1), dim3(64), 0, s, a,
@@ -1322,7 +1335,7 @@ extern "C" int scade_mse_fwd(const float* x, const float* y, const float* row_ma
                              float* loss, void* stream) {
   SCADE_REQUIRE(x && y && loss, -1, "scade_mse_fwd: null pointer");
   SCADE_REQUIRE(n > 0 && c > 0, -2, "scade_mse_fwd: empty input");
-  hipLaunchKernelGGL(mse_fwd_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, y, row_mask, n, c, loss);
+  hipLaunchKernelGGL(mse_fwd_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, x, y, row_mask, n, c, loss);
   return scade_check_launch("scade_mse_fwd");
 }
 

@@ -7,7 +7,7 @@
 // The operator API keeps img2mse / compute_space_carving_loss as separate entries (ray_ops.hip); a train
 // step built from them costs ~25 launches for this scalar (two mse, carve + its reduce, the affine map of
 // the hypotheses, three scalar adds / muls, and the mirror image of all that in the backward).  The
-// Trainer uses this fused form: one wave per ray does the ray's part of all three terms, a one-wave
+// Trainer uses this fused form: one wave per ray does the ray's part of all three terms, a one-workgroup
 // kernel reduces the per-ray partials in a fixed order (deterministic).  Same arithmetic as the separate
 // kernels: fp64 accumulation of the means, the affine map as a multiply and an add with separate
 // roundings, first-index tie rule of torch.min, sign(0) = 0.
@@ -107,14 +107,22 @@ __global__ void train_loss_fwd_kernel(TrainLossArgs a) {
   }
 }
 
-__global__ void train_loss_reduce_kernel(TrainLossArgs a) {
+// one workgroup of 1024 threads; the 16 wave sums meet in LDS and are added in a fixed order
+__global__ __launch_bounds__(1024) void train_loss_reduce_kernel(TrainLossArgs a) {
+  __shared__ double red[3][16];
   double s0 = 0.0, s1 = 0.0, s2 = 0.0;
-  for (int i = threadIdx.x; i < a.N; i += 64) {
+  for (int i = threadIdx.x; i < a.N; i += 1024) {
     const f32x4 v = reinterpret_cast<const f32x4*>(a.partial)[i];
     s0 += (double)v[0]; s1 += (double)v[1]; s2 += (double)v[2];
   }
   s0 = tl_wave_sum_d(s0); s1 = tl_wave_sum_d(s1); s2 = tl_wave_sum_d(s2);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; red[2][threadIdx.x >> 6] = s2;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    s0 = s1 = s2 = 0.0;
+    for (int w = 0; w < 16; ++w) { s0 += red[0][w]; s1 += red[1][w]; s2 += red[2][w]; }
     const float img = (float)(s0 / (double)(a.N * 3)), img0 = (float)(s1 / (double)(a.N * 3));   // helpers:11
     const float carve = (float)(s2 / (double)a.N);                                               // helpers:126
     float total = img;
@@ -196,14 +204,19 @@ __global__ void train_loss_bwd_kernel(TrainLossArgs a) {
   }
 }
 
-__global__ void train_loss_ss_reduce_kernel(TrainLossArgs a) {
+__global__ __launch_bounds__(1024) void train_loss_ss_reduce_kernel(TrainLossArgs a) {
+  __shared__ double red[2][16];
   double s0 = 0.0, s1 = 0.0;
-  for (int i = threadIdx.x; i < a.N; i += 64) {
+  for (int i = threadIdx.x; i < a.N; i += 1024) {
     const f32x4 v = reinterpret_cast<const f32x4*>(a.partial)[i];
     s0 += (double)v[0]; s1 += (double)v[1];
   }
   s0 = tl_wave_sum_d(s0); s1 = tl_wave_sum_d(s1);
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = s0; red[1][threadIdx.x >> 6] = s1; }
+  __syncthreads();
   if (threadIdx.x == 0) {
+    s0 = s1 = 0.0;
+    for (int w = 0; w < 16; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
     const int im = tl_image(a);
     a.g_scales[im] += (float)s0;
     a.g_shifts[im] += (float)s1;
@@ -229,7 +242,7 @@ extern "C" int scade_train_loss_fwd(const float* rgb, const float* rgb0, const f
   a.partial = workspace; a.loss = loss4;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(train_loss_fwd_kernel, dim3((N + TL_RAYS_PER_WG - 1) / TL_RAYS_PER_WG), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(train_loss_reduce_kernel, dim3(1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(train_loss_reduce_kernel, dim3(1), dim3(1024), 0, s, a);
   return scade_check_launch("scade_train_loss_fwd");
 }
 
@@ -251,6 +264,6 @@ extern "C" int scade_train_loss_bwd(const float* rgb, const float* rgb0, const f
   a.g_scales = g_scales; a.g_shifts = g_shifts;
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(train_loss_bwd_kernel, dim3((N + TL_RAYS_PER_WG - 1) / TL_RAYS_PER_WG), dim3(256), 0, s, a);
-  if (carve_on) hipLaunchKernelGGL(train_loss_ss_reduce_kernel, dim3(1), dim3(64), 0, s, a);
+  if (carve_on) hipLaunchKernelGGL(train_loss_ss_reduce_kernel, dim3(1), dim3(1024), 0, s, a);
   return scade_check_launch("scade_train_loss_bwd");
 }

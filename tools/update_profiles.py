@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Copy the outputs of tools/profile_gpu.sh <tag> (gpurun_out/prof_<tag>/) and an un-profiled bench line
-into profiles/ and regenerate the reading table at the end of profiles/README.md.
-Usage: python tools/update_profiles.py r01 gpurun_out/bench_final.json"""
+into profiles/ and (re)generate that round's reading block in profiles/README.md (between the markers
+<!-- BEGIN <tag> --> / <!-- END <tag> -->; blocks of other rounds are left alone).
+Usage: python tools/update_profiles.py r02 gpurun_out/bench_final.json"""
 import csv, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -22,27 +23,35 @@ st = {r["Name"]: r for r in csv.DictReader(open(os.path.join(dst, f"{tag}_render
 fw = next(v for k, v in st.items() if "mlp_fwd_kernel<1, false, 2>" in k)
 avg = float(fw["AverageNs"]) / 1e6
 notes = {
-    "mlp_fwd_kernel": f"headline render kernel; algorithmic HBM ~ 6.1 MB, the 2.4 MB weight blob is fetched once per XCD L2; "
-                      f"rocprofv3 average {avg:.4f} ms over {fw['Calls']} launches vs HIP events {dr['roofline']['avg_launch_ms']:.4f} ms "
-                      f"over the timed ones in the same run; {dr['roofline']['frac']:.3f} of the 157.3 TFLOP/s peak by timing",
+    "mlp_fwd_kernel": f"headline render kernel; algorithmic HBM ~ 6.1 MB, the 2.4 MB weight blob is fetched once per XCD L2 "
+                      f"(8 x 2.4 MB = the 4x over-fetch; 22 GB/s, harmless); rocprofv3 average {avg:.4f} ms over {fw['Calls']} "
+                      f"launches vs HIP events {dr['roofline']['avg_launch_ms']:.4f} ms over the timed ones in the same run; "
+                      f"{dr['roofline']['frac']:.3f} of the 157.3 TFLOP/s peak by timing",
     "mlp_fwd_kernel_train": "exact training forward (fp32 activation rows + one 32-bit ReLU word per lane, layer and point tile written)",
     "mlp_dgrad_kernel": "dZ rows written",
     "mlp_fwd_kernel_train_small": "32-point workgroups (the 128-ray launches of the graph region)",
     "mlp_dgrad_kernel_small": "32-point workgroups",
     "mlp_wgrad_kernel": "dZ and activations streamed once per layer; includes the low-MFMA embedding and rgb-head jobs",
+    "mlp_wgrad2_kernel": "round-2 weight gradient: half-layer workgroups, two per CU, transposed LDS image, ds_read_b128 fragments; "
+                         "the mean includes the 128-ray launches (one or two short workgroups per CU)",
     "wgrad_reduce4_kernel": "sums the per-chunk partials",
     "mlp_fwd_f16_kernel": "opt-in f16x3 render kernel (3 f16 MFMAs per fp32-class product)",
     "mlp_fwd_f16_kernel_train": "f16x3 training forward, bound by the fp32 activation rows it writes",
     "mlp_dgrad_f16_kernel": "",
     "mlp_wgrad_f16_kernel": "HBM-bound (~3 TB/s)",
-    "mlp_fwd_lp_kernel_bf16": "opt-in bf16 render kernel (config 5); a quarter of its LDS cycles are the 2-way conflict of the "
-                              "`ds_write_b64` epilogue (8-byte stores against 16-byte swizzle chunks)",
+    "mlp_fwd_lp_kernel_bf16": "opt-in bf16 render kernel (config 5); round 2: the epilogue trades chunk halves between lane r and "
+                              "r + 32 (v_permlane32_swap) and stores conflict-free ds_write_b128 (was 26.4 % conflict cycles)",
     "mlp_fwd_lp_kernel_f16": "same kernel, fp16 operands",
     "mlp_fwd_lp_kernel_bf16_train": "bf16 training forward: 16-bit activation rows",
     "mlp_dgrad_lp_kernel_bf16": "16-bit dZ rows",
     "mlp_fwd_lp_kernel_bf16_train_small": "64-point workgroups (128-ray launches)",
     "mlp_dgrad_lp_kernel_bf16_small": "64-point workgroups",
     "mlp_wgrad_lp_kernel_bf16": "HBM-bound by design (1 KB per point-layer); 16-bit rows + fp32 partials",
+    "ray_tail_coarse": "per-ray work between the coarse and the fine MLP launch (composite, sampler, sort-merge, points)",
+    "ray_tail_fine": "fine composite + depth-hypothesis sampler + z_std",
+    "ray_tail_bwd_fine": "round 2: backward of the fine tail in one launch (sampler backward + compositing backward)",
+    "train_loss_fwd": "round 2: the three-term train loss as one kernel (+ a one-wave reduce)",
+    "train_loss_bwd": "its backward (+ a one-wave scale/shift reduce)",
 }
 rows = []
 for k in notes:
@@ -52,31 +61,34 @@ for k in notes:
     hb = v["hbm_bytes_per_launch"]
     hbs = f"{hb / 1e9:.2f} GB" if hb >= 1e9 else f"{hb / 1e6:.1f} MB"
     rows.append(f"| `{k}` | {100 * v['mfma_util']:.1f} % | {hbs} | {100 * v['lds_bank_conflict_frac']:.1f} % | {notes[k]} |")
-table = f"""Round-1 reading (final build of the round; `{tag}_pmc.json`).  Every figure is a MEAN PER LAUNCH over
-all launches of that kernel in the profiled command - the coarse (65,536-point) and fine
-(196,608-point) pass of every 1024-ray step and, for the training kernels, the 128-ray launches of the
-graph region (wgrad; their forward / dgrad run the half-size workgroup variants, listed as `_small`) - so
-the byte counts are not those of one particular launch size.
+tr = d.get("train_step", {})
+block = f"""<!-- BEGIN {tag} -->
+## Round {int(tag[1:])} reading (`{tag}_pmc.json`, `{tag}_*_kernel_stats.csv`)
+
+Every figure is a MEAN PER LAUNCH over all launches of that kernel in the profiled command - the coarse
+(65,536-point) and fine (196,608-point) pass of every 1024-ray step and, for the training kernels, the
+128-ray launches of the graph region - so the byte counts are not those of one particular launch size.
 
 | kernel | MFMA busy | HBM bytes / launch | LDS conflict cycles | note |
 |---|---|---|---|---|
 """ + "\n".join(rows) + f"""
 
-Effective clocks (GRBM_GUI_ACTIVE / 8 XCDs / rocprofv3 average duration, same profiled command): the exact
-fp32 kernels run at 2.29-2.35 GHz of the 2.4 GHz the 157.3 TFLOP/s peak assumes (the headline kernel's
-0.888 of peak is 0.92 of what its own clock allows); the 16-bit kernels are power-limited to ~2.05 GHz
-(`mlp_fwd_lp_kernel`) and 1.84 GHz (`mlp_fwd_f16_kernel`), i.e. their fractions of the 2.5 PFLOP/s
-peak understate the pipe utilisation by 15-25 %.
+Headline kernel `mlp_fwd_kernel<1,false,2>` in `{tag}_render_kernel_stats.csv`: {fw['Calls']} launches, average
+**{avg:.4f} ms**, {float(fw['Percentage']):.1f} % of GPU time; bench.py's own HIP-event average over the timed launches of the same
+profiled run (`{tag}_render_bench_line_under_rocprof.json`): **{dr['roofline']['avg_launch_ms']:.4f} ms** (agree within
+{abs(avg / dr['roofline']['avg_launch_ms'] - 1) * 100:.1f} %).
 
 Un-profiled bench line of the same build (`{tag}_bench_line.json`): {d['value']:.0f} rays/s, {d['ms_per_step']:.3f} ms/step,
-`roofline.achieved` {d['roofline']['achieved']:.1f} TFLOP/s (frac {d['roofline']['frac']:.4f}), CPU baseline {d['cpu_baseline']['value']:.0f} rays/s on {d['cpu_baseline']['cores']} cores.
+`roofline.achieved` {d['roofline']['achieved']:.1f} TFLOP/s (frac {d['roofline']['frac']:.4f}), exact train step {tr.get('ms_per_step', float('nan')):.3f} ms,
+CPU baseline {d['cpu_baseline']['value']:.0f} rays/s forward / {d['cpu_baseline'].get('train_step', {}).get('value', float('nan')):.0f} rays/s train step on {d['cpu_baseline']['cores']} cores.
+<!-- END {tag} -->
 """
 p = os.path.join(dst, "README.md")
 s = open(p).read()
-s = s[:s.index("Round-1 reading")] + table
-ev = dr["roofline"]["avg_launch_ms"]
-s = re.sub(r"average \*\*[\d.]+ ms\*\*, [\d.]+ % of GPU time", f"average **{avg:.4f} ms**, {float(fw['Percentage']):.1f} % of GPU time", s)
-s = re.sub(r"over the 40 timed launches: \*\*[\d.]+ ms\*\* \(agrees within [\d.]+ %",
-           f"over the 40 timed launches: **{ev:.4f} ms** (agrees within {abs(avg / ev - 1) * 100:.1f} %", s)
+b0, b1 = f"<!-- BEGIN {tag} -->", f"<!-- END {tag} -->\n"
+if b0 in s:
+    s = s[:s.index(b0)] + block + s[s.index(b1) + len(b1):]
+else:
+    s = s.rstrip("\n") + "\n\n" + block
 open(p, "w").write(s)
-print(table[-400:])
+print(block[-900:])
