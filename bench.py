@@ -243,7 +243,9 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
         one = lambda: gt.step(rays, tgt, hyp)
     else:
         one = lambda: tr.step(rays, tgt, hyp)[0]
-    for _ in range(max(3, args.warmup)):
+    # (with a process group the first steps also pay RCCL's one-time work - channel setup, the first
+    # launch of its kernels beside ours - which has been seen to leak past five warm-up steps)
+    for _ in range(max(3, args.warmup) + (10 if dist.is_initialized() else 0)):
         one()
     barrier()
     timer = ops.KernelTimer()
