@@ -55,7 +55,7 @@ def spawn_ranks(args):
     torch.distributed.run on 127.0.0.1 - the launch line the driver itself uses.  Rank 0 of the child
     job prints the JSON line on the inherited stdout."""
     n_dev = torch.cuda.device_count()
-    if n_dev < args.gpus:
+    if n_dev < args.gpus and os.environ.get("SCADE_BENCH_SHARE_GPU") != "1":
         raise SystemExit(f"bench.py: --gpus {args.gpus} but this node exposes {n_dev} HIP device(s)")
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -400,6 +400,10 @@ def main():
         spawn_ranks(args)                       # does not return
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # SCADE_BENCH_SHARE_GPU=1 + SCADE_BENCH_BACKEND=gloo: logic self-test of the multi-rank path on a box with
+    # fewer GPUs than ranks (the ranks share devices; RCCL refuses that, gloo does not) - not a measurement
+    if os.environ.get("SCADE_BENCH_SHARE_GPU") == "1":
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     # a one-rank RCCL group is the 1-GPU self-test of the collective path (SCADE_BENCH_FORCE_SPAWN=1
@@ -411,7 +415,11 @@ def main():
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("SCADE_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import scade_amd as S
     from scade_amd import ops
@@ -576,16 +584,15 @@ def main():
             print(f"bench.py: secondary region {key} failed: {exc!r}", file=sys.stderr)
 
     # exact fp32 regions first, the opt-in reduced-precision regions after them (the 16-bit bursts
-    # leave the chip in a different power state for a few milliseconds)
+    # leave the chip in a different power state for a few milliseconds); every GRAPH-CAPTURED region last:
+    # a capture that fails (a collective the backend cannot capture, say) leaves the stream invalidated
+    # and every later launch of the process would fail with it
     tr_args = (args, dev, world, rank, barrier)
+    strong = world > 1 and args.rays % world == 0
     if not args.no_train:
         guarded("train_step", train_region, *tr_args)
         if use_dist:
             guarded("train_step_overlap", train_region, *tr_args, allreduce="overlap")
-        if world > 1 and args.rays % world == 0:
-            # BASELINE.json configs[3]: ONE 1024-ray batch sharded over the ranks, step replayed as a graph
-            guarded("train_step_strong_graph", train_region, *tr_args, rays_per_gpu=args.rays // world,
-                    graphed=True, scaling="strong")
     if not args.no_rayops and rank == 0:
         guarded("per_ray_kernels_16384", rayops_region, dev, 16384, args.hyp)
     if use_dist:
@@ -600,8 +607,15 @@ def main():
             guarded("train_step_bf16", train_region, *tr_args, precision="bf16")
             if use_dist:
                 guarded("train_step_bf16_overlap", train_region, *tr_args, precision="bf16", allreduce="overlap")
+    if not args.no_train:
+        if strong:
+            # BASELINE.json configs[3]: ONE 1024-ray batch sharded over the ranks, step replayed as a graph
+            guarded("train_step_strong_graph", train_region, *tr_args, rays_per_gpu=args.rays // world,
+                    graphed=True, scaling="strong")
+        if not args.no_fast:
+            if use_dist:
                 guarded("train_step_bf16_graph", train_region, *tr_args, precision="bf16", graphed=True)
-            if world > 1 and args.rays % world == 0:
+            if strong:
                 guarded("train_step_bf16_strong_graph", train_region, *tr_args, precision="bf16",
                         rays_per_gpu=args.rays // world, graphed=True, scaling="strong")
             if world == 1:
@@ -617,6 +631,8 @@ def main():
     if use_dist:
         out["rccl"] = {"ranks": dist.get_world_size(), "backend": dist.get_backend(),
                        "version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+        if dist.get_backend() != "nccl":
+            out["rccl"]["note"] = "NOT RCCL: logic self-test of the multi-rank path (SCADE_BENCH_BACKEND)"
         state["region"] = "destroy_process_group"
         barrier()
         dist.destroy_process_group()
