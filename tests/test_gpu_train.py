@@ -60,6 +60,33 @@ def test_mlp_backward_points_ragged_vs_oracle(dev):
         grad_close(p.grad, po[k].grad, f"d/d{k}")
 
 
+@pytest.mark.parametrize("P", [1, 15, 17, 63, 65, 130, 672, 1001, 1008])
+def test_mlp_backward_ragged_point_counts(dev, P):
+    """Point counts around the 16-point pipeline stage, the 32 / 64-point forward tiles and the chunking of
+    the weight-gradient kernel (mlp_wgrad2.hip: 4-point staging blocks, buffer loads that return zeros past
+    the chunk end): all 24 gradients against autograd through the oracle, norm-wise.  The bound allows for
+    ReLU FLIPS: with ~2,300 P pre-activations a few lie within fp32 rounding of zero, the two
+    implementations then disagree on that unit's mask, and ONE flipped unit of one point moves the gradients
+    of all layers below it by ~1/sqrt(256 P) relative (measured: 4e-3 at P = 672, none at P = 1000).  A lost
+    or doubled POINT would be 1/sqrt(P), 16x the bound."""
+    params = O.nerf_init(11)
+    net = make_net(params, dev)
+    g = torch.Generator().manual_seed(100 + P)
+    pts = torch.rand(P, 3, generator=g) * 2 - 1
+    vd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    x = torch.cat([O.embed(pts, 9), vd], -1)
+    G = torch.randn(P, 4, generator=g)
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    (O.nerf_forward(po, x) * G).sum().backward()
+    out = net(x.to(dev))
+    (out * G.to(dev)).sum().backward()
+    bound = max(2e-5, 2.5 / (256.0 * P) ** 0.5)
+    for k, p in net.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        e = rel_l2(p.grad, po[k].grad)
+        assert e < bound, f"P={P} d/d{k}: rel-L2 {e:.2e} (bound {bound:.1e})"
+
+
 def test_mlp_backward_many_chunks(dev):
     """P large enough for several wgrad chunks; compare against the oracle's autograd."""
     params = O.nerf_init(5)
