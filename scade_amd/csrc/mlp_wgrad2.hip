@@ -1,43 +1,47 @@
 // B2 of the exact fp32 backward: dW[n][k] = sum_points dZ[point][n] * In[point][k]   (what autograd's
 // addmm-backward computes for the 12 nn.Linear layers of NeRF.forward, model/run_nerf_helpers.py:223-247).
 //
-// The contraction runs over POINTS while both operands sit in HBM point-major, so the MFMA fragments
-// ("k-index = point") are columns of the staged tiles.  Second design of this kernel (the first fed
-// v_mfma_f32_32x32x2_f32 from one ds_read_b32 per operand and k-step, 512-thread workgroups, one per CU,
-// all eight waves in lock step on one barrier per stage):
+// The contraction runs over POINTS while both operands sit in HBM point-major.  Third design of this kernel
+// (first: 512-thread workgroups, one ds_read_b32 per operand and k-step; second: two 4-wave workgroups per
+// CU, tiles transposed through staging registers so that one ds_read_b128 fed four k-steps):
 //
 //  * workgroup = 4 waves = HALF of a layer's weight gradient (128 output features n x 256 inputs k) for
-//    one chunk of points; 48 KiB of LDS => TWO independent workgroups per CU, so the staging / barrier
-//    phase of one hides under the MFMAs of the other (the forward kernel's recipe);
-//  * tiles are TRANSPOSED on the way into LDS - a thread loads a 4-point x 4-feature block (four
-//    coalesced 16-byte row loads) and writes four ds_write_b128 "feature f: points p..p+3" - so that one
-//    ds_read_b128 is the operand of FOUR MFMA k-steps (lanes 0-31 carry points 8g..8g+3, lanes 32-63
-//    points 8g+4..8g+7 of k-group g; both operands use the same point <-> (k-step, lane half) map, and any
-//    permutation of the contraction index is legal): 6 LDS reads per 32 MFMAs instead of 24;
-//  * LDS image: 384 rows (128 dZ features | 256 input features) of 32 points = BOTH pipeline buffers of 16
-//    points side by side in one 128-byte row, 16-byte chunk c stored at c ^ key(row), key = (row ^ row>>2)
-//    & 7 for rows stored four per lane and (row ^ row>>1) & 7 for the dZ rows stored two per lane:
-//    conflict free for the transposed stores (8-lane groups) and for the fragment reads (the
-//    ds_read_b128 lane groups {0-3,12-15,20-27}, ...) - measured SQ_LDS_BANK_CONFLICT = 0;
-//  * bias / alpha-head / view-column riders work on the STAGING REGISTERS (no LDS traffic) and are reduced
-//    over the four waves once per workgroup;
-//  * the barrier sits BETWEEN the two k-groups of a stage and orders LDS only (fences restricted to the
-//    local address space: lgkmcnt(0), never vmcnt(0) - the global prefetch stays in flight); every
-//    fragment is read one k-group (32 MFMAs) ahead of its use, also across stages.
+//    one chunk of points, two workgroups per CU;
+//  * the tiles go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), POINT-MAJOR AS THEY LIE IN HBM: no
+//    staging registers, no ds_write, no transposition, and out-of-chunk rows arrive as zeros (buffer
+//    range check).  What makes the point-major image usable is a permutation of the OUTPUT rows: lane r of
+//    a fragment read takes 8 (dZ) / 16 (input) consecutive bytes of point p - features 2r, 2r+1 (4r..4r+3),
+//    the operands of TWO (FOUR) different 32x32 output tiles at the same k-step - so MFMA row r of tile t is
+//    feature 2r + t, column r of tile u is input 4r + u, and the epilogue un-permutes (which also turns the
+//    partial's stores into 16-byte ones).  8 LDS reads per 32 MFMAs, conflict free by construction (a
+//    ds_read_b64 lane group covers 256 contiguous bytes, a ds_read_b128 group 16 x 16 bytes in distinct
+//    banks);
+//  * a ring of W2_D = 3 slots of W2_S = 8 points (36 KiB): the slot of stage s is refilled with stage s+3
+//    right after the barrier that publishes stage s+1 (every wave has read all of stage s by then) and is
+//    waited for with a COUNTED vmcnt two barriers later - two stages stay in flight across every barrier.
+//    The barrier sits between the two halves of a stage and orders LDS only (fences restricted to the local
+//    address space); every fragment is read one half stage (32 MFMAs) ahead of its use;
+//  * bias / alpha-head / view-column riders read the published slot; their per-point scalars (d alpha, the
+//    view direction) ride the same ring as 4-byte LDS-DMA pieces, because an ordinary load's in-order vmcnt
+//    wait would drain the ring.
 //
-// Measured (MI355X, 196,608 points, alone on the chip): 1.93 ms against 2.01 ms of the first design, 0.67
-// against 0.80 ms at 65,536 points; knock-outs of this kernel: no global loads -7 %, no LDS stores -1 %,
-// no barrier -1.5 %, no fragment reads -2 %, all four -16 % (= the bare MFMA stream with its prologue /
-// epilogue, 84 % of the pipe's peak).  A ONE-ROUND variant (511 equal-cost workgroups resident from start
-// to end, per-job chunk lengths, both embedding blocks as one 512 x 64 job, halves of a layer on the same
-// XCD for L2 reuse: FETCH_SIZE -17 %) measured 3-7 % SLOWER at every size and was dropped.
+// Measured (MI355X, 196,608 points, same box, back to back): dgrad + wgrad + reduce 3.66 ms against 3.76 ms
+// with the second design (wgrad 1.83 against 1.93 ms; 0.64 against 0.67 ms at 65,536 points).  Ring depth
+// 2..6, 16-point stages, nt on/off and chunks of 1,600..3,600 points all measure within 1 %; knock-outs of
+// this kernel: no DMA -6 %, no fragment reads -6 %, no barrier 0, all three -11.5 % (= the bare MFMA stream
+// with its prologue / epilogue: 141 TFLOP/s, 90 % of the 2.4 GHz peak - the forward kernel's 88.8 % says
+// that is the clock the chip sustains under fp32 MFMA load).  Putting the two halves of a layer on the same
+// XCD (L2 reuse of the input rows) measured 2 % slower (padding of the chunk count to 8) and was dropped,
+// as were THREE workgroups per CU (168 VGPRs, no spill: +5 % time - a third wave per SIMD only adds contention
+// for a matrix pipe two already fill) and a ONE-ROUND variant of the second design (511 equal-cost resident workgroups: 3-7 % slower).
 #include "mlp_wgrad.h"
 
 namespace scade {
 
-constexpr int W2_PT = 16;                         // points per pipeline stage (two stages per LDS row)
-constexpr int W2_ROWS = 128 + 256;
-constexpr int W2_LDS_BYTES = W2_ROWS * 32 * 4;    // 49,152
+constexpr int W2_PT = 16;                         // chunk lengths are multiples of this
+constexpr int W2_S = 8;                           // points per ring slot
+constexpr int W2_D = 3;                           // ring slots
+constexpr int W2_LDS_BYTES = W2_D * (W2_S * (128 + 256) + 64) * 4;    // 37,632
 
 struct Wgrad2Job {
   long dz_off;       // float offset of the dZ matrix (row stride 256) in the dz workspace, n_base included
@@ -58,16 +62,9 @@ struct Wgrad2Args {
   int P, chunk, njobs;
 };
 
-// float offset of 16-byte chunk lc (0..7 = buffer*4 + point group) of LDS row `row` (swizzle key from the
-// row index LOCAL to its region, which is what both the stores and the reads use)
-__device__ __forceinline__ int w2_off(int row_abs, int row_local, int lc) {
-  return row_abs * 32 + ((lc ^ ((row_local ^ (row_local >> 2)) & 7)) << 2);
-}
-// the dZ rows are stored two per lane (rows 2 lane + j), which wants a different key: (row ^ row>>1) & 7
-__device__ __forceinline__ int w2_off_a(int row, int lc) { return row * 32 + ((lc ^ ((row ^ (row >> 1)) & 7)) << 2); }
 // workgroup barrier that orders LDS only: release/acquire fences restricted to the local address space
-// (lgkmcnt(0), no vmcnt(0) - the global prefetch stays in flight), visible to the compiler's own wait
-// counting, pinned in place against the MFMA groups on either side
+// (lgkmcnt(0), no vmcnt(0) - the ring stays in flight), visible to the compiler's own wait counting, pinned
+// in place against the MFMA groups on either side
 __device__ __forceinline__ void w2_barrier() {
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
@@ -89,8 +86,15 @@ __device__ __forceinline__ w2_rsrc_t w2_make_rsrc(const float* base, unsigned by
 template <int KW, int FLAGS>
 __device__ __forceinline__ void wgrad2_mfma_job(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0,
                                                 int c1, float* __restrict__ out) {
+  constexpr int S = W2_S, D = W2_D;
   constexpr int NKT = KW == 256 ? 4 : 1;          // k-tiles of 32 per wave
   constexpr int flags = FLAGS;
+  constexpr int XTRA = (FLAGS & (WF_ALPHA | WF_VIEWCOLS)) ? 64 : 0;   // rider scalars: d alpha [S] / view dirs [S][3]
+  constexpr int STAGE = S * (128 + KW) + XTRA;    // floats per ring slot: [S][128] dZ | [S][KW] inputs | riders
+  constexpr int NI = (KW == 256 ? (S / 8) * 3 : (S / 8) * 2) + (XTRA ? 1 : 0);   // LDS-DMA instructions per wave and stage
+  constexpr int H = S / 4;                        // k-pairs (2 points) per half stage
+  static_assert(D * STAGE * 4 <= W2_LDS_BYTES, "ring");
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
@@ -98,10 +102,13 @@ __device__ __forceinline__ void wgrad2_mfma_job(const Wgrad2Args& a, const Wgrad
   const int k0 = (wave & 1) * (KW / 2);
   const int P = a.P;
   const int npts = c1 - c0;
-  // dZ rows of this chunk (row stride 1 KiB; n_base is inside dz_off) and input rows (1 KiB or 256 B)
+  // dZ rows of this chunk (row stride 1 KiB; n_base is inside dz_off), input rows (1 KiB or 256 B), and
+  // the rider scalars of the chunk
   const w2_rsrc_t ra = w2_make_rsrc(a.dz + jb.dz_off + (size_t)c0 * 256, (unsigned)npts * 1024u);
   const w2_rsrc_t rb = w2_make_rsrc(a.acts + jb.in_off + (size_t)c0 * (KW == 256 ? 256 : 64),
                                     (unsigned)npts * (KW == 256 ? 1024u : 256u));
+  const w2_rsrc_t rx = (FLAGS & WF_ALPHA) ? w2_make_rsrc(a.dz + dz_dalpha_off(P) + c0, (unsigned)npts * 4u)
+                                          : w2_make_rsrc(a.acts + acts_emb_off(P) + (size_t)c0 * 64, (unsigned)npts * 256u);
 
   f32x16 acc[2][NKT];
 #pragma unroll
@@ -111,159 +118,183 @@ __device__ __forceinline__ void wgrad2_mfma_job(const Wgrad2Args& a, const Wgrad
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
-  // ---- staging: A block = 4 points x features {2 lane, 2 lane + 1}; B block = 4 points x features
-  // 4 lane .. 4 lane + 3 (KW = 64: wave 0 only, 16 column groups x 4 point groups); points 4 wave + q
+  // ---- LDS-DMA of stage st into slot sl: per 8 points a wave moves dZ rows 2w, 2w+1 (one instruction:
+  // lanes 0-31 | 32-63) and input rows 2w, 2w+1 (KW = 256: one instruction each; KW = 64: 256-byte rows,
+  // lanes 0-31 carry both).  Read once per workgroup: nt.
+  const int va = hh * 1024 + r * 16;
+  const int vb = lane * 16;
+  auto issue = [&](int st, int sl) {
+    float* slot = lds + sl * STAGE;
+#pragma unroll
+    for (int e = 0; e < S / 8; ++e) {
+      const int row = 8 * e + 2 * wave;
+      const int grow = st * S + row;              // row of the chunk (past its end: the buffer returns zeros)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + row * 128), 16, va, grow * 1024, 0, 2);
+      if (KW == 256) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 128 + (row + q) * 256), 16, vb,
+                                                   (grow + q) * 1024, 0, 2);
+      } else {
+        if (lane < 32)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 128 + row * 64), 16, vb, grow * 256, 0, 2);
+      }
+    }
+    constexpr int Q = S / 4;                      // rider points per wave
+    if (FLAGS & WF_ALPHA) {
+      if (lane < Q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(slot + S * (128 + KW) + Q * wave), 4, lane * 4,
+                                                 (st * S + Q * wave) * 4, 0, 0);
+    } else if (FLAGS & WF_VIEWCOLS) {
+      if (lane < 3 * Q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (lds_ptr_t)(slot + S * (128 + KW) + 3 * Q * wave), 4,
+                                                 (lane / 3) * 256 + (60 + lane % 3) * 4, (st * S + Q * wave) * 256, 0, 0);
+    }
+  };
+
+  // ---- fragments of one half stage: k-pair j = points 2j + hh of the slot
   typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 pa[4];
-  f32x4 pb[4];
-  float da[4] = {0.f, 0.f, 0.f, 0.f};             // d alpha_pre of the wave's 4 points (WF_ALPHA)
-  float vw[4][3];                                 // view directions of the wave's 4 points (WF_VIEWCOLS)
-  float bias_acc[2] = {0.f, 0.f}, alpha_acc[4] = {0.f, 0.f, 0.f, 0.f}, dal_acc = 0.f;
-  float vc[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
-  const int b_c4 = KW == 256 ? lane : (lane & 15), b_pg = KW == 256 ? wave : (lane >> 4);
-  const bool b_on = KW == 256 || wave == 0;
-
-  const int va = lane * 8;                                                       // byte offset inside a dZ row
-  const int vb = KW == 256 ? lane * 16 : (4 * b_pg) * 256 + b_c4 * 16;         // inside an input row (+ point group)
-  auto issue = [&](int pt0) {
-    const int rel = pt0 - c0 + 4 * wave;                                           // wave-uniform row index
+  struct Frag { f32x2 a[H]; f32x4 b[H]; };
+  const int fa_off = hh * 128 + nsub + 2 * r;
+  const int fb_off = S * 128 + hh * KW + k0 + NKT * r;
+  auto read_frag = [&](Frag& f, int sl, int half) {
+    const float* slot = lds + sl * STAGE;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      pa[q] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ra, va, (rel + q) * 1024, 2));   // read once: nt
-      const int pt = pt0 + 4 * wave + q;
-      if (flags & WF_ALPHA) da[q] = pt < c1 ? a.dz[dz_dalpha_off(P) + pt] : 0.f;
-      if (flags & WF_VIEWCOLS) {
-#pragma unroll
-        for (int c = 0; c < 3; ++c) vw[q][c] = pt < c1 ? a.acts[acts_emb_off(P) + (size_t)pt * 64 + 60 + c] : 0.f;
-      }
+    for (int j = 0; j < H; ++j) {
+      const int pp = 2 * (half * H + j);
+      f.a[j] = *reinterpret_cast<const f32x2*>(slot + fa_off + pp * 128);
+      if (NKT == 4) f.b[j] = *reinterpret_cast<const f32x4*>(slot + fb_off + pp * KW);
+      else f.b[j][0] = slot[fb_off + pp * KW];
     }
-    if (b_on) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-        pb[q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
-            rb, vb, KW == 256 ? (rel + q) * 1024 : (pt0 - c0 + q) * 256, 2));
-    }
-  };
-  auto commit = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int row = 2 * lane + j;
-      const f32x4 v = {pa[0][j], pa[1][j], pa[2][j], pa[3][j]};
-      *reinterpret_cast<f32x4*>(lds + w2_off_a(row, 4 * buf + wave)) = v;
-      bias_acc[j] += (pa[0][j] + pa[1][j]) + (pa[2][j] + pa[3][j]);
-    }
-    if (b_on) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int row = 4 * b_c4 + j;
-        const f32x4 v = {pb[0][j], pb[1][j], pb[2][j], pb[3][j]};
-        *reinterpret_cast<f32x4*>(lds + w2_off(128 + row, row, 4 * buf + b_pg)) = v;
-      }
-    }
-    if (flags & WF_ALPHA) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) alpha_acc[j] = fmaf(da[q], pb[q][j], alpha_acc[j]);
-        dal_acc += da[q];
-      }
-    }
-    if (flags & WF_VIEWCOLS) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-          for (int c = 0; c < 3; ++c) vc[j][c] = fmaf(pa[q][j], vw[q][c], vc[j][c]);
-    }
-  };
-
-  // ---- fragments: one ds_read_b128 = 4 points of this lane half = operand of 4 MFMA k-steps
-  struct Frag { f32x4 a[2]; f32x4 b[NKT]; };
-  int rowA[2], rowB[NKT];
-#pragma unroll
-  for (int t = 0; t < 2; ++t) rowA[t] = nsub + 32 * t + r;
-#pragma unroll
-  for (int u = 0; u < NKT; ++u) rowB[u] = k0 + 32 * u + r;
-  auto read_frag = [&](Frag& f, int buf, int g) {
-    const int lc = 4 * buf + 2 * g + hh;
-#pragma unroll
-    for (int t = 0; t < 2; ++t) f.a[t] = *reinterpret_cast<const f32x4*>(lds + w2_off_a(rowA[t], lc));
-#pragma unroll
-    for (int u = 0; u < NKT; ++u) f.b[u] = *reinterpret_cast<const f32x4*>(lds + w2_off(128 + rowB[u], rowB[u], lc));
   };
   auto mfma_group = [&](const Frag& f) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
+    for (int j = 0; j < H; ++j)
 #pragma unroll
       for (int t = 0; t < 2; ++t)
 #pragma unroll
         for (int u = 0; u < NKT; ++u)
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[t][j], f.b[u][j], acc[t][u], 0, 0, 0);
+          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(f.a[j][t], f.b[j][u], acc[t][u], 0, 0, 0);
   };
 
-  // ---- pipeline: stage s+2 in flight to registers, stage s+1 committed to the other half of the rows
-  // while stage s is multiplied; the barrier between the two k-groups of a stage publishes stage s+1
-  issue(c0);
-  commit(0);
-  if (c0 + W2_PT < c1) issue(c0 + W2_PT);
+  // ---- riders read the published slot: thread = (feature n = tid & 127, point half tid >> 7) for the bias
+  // and the view columns, thread = input column for the alpha head.  The reads are issued with the fragment
+  // reads, the arithmetic runs BEHIND the MFMA group (in front of it, its lgkmcnt(0) would hold the MFMAs
+  // back by an LDS round trip per half stage).
+  float bias_acc = 0.f, alpha_acc = 0.f, dal_acc = 0.f, vc[3] = {0.f, 0.f, 0.f};
+  const int rn = tid & 127, rph = __builtin_amdgcn_readfirstlane(tid >> 7);
+  float rv[S / 2], rs[(FLAGS & WF_VIEWCOLS) ? 3 * (S / 2) : 1], ra_in[(FLAGS & WF_ALPHA) ? S : 1], ra_da[(FLAGS & WF_ALPHA) ? S : 1];
+  auto riders_read = [&](int sl) {
+    const float* slot = lds + sl * STAGE;
+    if (flags & (WF_BIAS | WF_VIEWCOLS)) {
+#pragma unroll
+      for (int q = 0; q < S / 2; ++q) {
+        const int pp = rph * (S / 2) + q;
+        rv[q] = slot[pp * 128 + rn];
+        if (flags & WF_VIEWCOLS) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) rs[3 * q + c] = slot[S * (128 + KW) + 3 * pp + c];
+        }
+      }
+    }
+    if (flags & WF_ALPHA) {
+#pragma unroll
+      for (int pp = 0; pp < S; ++pp) {
+        ra_da[pp] = slot[S * (128 + KW) + pp];
+        ra_in[pp] = slot[S * 128 + pp * KW + tid];
+      }
+    }
+  };
+  auto riders_add = [&]() {
+    if (flags & (WF_BIAS | WF_VIEWCOLS)) {
+#pragma unroll
+      for (int q = 0; q < S / 2; ++q) {
+        bias_acc += rv[q];
+        if (flags & WF_VIEWCOLS) {
+#pragma unroll
+          for (int c = 0; c < 3; ++c) vc[c] = fmaf(rv[q], rs[3 * q + c], vc[c]);
+        }
+      }
+    }
+    if (flags & WF_ALPHA) {
+#pragma unroll
+      for (int pp = 0; pp < S; ++pp) {
+        alpha_acc = fmaf(ra_da[pp], ra_in[pp], alpha_acc);
+        dal_acc += ra_da[pp];
+      }
+    }
+  };
+
+  // ---- pipeline.  Stages past the chunk are issued too: zeros, no memory traffic, and the vmcnt stays a
+  // compile-time constant.
+  const int ns = (npts + S - 1) / S;
+#pragma unroll
+  for (int st = 0; st < D; ++st) issue(st, st);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
   w2_barrier();
   Frag f0, f1;
   read_frag(f0, 0, 0);
-  int buf = 0;
-  for (int pt0 = c0; pt0 < c1; pt0 += W2_PT, buf ^= 1) {
-    const bool has_next = pt0 + W2_PT < c1;
-    if (has_next) commit(buf ^ 1);
-    if (pt0 + 2 * W2_PT < c1) issue(pt0 + 2 * W2_PT);
-    read_frag(f1, buf, 1);
+  int sl = 0;
+  for (int st = 0; st < ns; ++st) {
+    const int sl1 = sl + 1 == D ? 0 : sl + 1;
+    read_frag(f1, sl, 1);
+    riders_read(sl);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(f0);
-    w2_barrier();
-    if (has_next) read_frag(f0, buf ^ 1, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    riders_add();
+    // stage st+1: this wave's pieces have landed (D-2 younger stages stay in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NI) : "memory");
+    w2_barrier();                                 // ... and so have everybody's; slot sl is read out
+    issue(st + D, sl);
+    read_frag(f0, sl1, 0);
     __builtin_amdgcn_sched_barrier(0);
     mfma_group(f1);
+    sl = sl1;
   }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land after the workgroup is gone / on the scratch below
 
-  // ---- write the partial ---------------------------------------------------------
+  // ---- write the partial: MFMA row m of tile t = feature 2m + t, column r of tile u = input NKT r + u
+  const bool vec_ok = NKT == 4 && (jb.ld & 3) == 0 && (jb.kcol0 & 3) == 0 && (jb.w_off & 3) == 0 &&
+                      (reinterpret_cast<unsigned long long>(out) & 15) == 0 && jb.kvalid == 256;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int u = 0; u < NKT; ++u) {
-      const int k = k0 + 32 * u + r;
+    for (int i = 0; i < 16; ++i) {
+      const int m = (i & 3) + 8 * (i >> 2) + 4 * hh;
+      const int n = jb.n_base + nsub + 2 * m + t;
+      if (n < jb.n_rows) {
+        float* dst = out + jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k0 + NKT * r;
+        if (NKT == 4 && vec_ok) {
+          const f32x4 v = {acc[t][0][i], acc[t][NKT > 1 ? 1 : 0][i], acc[t][NKT > 2 ? 2 : 0][i], acc[t][NKT > 3 ? 3 : 0][i]};
+          *reinterpret_cast<f32x4*>(dst) = v;
+        } else {
 #pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        const int n = jb.n_base + nsub + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-        if (n < jb.n_rows && k < jb.kvalid) out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k] = acc[t][u][i];
+          for (int u = 0; u < NKT; ++u)
+            if (k0 + NKT * r + u < jb.kvalid) dst[u] = acc[t][u][i];
+        }
       }
     }
-  // riders: every wave saw a quarter of the points -> sum the four waves through LDS
+  // riders: the two point halves meet in LDS
   if (flags & (WF_BIAS | WF_ALPHA | WF_VIEWCOLS)) {
-    w2_barrier();                                  // all fragment reads done: the rows are free
-    float* red = lds;                              // [4 waves][128 bias | 256 alpha | 384 view cols | 1]
-    float* rw = red + wave * 772;
-    rw[2 * lane] = bias_acc[0];
-    rw[2 * lane + 1] = bias_acc[1];
-    if (flags & WF_ALPHA) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rw[128 + 4 * lane + j] = alpha_acc[j];
-      if (lane == 0) rw[768] = dal_acc;
-    }
+    w2_barrier();                                  // all fragment reads done: the ring is free
+    float* red = lds;                              // [2 point halves][128 bias | 384 view cols]
+    red[rph * 512 + rn] = bias_acc;
     if (flags & WF_VIEWCOLS) {
 #pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) rw[384 + (2 * lane + j) * 3 + c] = vc[j][c];
+      for (int c = 0; c < 3; ++c) red[rph * 512 + 128 + rn * 3 + c] = vc[c];
     }
     w2_barrier();
-    auto sum4 = [&](int i) { return (red[i] + red[772 + i]) + (red[1544 + i] + red[2316 + i]); };
-    if ((jb.flags & WF_BIAS) && tid < 128 && jb.n_base + tid < jb.n_rows) out[jb.b_off + jb.n_base + tid] = sum4(tid);
+    if ((jb.flags & WF_BIAS) && tid < 128 && jb.n_base + tid < jb.n_rows)
+      out[jb.b_off + jb.n_base + tid] = red[tid] + red[512 + tid];
     if (flags & WF_ALPHA) {
-      out[jb.aux_off + tid] = sum4(128 + tid);
-      if (tid == 0) out[jb.aux_off + 256] = sum4(768);
+      out[jb.aux_off + tid] = alpha_acc;
+      if (tid == 0) out[jb.aux_off + 256] = dal_acc;
     }
     if ((flags & WF_VIEWCOLS) && tid < 128 && jb.n_base + tid < jb.n_rows) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) out[jb.w_off + (size_t)(jb.n_base + tid) * jb.ld + 256 + c] = sum4(384 + tid * 3 + c);
+      for (int c = 0; c < 3; ++c)
+        out[jb.w_off + (size_t)(jb.n_base + tid) * jb.ld + 256 + c] = red[128 + tid * 3 + c] + red[512 + 128 + tid * 3 + c];
     }
   }
 }
