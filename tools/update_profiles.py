@@ -32,7 +32,7 @@ notes = {
     "mlp_fwd_kernel_train_small": "32-point workgroups (the 128-ray launches of the graph region)",
     "mlp_dgrad_kernel_small": "32-point workgroups",
     "mlp_wgrad_kernel": "dZ and activations streamed once per layer; includes the low-MFMA embedding and rgb-head jobs",
-    "mlp_wgrad2_kernel": "round-2 weight gradient: half-layer workgroups, two per CU, transposed LDS image, ds_read_b128 fragments; "
+    "mlp_wgrad2_kernel": "round-2 weight gradient: half-layer workgroups, two per CU, point-major tiles by LDS-DMA into a 3-slot ring, output rows permuted (no transposition); "
                          "the mean includes the 128-ray launches (one or two short workgroups per CU)",
     "wgrad_reduce4_kernel": "sums the per-chunk partials",
     "mlp_fwd_f16_kernel": "opt-in f16x3 render kernel (3 f16 MFMAs per fp32-class product)",
