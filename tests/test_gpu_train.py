@@ -106,6 +106,33 @@ def test_mlp_backward_many_chunks(dev):
         assert rel_l2(p.grad, po[k].grad) < 2e-5, k
 
 
+@pytest.mark.parametrize("P", [4097, 65536])
+def test_mlp_backward_is_bitwise_repeatable_under_memory_load(dev, P):
+    """Race screen for the LDS-DMA ring of mlp_wgrad2.hip (and the dgrad in front of it): the kernels are
+    deterministic, so the backward of one workspace repeated while a side stream streams copies of varying
+    size must be BIT-identical every time - a ring slot read before its DMA landed, or refilled before it
+    was read out, shows up as a difference that comes and goes with the memory load (tools/soak_wgrad.py is
+    the long form)."""
+    from scade_amd import ops
+    net = make_net(O.nerf_init(21), dev)
+    g_ = torch.Generator().manual_seed(22)
+    pts = (torch.rand(P, 1, 3, generator=g_) * 2 - 1).to(dev)
+    vd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g_), dim=-1).to(dev)
+    bb = torch.tensor([0., 0., 0., 0.2], device=dev)
+    acts = ops.mlp_acts_alloc(P, dev)
+    ops.mlp_fwd_points(net.packed(), pts, vd, bb, acts)
+    G = (torch.randn(P, 4, generator=g_) * 1e-3).to(dev)
+    ref = ops.mlp_bwd(net.packed(), net.packed_t(), acts, G).clone()
+    assert torch.isfinite(ref).all() and float(ref.abs().max()) > 0
+    side, big = torch.cuda.Stream(), torch.empty(128 << 20, dtype=torch.uint8, device=dev)
+    for i in range(16):
+        with torch.cuda.stream(side):
+            n = (1 + (i * 5) % 4) * (16 << 20)
+            big[:n].copy_(big[n:2 * n])
+        assert torch.equal(ops.mlp_bwd(net.packed(), net.packed_t(), acts, G), ref), f"repetition {i} differs"
+    torch.cuda.synchronize()
+
+
 def train_step(dev, g, coarse, fine, query, scale, shift):
     ret = S.render_rays(g["rays"].to(dev), True, coarse, query, 64, embedded_cam=torch.empty(0, device=dev),
                         N_importance=128, network_fine=fine, perturb=1., retraw=True, pytest=True)
