@@ -231,34 +231,62 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
 constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4 + 16;   // + the four waves' gradient maxima
 
 // ---------------------------------------------------------------------------
-// B2': split-precision weight gradient.  dW[n][k] = sum_points dZ[p][n] * In[p][k] contracts
-// over POINTS, so both MFMA operands need 8 consecutive points of ONE column per lane: tiles are
-// transposed on their way into LDS -- a thread loads one column of 8 consecutive point rows
-// (a wave load = 64 consecutive columns of one row, 256 B coalesced), splits the 8 values into
-// two fp16 planes and stores each with ONE ds_write_b128 into [column][16 points + pad]; both
-// write and ds_read_b128 fragment patterns are bank-conflict free at a 48-byte row.
-//   x = h + l' with l' = fp16(x - h) UNSCALED (may be fp16-subnormal: absolute error <= 2^-25 of
-//   the operand scale), so ONE fp32 accumulator set (128 VGPRs for the 256x256 output) takes
-//   h*h + h*l' + l'*h.  dZ is multiplied by ONE power of two per launch (from max|g_out|, found
-//   by the dgrad kernel) so its large entries sit near 2^8; the partial is scaled back exactly.
-// The VALU riders (bias / alpha head / view columns) use the exact fp32 values in flight.
-// This kernel is HBM-bound (2 KB per point-layer at 5x the fp32 MFMA rate).
+// B2': split-precision weight gradient.  dW[n][k] = sum_points dZ[p][n] * In[p][k] contracts over POINTS,
+// so both MFMA operands need 8 consecutive points of ONE column per lane, while both matrices lie
+// point-major in HBM.  Second design (the first loaded 4-byte columns into registers, one 16-point stage
+// ahead: 32 KB per CU in flight, latency-bound at 2.4 TB/s):
+//   * the fp32 tiles go HBM -> LDS by LDS-DMA as they lie (1-KiB point rows), into a ring of 4 slots of 16
+//     points: three stages = 96 KB per CU in flight, no staging registers, rows past the chunk end arrive
+//     as zeros (buffer range check) - the ring of mlp_wgrad2.hip;
+//   * the fragments are gathered with the OUTPUT-ROW PERMUTATION of that kernel: lane r reads 8 (dZ) / 16
+//     (input) consecutive bytes of each of its 8 points - features 2r, 2r+1 (4r..4r+3), the operands of two
+//     (four) different output tiles - so MFMA row r of tile t is feature 2r + t, column r of tile u is input
+//     4r + u; 16 conflict-free LDS reads per 24 MFMAs, and the split into fp16 planes happens on the VALU
+//     behind the read (each value is split by the 2 / 4 waves that use it: ~240 VALU ops per wave and
+//     stage beside 24 MFMAs - this kernel is HBM-bound, 2 KB per point-layer);
+//   x = h + l' with l' = fp16(x - h) UNSCALED (may be fp16-subnormal: absolute error <= 2^-25 of the operand
+//   scale), so ONE fp32 accumulator set (128 VGPRs for the wave's 64 x 128 outputs) takes h*h + h*l' + l'*h.
+//   dZ is multiplied by ONE power of two per launch (from max|g_out|, found by the dgrad kernel) so its
+//   large entries sit near 2^8; the partial is scaled back exactly.
+// The VALU riders (bias / alpha head / view columns) use the exact fp32 values of the published slot; their
+// per-point scalars (d alpha, view direction) ride the ring as 4-byte LDS-DMA pieces.
 // ---------------------------------------------------------------------------
-constexpr int HW_PT = 16;                                 // points per stage = one k16 block
-constexpr int HW_ROW = 24;                                // halves per LDS row: 16 points + 8 pad (48 B)
-constexpr int HW_PLANE = 256 * HW_ROW;                    // halves per plane
-constexpr int HW_STAGE = 4 * HW_PLANE;                    // Ah Al Bh Bl
-constexpr int WGRAD_F16_LDS_BYTES = 2 * HW_STAGE * 2;     // double buffered: 98304
+constexpr int HW_PT = 16;                                 // points per ring slot = one k16 block
+constexpr int HW_D = 4;                                   // ring slots
+constexpr int HW_SLOT = HW_PT * 512 + 64;                 // floats: dZ [16][256] | input [16][KW] | d alpha [16] | view dirs [16][3]
+constexpr int WGRAD_F16_LDS_BYTES = HW_D * HW_SLOT * 4;   // 132,096
 
 struct WgradF16Args {
   WgradArgs w;
   const float* gmax;    // device scalar: max |g_out| of the launch (float bits)
 };
 
+typedef __amdgpu_buffer_rsrc_t hw_rsrc_t;
+__device__ __forceinline__ hw_rsrc_t hw_make_rsrc(const float* base, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// workgroup barrier that orders LDS only (lgkmcnt(0), never vmcnt(0): the ring stays in flight); a raw
+// s_barrier behind an explicit wait - a local-address-space release fence would be turned into
+// s_waitcnt vmcnt(0) by hipcc whenever an LDS-DMA is outstanding and no LDS read is
+__device__ __forceinline__ void hw_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
 template <int KW>
-__device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob& jb, _Float16* lds,
+__device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob& jb, float* lds,
                                               int c0, int c1, float S, float* __restrict__ out) {
   constexpr int NKT = KW == 256 ? 4 : 1;
+  constexpr int D = HW_D, PT = HW_PT;
+  constexpr int NI = (KW == 256 ? 4 : 3) + 2;     // LDS-DMA instructions per wave and stage
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
@@ -266,11 +294,11 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   const int k0 = (wave & 1) * (KW / 2);
   const bool active = n0 < jb.n_rows;
   const int P = a.P;
-  const float* __restrict__ dzm = a.dz + jb.dz_off;
-  const float* __restrict__ inm = a.acts + jb.in_off;
-  // staging item of this thread: column `col`, point group g (8 consecutive points)
-  const int col = tid & 255, g = tid >> 8;
-  const bool has_b = KW == 256 || col < 64;
+  const int npts = c1 - c0;
+  const hw_rsrc_t ra = hw_make_rsrc(a.dz + jb.dz_off + (size_t)c0 * 256, (unsigned)npts * 1024u);
+  const hw_rsrc_t rb = hw_make_rsrc(a.acts + jb.in_off + (size_t)c0 * KW, (unsigned)npts * (KW * 4u));
+  const hw_rsrc_t rd = hw_make_rsrc(a.dz + dz_dalpha_off(P) + c0, (unsigned)npts * 4u);
+  const hw_rsrc_t rv = hw_make_rsrc(a.acts + acts_emb_off(P) + (size_t)c0 * 64, (unsigned)npts * 256u);
 
   f32x16 acc[2][NKT];
 #pragma unroll
@@ -279,144 +307,165 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
     for (int u = 0; u < NKT; ++u)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+
+  // ---- LDS-DMA of stage st into slot sl: wave w moves point rows 2w, 2w+1 of both tiles (1-KiB rows: one
+  // instruction each; the 256-byte embedding rows: one instruction, lanes 0-31) and the rider scalars of
+  // those two points.  The same count in every stage, also past the chunk end (zeros, no traffic), so the
+  // vmcnt below is a compile-time constant.
+  auto issue = [&](int st, int sl) {
+    float* slot = lds + sl * HW_SLOT;
+    const int grow = st * PT + 2 * wave;
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + (2 * wave + q) * 256), 16, lane * 16, (grow + q) * 1024, 0, 2);
+    if (KW == 256) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + PT * 256 + (2 * wave + q) * 256), 16, lane * 16,
+                                                 (grow + q) * 1024, 0, 2);
+    } else {
+      if (lane < 32)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + PT * 256 + 2 * wave * 64), 16, lane * 16, grow * 256, 0, 2);
+    }
+    if (lane < 2)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(slot + PT * 512 + 2 * wave), 4, lane * 4, grow * 4, 0, 0);
+    if (lane < 6)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(slot + PT * 512 + 16 + 6 * wave), 4,
+                                               (lane / 3) * 256 + (60 + lane % 3) * 4, grow * 256, 0, 0);
+  };
+
+  // ---- riders on the exact fp32 values of the published slot: thread = (column tid & 255, point half
+  // tid >> 8).  The column reads are issued unconditionally with the fragment reads and summed behind the
+  // MFMAs; the two rare riders (one job each) take one wave-uniform branch per stage, not one per point.
   float bias_acc = 0.f, alpha_acc = 0.f, dal_acc = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
-
-  float pa[8], pb[8];
-  auto issue = [&](int pt0) {
+  const int col = tid & 255, ph = __builtin_amdgcn_readfirstlane(tid >> 8);
+  const bool want_view = (jb.flags & WF_VIEWCOLS) != 0, want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
+  float rcol[PT / 2];
+  auto riders_read = [&](int sl) {
+    const float* slot = lds + sl * HW_SLOT;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int pt = pt0 + 8 * g + j;
-      pa[j] = pt < c1 ? dzm[(size_t)pt * 256 + col] : 0.f;
-      pb[j] = (has_b && pt < c1) ? inm[(size_t)pt * jb.in_stride + col] : 0.f;
-    }
+    for (int q = 0; q < PT / 2; ++q) rcol[q] = slot[(ph * (PT / 2) + q) * 256 + col];
   };
-  auto commit = [&](int pt0, int buf) {
-    _Float16* st = lds + buf * HW_STAGE;
-    half8 h, l;
+  auto riders_add = [&](int sl) {
+    const float* slot = lds + sl * HW_SLOT;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float x = pa[j] * S;
-      const _Float16 hx = (_Float16)x;
-      h[j] = hx; l[j] = (_Float16)(x - (float)hx);
-    }
-    *reinterpret_cast<half8*>(st + 0 * HW_PLANE + col * HW_ROW + 8 * g) = h;
-    *reinterpret_cast<half8*>(st + 1 * HW_PLANE + col * HW_ROW + 8 * g) = l;
-    if (has_b) {
+    for (int q = 0; q < PT / 2; ++q) bias_acc += rcol[q];
+    if (want_view) {
+      const float* vw = slot + PT * 512 + 16 + 3 * ph * (PT / 2);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const _Float16 hx = (_Float16)pb[j];
-        h[j] = hx; l[j] = (_Float16)(pb[j] - (float)hx);
-      }
-      *reinterpret_cast<half8*>(st + 2 * HW_PLANE + col * HW_ROW + 8 * g) = h;
-      *reinterpret_cast<half8*>(st + 3 * HW_PLANE + col * HW_ROW + 8 * g) = l;
-    }
-    // exact fp32 riders on the values in flight
-    if (jb.flags & WF_BIAS) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) bias_acc += pa[j];
-    }
-    if (jb.flags & WF_ALPHA) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int pt = pt0 + 8 * g + j;
-        const float da = pt < c1 ? a.dz[dz_dalpha_off(P) + pt] : 0.f;
-        alpha_acc = fmaf(da, pb[j], alpha_acc);
-        if (col == 0) dal_acc += da;
+      for (int q = 0; q < PT / 2; ++q) {
+        vc0 = fmaf(rcol[q], vw[3 * q + 0], vc0); vc1 = fmaf(rcol[q], vw[3 * q + 1], vc1); vc2 = fmaf(rcol[q], vw[3 * q + 2], vc2);
       }
     }
-    if ((jb.flags & WF_VIEWCOLS) && col < 128) {
+    if (want_alpha) {
+      const float* da = slot + PT * 512 + ph * (PT / 2);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int pt = pt0 + 8 * g + j;
-        if (pt < c1) {
-          const float* vw = a.acts + acts_emb_off(P) + (size_t)pt * 64 + 60;
-          vc0 = fmaf(pa[j], vw[0], vc0);
-          vc1 = fmaf(pa[j], vw[1], vc1);
-          vc2 = fmaf(pa[j], vw[2], vc2);
-        }
+      for (int q = 0; q < PT / 2; ++q) {
+        alpha_acc = fmaf(da[q], slot[PT * 256 + (ph * (PT / 2) + q) * 256 + col], alpha_acc);
+        dal_acc += da[q];
       }
     }
   };
 
-  issue(c0);
-  commit(c0, 0);
-  if (c0 + HW_PT < c1) issue(c0 + HW_PT);
-  __syncthreads();
-  int buf = 0;
-  for (int pt0 = c0; pt0 < c1; pt0 += HW_PT, buf ^= 1) {
-    if (pt0 + HW_PT < c1) commit(pt0 + HW_PT, buf ^ 1);
-    if (pt0 + 2 * HW_PT < c1) issue(pt0 + 2 * HW_PT);
-    if (active) {
-      const _Float16* st = lds + buf * HW_STAGE;
-      half8 ah[2], al[2];
+  // ---- fragments: lane (r, hh) reads its 8 points p = 8 hh + j; features 2r + t of dZ, NKT r + u of the input
+  auto split = [](float x, _Float16& h, _Float16& l) { h = (_Float16)x; l = (_Float16)(x - (float)h); };
+  auto compute = [&](int sl) {
+    if (!active) return;
+    const float* slot = lds + sl * HW_SLOT;
+    f32x2 av[8];
+    f32x4 bv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int p = 8 * hh + j;
+      av[j] = *reinterpret_cast<const f32x2*>(slot + p * 256 + n0 + 2 * r);
+      if (NKT == 4) bv[j] = *reinterpret_cast<const f32x4*>(slot + PT * 256 + p * 256 + k0 + 4 * r);
+      else bv[j][0] = slot[PT * 256 + p * 64 + k0 + r];
+    }
+    half8 ah[2], al[2], bh[NKT], bl[NKT];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) { _Float16 h, l; split(av[j][t] * S, h, l); ah[t][j] = h; al[t][j] = l; }
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) { _Float16 h, l; split(bv[j][u], h, l); bh[u][j] = h; bl[u][j] = l; }
+    }
+#pragma unroll
+    for (int u = 0; u < NKT; ++u)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int o = (n0 + 32 * t + r) * HW_ROW + 8 * hh;
-        ah[t] = *reinterpret_cast<const half8*>(st + 0 * HW_PLANE + o);
-        al[t] = *reinterpret_cast<const half8*>(st + 1 * HW_PLANE + o);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], acc[t][u], 0, 0, 0);
       }
-#pragma unroll
-      for (int u = 0; u < NKT; ++u) {
-        const int o = (k0 + 32 * u + r) * HW_ROW + 8 * hh;
-        const half8 bh = *reinterpret_cast<const half8*>(st + 2 * HW_PLANE + o);
-        const half8 bl = *reinterpret_cast<const half8*>(st + 3 * HW_PLANE + o);
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh, acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl, acc[t][u], 0, 0, 0);
-          acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh, acc[t][u], 0, 0, 0);
-        }
-      }
-    }
-    __syncthreads();
-  }
+  };
 
-  // ---- write the partial (dZ scale removed) ---------------------------------------------
+  const int ns = (npts + PT - 1) / PT;
+#pragma unroll
+  for (int st = 0; st < D - 1; ++st) issue(st, st);
+  int sl = 0;
+  for (int st = 0; st < ns; ++st) {
+    // stage st: this wave's pieces have landed (D-2 younger stages stay in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NI) : "memory");
+    hw_barrier();                                 // ... and so have everybody's; the slot of stage st-1 is read out
+    issue(st + D - 1, sl == 0 ? D - 1 : sl - 1);
+    riders_read(sl);
+    compute(sl);
+    riders_add(sl);
+    sl = sl + 1 == D ? 0 : sl + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land on the reduction scratch below
+  hw_barrier();
+
+  // ---- write the partial (dZ scale removed): MFMA row m of tile t = feature 2m + t, column r of tile u =
+  // input NKT r + u
   const float invS = 1.0f / S;
   if (active) {
+    const bool vec_ok = NKT == 4 && (jb.ld & 3) == 0 && (jb.kcol0 & 3) == 0 && (jb.w_off & 3) == 0 &&
+                        (reinterpret_cast<unsigned long long>(out) & 15) == 0 && jb.kvalid == 256;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int u = 0; u < NKT; ++u) {
-        const int k = k0 + 32 * u + r;
+      for (int i = 0; i < 16; ++i) {
+        const int m = (i & 3) + 8 * (i >> 2) + 4 * hh;
+        const int n = n0 + 2 * m + t;
+        if (n < jb.n_rows) {
+          float* dst = out + jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k0 + NKT * r;
+          if (NKT == 4 && vec_ok) {
+            const f32x4 v = {acc[t][0][i] * invS, acc[t][NKT > 1 ? 1 : 0][i] * invS, acc[t][NKT > 2 ? 2 : 0][i] * invS,
+                             acc[t][NKT > 3 ? 3 : 0][i] * invS};
+            *reinterpret_cast<f32x4*>(dst) = v;
+          } else {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int n = n0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (n < jb.n_rows && k < jb.kvalid)
-            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k] = acc[t][u][i] * invS;
+            for (int u = 0; u < NKT; ++u)
+              if (k0 + NKT * r + u < jb.kvalid) dst[u] = acc[t][u][i] * invS;
+          }
         }
       }
   }
-  // riders: the two point groups of a column are combined through LDS
-  float* red = reinterpret_cast<float*>(lds);      // [2][256][5]
-  red[(g * 256 + col) * 5 + 0] = bias_acc;
-  red[(g * 256 + col) * 5 + 1] = alpha_acc;
-  red[(g * 256 + col) * 5 + 2] = vc0;
-  red[(g * 256 + col) * 5 + 3] = vc1;
-  red[(g * 256 + col) * 5 + 4] = vc2;
+  // riders: the two point halves of a column are combined through LDS
+  float* red = lds;      // [2][256][5] | [2]
+  red[(ph * 256 + col) * 5 + 0] = bias_acc;
+  red[(ph * 256 + col) * 5 + 1] = alpha_acc;
+  red[(ph * 256 + col) * 5 + 2] = vc0;
+  red[(ph * 256 + col) * 5 + 3] = vc1;
+  red[(ph * 256 + col) * 5 + 4] = vc2;
+  if (col == 0) red[2 * 256 * 5 + ph] = dal_acc;
   __syncthreads();
   if (tid < 256) {
     const float* r0 = red + (size_t)tid * 5, *r1 = red + (size_t)(256 + tid) * 5;
     if ((jb.flags & WF_BIAS) && tid < jb.n_rows) out[jb.b_off + tid] = r0[0] + r1[0];
-    if (jb.flags & WF_ALPHA) out[jb.aux_off + tid] = r0[1] + r1[1];
+    if (KW == 256 && (jb.flags & WF_ALPHA)) out[jb.aux_off + tid] = r0[1] + r1[1];
     if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
       out[jb.w_off + (size_t)tid * jb.ld + 256] = r0[2] + r1[2];
       out[jb.w_off + (size_t)tid * jb.ld + 257] = r0[3] + r1[3];
       out[jb.w_off + (size_t)tid * jb.ld + 258] = r0[4] + r1[4];
     }
   }
-  if (jb.flags & WF_ALPHA) {
-    // d alpha bias: the two group partials held by the col == 0 threads (tid 0 and 256); no
-    // static __shared__ here (it would shift the 16-byte aligned dynamic LDS base)
-    float* dsum = red + 2 * 256 * 5;
-    if (col == 0) dsum[g] = dal_acc;
-    __syncthreads();
-    if (tid == 0) out[jb.aux_off + 256] = dsum[0] + dsum[1];
-  }
+  if (KW == 256 && (jb.flags & WF_ALPHA) && tid == 0) out[jb.aux_off + 256] = red[2 * 256 * 5] + red[2 * 256 * 5 + 1];
 }
 
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) {
-  extern __shared__ __attribute__((aligned(16))) _Float16 ldsw[];
+  extern __shared__ __attribute__((aligned(16))) float ldsw[];
   const WgradArgs& a = fa.w;
   const WgradJob& jb = a.jobs[blockIdx.y];
   const int c0 = blockIdx.x * a.chunk;
@@ -431,7 +480,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) 
     S = ldexpf(1.f, min(8 - e, 96));
   }
   if (jb.flags & WF_RGB) {
-    wgrad_rgb_job(a, jb, reinterpret_cast<float*>(ldsw), c0, c1, out);
+    wgrad_rgb_job(a, jb, ldsw, c0, c1, out);
   } else if (jb.kw == 256) {
     wgrad_f16_job<256>(a, jb, ldsw, c0, c1, S, out);
   } else {
@@ -482,12 +531,12 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   hipLaunchKernelGGL(mlp_dgrad_f16_kernel, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(dgrad)")) return e;
   if (!wgrad_f16) return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
-  static bool wattr = false;
-  if (!wattr) {
+  static unsigned long long wattr = 0;   // one bit per device ordinal
+  if (scade_attr_needed(wattr)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_f16_kernel),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_F16_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    wattr = true;
+    scade_attr_done(wattr);
   }
   WgradF16Args fa{};
   const int grid_x = build_wgrad_jobs(fa.w, acts, dz, g_out, partial, P, HW_PT);
