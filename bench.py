@@ -580,7 +580,7 @@ def main():
         try:
             out[key] = fn(*a, **k)
         except Exception as exc:   # noqa: BLE001 - reported, not swallowed
-            out[key] = {"error": f"{type(exc).__name__}: {exc}"}
+            out[key] = {"error": f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}"}
             print(f"bench.py: secondary region {key} failed: {exc!r}", file=sys.stderr)
 
     # exact fp32 regions first, the opt-in reduced-precision regions after them (the 16-bit bursts
