@@ -242,8 +242,11 @@ constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4 + 16;   // + the fo
 //     (input) consecutive bytes of each of its 8 points - features 2r, 2r+1 (4r..4r+3), the operands of two
 //     (four) different output tiles - so MFMA row r of tile t is feature 2r + t, column r of tile u is input
 //     4r + u; 16 conflict-free LDS reads per 24 MFMAs, and the split into fp16 planes happens on the VALU
-//     behind the read (each value is split by the 2 / 4 waves that use it: ~240 VALU ops per wave and
-//     stage beside 24 MFMAs - this kernel is HBM-bound, 2 KB per point-layer);
+//     behind the read (each value is split by the 2 / 4 waves that use it: 88 hand-selected VALU ops per
+//     wave and stage - v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16 - beside 24 MFMAs).  Knock-outs: the memory
+//     system alone would take 0.53 ms over the train step's launch mix, the compute phases alone 0.57 ms
+//     (the MFMAs themselves are free: the conversion-class VALU ops run at a fraction of the plain VALU
+//     rate and both waves of a SIMD do them in lock step), the kernel 0.63 ms;
 //   x = h + l' with l' = fp16(x - h) UNSCALED (may be fp16-subnormal: absolute error <= 2^-25 of the operand
 //   scale), so ONE fp32 accumulator set (128 VGPRs for the wave's 64 x 128 outputs) takes h*h + h*l' + l'*h.
 //   dZ is multiplied by ONE power of two per launch (from max|g_out|, found by the dgrad kernel) so its
@@ -368,7 +371,17 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   };
 
   // ---- fragments: lane (r, hh) reads its 8 points p = 8 hh + j; features 2r + t of dZ, NKT r + u of the input
-  auto split = [](float x, _Float16& h, _Float16& l) { h = (_Float16)x; l = (_Float16)(x - (float)h); };
+  // two values -> packed fp16 planes: h = rne16(x), l = rne16(x - h).  Three VALU ops per pair: v_cvt_pk_f16_f32,
+  // then v_fma_mixlo/hi_f16 (h * -1 + x in fp32 - exact - rounded to fp16 into the low / high half), which read
+  // the fp16 h in place; hipcc's own selection converts h back, subtracts and converts again (and SLP-packs the
+  // arithmetic into v_pk_* at the price of a register move per operand): 320 VALU ops per wave and stage, 4x
+  // the MFMA time of the stage.
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  auto split_pair = [](float x0, float x1, unsigned& h, unsigned& l) {
+    asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
+    asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
+  };
   auto compute = [&](int sl) {
     if (!active) return;
     const float* slot = lds + sl * HW_SLOT;
@@ -381,21 +394,31 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
       if (NKT == 4) bv[j] = *reinterpret_cast<const f32x4*>(slot + PT * 256 + p * 256 + k0 + 4 * r);
       else bv[j][0] = slot[PT * 256 + p * 64 + k0 + r];
     }
-    half8 ah[2], al[2], bh[NKT], bl[NKT];
+    u32x4 ahp[2], alp[2], bhp[NKT], blp[NKT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j2 = 0; j2 < 4; ++j2) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) { _Float16 h, l; split(av[j][t] * S, h, l); ah[t][j] = h; al[t][j] = l; }
+      for (int t = 0; t < 2; ++t) {
+        unsigned h, l;
+        split_pair(av[2 * j2][t] * S, av[2 * j2 + 1][t] * S, h, l);
+        ahp[t][j2] = h; alp[t][j2] = l;
+      }
 #pragma unroll
-      for (int u = 0; u < NKT; ++u) { _Float16 h, l; split(bv[j][u], h, l); bh[u][j] = h; bl[u][j] = l; }
+      for (int u = 0; u < NKT; ++u) {
+        unsigned h, l;
+        split_pair(bv[2 * j2][u], bv[2 * j2 + 1][u], h, l);
+        bhp[u][j2] = h; blp[u][j2] = l;
+      }
     }
 #pragma unroll
     for (int u = 0; u < NKT; ++u)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bh[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[t], bl[u], acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[t], bh[u], acc[t][u], 0, 0, 0);
+        const half8 ah = __builtin_bit_cast(half8, ahp[t]), al = __builtin_bit_cast(half8, alp[t]);
+        const half8 bh = __builtin_bit_cast(half8, bhp[u]), bl = __builtin_bit_cast(half8, blp[u]);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][u], 0, 0, 0);
       }
   };
 
