@@ -85,15 +85,15 @@ __device__ __forceinline__ void dgrad_store_h(const f32x16 (&acc0)[2][2], const 
       for (int p = 0; p < 2; ++p) {
         const int row = p * 32 + r;
         half4 vh, vl;
+        float xs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
           if (ADD_ALPHA) x = x + wa[i] * dal_scaled[row];
           if (MASK) x = ((bits >> (p * 32 + (t * 4 + q) * 4 + i)) & 1ull) ? x : 0.f;
-          _Float16 h, l;
-          split2(x, h, l);
-          vh[i] = h; vl[i] = l;
+          xs[i] = x;
         }
+        split4(xs, vh, vl);
         const int o = x_idx(row, f >> 3) + (f & 7);
         *reinterpret_cast<half4*>(gh + o) = vh;
         *reinterpret_cast<half4*>(gl + o) = vl;

@@ -68,15 +68,15 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
       for (int q = 0; q < 4; ++q) {
         const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
         half4 vh, vl;
+        float xs[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
           if (RELU && x > 0.f) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
           if (RELU) x = x < 0.f ? 0.f : x;     // NaN-propagating relu (torch.relu semantics)
-          _Float16 h, l;
-          split2(x, h, l);
-          vh[i] = h; vl[i] = l;
+          xs[i] = x;
         }
+        split4(xs, vh, vl);
         const int row = p * 32 + r;
         const int o = x_idx(row, f >> 3) + (f & 7);
         *reinterpret_cast<half4*>(xh + o) = vh;
