@@ -593,6 +593,25 @@ def main():
         guarded("train_step", train_region, *tr_args)
         if use_dist:
             guarded("train_step_overlap", train_region, *tr_args, allreduce="overlap")
+    if use_dist and not args.no_image:
+        # ONE 468 x 624 test image with its rays split over the ranks, maps all-gathered
+        def sharded_image():
+            Hh, Ww = 468, 624
+            intr = torch.tensor([578.0, 578.0, 312.0, 234.0], device=dev)
+            c2w = torch.eye(4, device=dev)[:3, :4].contiguous()
+            kw = dict(chunk=16384, c2w=c2w, near=0.1, far=5.0, use_viewdirs=True, network_fn=coarse, shard_group=True,
+                      network_query_fn=query, N_samples=N_COARSE, N_importance=N_FINE, network_fine=fine, perturb=0.)
+            with torch.no_grad():
+                S.render(Hh, Ww, intr, **kw)
+                barrier()
+                t0 = time.perf_counter()
+                rgb = S.render(Hh, Ww, intr, **kw)[0]
+                barrier()
+            dt = time.perf_counter() - t0
+            assert rgb.shape == (Hh, Ww, 3) and bool(torch.isfinite(rgb).all())
+            return {"ms_per_image": dt * 1e3, "rays_per_s": Hh * Ww / dt, "ranks": world,
+                    "note": "one image, rays sharded over the ranks, per-pixel maps all-gathered to every rank"}
+        guarded("full_image_468x624_sharded", sharded_image)
     if not args.no_rayops and rank == 0:
         guarded("per_ray_kernels_16384", rayops_region, dev, 16384, args.hyp)
     if use_dist:

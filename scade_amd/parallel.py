@@ -179,6 +179,44 @@ def combine_shard_means(means: torch.Tensor, n_local: int, group=None, n_total: 
     return share, world
 
 
+def gather_rows(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor:
+    """Rows of a tensor that was split with ``shard_range(n_total, rank, world)`` -> all ``n_total`` rows on
+    EVERY rank (one all-gather of equal, zero-padded pieces: the collective needs equal sizes, shards differ
+    by at most one row)."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return local
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (n_total + world - 1) // world
+    a, b = shard_range(n_total, rank, world)
+    assert local.shape[0] == b - a, (local.shape, a, b)
+    piece = local.new_zeros((per,) + tuple(local.shape[1:]))
+    piece[:b - a] = local
+    pieces = [torch.empty_like(piece) for _ in range(world)]
+    dist.all_gather(pieces, piece, group=group)
+    parts = []
+    for r in range(world):
+        ra, rb = shard_range(n_total, r, world)
+        parts.append(pieces[r][:rb - ra])
+    return torch.cat(parts, 0)
+
+
+IMAGE_KEYS = ("rgb_map", "disp_map", "acc_map", "depth_map", "rgb0", "disp0", "acc0", "depth0", "z_std")
+
+
+def render_rays_sharded(rays_flat: torch.Tensor, render_fn, group=None, keys: Optional[Sequence[str]] = IMAGE_KEYS):
+    """Test render over the ranks (rays are independent units): this rank renders its
+    contiguous share of the ray rows with ``render_fn(rows) -> dict`` and the per-ray maps are all-gathered,
+    so every rank ends up with the whole image.  ``keys`` limits what travels (default: the per-pixel maps the
+    eval loop reads; ``None`` = every key, including the [N,192] sample arrays).  Rays never interact, so the
+    result is bit-identical to the single-process render."""
+    n = rays_flat.shape[0]
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return render_fn(rays_flat)
+    a, b = shard_range(n, dist.get_rank(group), dist.get_world_size(group))
+    ret = render_fn(rays_flat[a:b])
+    return {k: gather_rows(v.contiguous(), n, group) for k, v in ret.items() if keys is None or k in keys}
+
+
 def shared_uniform(shape, device, generator=None, src: int = 0, group=None) -> torch.Tensor:
     """One uniform draw shared by all ranks (sample_pdf_joint draws ONE u[S] for the whole batch,
     helpers:452-453): drawn on ``src`` and broadcast."""

@@ -347,9 +347,13 @@ def _assemble_rays(H, W, intrinsic, rays, c2w, near, far, use_viewdirs, c2w_stat
 
 
 def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near=0., far=1.,
-           with_5_9=False, use_viewdirs=False, c2w_staticcam=None, rays_depth=None, streams=1, **kwargs):
+           with_5_9=False, use_viewdirs=False, c2w_staticcam=None, rays_depth=None, streams=1,
+           shard_group=None, shard_keys="image", **kwargs):
     """run_scade_scannet.py:80-155 (ray-row assembly is host plumbing).  ``with_5_9`` keeps the centre
-    columns of a full-image render (:108-115, one third of 16:9, used by render_video)."""
+    columns of a full-image render (:108-115, one third of 16:9, used by render_video).
+    ``shard_group`` (a torch.distributed group, or True for the default group): the ray rows are split
+    over the ranks and the per-pixel maps all-gathered (parallel.render_rays_sharded) - every rank returns
+    the whole image; ``shard_keys`` = "image" (per-pixel maps only) or None (every key)."""
     if c2w is not None and use_viewdirs and c2w_staticcam is None and rays_depth is None:
         # full image: ray rows straight from the generation kernel (no [H,W,3] intermediates)
         rays_flat = ops.gen_rays(H, W, intrinsic, c2w, near=near, far=far)["rays"]
@@ -363,7 +367,14 @@ def render(H, W, intrinsic, chunk=1024 * 32, rays=None, c2w=None, ndc=True, near
         start = (W - Wc) // 2
         rays_flat = rays_flat.reshape(H, W, -1)[:, start:start + Wc].reshape(H * Wc, -1).contiguous()
         sh = (H, Wc, 3)
-    all_ret = batchify_rays(rays_flat, chunk, use_viewdirs, streams=streams, **kwargs)
+    if shard_group is not None and shard_group is not False:
+        from . import parallel
+        all_ret = parallel.render_rays_sharded(
+            rays_flat, lambda rows: batchify_rays(rows, chunk, use_viewdirs, streams=streams, **kwargs),
+            group=None if shard_group is True else shard_group,
+            keys=parallel.IMAGE_KEYS if shard_keys == "image" else shard_keys)
+    else:
+        all_ret = batchify_rays(rays_flat, chunk, use_viewdirs, streams=streams, **kwargs)
     for k in all_ret:
         all_ret[k] = torch.reshape(all_ret[k], list(sh[:-1]) + list(all_ret[k].shape[1:]))
     k_extract = ['rgb_map', 'disp_map', 'acc_map']

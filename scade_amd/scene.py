@@ -226,13 +226,15 @@ class MeanTracker:
 
 @torch.no_grad()
 def render_images_with_metrics(images, depths, valid_depths, poses, Hh, Ww, intrinsics, render_kwargs_test,
-                               chunk=1024 * 16, count=None, indices=None) -> Dict[str, object]:
+                               chunk=1024 * 16, count=None, indices=None, shard_group=None) -> Dict[str, object]:
     """The render + PSNR + depth-RMSE part of run_scade_scannet.py:304-394 (SSIM = skimage and
     LPIPS = AlexNet are third-party metrics and stay with the caller).  images [M,H,W,3],
     depths [M,H,W,1], valid_depths [M,H,W] are device tensors; returns per-image and mean metrics,
     the rendered rgb / depth maps, and under ``"images"`` / ``"mean_metrics"`` the result dict and
     tracker in the reference's layout (:380-394: channel-first CPU tensors, rgb clamped to [0,1],
-    depths divided by ``far``) that ``write_images_with_metrics`` consumes."""
+    depths divided by ``far``) that ``write_images_with_metrics`` consumes.  ``shard_group``: every image's
+    rays are split over the ranks of that torch.distributed group (True = default group) and the maps
+    all-gathered, so each rank computes the same metrics from the same whole images."""
     idx = list(range(images.shape[0])) if indices is None else list(indices)
     if count is not None:
         idx = idx[:count]
@@ -241,7 +243,8 @@ def render_images_with_metrics(images, depths, valid_depths, poses, Hh, Ww, intr
     res = {k: [] for k in ("rgbs", "target_rgbs", "depths", "target_depths", "target_valid_depths", "rgbs0", "depths0")}
     mean_metrics, mean_depth_metrics = MeanTracker(), MeanTracker()
     for n in idx:
-        rgb, _, _, extras = R.render(Hh, Ww, intrinsics[n], chunk=chunk, c2w=poses[n], **render_kwargs_test)
+        rgb, _, _, extras = R.render(Hh, Ww, intrinsics[n], chunk=chunk, c2w=poses[n], shard_group=shard_group,
+                                     **render_kwargs_test)
         target = images[n]
         img_loss = H.img2mse(rgb, target)
         out["img_loss"].append(float(img_loss))

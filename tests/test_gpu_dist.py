@@ -68,6 +68,27 @@ def _run_case(dev, kw, use_mask, a, b, n_total, two_steps=True):
     return grad.cpu(), tr.bucket.data.clone().cpu(), float(loss)
 
 
+IMG_H, IMG_W = 21, 23          # 483 rays: uneven shards, a ragged last chunk
+
+
+def _render_image(dev, shard):
+    """One full-image test render (run_scade_scannet.py:80-155) through scade_amd.render."""
+    import scade_amd as S
+    from scade_amd.train import make_scade_nets
+    coarse, fine = make_scade_nets(dev, seed=5)
+    e, _ = S.get_embedder(9, 0)
+    ed, _ = S.get_embedder(0, 0)
+    query = S.make_network_query_fn(e, ed, torch.zeros(3, device=dev), torch.tensor(0.2, device=dev))
+    intr = torch.tensor([30.0, 30.0, IMG_W / 2, IMG_H / 2], device=dev)
+    c2w = torch.eye(4, device=dev)[:3, :4].contiguous()
+    with torch.no_grad():
+        rgb, disp, acc, extras = S.render(IMG_H, IMG_W, intr, chunk=128, c2w=c2w, near=0.1, far=5.0, use_viewdirs=True,
+                                          shard_group=True if shard else None, network_fn=coarse, network_fine=fine,
+                                          network_query_fn=query, N_samples=NS, N_importance=NI, perturb=0.)
+    return {"rgb": rgb.cpu(), "disp": disp.cpu(), "acc": acc.cpu(), "depth": extras["depth_map"].cpu(),
+            "rgb0": extras["rgb0"].cpu(), "z_std": extras["z_std"].cpu(), "keys": sorted(extras)}
+
+
 def _worker(rank, world, port, out_dir, backend):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -86,6 +107,7 @@ def _worker(rank, world, port, out_dir, backend):
         out[name] = _run_case(dev, kw, use_mask, a, b, N_RAYS)
     torch.manual_seed(100 + rank)
     out["shared_u"] = shared_uniform((NI,), dev).cpu()
+    out["render"] = _render_image(dev, shard=True)          # test render sharded over the ranks
     if backend == "nccl":
         # the whole sharded step as ONE HIP graph (RCCL all-reduce captured), joint exchange included
         from scade_amd.graphs import GraphedTrainer
@@ -136,6 +158,14 @@ def test_sharded_trainer_two_ranks_matches_single_process(dev, tmp_path):
             # element that is summation-order noise around zero moves its weight by +-lr in either run
             # (2 lr = 1e-3 against weights of ~0.1); the gradient comparison above is the sharp test
             assert rel_l2(p0, p) < 1e-3, f"{name}: parameters after two steps {rel_l2(p0, p):.2e}"
+    # sharded test render: every rank holds the whole image, bit-identical to the one-process render
+    want = _render_image(dev, shard=False)
+    for r in range(world):
+        got = outs[r]["render"]
+        assert got["rgb"].shape == (IMG_H, IMG_W, 3)
+        for k in ("rgb", "disp", "acc", "depth", "rgb0", "z_std"):
+            assert torch.equal(torch.nan_to_num(got[k]), torch.nan_to_num(want[k])), f"rank {r}: sharded render {k} differs"
+        assert "z_vals" not in got["keys"] and "z_vals" in want["keys"], "only the per-pixel maps travel by default"
     if backend == "nccl":
         for name in ("graph", "graph_joint"):
             eager, graphed = outs[0][name]

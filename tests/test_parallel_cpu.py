@@ -11,7 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import scade_oracle as O
-from scade_amd.parallel import FlatParams, batch_share, shard_batch, shard_range, staircase_lr
+from scade_amd.parallel import (FlatParams, batch_share, gather_rows, render_rays_sharded, shard_batch, shard_range,
+                                staircase_lr)
 
 
 def test_shard_range_covers_everything():
@@ -218,3 +219,45 @@ def test_joint_space_carving_exchange_matches_single_process(tmp_path):
     assert torch.allclose(gp, p.grad, rtol=1e-5, atol=1e-8)
     assert torch.allclose(gh, h.grad, rtol=1e-5, atol=1e-8)
     assert torch.equal(outs[0][3], outs[1][3]), "sample_pdf_joint's u must be one draw for all ranks"
+
+
+def _fake_render(rows):
+    """Stands in for batchify_rays on CPU: per-ray maps that depend on the ray row only."""
+    return {"rgb_map": rows[:, :3] * 2.0, "depth_map": rows.sum(-1), "z_vals": rows[:, :4].repeat(1, 2)}
+
+
+def _render_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rays = O.synthetic_rays(17, seed=9)                       # 17 rays over 2 ranks: shards of 9 and 8
+    a, b = shard_range(17, rank, world)
+    full = gather_rows(rays[a:b].contiguous(), 17)
+    img = render_rays_sharded(rays, _fake_render)             # default keys: per-pixel maps only
+    everything = render_rays_sharded(rays, _fake_render, keys=None)
+    q.put((rank, full, img, everything))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_test_render_gathers_whole_image_on_every_rank():
+    """the test render shards the H*W rays over the ranks and gathers the image."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_render_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(60)
+    rays = O.synthetic_rays(17, seed=9)
+    want = _fake_render(rays)
+    for rank, full, img, everything in res:
+        assert torch.equal(full, rays), f"rank {rank}: gather_rows"
+        assert sorted(img) == ["depth_map", "rgb_map"], sorted(img)
+        assert sorted(everything) == ["depth_map", "rgb_map", "z_vals"]
+        for k in everything:
+            assert torch.equal(everything[k], want[k]), (rank, k)
+    # one process (no group): the function is the identity wrapper
+    assert torch.equal(render_rays_sharded(rays, _fake_render)["z_vals"], want["z_vals"])
