@@ -225,7 +225,7 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
     coarse backward chain), fused Adam.  ``rays_per_gpu`` rays on every rank; ``graphed``: the whole
     step (collective included) replayed as one HIP graph."""
     import torch.distributed as dist
-    from scade_amd import ops
+    from scade_amd import ops, parallel
     from scade_amd.graphs import GraphedTrainer
     from scade_amd.train import Trainer, make_scade_nets
     from scade_amd.synthetic import synthetic_rays
@@ -235,6 +235,7 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
                  allreduce=allreduce)
     tr.force_allreduce = dist.is_initialized() and world == 1      # one-rank RCCL self-test of the exchange
     rays = synthetic_rays(n, seed=2000 + rank).to(dev)
+    parallel.seed_rank_streams(7000)                 # identical weights above, per-rank distinct jitter / u draws
     g = torch.Generator(device="cpu").manual_seed(3000 + rank)
     tgt = torch.rand(n, 3, generator=g).to(dev)
     hyp = (torch.rand(args.hyp, n, 1, generator=g) * 4.9 + 0.1).to(dev)

@@ -217,6 +217,16 @@ def render_rays_sharded(rays_flat: torch.Tensor, render_fn, group=None, keys: Op
     return {k: gather_rows(v.contiguous(), n, group) for k, v in ret.items() if keys is None or k in keys}
 
 
+def seed_rank_streams(seed: int, group=None) -> int:
+    """Per-rank distinct jitter / u streams (identical weight init on all ranks, distinct
+    random draws): seeds the CPU and device generators of this process with ``seed + rank``.  Call it AFTER the
+    networks are built (their init wants the SAME seed everywhere, or ``FlatParams.broadcast``); draws that
+    must be common to all ranks (sample_pdf_joint's u) go through ``shared_uniform``."""
+    rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
+    torch.manual_seed(seed + rank)
+    return seed + rank
+
+
 def shared_uniform(shape, device, generator=None, src: int = 0, group=None) -> torch.Tensor:
     """One uniform draw shared by all ranks (sample_pdf_joint draws ONE u[S] for the whole batch,
     helpers:452-453): drawn on ``src`` and broadcast."""

@@ -11,8 +11,8 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 from oracle import scade_oracle as O
-from scade_amd.parallel import (FlatParams, batch_share, gather_rows, render_rays_sharded, shard_batch, shard_range,
-                                staircase_lr)
+from scade_amd.parallel import (FlatParams, batch_share, gather_rows, render_rays_sharded, seed_rank_streams,
+                                shard_batch, shard_range, staircase_lr)
 
 
 def test_shard_range_covers_everything():
@@ -235,7 +235,8 @@ def _render_worker(rank, world, port, q):
     full = gather_rows(rays[a:b].contiguous(), 17)
     img = render_rays_sharded(rays, _fake_render)             # default keys: per-pixel maps only
     everything = render_rays_sharded(rays, _fake_render, keys=None)
-    q.put((rank, full, img, everything))
+    seed_rank_streams(5)
+    q.put((rank, full, img, everything, torch.rand(4)))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -253,11 +254,15 @@ def test_sharded_test_render_gathers_whole_image_on_every_rank():
         p.join(60)
     rays = O.synthetic_rays(17, seed=9)
     want = _fake_render(rays)
-    for rank, full, img, everything in res:
+    draws = {}
+    for rank, full, img, everything, draw in res:
+        draws[rank] = draw
+        assert torch.equal(draw, torch.rand(4, generator=torch.Generator().manual_seed(5 + rank))), "seed + rank"
         assert torch.equal(full, rays), f"rank {rank}: gather_rows"
         assert sorted(img) == ["depth_map", "rgb_map"], sorted(img)
         assert sorted(everything) == ["depth_map", "rgb_map", "z_vals"]
         for k in everything:
             assert torch.equal(everything[k], want[k]), (rank, k)
+    assert not torch.equal(draws[0], draws[1]), "per-rank distinct jitter streams (SURVEY 8e)"
     # one process (no group): the function is the identity wrapper
     assert torch.equal(render_rays_sharded(rays, _fake_render)["z_vals"], want["z_vals"])
