@@ -185,6 +185,15 @@ __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc
 #undef MFMA6
 }
 
+// x = h + l * 2^-11 for the two halves of a packed pair, one v_fma_mix_f32 each (it reads the fp16 operands in
+// place; l * 2^-11 is exact, so this is the same single rounding as convert, convert, scale, add - which is
+// what hipcc selects under -ffp-contract=off: two conversion-class VALU ops per value instead of none)
+__device__ __forceinline__ void join2(unsigned hp, unsigned lp, float& x0, float& x1) {
+  const float inv = LINV;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(x0) : "v"(lp), "s"(inv), "v"(hp));
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,1] op_sel_hi:[1,0,1]" : "=v"(x1) : "v"(lp), "s"(inv), "v"(hp));
+}
+
 // coalesced fp32 copy of the two-plane tile (first ncols columns, optional per-row scale) to
 // dst[P][256] as full rows
 __device__ __forceinline__ void save_tile_h(const _Float16* xh, const _Float16* xl, float* __restrict__ dst,
@@ -193,15 +202,14 @@ __device__ __forceinline__ void save_tile_h(const _Float16* xh, const _Float16* 
   for (int i = tid; i < HM * cpr; i += 256) {
     const int row = i / cpr, c = i - row * cpr;
     if (p0 + row < P) {
-      const half8 vh = *reinterpret_cast<const half8*>(xh + x_idx(row, c));
-      const half8 vl = *reinterpret_cast<const half8*>(xl + x_idx(row, c));
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(xh + x_idx(row, c));
+      const u32x4 vl = *reinterpret_cast<const u32x4*>(xl + x_idx(row, c));
       const float sc = row_scale ? row_scale[row] : 1.0f;
-      f32x4 o0, o1;
+      float x[8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        o0[j] = ((float)vh[j] + (float)vl[j] * LINV) * sc;
-        o1[j] = ((float)vh[4 + j] + (float)vl[4 + j] * LINV) * sc;
-      }
+      for (int k = 0; k < 4; ++k) join2(vh[k], vl[k], x[2 * k], x[2 * k + 1]);
+      const f32x4 o0 = {x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc}, o1 = {x[4] * sc, x[5] * sc, x[6] * sc, x[7] * sc};
       float* o = dst + (size_t)(p0 + row) * W + 8 * c;
       __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(o));       // streamed once: non-temporal
       __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(o + 4));
