@@ -743,6 +743,7 @@ class TrainLossFn(torch.autograd.Function):
         ctx.ss = (scales, shifts)
         comps = loss4[1:]
         ctx.mark_non_differentiable(comps)
+        ctx.set_materialize_grads(False)      # no zero-fill launch for the non-differentiable second output
         return loss4[0], comps
 
     @staticmethod

@@ -97,7 +97,15 @@ class Trainer:
         # the three-term loss as one fused operator (ops.TrainLossFn) instead of the separate public
         # operators (same arithmetic; ``fused_loss=False`` keeps the operator-by-operator path)
         self.fused_loss = fused_loss
+        self._one = torch.ones((), device=dev)      # see _unit_grad (built here, never inside a graph capture)
         self.bucket.broadcast_params(0)
+
+    def _unit_grad(self, loss):
+        """d loss / d loss = 1 from a cached tensor (autograd would launch a fill for it every step)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.shape != loss.shape or one.device != loss.device:
+            one = self._one = torch.ones_like(loss)
+        return one
 
     # -- reference loop predicates on i = it + 1 ------------------------------------------------
     def carving_active(self):
@@ -195,7 +203,7 @@ class Trainer:
         aux).  ``n_total``: rays of the whole batch when the shards are uneven."""
         self.bucket.zero_grad()
         loss, aux = self.forward_loss(rays, target_s, target_hyp, img_i, mask, n_total, **render_kw)
-        loss.backward()                                                                       # :985
+        loss.backward(self._unit_grad(loss))                                                  # :985
         self.reduce_grads()
         lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it + 1)  # :988-991
         self.opt.step(lr=lr)                                                                  # :993
