@@ -182,7 +182,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   const float* __restrict__ alpha_pre = reinterpret_cast<const float*>(a.acts + lp_acts_alpha_byte(P));
   float* __restrict__ dalpha = reinterpret_cast<float*>(a.dz + lp_dz_dalpha_byte(P));
   const u32x4* __restrict__ masks = reinterpret_cast<const u32x4*>(a.acts + lp_acts_mask_byte(P));
-  const float S = lp_loss_scale(a.gmax[0]);
+  // bf16 carries fp32's exponent range: the launch-wide loss scale (and the two launches that find it) is an
+  // fp16 matter; a power-of-two scale commutes with every rounding here, so S = 1 gives the same bits
+  const float S = BF ? 1.f : lp_loss_scale(a.gmax[0]);
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
 #pragma unroll
@@ -581,7 +583,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs a) {
   const int c0 = blockIdx.x * a.chunk;
   const int c1 = min(a.P, c0 + a.chunk);
   float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
-  const float invS = 1.0f / lp_loss_scale(a.gmax[0]);
+  const float invS = BF ? 1.0f : 1.0f / lp_loss_scale(a.gmax[0]);
   if (jb.flags & WF_RGB) {
     wgrad_rgb_lp_job<BF>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);
   } else if (jb.kw == 256) {
@@ -665,12 +667,14 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   unsigned char* dz = ws;
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
   unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)pick_chunks(P, LP_CHUNK_PTS) * N_PARAM_FLOATS);
-  hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
-  SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
-  const long ng = 4L * P;
-  const int gblocks = (int)((ng + 256 * 16 - 1) / (256 * 16) < 256 ? (ng + 256 * 16 - 1) / (256 * 16) : 256);   // ng = 4 P
-  hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(256), 0, s, g_out, ng, gmax);
-  if (int e = scade_check_launch("scade_mlp_bwd_lp(gmax)")) return e;
+  if (!BF) {   // fp16 only: the launch-wide loss scale (bf16 kernels use S = 1 and never read gmax)
+    hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
+    SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
+    const long ng = 4L * P;
+    const int gblocks = (int)((ng + 256 * 16 - 1) / (256 * 16) < 256 ? (ng + 256 * 16 - 1) / (256 * 16) : 256);   // ng = 4 P
+    hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(256), 0, s, g_out, ng, gmax);
+    if (int e = scade_check_launch("scade_mlp_bwd_lp(gmax)")) return e;
+  }
   MlpDgradLpArgs d{packed, packed_t, acts, g_out, dz, reinterpret_cast<const float*>(gmax), P};
   // same point tiling as the forward that wrote the sign words of this workspace
   if (lp_pick_point_tiles(P) == 2)
