@@ -129,13 +129,23 @@ def mlp_acts_alloc(P: int, device) -> Tensor:
     return torch.empty(int(_lib.load().scade_mlp_acts_floats(P)), device=device, dtype=torch.float32)
 
 
-def mlp_bwd(packed: Tensor, packed_t: Tensor, acts: Tensor, g_out: Tensor) -> Tensor:
-    """-> flat gradient [589700] in PARAM_ORDER."""
+def _grad_out(out: Optional[Tensor], device) -> Tensor:
+    """the flat gradient buffer of an MLP backward: a fresh tensor, or the caller's (OVERWRITTEN: the reduce
+    kernel writes every one of its N_PARAM_FLOATS elements)"""
+    if out is None:
+        return torch.empty(N_PARAM_FLOATS, device=device, dtype=torch.float32)
+    if out.dtype != torch.float32 or not out.is_contiguous() or out.numel() != N_PARAM_FLOATS or out.device != device:
+        raise ValueError("mlp_bwd: out must be a contiguous fp32 tensor of N_PARAM_FLOATS elements on the device of g_out")
+    return out
+
+
+def mlp_bwd(packed: Tensor, packed_t: Tensor, acts: Tensor, g_out: Tensor, out: Optional[Tensor] = None) -> Tensor:
+    """-> flat gradient [589700] in PARAM_ORDER (written into ``out`` when given)."""
     g = _c(check(g_out, "mlp_bwd: g_out")).reshape(-1, 4)
     P = g.shape[0]
     ws = torch.empty(int(_lib.load().scade_mlp_bwd_workspace_floats(P)), device=g.device,
                      dtype=torch.float32)
-    grad = torch.empty(N_PARAM_FLOATS, device=g.device, dtype=torch.float32)
+    grad = _grad_out(out, g.device)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
     call("scade_mlp_bwd", ptr(packed), ptr(packed_t), ptr(acts), ptr(g), P, ptr(ws), ptr(grad), stream())
     if t0 is not None:
@@ -163,12 +173,12 @@ def mlp_pack_t_f16(params: Sequence[Tensor]) -> Tensor:
 
 
 def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tensor,
-                wgrad_f16: bool = True) -> Tensor:
+                wgrad_f16: bool = True, out: Optional[Tensor] = None) -> Tensor:
     """Split-precision dgrad + exact wgrad -> flat gradient [589700] in PARAM_ORDER."""
     g = _c(check(g_out, "mlp_bwd_f16: g_out")).reshape(-1, 4)
     P = g.shape[0]
     ws = torch.empty(int(_lib.load().scade_mlp_bwd_workspace_floats(P)), device=g.device, dtype=torch.float32)
-    grad = torch.empty(N_PARAM_FLOATS, device=g.device, dtype=torch.float32)
+    grad = _grad_out(out, g.device)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
     call("scade_mlp_bwd_f16", ptr(packed), ptr(packed_t_f16), ptr(acts), ptr(g), P, int(wgrad_f16), ptr(ws),
          ptr(grad), stream())
@@ -222,12 +232,13 @@ def mlp_pack_t_lp(params: Sequence[Tensor], bf16: bool) -> Tensor:
     return out
 
 
-def mlp_bwd_lp(packed: Optional[Tensor], packed_t_lp: Tensor, bf16: bool, acts: Tensor, g_out: Tensor) -> Tensor:
+def mlp_bwd_lp(packed: Optional[Tensor], packed_t_lp: Tensor, bf16: bool, acts: Tensor, g_out: Tensor,
+               out: Optional[Tensor] = None) -> Tensor:
     """16-bit dgrad + wgrad (fp32 accumulate, power-of-two loss scaling) -> flat gradient [589700]."""
     g = _c(check(g_out, "mlp_bwd_lp: g_out")).reshape(-1, 4)
     P = g.shape[0]
     ws = torch.empty(int(_lib.load().scade_mlp_bwd_lp_workspace_bytes(P)), device=g.device, dtype=torch.uint8)
-    grad = torch.empty(N_PARAM_FLOATS, device=g.device, dtype=torch.float32)
+    grad = _grad_out(out, g.device)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
     call("scade_mlp_bwd_lp", ptr(packed), ptr(packed_t_lp), int(bf16), ptr(acts), ptr(g), P, ptr(ws), ptr(grad),
          stream())

@@ -45,6 +45,7 @@ class FlatParams:
         self.numel = sum(p.numel() for p in self.params)
         self.data = torch.empty(self.numel, device=dev, dtype=torch.float32)
         self.grad = torch.zeros(self.numel, device=dev, dtype=torch.float32)
+        self._sinks = []            # (net, offset) of the networks attach_grad_sinks() gave a sink
         o = 0
         for p in self.params:
             n = p.numel()
@@ -64,6 +65,7 @@ class FlatParams:
         for p in self.params:
             starts[id(p)] = o
             o += p.numel()
+        self._sinks = []
         for net in nets:
             ps = net.ordered_params()
             o0 = starts.get(id(ps[0]))
@@ -73,9 +75,37 @@ class FlatParams:
                 ok = ok and starts.get(id(p)) == o
                 o += p.numel()
             net._grad_sink = self.grad[o0:o0 + ops.N_PARAM_FLOATS] if ok else None
+            net._sink_fresh = False
+            if ok:
+                self._sinks.append((net, o0))
+
+    def begin_step(self):
+        """Start of a train step, instead of ``zero_grad()``: a network with a gradient sink gets its
+        gradient WRITTEN into the sink by the first fused backward of the step (ops.mlp_bwd*(out=sink)), so
+        only what lies outside the sinks is zero-filled here.  ``end_backward()`` zero-fills the sink of a
+        network whose backward did not run this step."""
+        if not self._sinks:
+            return self.zero_grad()
+        from . import ops
+        pos = 0
+        for net, o0 in sorted(self._sinks, key=lambda t: t[1]):
+            if o0 > pos:
+                self.grad[pos:o0].zero_()
+            net._sink_fresh = True
+            pos = o0 + ops.N_PARAM_FLOATS
+        if pos < self.numel:
+            self.grad[pos:].zero_()
+
+    def end_backward(self):
+        for net, o0 in self._sinks:
+            if getattr(net, "_sink_fresh", False):
+                net._grad_sink.zero_()
+                net._sink_fresh = False
 
     def zero_grad(self):
         self.grad.zero_()
+        for net, _ in self._sinks:
+            net._sink_fresh = False
         o = 0
         for p in self.params:      # re-attach if someone did zero_grad(set_to_none=True)
             n = p.numel()

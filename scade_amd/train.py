@@ -201,9 +201,10 @@ class Trainer:
     def step(self, rays, target_s, target_hyp, img_i=0, mask=None, n_total=None, **render_kw):
         """One optimisation step on this rank's shard; returns (this rank's term of the global loss,
         aux).  ``n_total``: rays of the whole batch when the shards are uneven."""
-        self.bucket.zero_grad()
+        self.bucket.begin_step()
         loss, aux = self.forward_loss(rays, target_s, target_hyp, img_i, mask, n_total, **render_kw)
         loss.backward(self._unit_grad(loss))                                                  # :985
+        self.bucket.end_backward()
         self.reduce_grads()
         lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it + 1)  # :988-991
         self.opt.step(lr=lr)                                                                  # :993

@@ -172,8 +172,8 @@ def test_f16x3_train_step_golden(dev):
     cap = {}
     orig = ops.mlp_bwd_f16
 
-    def spy(packed, packed_t_f16, acts, g_out, wgrad_f16=True):
-        flat = orig(packed, packed_t_f16, acts, g_out, wgrad_f16)
+    def spy(packed, packed_t_f16, acts, g_out, wgrad_f16=True, out=None):
+        flat = orig(packed, packed_t_f16, acts, g_out, wgrad_f16, out=out)
         cap[g_out.numel() // 4] = (acts, g_out, flat)
         return flat
 

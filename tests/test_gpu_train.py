@@ -405,6 +405,46 @@ def test_fused_train_loss_equals_the_separate_operators(dev, variant):
         assert float(gf[n_net:].abs().sum()) == float(gf[n_net + 2].abs() + gf[n_net + 6].abs())
 
 
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_gradient_sinks_are_written_by_the_first_backward_of_a_step(dev, prec):
+    """FlatParams.begin_step(): instead of zero-filling the bucket, the first fused backward of a step WRITES
+    a network's gradient into its sink (no temporary, no add); a second backward accumulates as autograd
+    does; end_backward() clears the sink of a network whose backward did not run.  Same bits as the classic
+    zero_grad() + accumulate path."""
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K = 96, 20
+    rays = O.synthetic_rays(N, seed=15).to(dev)
+    g = torch.Generator().manual_seed(16)
+    tgt = torch.rand(N, 3, generator=g).to(dev)
+    hyp = (torch.rand(K, N, 1, generator=g) * 4.9 + 0.1).to(dev)
+    draws = dict(t_rand=torch.rand(N, 64, generator=g).to(dev), u_coarse=torch.rand(N, 128, generator=g).to(dev),
+                 cached_u=torch.rand(N, 128, generator=g).to(dev))
+    coarse, fine = make_scade_nets(dev, seed=6)
+    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=2, precision=prec, overlap_coarse=False)
+
+    def run(prepare, times=1):
+        tr.bucket.grad.fill_(123.0)                # stale contents the step must not see
+        prepare()
+        for _ in range(times):
+            loss, _ = tr.forward_loss(rays, tgt, hyp, img_i=1, **draws)
+            loss.backward()
+        tr.bucket.end_backward()
+        return tr.bucket.grad.clone()
+
+    classic = run(tr.bucket.zero_grad)
+    direct = run(tr.bucket.begin_step)
+    assert torch.equal(direct, classic), "begin_step path differs from zero_grad + accumulate"
+    assert not coarse._sink_fresh and not fine._sink_fresh
+    twice = run(tr.bucket.begin_step, times=2)      # second backward of the step accumulates
+    assert_close(twice, 2 * classic, rtol=1e-6, atol=1e-12, what="accumulation after the first write")
+    # a network without a backward this step: its sink is cleared, not left stale
+    tr.bucket.grad.fill_(7.0)
+    tr.bucket.begin_step()
+    assert coarse._sink_fresh and fine._sink_fresh and float(tr.flat_ss.grad.abs().max()) == 0.0
+    tr.bucket.end_backward()
+    assert float(tr.bucket.grad.abs().max()) == 0.0
+
+
 def test_trainer_coarse_stream_overlap_is_bitwise_neutral(dev):
     """The Trainer runs the coarse stage on a side stream so that its backward chain overlaps the
     fine one: same kernels, same inputs -> bit-identical losses and parameters after several steps."""
