@@ -183,8 +183,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     __syncthreads();                                                                               \
     const unsigned long long bits_ = layer_store<2, true, PT>(acc, bias, nt0, hbuf, lane);         \
     if (SAVE) store_relu_words<PT>(a.acts, P, L, tid, bits_);                                      \
+    if (SAVE) save_tile_wave(hbuf, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, 64, lane, TM);    \
     __syncthreads();                                                                               \
-    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, L), p0, P, W, tid, TM);                      \
   }
 
   an[0] = WBASE(0)[lane];
@@ -240,8 +240,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
   __syncthreads();
   layer_store<2, false, PT>(acc, bias, nt0, hbuf, lane);
+  if (SAVE) save_tile_wave(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, 64, lane, TM);
   __syncthreads();
-  if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, W, tid, TM);
 
   // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
   {
@@ -252,8 +252,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     layer_gemm<1, 1, 32, VIEW_PAD, PT>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
     __syncthreads();
     layer_store<1, true, PT>(accv, biasv, wave, hbuf, lane);
+    if (SAVE) save_tile_wave(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, 32, lane, TM);
     __syncthreads();
-    if (SAVE) save_tile(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 128, tid, TM);
   }
 
 #undef WBASE

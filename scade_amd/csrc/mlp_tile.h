@@ -107,4 +107,18 @@ __device__ __forceinline__ void save_tile(const float* hbuf, float* __restrict__
   }
 }
 
+// the same copy for the columns ONE WAVE has just written (ncw columns from column c0, every row of the tile):
+// a wave's LDS accesses execute in order, so it may read its own layer_store back without a barrier and its
+// rows leave for HBM while the other waves are still in their epilogues
+__device__ __forceinline__ void save_tile_wave(const float* hbuf, float* __restrict__ dst, int p0, int P,
+                                               int c0, int ncw, int lane, int tm = TM) {
+  const int cpr = ncw >> 2;                      // 16-byte chunks per row of this wave's columns: 16 or 8
+  for (int i = lane; i < tm * cpr; i += 64) {
+    const int row = i / cpr, c = (c0 >> 2) + (i - row * cpr);
+    if (p0 + row < P)
+      __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(hbuf + h_idx(row, c)),
+                                  reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c));
+  }
+}
+
 }  // namespace scade
