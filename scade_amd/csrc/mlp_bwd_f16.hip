@@ -197,16 +197,16 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   layer_gemm_h<2, 0, 8, false>(acc0, acc1, an, WT16(8, 8), WT16(7, 16), 16, gh, gl, gh, gl, lane);
   __syncthreads();
   dgrad_store_h<false, false>(acc0, acc1, kt0, gh, gl, 0ull, nullptr, dal, lane);
+  save_tile_h_wave(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, 64, inv_s, lane);
   __syncthreads();
-  save_tile_h(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, W, inv_s, tid);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   unsigned long long mbits = mask_of(7);
   layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16(7, 16), WT16(6, 16), 16, gh, gl, gh, gl, lane);
   __syncthreads();
   dgrad_store_h<true, true>(acc0, acc1, kt0, gh, gl, mbits, pk + OFF_WA, dal, lane);
+  save_tile_h_wave(gh, gl, dz + acts_slot_off(P, 7), p0, P, 64 * wave, 64, inv_s, lane);
   __syncthreads();
-  save_tile_h(gh, gl, dz + acts_slot_off(P, 7), p0, P, W, inv_s, tid);
 
 #define DGRAD_LAYER_H(L)                                                                         \
   mbits = mask_of((L)-1);                                                                        \
@@ -214,8 +214,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
                                 gh, gl, gh, gl, lane);                                           \
   __syncthreads();                                                                               \
   dgrad_store_h<true, false>(acc0, acc1, kt0, gh, gl, mbits, nullptr, dal, lane);                \
-  __syncthreads();                                                                               \
-  save_tile_h(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, W, inv_s, tid);
+  save_tile_h_wave(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, 64, inv_s, lane);     \
+  __syncthreads();
 
   DGRAD_LAYER_H(7)
   DGRAD_LAYER_H(6)

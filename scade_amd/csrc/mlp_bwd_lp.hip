@@ -260,16 +260,16 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), 3, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
+  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, fac, 64 * wave, lane);
   __syncthreads();
-  save_tile_lp<BF, 256, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, fac, tid);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
   layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), 3, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
+  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, fac, 64 * wave, lane);
   __syncthreads();
-  save_tile_lp<BF, 256, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, fac, tid);
 
 #define DGRAD_LAYER_L(L)                                                                            \
   load_mask((L)-1);                                                                                 \
@@ -277,8 +277,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
                                                     g, g, lane, nullptr);                           \
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
-  __syncthreads();                                                                                  \
-  save_tile_lp<BF, 256, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, fac, tid);
+  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, fac, 64 * wave, lane);    \
+  __syncthreads();
 
   DGRAD_LAYER_L(7)
   DGRAD_LAYER_L(6)

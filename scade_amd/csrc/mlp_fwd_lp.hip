@@ -194,8 +194,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[                                  \
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
     }                                                                                           \
+    if (SAVE) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
     __syncthreads();                                                                            \
-    if (SAVE) save_tile_lp<BF, 256, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, tid);         \
   }
 
   A.s[0].t0 = WLBASE(0)[lane];
@@ -276,8 +276,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS, NPT>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
   __syncthreads();
   layer_store_lp<BF, 2, false, false, 1, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
+  if (SAVE) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, 64 * wave, lane);
   __syncthreads();
-  if (SAVE) save_tile_lp<BF, 256, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, tid);
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
@@ -285,8 +285,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
     __syncthreads();
     layer_store_lp<BF, 1, true, false, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
+    if (SAVE) save_tile_lp_wave<BF, 32, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
     __syncthreads();
-    if (SAVE) save_tile_lp<BF, 128, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, tid);
   }
 #undef WLBASE
 

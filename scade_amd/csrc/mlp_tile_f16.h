@@ -217,4 +217,26 @@ __device__ __forceinline__ void save_tile_h(const _Float16* xh, const _Float16* 
   }
 }
 
+// the same copy for the ncw columns (from column c0) ONE WAVE has just written (see save_tile_wave in mlp_tile.h)
+__device__ __forceinline__ void save_tile_h_wave(const _Float16* xh, const _Float16* xl, float* __restrict__ dst,
+                                                 int p0, int P, int c0, int ncw, const float* row_scale, int lane) {
+  const int cpr = ncw >> 3;                             // 8-half chunks per row of this wave's columns
+  for (int i = lane; i < HM * cpr; i += 64) {
+    const int row = i / cpr, c = (c0 >> 3) + (i - row * cpr);
+    if (p0 + row < P) {
+      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+      const u32x4 vh = *reinterpret_cast<const u32x4*>(xh + x_idx(row, c));
+      const u32x4 vl = *reinterpret_cast<const u32x4*>(xl + x_idx(row, c));
+      const float sc = row_scale ? row_scale[row] : 1.0f;
+      float x[8];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) join2(vh[k], vl[k], x[2 * k], x[2 * k + 1]);
+      const f32x4 o0 = {x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc}, o1 = {x[4] * sc, x[5] * sc, x[6] * sc, x[7] * sc};
+      float* o = dst + (size_t)(p0 + row) * W + 8 * c;
+      __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(o));
+      __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(o + 4));
+    }
+  }
+}
+
 }  // namespace scade

@@ -106,6 +106,41 @@ __device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typena
   }
 }
 
+// the same copy for the NCW columns (from column c0) ONE WAVE has just written, every row of the tile: a
+// wave's LDS accesses execute in order, so it reads its own epilogue back without a barrier and its rows
+// leave for HBM while the other waves are still in their epilogues (the exact kernels' save_tile_wave)
+template <bool BF, int NCW, int NPT = LPT>
+__device__ __forceinline__ void save_tile_lp_wave(const typename LP<BF>::T* x, typename LP<BF>::T* __restrict__ dst,
+                                                  int p0, int P, const float* row_fac, int c0, int lane) {
+  typedef typename LP<BF>::T T;
+  typedef typename LP<BF>::V8 V8;
+  constexpr int CPR = NCW >> 3;                       // 16-byte chunks per row of this wave's columns
+  constexpr int ITERS = 32 * NPT * CPR / 64;
+  static_assert(ITERS % 4 == 0, "save_tile_lp_wave: batches of four");
+#pragma unroll 1
+  for (int it0 = 0; it0 < ITERS; it0 += 4) {
+    V8 v[4];
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + 64 * (it0 + j);
+      const int row = i / CPR, c = (c0 >> 3) + (i - row * CPR);
+      v[j] = *reinterpret_cast<const V8*>(x + x_idx(row, c));
+      f[j] = row_fac ? row_fac[row] : 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = lane + 64 * (it0 + j);
+      const int row = i / CPR, c = (c0 >> 3) + (i - row * CPR);
+      if (row_fac) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[j][e] = (T)((float)v[j][e] * f[j]);
+      }
+      if (p0 + row < P) __builtin_nontemporal_store(v[j], reinterpret_cast<V8*>(dst + (size_t)(p0 + row) * W + 8 * c));
+    }
+  }
+}
+
 // ReLU sign bits of one layer: 4 x 32-bit words per lane.  The 64 packed dwords a lane produces
 // per layer are numbered d = ((t*4 + q)*4 + p)*2 + j (n-tile t, row group q, point tile p, value
 // pair j); word d >> 4 holds, at bit (d & 15), the sign of the dword's LOW half and at bit
