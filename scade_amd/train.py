@@ -85,13 +85,12 @@ class Trainer:
             raise ValueError('Trainer: allreduce must be "single" or "overlap"')
         self.allreduce = allreduce
         # coarse stage on a side stream: its backward chain then runs beside the fine one.  Off by default
-        # since the weight-gradient kernel runs two workgroups per CU (round 2): two kernels sharing the
-        # chip no longer beat the same two back to back (measured 1024 rays: exact 7.66 vs 7.54 ms, bf16
-        # 1.68 vs 1.60 ms; 128 rays: 1.60 vs 1.41 ms of mostly host time; only f16x3 still gains, 4.22 vs
-        # 4.32 ms, and keeps it on).  The two-piece overlapped all-reduce needs the side stream and turns it on.
+        # since round 2: with two weight-gradient workgroups per CU, two kernels sharing the chip no longer
+        # beat the same two back to back (measured 1024 rays, on / off: exact 7.28 / 7.17 ms, bf16 1.55 /
+        # 1.50 ms, f16x3 3.47 / 3.43 ms).  The two-piece overlapped all-reduce needs the side stream and
+        # turns it on; SCADE_OVERLAP_COARSE=1/0 forces it.
         if overlap_coarse is None:
-            overlap_coarse = os.environ.get("SCADE_OVERLAP_COARSE", "1" if precision == "f16x3" else "0") != "0" \
-                or allreduce == "overlap"
+            overlap_coarse = os.environ.get("SCADE_OVERLAP_COARSE", "0") != "0" or allreduce == "overlap"
         self.coarse_stream = torch.cuda.Stream(device=dev) if overlap_coarse and dev.type == "cuda" else None
         self.force_allreduce = False        # self-tests: issue the collective on a one-rank group too
         # the three-term loss as one fused operator (ops.TrainLossFn) instead of the separate public
