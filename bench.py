@@ -246,28 +246,34 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
         one = lambda: tr.step(rays, tgt, hyp)[0]
     # (with a process group the first steps also pay RCCL's one-time work - channel setup, the first
     # launch of its kernels beside ours - which has been seen to leak past five warm-up steps)
-    for _ in range(max(3, args.warmup) + (10 if dist.is_initialized() else 0)):
+    # secondary region: steady state, not the contract's W / K (those govern the headline only) - at least
+    # 10 warm-up and 40 timed steps, so that allocator start-up and the clock ramp are not in the figure
+    nwarm, nsteps = max(10, args.warmup) + (10 if dist.is_initialized() else 0), max(40, args.steps)
+    for _ in range(nwarm):
         one()
     barrier()
-    timer = ops.KernelTimer()
-    if not graphed:
-        ops.KERNEL_TIMER = timer
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(nsteps):
         loss = one()
     barrier()
     elapsed = time.perf_counter() - t0
-    ops.KERNEL_TIMER = None
     assert bool(torch.isfinite(loss))
+    timer = ops.KernelTimer()        # per-kernel events in a few EXTRA steps (they cost ~1 % of a step)
+    if not graphed:
+        ops.KERNEL_TIMER = timer
+        for _ in range(5):
+            one()
+        barrier()
+        ops.KERNEL_TIMER = None
     if dist.is_initialized():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     flops = 3.0 * n * (N_COARSE + N_COARSE + N_FINE) * FLOP_PER_POINT   # fwd + dgrad + wgrad
     peak, peak_name = TRAIN_PEAKS[precision]
-    tfl = flops / (elapsed / args.steps) / 1e12
-    out = {"value": n * world * args.steps / elapsed, "unit": "rays/s", "precision": precision,
-           "ms_per_step": elapsed / args.steps * 1e3, "rays_per_gpu": n, "global_rays": n * world,
+    tfl = flops / (elapsed / nsteps) / 1e12
+    out = {"value": n * world * nsteps / elapsed, "unit": "rays/s", "precision": precision,
+           "ms_per_step": elapsed / nsteps * 1e3, "steps_timed": nsteps, "rays_per_gpu": n, "global_rays": n * world,
            "scaling": scaling, "hypotheses": args.hyp, "graphed": graphed,
            "collective": (f"RCCL all-reduce(sum, fp32) of ONE bucket of {tr.bucket.numel} floats per step over "
                           f"{world} ranks, mode={allreduce}" if world > 1 else "none (1 GPU)"),
@@ -362,8 +368,9 @@ def rayops_region(dev, n_rays=16384, n_hyp=20, iters=20):
 def graph_region(args, dev, n_rays, precision):
     """Secondary measurement (single process): the same train step at ``n_rays`` rays, eager vs
     captured in one HIP graph (scade_amd/graphs.py).  128 rays = the per-GPU shard of a strongly-
-    scaled 1024-ray batch on 8 GPUs (BASELINE.json configs[3]), where the ~1.7 ms of host work per
-    eager step is the limit."""
+    scaled 1024-ray batch on 8 GPUs (BASELINE.json configs[3]), where the host work of an eager step
+    (27-31 launches + the autograd engine, ~0.6 ms) is the limit.  Steady state: 20 warm-up and >= 100 timed
+    steps per mode (these steps are ~1 ms; three warm-up steps still carried allocator start-up)."""
     from scade_amd.graphs import GraphedTrainer
     from scade_amd.synthetic import synthetic_rays
     from scade_amd.train import Trainer, make_scade_nets
@@ -377,14 +384,15 @@ def graph_region(args, dev, n_rays, precision):
         hyp = (torch.rand(args.hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
         gt = GraphedTrainer(tr, n_rays, args.hyp) if mode == "graph" else None
         f = (lambda: gt.step(rays, tgt, hyp)) if gt else (lambda: tr.step(rays, tgt, hyp)[0])
-        for _ in range(max(3, args.warmup)):
+        nsteps = max(100, args.steps)
+        for _ in range(max(20, args.warmup)):
             f()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(nsteps):
             loss = f()
         torch.cuda.synchronize()
-        out[f"ms_per_step_{mode}"] = (time.perf_counter() - t0) / args.steps * 1e3
+        out[f"ms_per_step_{mode}"] = (time.perf_counter() - t0) / nsteps * 1e3
         assert bool(torch.isfinite(loss))
     out["rays"] = n_rays
     out["precision"] = precision
