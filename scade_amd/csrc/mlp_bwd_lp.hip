@@ -200,8 +200,11 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
       da = bx > 20.f ? go[3] : go[3] / (1.f + expf(-bx));
     }
     const float m = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(da)));
+    // per-point power-of-two scale: an fp16 matter like S (bf16 carries fp32's exponent range and a power of
+    // two commutes with every rounding of the chain: s = 1 gives the same bits, and the dZ rows then leave
+    // LDS as plain copies - no un-scaling multiply, i.e. no bf16 -> fp32 -> bf16 round trip per element)
     float s = 1.f;
-    if (m > 0.f && m < 3.0e38f) {
+    if (!BF && m > 0.f && m < 3.0e38f) {
       int e;
       frexpf(m, &e);
       s = ldexpf(1.f, min(-4 - e, 96));    // denormal gradients: keep the scale finite
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), 3, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
-  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, fac, 64 * wave, lane);
+  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   __syncthreads();
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
@@ -268,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), 3, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
-  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, fac, 64 * wave, lane);
+  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   __syncthreads();
 
 #define DGRAD_LAYER_L(L)                                                                            \
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
                                                     g, g, lane, nullptr);                           \
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
-  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, fac, 64 * wave, lane);    \
+  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
   __syncthreads();
 
   DGRAD_LAYER_L(7)
