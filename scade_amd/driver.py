@@ -1,0 +1,175 @@
+"""Thin train / test driver over the HIP operators: the per-scene call sequence of the reference's
+``train_nerf`` / ``run_nerf`` (run_scade_scannet.py:830-1089, :1207-1285; run_scade_wild.py likewise), one
+process per GPU.  It is NOT a port of the reference's CLI (configargparse, tensorboard, lpips / skimage
+metrics and ffmpeg stay with the caller): it ties the pieces this package owns -
+scene loader, batch gather, ``Trainer.step``, checkpoints in the reference's format, the full-image eval
+loop and the image writer - so that a scene directory goes in and checkpoints, test images and
+``metrics.txt`` come out.
+
+    python -m scade_amd.driver --data_dir <datasets/scannet> --scene_id scene0758_00 --cimle_dir dump_... \\
+        --ckpt_dir checkpoints --expname demo --num_iterations 500000
+    torchrun --nproc-per-node 8 -m scade_amd.driver ...        # rays of every batch sharded over the ranks
+
+Per iteration i (counted from 1 like the reference, :899-900): pick a training image (numpy stream seeded
+like :831), pick N_rand pixels without replacement (:786), gather ray rows / colours / K hypotheses / corner
+mask for THOSE pixels only (``get_ray_batch``: the reference generates all H*W rays first), one
+``Trainer.step`` (hypotheses * scale + shift, render, three-term loss, backward, gradient all-reduce, both
+Adam updates, staircase learning rate, scale/shift freeze).  With a process group every rank takes its
+contiguous share of the SAME N_rand pixels, so the global batch is the reference's batch.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import time
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import parallel, scene
+from . import run_nerf_helpers as H
+from .train import Trainer, make_scade_nets
+
+
+def render_kwargs_test(trainer: Trainer, near: float, far: float, precision: Optional[str] = None):
+    """create_nerf's render_kwargs_test (:488-507): deterministic sampling, no noise."""
+    coarse, fine = trainer.coarse, trainer.fine
+    if precision is not None:
+        coarse.inference_precision = fine.inference_precision = precision
+    c = trainer.cfg
+    return dict(network_query_fn=trainer.query, perturb=False, N_importance=c["Ni"], network_fine=fine,
+                N_samples=c["Ns"], network_fn=coarse, use_viewdirs=True, raw_noise_std=0., lindisp=c["lindisp"],
+                near=near, far=far)
+
+
+def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "scene", num_iterations: int = 500000,
+                N_rand: int = 1024,
+                i_weights: int = 100000, i_print: int = 1000, mask_corners: bool = False, mask_edges: bool = False,
+                wild: bool = False, scale_init: float = 1.0, shift_init: float = 0.0, scales_init=None,
+                shifts_init=None, seed: int = 0, precision: str = "f32", eval_precision: Optional[str] = None,
+                test_chunk: int = 1024 * 16, no_reload: bool = False, log=print, **trainer_kw):
+    """``data`` = the tuple of scene.load_scene_scannet / load_scene_processed.  Returns a dict with the
+    trainer, the loss trace and (rank 0) the test metrics.  ``trainer_kw`` goes to ``Trainer`` (lrate,
+    scaleshift_lr, space_carving_weight, is_joint, warm_start_nerf, freeze_ss, allreduce, ...)."""
+    imgs, depths, valid, poses, Hh, Ww, intr, near, far, i_split, gt_d, gt_v, hyps = data[:13]
+    if len(data) >= 15 and scales_init is None:
+        scales_init, shifts_init = data[13], data[14]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    i_train, i_val, i_test = i_split[0], i_split[1], i_split[2]
+    if len(i_test) == 0:
+        raise ValueError("train_scene: the scene has no test split (:851-853)")
+    if gt_d is not None:                       # ground-truth depth for validation / test when there is any (:843-847)
+        for ix in (i_test, i_val):
+            depths[ix], valid[ix] = gt_d[ix], gt_v[ix]
+    to = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+    # the whole training set is resident (288 GB of HBM: a ScanNet scene is a few hundred MB)
+    t_img, t_pose, t_intr = to(imgs[i_train]), to(poses[i_train]), to(intr[i_train])
+    t_hyp = to(hyps)                                                        # [N_train, K, H, W, 1]
+    n_train = t_img.shape[0]
+
+    np.random.seed(seed)                                                    # :831-833
+    coarse, fine = make_scade_nets(dev, seed=seed)
+    bbc, bbs = scene.scene_bbox(Hh, Ww, intr, poses, i_train, far, dev)      # :1236-1244
+    ckpt = scene.load_checkpoint(out_dir, expname, no_reload=no_reload)
+    start = scene.restore(coarse, fine, ckpt) if ckpt is not None else 0
+    tr = Trainer(coarse, fine, bbc, bbs, n_images=n_train, precision=precision, start_iter=start,
+                 mask_mode="wild" if wild else "scannet", **trainer_kw)
+    with torch.no_grad():
+        if ckpt is not None and "depth_scales" in ckpt:                     # :931-933
+            tr.depth_scales.copy_(ckpt["depth_scales"].to(dev)[:n_train].reshape(n_train, 1))
+            tr.depth_shifts.copy_(ckpt["depth_shifts"].to(dev)[:n_train].reshape(n_train, 1))
+        elif scales_init is not None:
+            tr.depth_scales.copy_(to(scales_init).reshape(n_train, 1))
+            tr.depth_shifts.copy_(to(shifts_init).reshape(n_train, 1))
+        else:
+            tr.depth_scales.fill_(scale_init)
+            tr.depth_shifts.fill_(shift_init)
+    parallel.seed_rank_streams(seed + 1)       # identical weights everywhere, per-rank jitter / u streams
+    all_coords = torch.stack(torch.meshgrid(torch.arange(Hh), torch.arange(Ww), indexing="ij"), -1).reshape(-1, 2)
+
+    trace, t0 = [], time.time()
+    for i in range(start + 1, num_iterations + 1):
+        img_i = int(np.random.choice(n_train))                             # :946 (same stream on every rank)
+        sel = np.random.choice(Hh * Ww, size=[N_rand], replace=False)      # :786 / helpers:279-283
+        a, b = parallel.shard_range(N_rand, rank, world)
+        coords = all_coords[torch.from_numpy(sel[a:b])].to(dev)
+        rays, target_s, target_h, mask = H.get_ray_batch(
+            Hh, Ww, t_intr[img_i], t_pose[img_i], coords, near, far, image=t_img[img_i], hypotheses=t_hyp[img_i],
+            mask_corners=mask_corners, mask_edges=mask_edges)
+        loss, aux = tr.step(rays, target_s, target_h, img_i=img_i, mask=mask, n_total=N_rand)
+        if i % i_print == 0 or i == num_iterations:
+            lv = float(loss)
+            trace.append((i, lv))
+            if rank == 0:
+                log(f"[TRAIN] iter {i}  loss (this rank's term) {lv:.6f}  psnr {float(H.mse2psnr(aux['img_loss'])):.2f}"
+                    f"  {(time.time() - t0) / max(1, i - start) * 1e3:.2f} ms/it")
+        if i % i_weights == 0 and rank == 0:                                # :1004-1021, reference key names
+            path = os.path.join(out_dir, expname, "{:06d}.tar".format(i))
+            scene.save_checkpoint(path, i, coarse, fine, tr.depth_shifts, tr.depth_scales)
+            log("Saved checkpoints at " + path)
+
+    # ---- test at the last iteration (:1071-1086): every test image, metrics, images on disk -------------
+    kw = render_kwargs_test(tr, near, far, eval_precision)
+    group = True if world > 1 else None
+    res = scene.render_images_with_metrics(to(imgs[i_test]), to(depths[i_test]), to(valid[i_test], torch.bool),
+                                           to(poses[i_test]), Hh, Ww, to(intr[i_test]), kw,
+                                           chunk=test_chunk, shard_group=group)
+    out = {"trainer": tr, "trace": trace, "test": res["mean"], "iterations": num_iterations}
+    if rank == 0:
+        args = SimpleNamespace(ckpt_dir=out_dir, expname=expname, scene_id=scene_id)
+        scene.write_images_with_metrics(res["images"], res["mean_metrics"], far, args)
+        log(f"[TEST] {res['mean']}")
+    return out
+
+
+def main(argv=None):
+    p = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    p.add_argument("--data_dir", required=True)
+    p.add_argument("--scene_id", required=True)
+    p.add_argument("--cimle_dir", required=True)
+    p.add_argument("--dataset", default="scannet", choices=["scannet", "processed"],
+                   help="scannet: load_scene_scannet; processed: the in-the-wild loader (run_scade_wild.py)")
+    p.add_argument("--ckpt_dir", default="checkpoints")
+    p.add_argument("--expname", default="scade")
+    p.add_argument("--num_hypothesis", type=int, default=20)
+    p.add_argument("--N_rand", type=int, default=1024)
+    p.add_argument("--num_iterations", type=int, default=500000)
+    p.add_argument("--i_weights", type=int, default=100000)
+    p.add_argument("--i_print", type=int, default=1000)
+    p.add_argument("--lrate", type=float, default=5e-4)
+    p.add_argument("--scaleshift_lr", type=float, default=None, help="default 1e-7 (scannet) / 1e-5 (processed)")
+    p.add_argument("--space_carving_weight", type=float, default=0.007)
+    p.add_argument("--warm_start_nerf", type=int, default=0)
+    p.add_argument("--freeze_ss", type=int, default=400000)
+    p.add_argument("--is_joint", action="store_true")
+    p.add_argument("--mask_corners", action="store_true")
+    p.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16", "f16"])
+    p.add_argument("--eval_precision", default=None, choices=[None, "f32", "f16x3", "bf16", "f16"])
+    p.add_argument("--no_reload", action="store_true")
+    a = p.parse_args(argv)
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    wild = a.dataset == "processed"
+    load = scene.load_scene_processed if wild else scene.load_scene_scannet
+    data = load(os.path.join(a.data_dir, a.scene_id), a.cimle_dir, a.num_hypothesis)
+    train_scene(data, a.ckpt_dir, a.expname, a.scene_id, a.num_iterations, a.N_rand, a.i_weights, a.i_print,
+                mask_corners=a.mask_corners, mask_edges=wild, wild=wild, precision=a.precision,
+                eval_precision=a.eval_precision, no_reload=a.no_reload, lrate=a.lrate,
+                scaleshift_lr=a.scaleshift_lr if a.scaleshift_lr is not None else (1e-5 if wild else 1e-7),
+                space_carving_weight=a.space_carving_weight, warm_start_nerf=a.warm_start_nerf,
+                freeze_ss=a.freeze_ss, is_joint=a.is_joint)
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,15 @@ def _render_image(dev, shard):
             "rgb0": extras["rgb0"].cpu(), "z_std": extras["z_std"].cpu(), "keys": sorted(extras)}
 
 
+def _run_driver(out_dir, rank):
+    """scade_amd.driver.train_scene on the tiny scene the parent wrote: 20 iterations of 96-ray batches."""
+    from scade_amd import driver, scene
+    data = scene.load_scene_scannet(os.path.join(out_dir, "scene"), "dump", num_hypothesis=4)
+    res = driver.train_scene(data, os.path.join(out_dir, f"ckpt_rank{rank}"), "t", "tiny", num_iterations=20, N_rand=97,
+                             i_weights=1000, i_print=10, scaleshift_lr=1e-4, test_chunk=256, log=lambda *_: None)
+    return {"params": res["trainer"].bucket.data.clone().cpu(), "trace": res["trace"], "test": res["test"]}
+
+
 def _worker(rank, world, port, out_dir, backend):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -108,6 +117,7 @@ def _worker(rank, world, port, out_dir, backend):
     torch.manual_seed(100 + rank)
     out["shared_u"] = shared_uniform((NI,), dev).cpu()
     out["render"] = _render_image(dev, shard=True)          # test render sharded over the ranks
+    out["driver"] = _run_driver(out_dir, rank)               # the thin driver, rays of every batch sharded
     if backend == "nccl":
         # the whole sharded step as ONE HIP graph (RCCL all-reduce captured), joint exchange included
         from scade_amd.graphs import GraphedTrainer
@@ -137,6 +147,8 @@ def _worker(rank, world, port, out_dir, backend):
 
 
 def test_sharded_trainer_two_ranks_matches_single_process(dev, tmp_path):
+    from test_gpu_driver import write_smooth_scene
+    write_smooth_scene(str(tmp_path / "scene"))
     world = 2
     backend = "nccl" if torch.cuda.device_count() >= world else "gloo"
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
@@ -166,6 +178,17 @@ def test_sharded_trainer_two_ranks_matches_single_process(dev, tmp_path):
         for k in ("rgb", "disp", "acc", "depth", "rgb0", "z_std"):
             assert torch.equal(torch.nan_to_num(got[k]), torch.nan_to_num(want[k])), f"rank {r}: sharded render {k} differs"
         assert "z_vals" not in got["keys"] and "z_vals" in want["keys"], "only the per-pixel maps travel by default"
+    # the driver: 97-ray batches split 49 + 48, same image / pixel stream on both ranks -> identical parameters
+    # on both, the one-process run's parameters up to summation order, the same test metrics everywhere
+    d0, d1 = outs[0]["driver"], outs[1]["driver"]
+    assert torch.equal(d0["params"], d1["params"]), "driver: ranks diverged"
+    assert d0["test"] == d1["test"], "every rank holds the whole test image -> the same metrics"
+    from scade_amd import driver, scene
+    data = scene.load_scene_scannet(str(tmp_path / "scene"), "dump", num_hypothesis=4)
+    one = driver.train_scene(data, str(tmp_path / "ckpt_one"), "t", "tiny", num_iterations=20, N_rand=97, i_weights=1000,
+                             i_print=10, scaleshift_lr=1e-4, test_chunk=256, log=lambda *_: None)
+    assert rel_l2(d0["params"], one["trainer"].bucket.data.cpu()) < 2e-2, "driver: sharded vs one process after 20 Adam steps"
+    assert abs(d0["test"]["psnr"] - one["test"]["psnr"]) < 1.0
     if backend == "nccl":
         for name in ("graph", "graph_joint"):
             eager, graphed = outs[0][name]
