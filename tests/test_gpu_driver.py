@@ -71,3 +71,6 @@ def test_driver_trains_checkpoints_resumes_and_writes_test_images(dev, tmp_path)
     res2 = driver.train_scene(data, out, "t", "tiny", num_iterations=70, **kw)
     assert res2["trainer"].it == 70 and [i for i, _ in res2["trace"]] == [70], "resumed at global_step 60 (:411-420)"
     assert res2["trace"][0][1] < trace[0][1], "the restored weights, not a fresh init"
+    # the reference's host-side pixel stream (np.random.choice without replacement) is available too
+    res3 = driver.train_scene(data, str(tmp_path / "ckpt_np"), "t", "tiny", num_iterations=20, pixel_sampler="numpy", **kw)
+    assert np.isfinite(res3["trace"][-1][1])
