@@ -51,7 +51,7 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
                 wild: bool = False, scale_init: float = 1.0, shift_init: float = 0.0, scales_init=None,
                 shifts_init=None, seed: int = 0, precision: str = "f32", eval_precision: Optional[str] = None,
                 test_chunk: int = 1024 * 16, no_reload: bool = False, log=print, pixel_sampler: str = "device",
-                **trainer_kw):
+                i_img: int = 0, n_val_images: int = 8, **trainer_kw):
     """``data`` = the tuple of scene.load_scene_scannet / load_scene_processed.  Returns a dict with the
     trainer, the loss trace and (rank 0) the test metrics.  ``trainer_kw`` goes to ``Trainer`` (lrate,
     scaleshift_lr, space_carving_weight, is_joint, warm_start_nerf, freeze_ss, allreduce, ...).
@@ -60,7 +60,9 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
     N_rand-subset without replacement like the reference's, and one 150 us permutation serves H*W / N_rand
     steps; "numpy" is the reference's
     ``np.random.choice(H*W, N_rand, replace=False)`` (:786) - 4 ms of host time per step at 468 x 624, which
-    is more than a whole bf16 train step."""
+    is more than a whole bf16 train step.  ``i_img`` > 0: every i_img iterations the first ``n_val_images``
+    validation views (the test views when the scene has no validation split, :854-857) are rendered and their
+    mean metrics logged and kept in the result (:1036-1045)."""
     imgs, depths, valid, poses, Hh, Ww, intr, near, far, i_split, gt_d, gt_v, hyps = data[:13]
     if len(data) >= 15 and scales_init is None:
         scales_init, shifts_init = data[13], data[14]
@@ -104,6 +106,12 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
     g_pix = torch.Generator(device=dev).manual_seed(seed + 12345)         # the SAME stream on every rank
     perm, cursor = None, 0
 
+    i_eval = i_val if len(i_val) > 0 else i_test
+    val = None
+    if i_img > 0:
+        ix = i_eval[:n_val_images]
+        val = (to(imgs[ix]), to(depths[ix]), to(valid[ix], torch.bool), to(poses[ix]), to(intr[ix]))
+    val_trace = []
     trace, t0 = [], time.time()
     for i in range(start + 1, num_iterations + 1):
         img_i = int(np.random.choice(n_train))                             # :946 (same stream on every rank)
@@ -126,6 +134,13 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
             if rank == 0:
                 log(f"[TRAIN] iter {i}  loss (this rank's term) {lv:.6f}  psnr {float(H.mse2psnr(aux['img_loss'])):.2f}"
                     f"  {(time.time() - t0) / max(1, i - start) * 1e3:.2f} ms/it")
+        if val is not None and i % i_img == 0:                              # :1036-1045
+            m = scene.render_images_with_metrics(val[0], val[1], val[2], val[3], Hh, Ww, val[4],
+                                                 render_kwargs_test(tr, near, far, eval_precision), chunk=test_chunk,
+                                                 shard_group=True if world > 1 else None)["mean"]
+            val_trace.append((i, m))
+            if rank == 0:
+                log(f"[VAL] iter {i}  {m}")
         if i % i_weights == 0 and rank == 0:                                # :1004-1021, reference key names
             path = os.path.join(out_dir, expname, "{:06d}.tar".format(i))
             scene.save_checkpoint(path, i, coarse, fine, tr.depth_shifts, tr.depth_scales)
@@ -141,7 +156,7 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
                                            to(poses[i_test]), Hh, Ww, to(intr[i_test]), kw,
                                            chunk=test_chunk, shard_group=group)
     out = {"trainer": tr, "trace": trace, "test": res["mean"], "iterations": num_iterations,
-           "ms_per_iteration": loop_ms}
+           "ms_per_iteration": loop_ms, "val": val_trace}
     if rank == 0:
         args = SimpleNamespace(ckpt_dir=out_dir, expname=expname, scene_id=scene_id)
         scene.write_images_with_metrics(res["images"], res["mean_metrics"], far, args)
@@ -163,6 +178,7 @@ def main(argv=None):
     p.add_argument("--num_iterations", type=int, default=500000)
     p.add_argument("--i_weights", type=int, default=100000)
     p.add_argument("--i_print", type=int, default=1000)
+    p.add_argument("--i_img", type=int, default=20000, help="validation render every i_img iterations (0: never)")
     p.add_argument("--lrate", type=float, default=5e-4)
     p.add_argument("--scaleshift_lr", type=float, default=None, help="default 1e-7 (scannet) / 1e-5 (processed)")
     p.add_argument("--space_carving_weight", type=float, default=0.007)
@@ -184,7 +200,7 @@ def main(argv=None):
     data = load(os.path.join(a.data_dir, a.scene_id), a.cimle_dir, a.num_hypothesis)
     train_scene(data, a.ckpt_dir, a.expname, a.scene_id, a.num_iterations, a.N_rand, a.i_weights, a.i_print,
                 mask_corners=a.mask_corners, mask_edges=wild, wild=wild, precision=a.precision,
-                eval_precision=a.eval_precision, no_reload=a.no_reload, lrate=a.lrate,
+                eval_precision=a.eval_precision, no_reload=a.no_reload, i_img=a.i_img, lrate=a.lrate,
                 scaleshift_lr=a.scaleshift_lr if a.scaleshift_lr is not None else (1e-5 if wild else 1e-7),
                 space_carving_weight=a.space_carving_weight, warm_start_nerf=a.warm_start_nerf,
                 freeze_ss=a.freeze_ss, is_joint=a.is_joint)

@@ -50,7 +50,9 @@ def test_driver_trains_checkpoints_resumes_and_writes_test_images(dev, tmp_path)
     logs = []
     kw = dict(N_rand=128, i_weights=30, i_print=10, mask_corners=False, scaleshift_lr=1e-4, test_chunk=256,
               log=logs.append)
-    res = driver.train_scene(data, out, "t", "tiny", num_iterations=60, **kw)
+    res = driver.train_scene(data, out, "t", "tiny", num_iterations=60, i_img=30, **kw)
+    assert [i for i, _ in res["val"]] == [30, 60] and res["val"][1][1]["psnr"] > res["val"][0][1]["psnr"] - 1.0, \
+        "periodic validation render (:1036-1045; the test views stand in when there is no validation split)"
     trace = res["trace"]
     assert [i for i, _ in trace] == [10, 20, 30, 40, 50, 60] and all(np.isfinite(l) for _, l in trace)
     assert np.mean([l for _, l in trace[-2:]]) < 0.7 * trace[0][1], f"loss did not fall: {trace}"
