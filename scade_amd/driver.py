@@ -164,8 +164,48 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
     return out
 
 
+def test_scene(data, ckpt_dir: str, expname: str, scene_id: str = "scene", task: str = "test",
+               precision: Optional[str] = None, test_chunk: int = 1024 * 16, log=print):
+    """``--task test`` / ``--task video`` of the reference's run_nerf (:1262-1282): the latest checkpoint under
+    ckpt_dir/expname (the reference's own files load: ``module.``-prefixed keys), then every test view rendered,
+    scored and written (``test``), or the video poses rendered as frames (``video``).  With a process group the
+    rays of every image are sharded over the ranks."""
+    imgs, depths, valid, poses, Hh, Ww, intr, near, far, i_split, gt_d, gt_v, _ = data[:13]
+    dev = torch.device("cuda", torch.cuda.current_device())
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    to = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+    coarse, fine = make_scade_nets(dev, seed=0)
+    ckpt = scene.load_checkpoint(ckpt_dir, expname)
+    if ckpt is None:
+        raise FileNotFoundError(f"no '*000.tar' checkpoint under {os.path.join(ckpt_dir, expname)}")
+    step = scene.restore(coarse, fine, ckpt)
+    bbc, bbs = scene.scene_bbox(Hh, Ww, intr, poses, i_split[0], far, dev)
+    tr = Trainer(coarse, fine, bbc, bbs, n_images=1, start_iter=step)      # query fn + sample counts; never stepped
+    kw = render_kwargs_test(tr, near, far, precision)
+    group = True if world > 1 else None
+    if task == "video":
+        i_video = i_split[3]
+        kwv = dict(kw, shard_group=group, shard_keys=None) if group else kw
+        out_dir = os.path.join(ckpt_dir, expname)
+        return scene.render_video(to(poses[i_video]), Hh, Ww, to(intr[i_video]), "0", kwv, out_dir, chunk=test_chunk,
+                                  run_ffmpeg=rank == 0)
+    i_test = i_split[2]
+    d, v = (depths, valid) if gt_d is None else (gt_d, gt_v)               # :1268-1273
+    with torch.no_grad():
+        res = scene.render_images_with_metrics(to(imgs[i_test]), to(d[i_test]), to(v[i_test], torch.bool),
+                                               to(poses[i_test]), Hh, Ww, to(intr[i_test]), kw, chunk=test_chunk,
+                                               shard_group=group)
+    if rank == 0:
+        args = SimpleNamespace(ckpt_dir=ckpt_dir, expname=expname, scene_id=scene_id)
+        scene.write_images_with_metrics(res["images"], res["mean_metrics"], far, args)
+        log(f"[TEST] checkpoint step {step}: {res['mean']}")
+    return res
+
+
 def main(argv=None):
     p = argparse.ArgumentParser(description=__doc__.split("\n\n")[0])
+    p.add_argument("--task", default="train", choices=["train", "test", "video"])
     p.add_argument("--data_dir", required=True)
     p.add_argument("--scene_id", required=True)
     p.add_argument("--cimle_dir", required=True)
@@ -198,6 +238,9 @@ def main(argv=None):
     wild = a.dataset == "processed"
     load = scene.load_scene_processed if wild else scene.load_scene_scannet
     data = load(os.path.join(a.data_dir, a.scene_id), a.cimle_dir, a.num_hypothesis)
+    if a.task != "train":
+        test_scene(data, a.ckpt_dir, a.expname, a.scene_id, a.task, a.eval_precision)
+        return
     train_scene(data, a.ckpt_dir, a.expname, a.scene_id, a.num_iterations, a.N_rand, a.i_weights, a.i_print,
                 mask_corners=a.mask_corners, mask_edges=wild, wild=wild, precision=a.precision,
                 eval_precision=a.eval_precision, no_reload=a.no_reload, i_img=a.i_img, lrate=a.lrate,

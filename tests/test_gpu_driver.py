@@ -73,6 +73,12 @@ def test_driver_trains_checkpoints_resumes_and_writes_test_images(dev, tmp_path)
     res2 = driver.train_scene(data, out, "t", "tiny", num_iterations=70, **kw)
     assert res2["trainer"].it == 70 and [i for i, _ in res2["trace"]] == [70], "resumed at global_step 60 (:411-420)"
     assert res2["trace"][0][1] < trace[0][1], "the restored weights, not a fresh init"
+    # --task test (:1262-1279): the latest checkpoint re-loaded into fresh networks gives the images of the run's end
+    import shutil
+    shutil.rmtree(rd)
+    res_t = driver.test_scene(data, out, "t", "tiny", log=logs.append)
+    assert sorted(os.listdir(rd)) == ["0_d.png", "0_rgb.jpg", "metrics.txt"]
+    assert abs(res_t["mean"]["psnr"] - res["test"]["psnr"]) < 1e-3, "the step-60 checkpoint -> the test render of the 60-step run"
     # the reference's host-side pixel stream (np.random.choice without replacement) is available too
     res3 = driver.train_scene(data, str(tmp_path / "ckpt_np"), "t", "tiny", num_iterations=20, pixel_sampler="numpy", **kw)
     assert np.isfinite(res3["trace"][-1][1])
