@@ -234,8 +234,9 @@ int scade_mse_bwd(const float* x, const float* y, const float* row_mask, int n, 
  *      :968-983; the wild variant's masked photometric terms run_scade_wild.py:977-1008):
  *          target_h = hyp * scales[img] + shifts[img]
  *          loss = mse(rgb, target) + carve_weight * space_carving(pred, target_h) + mse(rgb0, target)
- *      (non-joint space carving, hyp [K,N]).  img = *img_i_dev when that device pointer is given (graph
- *      captured steps), else img_i.  mask [N] or NULL multiplies the carving distances, and the squared
+ *      (non-joint space carving, hyp [K,N]).  img = img_i, or - when the device pointer img_i_dev is given
+ *      (graph captured steps) - *img_i_dev (int64), with img_i = n_images as its bound: a device index outside
+ *      [0, n_images) makes the loss NaN and writes no scale / shift gradient (never out of bounds).  mask [N] or NULL multiplies the carving distances, and the squared
  *      errors too when mse_masked.  carve_on = 0 drops the middle term (warm start, :973).  out_scale
  *      multiplies the total (a rank's share of a ray-sharded batch).  loss4 = {total, img_loss, carve,
  *      img_loss0}; workspace [4 N] floats.  The backward writes g_rgb / g_rgb0 [N,3], g_pred [N,P] and ADDS

@@ -202,7 +202,11 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
     const float m = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(da)));
     // per-point power-of-two scale: an fp16 matter like S (bf16 carries fp32's exponent range and a power of
     // two commutes with every rounding of the chain: s = 1 gives the same bits, and the dZ rows then leave
-    // LDS as plain copies - no un-scaling multiply, i.e. no bf16 -> fp32 -> bf16 round trip per element)
+    // LDS as plain copies - no un-scaling multiply, i.e. no bf16 -> fp32 -> bf16 round trip per element).
+    // CAVEAT: "same bits" holds while every value of the chain stays in bf16's NORMAL range.  A point whose
+    // output gradient is below ~1e-30 produces dZ values under 2^-126: those flush to bf16 subnormals / zero
+    // here, where the per-point scale would have kept them normal.  Such gradients are 22 decades under
+    // Adam's eps (1e-8) and change no update; tests/test_gpu_lp.py pins the behaviour (finite, -> 0).
     float s = 1.f;
     if (!BF && m > 0.f && m < 3.0e38f) {
       int e;

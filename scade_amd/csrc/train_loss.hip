@@ -54,7 +54,15 @@ __device__ __forceinline__ float tl_dist(float pred, float h, float m, bool has_
   if (thr > 0.f && dd < thr) dd = 0.f;            // helpers:112-113
   return dd;
 }
-__device__ __forceinline__ int tl_image(const TrainLossArgs& a) { return a.img_i_dev ? (int)a.img_i_dev[0] : a.img_i; }
+// image of the batch: the host index, or (graph-captured steps) a device index bounded by img_i = n_images.
+// A device index outside [0, n_images) returns -1: the affine map becomes NaN (the loss says so) and no
+// scale / shift gradient is written - never an out-of-bounds access.
+__device__ __forceinline__ int tl_image(const TrainLossArgs& a) {
+  if (!a.img_i_dev) return a.img_i;
+  const long long im = a.img_i_dev[0];
+  return (im >= 0 && im < (long long)a.img_i) ? (int)im : -1;
+}
+__device__ __forceinline__ float tl_row(const float* v, int im) { return im >= 0 ? v[im] : __builtin_nanf(""); }
 
 __global__ void train_loss_fwd_kernel(TrainLossArgs a) {
   const int ray = blockIdx.x * TL_RAYS_PER_WG + (threadIdx.x >> 6);
@@ -76,7 +84,7 @@ __global__ void train_loss_fwd_kernel(TrainLossArgs a) {
   float carve_ray = 0.f;
   if (a.carve_on) {
     const int im = tl_image(a);
-    const float sc = a.scales[im], sh = a.shifts[im];
+    const float sc = tl_row(a.scales, im), sh = tl_row(a.shifts, im);
     double acc = 0.0;
     if (a.K <= 64) {
       float hreg = 0.f;
@@ -152,7 +160,7 @@ __global__ void train_loss_bwd_kernel(TrainLossArgs a) {
   float gsc = 0.f, gsh = 0.f;
   if (a.carve_on) {
     const int im = tl_image(a);
-    const float sc = a.scales[im], sh = a.shifts[im];
+    const float sc = tl_row(a.scales, im), sh = tl_row(a.shifts, im);
     const float gl = g * a.carve_weight;
     const float scale = gl / ((float)a.N * (float)a.P);
     for (int k0 = 0; k0 < a.K; k0 += 64) {
@@ -218,8 +226,10 @@ __global__ __launch_bounds__(1024) void train_loss_ss_reduce_kernel(TrainLossArg
     s0 = s1 = 0.0;
     for (int w = 0; w < 16; ++w) { s0 += red[0][w]; s1 += red[1][w]; }
     const int im = tl_image(a);
-    a.g_scales[im] += (float)s0;
-    a.g_shifts[im] += (float)s1;
+    if (im >= 0) {
+      a.g_scales[im] += (float)s0;
+      a.g_shifts[im] += (float)s1;
+    }
   }
 }
 
@@ -235,6 +245,7 @@ extern "C" int scade_train_loss_fwd(const float* rgb, const float* rgb0, const f
   SCADE_REQUIRE(rgb && rgb0 && target && workspace && loss4, -1, "scade_train_loss_fwd: null pointer");
   SCADE_REQUIRE(!carve_on || (pred && hyp && scales && shifts), -1, "scade_train_loss_fwd: the carving term needs pred, hyp, scales, shifts");
   SCADE_REQUIRE(N > 0 && (!carve_on || (P > 0 && K > 0)), -2, "scade_train_loss_fwd: empty problem");
+  SCADE_REQUIRE(img_i_dev ? img_i > 0 : img_i >= 0, -2, "scade_train_loss_fwd: img_i (host index, or n_images beside a device index)");
   TrainLossArgs a{};
   a.rgb = rgb; a.rgb0 = rgb0; a.target = target; a.pred = pred; a.hyp = hyp; a.scales = scales; a.shifts = shifts;
   a.img_i_dev = img_i_dev; a.img_i = img_i; a.mask = mask; a.mse_masked = mse_masked; a.carve_on = carve_on;
@@ -256,6 +267,7 @@ extern "C" int scade_train_loss_bwd(const float* rgb, const float* rgb0, const f
   SCADE_REQUIRE(!carve_on || (pred && hyp && scales && shifts && g_pred && g_scales && g_shifts), -1,
                 "scade_train_loss_bwd: the carving term needs pred, hyp, scales, shifts and their gradient buffers");
   SCADE_REQUIRE(N > 0 && (!carve_on || (P > 0 && K > 0)), -2, "scade_train_loss_bwd: empty problem");
+  SCADE_REQUIRE(img_i_dev ? img_i > 0 : img_i >= 0, -2, "scade_train_loss_bwd: img_i (host index, or n_images beside a device index)");
   TrainLossArgs a{};
   a.rgb = rgb; a.rgb0 = rgb0; a.target = target; a.pred = pred; a.hyp = hyp; a.scales = scales; a.shifts = shifts;
   a.img_i_dev = img_i_dev; a.img_i = img_i; a.mask = mask; a.mse_masked = mse_masked; a.carve_on = carve_on;

@@ -73,6 +73,7 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
     if len(i_test) == 0:
         raise ValueError("train_scene: the scene has no test split (:851-853)")
     if gt_d is not None:                       # ground-truth depth for validation / test when there is any (:843-847)
+        depths, valid = np.array(depths, copy=True), np.array(valid, copy=True)   # the caller's arrays stay as loaded
         for ix in (i_test, i_val):
             depths[ix], valid[ix] = gt_d[ix], gt_v[ix]
     to = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
@@ -112,7 +113,7 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
         ix = i_eval[:n_val_images]
         val = (to(imgs[ix]), to(depths[ix]), to(valid[ix], torch.bool), to(poses[ix]), to(intr[ix]))
     val_trace = []
-    trace, t0 = [], time.time()
+    trace, t0, t_aux = [], time.time(), 0.0     # t_aux: validation renders + checkpoint writes, not loop time
     for i in range(start + 1, num_iterations + 1):
         img_i = int(np.random.choice(n_train))                             # :946 (same stream on every rank)
         a, b = parallel.shard_range(N_rand, rank, world)
@@ -133,21 +134,28 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
             trace.append((i, lv))
             if rank == 0:
                 log(f"[TRAIN] iter {i}  loss (this rank's term) {lv:.6f}  psnr {float(H.mse2psnr(aux['img_loss'])):.2f}"
-                    f"  {(time.time() - t0) / max(1, i - start) * 1e3:.2f} ms/it")
+                    f"  {(time.time() - t0 - t_aux) / max(1, i - start) * 1e3:.2f} ms/it")
         if val is not None and i % i_img == 0:                              # :1036-1045
+            torch.cuda.synchronize()
+            ta = time.time()
             m = scene.render_images_with_metrics(val[0], val[1], val[2], val[3], Hh, Ww, val[4],
                                                  render_kwargs_test(tr, near, far, eval_precision), chunk=test_chunk,
                                                  shard_group=True if world > 1 else None)["mean"]
             val_trace.append((i, m))
             if rank == 0:
                 log(f"[VAL] iter {i}  {m}")
+            torch.cuda.synchronize()
+            t_aux += time.time() - ta
         if i % i_weights == 0 and rank == 0:                                # :1004-1021, reference key names
+            torch.cuda.synchronize()
+            ta = time.time()
             path = os.path.join(out_dir, expname, "{:06d}.tar".format(i))
             scene.save_checkpoint(path, i, coarse, fine, tr.depth_shifts, tr.depth_scales)
             log("Saved checkpoints at " + path)
+            t_aux += time.time() - ta
 
     torch.cuda.synchronize()
-    loop_ms = (time.time() - t0) * 1e3 / max(1, num_iterations - start)
+    loop_ms = (time.time() - t0 - t_aux) * 1e3 / max(1, num_iterations - start)
 
     # ---- test at the last iteration (:1071-1086): every test image, metrics, images on disk -------------
     kw = render_kwargs_test(tr, near, far, eval_precision)
@@ -189,7 +197,7 @@ def test_scene(data, ckpt_dir: str, expname: str, scene_id: str = "scene", task:
         kwv = dict(kw, shard_group=group, shard_keys=None) if group else kw
         out_dir = os.path.join(ckpt_dir, expname)
         return scene.render_video(to(poses[i_video]), Hh, Ww, to(intr[i_video]), "0", kwv, out_dir, chunk=test_chunk,
-                                  run_ffmpeg=rank == 0)
+                                  run_ffmpeg=rank == 0, write=rank == 0)
     i_test = i_split[2]
     d, v = (depths, valid) if gt_d is None else (gt_d, gt_v)               # :1268-1273
     with torch.no_grad():

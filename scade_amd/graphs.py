@@ -41,7 +41,9 @@ class GraphedTrainer:
         if inject_draws:
             self.draws = (torch.zeros(n_rays, c["Ns"], device=dev), torch.zeros(n_rays, c["Ni"], device=dev),
                           torch.zeros(n_rays, c["Ni"], device=dev))
-        tr.opt.use_device_state(c["rate"], c["step"])
+        # the staircase runs on the reference's loop index (:899-900): a resumed Trainer (start_iter = N,
+        # optimizer state not restored, :480) has taken opt.steps = 0 steps but stands at iteration N
+        tr.opt.use_device_state(c["rate"], c["step"], iter_offset=tr.it - tr.opt.steps)
         tr.opt_ss.use_device_state()
         self.graph = None
         self.loss = None

@@ -737,8 +737,15 @@ class TrainLossFn(torch.autograd.Function):
         rgb_c, rgb0_c, tgt_c, pred_c, hyp_c = _c(rgb), _c(rgb0), _c(target), _c(pred), _c(hyp.reshape(K, N))
         sc, sh = _c(scales.detach().reshape(-1)), _c(shifts.detach().reshape(-1))
         mask_c = None if mask is None else _c(check(mask, "train_loss: mask").reshape(N))
-        idx_t = img_i.reshape(1) if torch.is_tensor(img_i) else None
-        idx = 0 if torch.is_tensor(img_i) else int(img_i)
+        idx_t = None
+        if torch.is_tensor(img_i):
+            # the kernel reads it as one int64 on the device and indexes scales / shifts / their gradients with it
+            if img_i.dtype != torch.int64 or img_i.device != pred.device or img_i.numel() != 1:
+                raise TypeError(f"train_loss: a tensor img_i must be ONE int64 on {pred.device}, got "
+                                f"{img_i.dtype} x {img_i.numel()} on {img_i.device}")
+            idx_t = _c(img_i.reshape(1))
+        # beside a device index the ABI's img_i argument is its bound (n_images)
+        idx = sc.numel() if idx_t is not None else int(img_i)
         if idx_t is None and not 0 <= idx < sc.numel():
             raise IndexError(f"train_loss: img_i {idx} outside [0, {sc.numel()})")
         ws = torch.empty(4 * N, device=pred.device, dtype=torch.float32)

@@ -318,30 +318,35 @@ def _colormap(x01, anchors):
 
 @torch.no_grad()
 def render_video(poses, Hh, Ww, intrinsics, filename, render_kwargs_test, out_dir, chunk=1024 * 16, fps=25,
-                 every=3, run_ffmpeg=True):
+                 every=3, run_ffmpeg=True, write=True):
     """The frame loop of run_scade_scannet.py:236-264: every third pose rendered 16:9 with the centre
     third kept (``with_5_9``), frame = rgb | depth / far (turbo) | depth standard deviation (viridis),
     written as ``video_<filename>/<idx>.jpg``; ffmpeg assembles the mp4 when it is installed.
-    Returns (frame directory, maximal depth seen)."""
+    Returns (frame directory, maximal depth seen).  With a sharded render (``shard_group`` in the kwargs) every
+    rank calls this and takes part in each frame's render; only the rank with ``write=True`` touches the
+    directory, the frames and ffmpeg."""
     import shutil
     import subprocess
     from PIL import Image
     video_dir = os.path.join(out_dir, "video_" + filename)
-    if os.path.exists(video_dir):
-        shutil.rmtree(video_dir)
-    os.makedirs(video_dir, exist_ok=True)
+    if write:
+        if os.path.exists(video_dir):
+            shutil.rmtree(video_dir)
+        os.makedirs(video_dir, exist_ok=True)
     depth_scale = float(render_kwargs_test["far"])
     max_depth = 0.0
     for img_idx in range(0, len(poses), every):
         rgb, _, _, extras = R.render(Hh, Ww, intrinsics[img_idx], chunk=chunk, c2w=poses[img_idx][:3, :4],
                                      with_5_9=True, **render_kwargs_test)
         max_depth = max(max_depth, float(extras["depth_map"].max()))
+        if not write:
+            continue
         frame = [H.to8b(rgb.cpu().numpy()),
                  _colormap((extras["depth_map"] / depth_scale).cpu().numpy(), _TURBO),
                  _colormap(depth_std_map(extras["z_vals"], extras["weights"], extras["depth_map"]).cpu().numpy(),
                            _VIRIDIS)]
         Image.fromarray(np.concatenate(frame, 1)).save(os.path.join(video_dir, f"{img_idx}.jpg"))
-    if run_ffmpeg and shutil.which("ffmpeg"):
+    if write and run_ffmpeg and shutil.which("ffmpeg"):
         subprocess.call(["ffmpeg", "-y", "-framerate", str(fps), "-i", os.path.join(video_dir, "%d.jpg"), "-c:v",
                          "libx264", "-profile:v", "high", "-crf", str(fps), os.path.join(out_dir, filename + ".mp4")])
     return video_dir, max_depth

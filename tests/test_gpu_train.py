@@ -617,3 +617,64 @@ def test_train_step_other_sample_counts_vs_oracle_autograd(dev, ns, ni):
     assert torch.isfinite(gc).all() and torch.isfinite(gf).all()
     assert rel_l2(gc, wc) < 1e-3, rel_l2(gc, wc)
     assert rel_l2(gf, wf) < 5e-2, rel_l2(gf, wf)
+
+
+def test_graphed_trainer_resumed_run_uses_the_decayed_learning_rate(dev):
+    """A Trainer resumed at start_iter >= decay_step (weights restored, optimizer not: :477-480) steps at
+    lrate * rate^floor(i / step) (:988-991) when graph-captured too: the device-side staircase gets the
+    iteration offset, and the graphed parameters match the eager ones step for step."""
+    from scade_amd.graphs import GraphedTrainer
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K, steps, start = 64, 8, 3, 11
+    g = torch.Generator().manual_seed(21)
+    rays = O.synthetic_rays(N, seed=80).to(dev)
+    tgt = torch.rand(N, 3, generator=g).to(dev)
+    hyp = (torch.rand(K, N, 1, generator=g) * 4.9 + 0.1).to(dev)
+    draws = [tuple(torch.rand(N, s, generator=g).to(dev) for s in (64, 128, 128)) for _ in range(steps)]
+    res = {}
+    for mode in ("eager", "graph", "eager_fresh"):
+        coarse, fine = make_scade_nets(dev, seed=8)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), lrate_decay_step=4, lrate_decay_rate=0.1,
+                     start_iter=0 if mode == "eager_fresh" else start)
+        gt = GraphedTrainer(tr, N, K, inject_draws=True) if mode == "graph" else None
+        p0 = tr.flat.data.clone()
+        for a, b, c in draws:
+            kw = dict(t_rand=a, u_coarse=b, cached_u=c)
+            gt.step(rays, tgt, hyp, **kw) if gt else tr.step(rays, tgt, hyp, **kw)
+        torch.cuda.synchronize()
+        res[mode] = (tr.flat.data - p0).clone()
+        if gt:
+            # i = 12, 13, 14 -> floor(i / 4) = 3 -> lr = 5e-4 * 1e-3
+            assert abs(float(tr.opt.state[8]) - 5e-4 * 0.1 ** 3) < 1e-12, float(tr.opt.state[8])
+    assert_close(res["graph"], res["eager"], rtol=1e-4, atol=1e-10, what="resumed graphed update vs eager")
+    # and it IS the decayed rate: the un-resumed run moves the parameters ~1000x further
+    assert float(res["eager_fresh"].abs().max()) > 100 * float(res["eager"].abs().max())
+
+
+def test_fused_train_loss_device_image_index_is_checked(dev):
+    """The device-resident img_i (graph-captured steps) indexes scales / shifts and their gradient rows inside
+    the kernel: a wrong dtype is refused on the host, an out-of-range value poisons the loss with NaN and
+    leaves the gradient bucket's scale / shift rows untouched - never an out-of-bounds access."""
+    from scade_amd import ops
+    N, P, K, n_img = 16, 128, 5, 3
+    g = torch.Generator().manual_seed(3)
+    rgb, rgb0, tgt = (torch.rand(N, 3, generator=g).to(dev).requires_grad_(i < 2) for i in range(3))
+    pred = (torch.rand(N, P, generator=g) * 4 + 0.2).to(dev).requires_grad_(True)
+    hyp = (torch.rand(K, N, 1, generator=g) * 4.9 + 0.1).to(dev)
+    scales = torch.ones(n_img, 1, device=dev, requires_grad=True)
+    shifts = torch.zeros(n_img, 1, device=dev, requires_grad=True)
+    args = lambda idx: (rgb, rgb0, tgt, pred, hyp, scales, shifts, idx, None, False, True, 0.007, 0.0, 1.0)
+    with pytest.raises(TypeError):
+        ops.TrainLossFn.apply(*args(torch.tensor([1], device=dev, dtype=torch.int32)))
+    with pytest.raises(TypeError):
+        ops.TrainLossFn.apply(*args(torch.tensor([1])))
+    ok, _ = ops.TrainLossFn.apply(*args(torch.tensor([1], device=dev)))
+    assert torch.isfinite(ok)
+    for bad in (-1, n_img, 10 ** 6):
+        scales.grad = torch.zeros_like(scales)
+        shifts.grad = torch.zeros_like(shifts)
+        loss, _ = ops.TrainLossFn.apply(*args(torch.tensor([bad], device=dev)))
+        assert torch.isnan(loss), (bad, float(loss))
+        loss.backward()
+        torch.cuda.synchronize()
+        assert float(scales.grad.abs().sum()) == 0.0 and float(shifts.grad.abs().sum()) == 0.0
