@@ -477,12 +477,21 @@ def main():
     avg_ms = k["ms"] / k["launches"]
     flops_per_launch = k["work"] / k["launches"]
     achieved = flops_per_launch / (avg_ms * 1e-3) / 1e12
-    traffic, traffic_src, pmc_util = None, None, None
+    # one row per launch size (coarse 64 / fine 192 samples per ray), as the committed rocprofv3 per-dispatch
+    # statistics (profiles/rNN_render_kernel_stats_timed.csv) list them
+    by_launch = {}
+    for work, r in sorted(timer.by_work("mlp_fwd_kernel").items()):
+        ms = r["ms"] / r["launches"]
+        by_launch[f"{int(round(work / ops.MLP_FLOP_PER_POINT))}_points"] = {
+            "launches_timed": r["launches"], "avg_launch_ms": ms, "achieved": work / (ms * 1e-3) / 1e12,
+            "frac": work / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS}
+    traffic, traffic_src, pmc_util, pmc_clock = None, None, None, None
     try:   # HBM bytes per launch from the committed rocprofv3 --pmc passes of this same command
         import glob
         f = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc.json")))[-1]
         pmc = json.load(open(f))["mlp_fwd_kernel"]
         traffic, pmc_util, traffic_src = pmc["hbm_bytes_per_launch"], pmc["mfma_util"], os.path.basename(f)
+        pmc_clock = pmc.get("effective_clock_ghz")
     except Exception:
         pass
     total_rays = args.rays * world * args.steps
@@ -512,6 +521,11 @@ def main():
                                         "--pmc passes of this command), not measured in this run"
                                         if traffic_src else None),
                      "mfma_util_pmc": pmc_util,
+                     "effective_clock_ghz_pmc": pmc_clock,
+                     "effective_clock_note": ("static, same source as traffic: GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration "
+                                              "over the timed launches of the profiled run; the 157.3 TFLOP/s peak assumes 2.4 GHz"
+                                              if pmc_clock else None),
+                     "by_launch": by_launch,
                      "launches_timed": k["launches"], "avg_launch_ms": avg_ms,
                      "flops_per_launch": flops_per_launch,
                      "note": "algorithmic 1,174,528 FLOP/point x mean points per launch "

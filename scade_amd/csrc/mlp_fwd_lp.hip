@@ -235,8 +235,19 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   // NaN (sin(inf) = NaN feeds every feature), a non-finite view direction its colour.  The
   // reference's isnan/isinf scan (run_scade_scannet.py:747-749) then still sees it.  The six input
   // floats are fetched here so that their latency hides under the alpha dot products.
+  // A NaN in a HIDDEN layer's parameters cannot be trusted to survive this path either (a negative-signed
+  // NaN is a negative int16 to the packed ReLU), so the pack kernel takes a census of the fp32 parameters and
+  // leaves it in the tail as 0 / NaN floats (LP_NAN_TRUNK: pts_linears - the reference then returns NaN in
+  // all four outputs of every point; LP_NAN_COLOUR: feature_linear / views_linears - NaN colour, finite
+  // density).  NaN head parameters need no help: the heads are fp32 arithmetic.
   float alpha[LM / 64];
   int badf[LM / 64];
+  bool nan_trunk, nan_colour;
+  {
+    const float ft = TAIL(LP_NAN_TRUNK)[lane], fc = TAIL(LP_NAN_COLOUR)[lane];
+    nan_trunk = __any(ft != ft) != 0;
+    nan_colour = __any(fc != fc) != 0;
+  }
   {
     const float* wa = TAIL(OFF_WA);
 #pragma unroll
@@ -264,8 +275,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
       alpha[rb] = s + TAIL(OFF_BA)[0];
-      const bool badp = lp_nonfinite(q0) | lp_nonfinite(q1) | lp_nonfinite(q2);
-      badf[rb] = badp | lp_nonfinite(v0) | lp_nonfinite(v1) | lp_nonfinite(v2);
+      const bool badp = lp_nonfinite(q0) | lp_nonfinite(q1) | lp_nonfinite(q2) | nan_trunk;
+      badf[rb] = badp | lp_nonfinite(v0) | lp_nonfinite(v1) | lp_nonfinite(v2) | nan_colour;
       if (badp) alpha[rb] = __builtin_nanf("");
       if (SAVE && sub == 0 && p0 + row < P)
         reinterpret_cast<float*>(a.acts + lp_acts_alpha_byte(P))[p0 + row] = alpha[rb];
@@ -378,6 +389,22 @@ __global__ void mlp_pack_lp_kernel(PackLpArgs a) {
     for (int i = t0; i < 384; i += stride) tail[OFF_WR - OFF_BIAS + i] = a.p[22][i];
     for (int i = t0; i < 4; i += stride) tail[OFF_BR - OFF_BIAS + i] = i < 3 ? a.p[23][i] : 0.f;
     for (int i = t0; i < 2 * 64 * 8; i += stride) wpk[off_wl(NLAYER_MFMA) + i] = (T)0.f;
+    // NaN census of the hidden layers' fp32 parameters (see the forward's alpha head): this block's slice of
+    // every tensor, one 0 / NaN float per block and class; gridDim.x = LP_NAN_BLOCKS
+    int bad_trunk = 0, bad_colour = 0;
+    for (int t = 0; t < 20; ++t) {
+      const float* __restrict__ src = a.p[t];
+      const int n = lp_param_numel(t);
+      int bad = 0;
+      for (int i = t0; i < n; i += stride) { const float v = src[i]; bad |= (v != v) ? 1 : 0; }
+      if (t < 16) bad_trunk |= bad; else bad_colour |= bad;
+    }
+    bad_trunk = __syncthreads_or(bad_trunk);
+    bad_colour = __syncthreads_or(bad_colour);
+    if (threadIdx.x == 0) {
+      tail[LP_NAN_TRUNK - OFF_BIAS + blockIdx.x] = bad_trunk ? __builtin_nanf("") : 0.f;
+      tail[LP_NAN_COLOUR - OFF_BIAS + blockIdx.x] = bad_colour ? __builtin_nanf("") : 0.f;
+    }
   }
 }
 
@@ -396,8 +423,8 @@ extern "C" int scade_mlp_pack_lp(const float* const* params, void* packed, int b
     a.p[i] = params[i];
   }
   a.packed = packed;
-  if (bf16) hipLaunchKernelGGL(mlp_pack_lp_kernel<true>, dim3(64, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(mlp_pack_lp_kernel<false>, dim3(64, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
+  if (bf16) hipLaunchKernelGGL(mlp_pack_lp_kernel<true>, dim3(LP_NAN_BLOCKS, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mlp_pack_lp_kernel<false>, dim3(LP_NAN_BLOCKS, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_mlp_pack_lp");
 }
 

@@ -57,6 +57,17 @@ constexpr long off_wl(int l) {
   return o;
 }
 constexpr long PACKED_LP_ELEMS = off_wl(NLAYER_MFMA) + 2 * 64 * 8;   // + slack for the prefetch
+// NaN census of the hidden layers' fp32 parameters, written by the pack kernel into the (otherwise unused)
+// 256-float slack at the end of the fp32 tail: one 0 / NaN float per pack block for the trunk
+// (pts_linears.*) and one for the colour branch (feature_linear, views_linears.0); offsets like OFF_*
+constexpr int LP_NAN_BLOCKS = 64;
+constexpr int LP_NAN_TRUNK = OFF_BR + 4, LP_NAN_COLOUR = LP_NAN_TRUNK + LP_NAN_BLOCKS;
+static_assert(LP_NAN_COLOUR + LP_NAN_BLOCKS <= PACKED_FWD_FLOATS, "census slots must fit the tail's slack");
+// elements of raw parameter tensor t (order of mlp_layout.h: 0..15 pts w/b, 16/17 views, 18/19 feature)
+__host__ __device__ constexpr int lp_param_numel(int t) {
+  return (t & 1) ? (t == 17 ? 128 : 256)
+                 : (t == 0 ? 256 * EMB : (t == 10 ? 256 * (EMB + W) : (t == 16 ? 128 * (W + 3) : W * W)));
+}
 constexpr long PACKED_LP_BYTES = PACKED_LP_ELEMS * 2 + F16_TAIL_FLOATS * 4;
 
 // ---- training workspaces of the 16-bit path (BYTE offsets; T = 16-bit element) ------------

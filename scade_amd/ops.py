@@ -62,6 +62,18 @@ class KernelTimer:
             d["work"] += work
         return out
 
+    def by_work(self, name):
+        """The records of one kernel split by launch size: {work per launch: {"launches", "ms"}} (one row
+        per launch size, like rocprofv3's per-dispatch trace grouped by grid)."""
+        torch.cuda.synchronize()
+        out = {}
+        for n, e0, e1, work in self.records:
+            if n == name:
+                d = out.setdefault(work, {"launches": 0, "ms": 0.0})
+                d["launches"] += 1
+                d["ms"] += e0.elapsed_time(e1)
+        return out
+
 
 KERNEL_TIMER: Optional[KernelTimer] = None
 PARAM_EPOCH = 0   # bumped by optimizers that update parameters through raw pointers

@@ -133,18 +133,21 @@ def test_poisoned_rays_show_the_references_nan_pattern(dev, prec):
             assert_close(ret[k][clean], want[k][clean], rtol=1e-4, atol=1e-6, what=k)
 
 
-@pytest.mark.parametrize("prec", ["f32", "f16x3"])
+@pytest.mark.parametrize("prec", ["f32", "f16x3", "bf16", "f16"])
 @pytest.mark.parametrize("sign", [1.0, -1.0])
 def test_nan_parameters_poison_every_output_like_the_reference(dev, prec, sign):
     """A NaN (either sign) in a HIDDEN layer's weight or bias - a diverged training run - must surface as
     NaN in every output, as torch.relu lets it in the reference; a ReLU that returned 0 for NaN would
-    render finite garbage from the layers behind it.  (The opt-in 16-bit path guarantees this for poisoned
-    INPUTS only - test above - and for NaN head parameters, whose arithmetic is fp32; a NaN in a hidden
-    layer's 16-bit weight copy is not guaranteed to survive its packed integer ReLU: INTEGRATION.md.)"""
+    render finite garbage from the layers behind it.  The 16-bit path's packed integer ReLU cannot carry a
+    negative-signed NaN, so its pack kernel takes a NaN census of the fp32 parameters and the heads poison
+    the outputs the reference's arithmetic would (trunk: all four; colour branch: rgb only); NaN head
+    parameters propagate through the fp32 heads by themselves."""
     N = 16
     rays = O.synthetic_rays(N, seed=70)
     bbc, bbs = torch.zeros(3), torch.tensor(0.2)
-    for key, idx in (("pts_linears.3.weight", (5, 7)), ("pts_linears.6.bias", (100,)), ("views_linears.0.weight", (3, 200))):
+    for key, idx in (("pts_linears.3.weight", (5, 7)), ("pts_linears.6.bias", (100,)), ("views_linears.0.weight", (3, 200)),
+                     ("pts_linears.0.weight", (255, 56)), ("feature_linear.bias", (17,)), ("views_linears.0.bias", (127,)),
+                     ("alpha_linear.weight", (0, 3)), ("rgb_linear.bias", (1,))):
         pc, pf = O.nerf_init(71), O.nerf_init(72)
         pc[key][idx] = sign * float("nan")
         with torch.no_grad():

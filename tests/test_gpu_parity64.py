@@ -112,15 +112,15 @@ def test_render_rays_error_against_fp64_is_the_references_own(dev):
     _dump("render_rays_512rays", table)
 
 
-def test_train_step_gradient_error_against_fp64_is_the_references_own(dev):
-    """All 48 parameter gradients + scale/shift of the 3-term loss (:968-985)."""
-    N, K = 256, 20
-    rays = O.synthetic_rays(N, seed=95)
-    g = torch.Generator().manual_seed(96)
+def _train_step_grads(dev, N, K, seed):
+    """All 48 parameter gradients + scale/shift + loss of the 3-term loss (:968-985) for one seeded problem:
+    (HIP, oracle fp32 = the reference's arithmetic, oracle fp64)."""
+    rays = O.synthetic_rays(N, seed=seed)
+    g = torch.Generator().manual_seed(seed + 1)
     tgt = torch.rand(N, 3, generator=g)
     hyp = torch.rand(K, N, 1, generator=g) * 4.9 + 0.1
     t_rand, uc, uf = torch.rand(N, 64, generator=g), torch.rand(N, 128, generator=g), torch.rand(N, 128, generator=g)
-    pc0, pf0 = O.nerf_init(97), O.nerf_init(98)
+    pc0, pf0 = O.nerf_init(seed + 2), O.nerf_init(seed + 3)
     bbc, bbs = torch.zeros(3), torch.tensor(0.2)
 
     def oracle_grads(cast):
@@ -151,6 +151,19 @@ def test_train_step_gradient_error_against_fp64_is_the_references_own(dev):
     hipg = {"coarse." + k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in coarse.named_parameters()}
     hipg.update({"fine." + k: (p.grad if p.grad is not None else torch.zeros_like(p)) for k, p in fine.named_parameters()})
     hipg["depth_scale"], hipg["depth_shift"], hipg["loss"] = sc.grad, sh.grad, loss.detach()
+    return hipg, g32, g64
+
+
+# gradient tensors with fewer than 16 elements (depth scale / shift, the alpha head's bias, the rgb head's
+# bias): ONE seeded problem gives one error draw per element, not a statistic - they are bounded over many
+# seeds by test_small_gradient_tensors_error_is_the_references_own_over_16_seeds below
+def _is_small(t):
+    return t.numel() < 16
+
+
+def test_train_step_gradient_error_against_fp64_is_the_references_own(dev):
+    """All 48 parameter gradients + scale/shift of the 3-term loss (:968-985)."""
+    hipg, g32, g64 = _train_step_grads(dev, 256, 20, seed=95)
     table = {}
     for k in g64:
         if float(g64[k].abs().max()) == 0.0:
@@ -162,12 +175,45 @@ def test_train_step_gradient_error_against_fp64_is_the_references_own(dev):
         _record(table, "_all_" + pre[:-1], cat(hipg, pre), cat(g32, pre), cat(g64, pre))
     _dump("train_step_grads_256rays_K20", table)
     # a single gradient tensor's max/percentile is dominated by a handful of near-knot samples;
-    # bound the norm-wise error of every tensor and both statistics of the whole networks
-    # (a scalar - depth scale / shift, a 1-element bias - has ONE error draw, not a statistic: its
-    # bound is C x the reference's or 5e-3, whichever is larger)
-    small = {k for k in table if not k.startswith("_") and g64[k].numel() < 16}
+    # bound the norm-wise error of every tensor and both statistics of the whole networks.  The few-element
+    # tensors are recorded here and BOUNDED by the multi-seed test (no absolute floor any more).
+    small = {k for k in table if not k.startswith("_") and _is_small(g64[k])}
     bad = [(k, r["hip_rel_l2"], r["oracle32_rel_l2"]) for k, r in table.items()
-           if r["hip_rel_l2"] > max(C_BOUND * r["oracle32_rel_l2"] + 2e-7, 5e-3 if k in small else 0.0)]
+           if k not in small and r["hip_rel_l2"] > C_BOUND * r["oracle32_rel_l2"] + 2e-7]
     assert not bad, "HIP gradients farther from fp64 than C x the reference's fp32: %s" % bad
     for k in ("_all_coarse", "_all_fine"):
         assert table[k]["hip_p999"] <= C_BOUND * table[k]["oracle32_p999"] + 2e-7, (k, table[k])
+
+
+def test_small_gradient_tensors_error_is_the_references_own_over_16_seeds(dev):
+    """depth_scale / depth_shift (the two tensors optimizer_ss steps on, :954 / :996) and the other
+    few-element gradients are signed sums over (ray, sample, argmin-hypothesis) events that largely cancel:
+    the reference's OWN fp32 arithmetic is 1e-4 ... 1e-1 away from the fp64 answer on them, differently on
+    every draw.  So the bound is a statistic over 16 seeded problems (rays, targets, hypotheses, draws, both
+    networks re-drawn): median over seeds of err(HIP) / err(reference fp32) <= 2, and the median errors
+    themselves within the same factor - no absolute floor."""
+    seeds = [1000 + 17 * i for i in range(16)]
+    per_key = {}
+    for sd in seeds:
+        hipg, g32, g64 = _train_step_grads(dev, 128, 20, seed=sd)
+        for k in g64:
+            if k == "loss" or not _is_small(g64[k]) or float(g64[k].abs().max()) == 0.0:
+                continue
+            ref = g64[k].detach().double().cpu().flatten()
+            den = float(ref.norm()) + 1e-300
+            eh = float((hipg[k].detach().double().cpu().flatten() - ref).norm()) / den
+            eo = float((g32[k].detach().double().cpu().flatten() - ref).norm()) / den
+            per_key.setdefault(k, []).append((eh, eo))
+    med = lambda v: float(torch.tensor(v, dtype=torch.float64).median())
+    table, bad = {}, []
+    for k, pairs in per_key.items():
+        eh, eo = [p[0] for p in pairs], [p[1] for p in pairs]
+        ratios = [h / max(o, 1e-300) for h, o in pairs]
+        table[k] = {"seeds": len(pairs), "median_ratio_hip_over_oracle32": med(ratios),
+                    "median_hip_rel_err": med(eh), "median_oracle32_rel_err": med(eo),
+                    "max_hip_rel_err": max(eh), "max_oracle32_rel_err": max(eo), "ratios": ratios}
+        if med(ratios) > C_BOUND or med(eh) > C_BOUND * med(eo) + 2e-7:
+            bad.append((k, table[k]["median_ratio_hip_over_oracle32"], med(eh), med(eo)))
+    _dump("small_gradient_tensors_16seeds_128rays_K20", table)
+    assert {"depth_scale", "depth_shift"} <= set(table), sorted(table)
+    assert not bad, "few-element gradients: HIP farther from fp64 than C x the reference's fp32 (medians over seeds): %s" % bad

@@ -4,7 +4,10 @@
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) KB  (the gfx950 FETCH_SIZE correction of
 MI355X_MICROARCH.md, HBM / rocprofv3 section); MFMA utilisation = (SQ_VALU_MFMA_BUSY_CYCLES / 1024
 SIMDs) / (GRBM_GUI_ACTIVE / 8 XCDs); LDS conflict fraction = SQ_LDS_BANK_CONFLICT /
-SQ_LDS_IDX_ACTIVE; L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS)."""
+SQ_LDS_IDX_ACTIVE; L2 hit rate = TCC_HIT / (TCC_HIT + TCC_MISS).  Optional further arguments: the
+``clock`` tables of tools/trace_stats.py (train command: every launch; render command: the timed launches of
+the headline kernel, one row per launch size) -> ``effective_clock_ghz`` = GRBM_GUI_ACTIVE / 8 XCDs /
+dispatch duration per kernel (the 157.3 TFLOP/s and 2.5 PFLOP/s peaks assume 2.4 GHz)."""
 import collections, csv, json, re, sys
 
 KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-size workgroup variants
@@ -27,7 +30,27 @@ KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-siz
 ]
 
 
-def main(src, dst):
+def _key(name):
+    return next((k for rx, k in KEYS if re.search(rx, name)), None)
+
+
+def clocks(path):
+    """clock csv -> {key: {"ghz", "launches", "by_grid": {grid: {...}}}} (launch-weighted mean over grid sizes)."""
+    out = {}
+    for r in csv.DictReader(open(path)):
+        key = _key(r["Name"])
+        if key is None:
+            continue
+        n, ghz = int(r["Launches_Timed"]), float(r["Effective_Clock_GHz"])
+        d = out.setdefault(key, {"n": 0, "sum": 0.0, "by_grid": {}})
+        d["n"] += n
+        d["sum"] += n * ghz
+        d["by_grid"][r["Grid_Size"]] = {"launches": n, "avg_ms": float(r["AverageNs"]) / 1e6, "effective_clock_ghz": ghz,
+                                        "mfma_busy": float(r["MFMA_Busy_Frac"]) if r["MFMA_Busy_Frac"] else None}
+    return {k: {"ghz": d["sum"] / d["n"], "launches": d["n"], "by_grid": d["by_grid"]} for k, d in out.items()}
+
+
+def main(src, dst, train_clock=None, render_clock=None):
     rows = collections.defaultdict(dict)
     for r in csv.reader(open(src)):
         if r[0] == "kernel":
@@ -35,7 +58,7 @@ def main(src, dst):
         rows[r[0]][r[1]] = float(r[3])
     out = {}
     for name, v in rows.items():
-        key = next((k for rx, k in KEYS if re.search(rx, name)), None)
+        key = _key(name)
         if key is None:
             continue
         gui, mf = v.get("GRBM_GUI_ACTIVE", 0.0), v.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
@@ -48,11 +71,24 @@ def main(src, dst):
             "l2_hit_rate": hit / (hit + miss) if hit + miss else None,
             "wave_wait_any_frac": v.get("SQ_WAIT_ANY", 0.0) / max(v.get("SQ_WAVE_CYCLES", 0.0), 1.0),
         }
+    if train_clock:
+        for k, c in clocks(train_clock).items():
+            if k in out:
+                out[k]["effective_clock_ghz"] = c["ghz"]
+    if render_clock:
+        c = clocks(render_clock).get("mlp_fwd_kernel")
+        if c and "mlp_fwd_kernel" in out:
+            # the headline kernel: the TIMED launches of the render command, one row per launch size
+            # (grid = threads: 256 per 64-point workgroup -> points = grid / 4)
+            out["mlp_fwd_kernel"]["effective_clock_ghz"] = c["ghz"]
+            out["mlp_fwd_kernel"]["timed_launches_by_points"] = {
+                str(int(g) // 4): v for g, v in sorted(c["by_grid"].items(), key=lambda kv: int(kv[0]))}
     json.dump(out, open(dst, "w"), indent=1)
     for k, v in out.items():
-        print(f"{k:32s} mfma {v['mfma_util']:.3f}  hbm {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  "
-              f"lds-conflict {v['lds_bank_conflict_frac']:.3f}  L2 hit {v['l2_hit_rate']:.3f}")
+        print(f"{k:32s} mfma {v['mfma_util'] or 0:.3f}  hbm {v['hbm_bytes_per_launch'] / 1e6:9.1f} MB  "
+              f"lds-conflict {v['lds_bank_conflict_frac']:.3f}  L2 hit {v['l2_hit_rate'] or 0:.3f}  "
+              f"clock {v.get('effective_clock_ghz') or 0:.3f} GHz")
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:5])

@@ -2,13 +2,49 @@
 """Copy the outputs of tools/profile_gpu.sh <tag> (gpurun_out/prof_<tag>/) and an un-profiled bench line
 into profiles/ and (re)generate that round's reading block in profiles/README.md (between the markers
 <!-- BEGIN <tag> --> / <!-- END <tag> -->; blocks of other rounds are left alone).
-Usage: python tools/update_profiles.py r02 gpurun_out/bench_final.json"""
+Refuses (non-zero exit, nothing copied) when the kernel statistics do not fit the bench lines they are meant to
+back: the headline kernel's timed average of the coarse launch + that of the fine launch (= the MLP time of ONE
+step) must not exceed ms_per_step of the profiled run's own line NOR of the un-profiled line of the same box,
+and the rocprofv3-derived roofline fraction must agree with the same-run HIP-event fraction within 1 %.
+Usage: python tools/update_profiles.py r03 gpurun_out/bench_final.json [--force]"""
 import csv, json, os, re, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, bench = sys.argv[1], sys.argv[2]
+force = "--force" in sys.argv
 src, dst = os.path.join(ROOT, "gpurun_out", "prof_" + tag), os.path.join(ROOT, "profiles")
-for a, b in (("kernel_stats.csv", "render_kernel_stats.csv"), ("kernel_stats_train.csv", "train_kernel_stats.csv"),
+PEAK, FLOP_PER_POINT = 157.3, 2 * 587264
+
+
+def load_line(path):
+    return json.loads([l for l in open(path).read().splitlines() if l.startswith('{"metric')][-1])
+
+
+# ---- consistency gate (VERDICT r2 item 1) -----------------------------------------------------------------
+timed = [r for r in csv.DictReader(open(os.path.join(src, "kernel_stats_timed.csv")))
+         if "mlp_fwd_kernel<1, false, 2>" in r["Name"]]
+assert len(timed) == 2, f"expected the coarse and the fine launch size of the headline kernel, got {len(timed)} rows"
+per_step_ms = sum(float(r["AverageNs"]) for r in timed) / 1e6
+fl = sum(int(r["Grid_Size"]) // 4 * FLOP_PER_POINT for r in timed) / 2          # mean FLOP per launch
+frac_prof = fl / (per_step_ms / 2 * 1e-3) / 1e12 / PEAK
+under = load_line(os.path.join(src, "bench_line_under_rocprof.json"))
+same_box = load_line(os.path.join(src, "bench_line_unprofiled_same_box.json"))
+problems = []
+for what, ln in (("the profiled run's own line", under), ("the un-profiled line of the same box", same_box)):
+    if per_step_ms > ln["ms_per_step"]:
+        problems.append(f"coarse + fine timed average {per_step_ms:.4f} ms exceeds ms_per_step {ln['ms_per_step']:.4f} of {what}")
+if abs(frac_prof / under["roofline"]["frac"] - 1) > 0.01:
+    problems.append(f"rocprofv3-derived frac {frac_prof:.4f} vs same-run HIP-event frac {under['roofline']['frac']:.4f}: > 1 %")
+print(f"gate: rocprofv3 timed launches {per_step_ms:.4f} ms per step -> frac {frac_prof:.4f}; same-run HIP events "
+      f"{under['roofline']['frac']:.4f}; un-profiled same box {same_box['roofline']['frac']:.4f} "
+      f"(ms_per_step {same_box['ms_per_step']:.4f})")
+if problems and not force:
+    sys.exit("update_profiles: REFUSING to copy these profiles:\n  " + "\n  ".join(problems))
+
+for a, b in (("kernel_stats_timed.csv", "render_kernel_stats_timed.csv"), ("render_clock.csv", "render_clock.csv"),
+             ("train_clock.csv", "train_clock.csv"),
+             ("bench_line_unprofiled_same_box.json", "render_bench_line_unprofiled_same_box.json"),
+             ("kernel_stats.csv", "render_kernel_stats.csv"), ("kernel_stats_train.csv", "train_kernel_stats.csv"),
              ("bench_line_under_rocprof.json", "render_bench_line_under_rocprof.json"),
              ("bench_line_train_under_rocprof.json", "train_bench_line_under_rocprof.json"),
              ("pmc_summary.csv", "pmc_summary.csv"), ("pmc.json", "pmc.json")):
@@ -21,7 +57,15 @@ d = json.loads(line)
 dr = json.load(open(os.path.join(dst, f"{tag}_render_bench_line_under_rocprof.json")))
 st = {r["Name"]: r for r in csv.DictReader(open(os.path.join(dst, f"{tag}_render_kernel_stats.csv")))}
 fw = next(v for k, v in st.items() if "mlp_fwd_kernel<1, false, 2>" in k)
-avg = float(fw["AverageNs"]) / 1e6
+avg = per_step_ms / 2          # mean over the TIMED launches (coarse and fine in equal numbers)
+fw = dict(fw, Calls=str(sum(int(r["Launches_Timed"]) for r in timed)))
+size_rows = "\n".join(
+    f"| {int(r['Grid_Size']) // 4:,} | {r['Launches_Timed']} of {r['Launches_In_Process']} | {float(r['AverageNs']) / 1e6:.4f} | "
+    f"{int(r['MinNs']) / 1e6:.4f} | {int(r['MaxNs']) / 1e6:.4f} | "
+    f"{int(r['Grid_Size']) // 4 * FLOP_PER_POINT / float(r['AverageNs']) / 1e3:.1f} | "
+    f"{int(r['Grid_Size']) // 4 * FLOP_PER_POINT / float(r['AverageNs']) / 1e3 / PEAK:.4f} | "
+    f"{pm['mlp_fwd_kernel'].get('timed_launches_by_points', {}).get(str(int(r['Grid_Size']) // 4), {}).get('effective_clock_ghz', float('nan')):.3f} |"
+    for r in sorted(timed, key=lambda r: int(r["Grid_Size"])))
 notes = {
     "mlp_fwd_kernel": f"headline render kernel; algorithmic HBM ~ 6.1 MB, the 2.4 MB weight blob is fetched once per XCD L2 "
                       f"(8 x 2.4 MB = the 4x over-fetch; 22 GB/s, harmless); rocprofv3 average {avg:.4f} ms over {fw['Calls']} "
@@ -73,10 +117,20 @@ Every figure is a MEAN PER LAUNCH over all launches of that kernel in the profil
 |---|---|---|---|---|
 """ + "\n".join(rows) + f"""
 
-Headline kernel `mlp_fwd_kernel<1,false,2>` in `{tag}_render_kernel_stats.csv`: {fw['Calls']} launches, average
-**{avg:.4f} ms**, {float(fw['Percentage']):.1f} % of GPU time; bench.py's own HIP-event average over the timed launches of the same
-profiled run (`{tag}_render_bench_line_under_rocprof.json`): **{dr['roofline']['avg_launch_ms']:.4f} ms** (agree within
-{abs(avg / dr['roofline']['avg_launch_ms'] - 1) * 100:.1f} %).
+Headline kernel `mlp_fwd_kernel<1,false,2>`, TIMED launches only (`{tag}_render_kernel_stats_timed.csv`: the last 100
+launches of each size from the per-dispatch trace; `{tag}_render_kernel_stats.csv` is rocprofv3's own summary over all
+launches of the process, setup and warm-up included), one row per launch size, clock from the separate PMC pass
+(`{tag}_render_clock.csv`):
+
+| points | launches (timed of all) | average ms | min | max | TFLOP/s | of 157.3 | effective clock GHz |
+|---|---|---|---|---|---|---|---|
+{size_rows}
+
+Mean over both sizes **{avg:.4f} ms** -> **{frac_prof:.4f}** of the peak from the rocprofv3 trace; bench.py's own HIP-event
+figure in the SAME profiled run (`{tag}_render_bench_line_under_rocprof.json`): {dr['roofline']['avg_launch_ms']:.4f} ms, frac
+{dr['roofline']['frac']:.4f} (agree within {abs(avg / dr['roofline']['avg_launch_ms'] - 1) * 100:.2f} %); the same command UN-profiled on the
+same box right before (`{tag}_render_bench_line_unprofiled_same_box.json`): frac {same_box['roofline']['frac']:.4f},
+{same_box['ms_per_step']:.4f} ms per step (profiler effect {100 * (under['ms_per_step'] / same_box['ms_per_step'] - 1):+.2f} % on the step).
 
 Un-profiled bench line of the same build (`{tag}_bench_line.json`): {d['value']:.0f} rays/s, {d['ms_per_step']:.3f} ms/step,
 `roofline.achieved` {d['roofline']['achieved']:.1f} TFLOP/s (frac {d['roofline']['frac']:.4f}), exact train step {tr.get('ms_per_step', float('nan')):.3f} ms,
