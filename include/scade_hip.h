@@ -71,6 +71,18 @@ int scade_mlp_bwd_chunks(int P);
 int scade_mlp_bwd(const float* packed, const float* packed_t, const float* acts,
                   const float* g_out, int P, float* workspace, float* grad_flat, void* stream);
 
+/* The backward of TWO network calls in one go - the coarse and the fine NeRF of a train step, whose backward
+ * chains are independent (run_scade_scannet.py:711 detaches the samples between them): ONE dgrad launch, ONE
+ * weight-gradient launch and ONE reduce over both instead of three launches each.  Every argument is a HOST
+ * array of two entries with the meaning it has in scade_mlp_bwd; workspace[i] must hold
+ * scade_mlp_bwd2_workspace_floats(P[i], P[1-i]) floats (never less than scade_mlp_bwd_workspace_floats(P[i])).
+ * Same result per network as two scade_mlp_bwd calls up to the summation order over point chunks (the joint
+ * launch picks one chunk length for both). */
+long scade_mlp_bwd2_workspace_floats(int P, int P_other);
+int scade_mlp_bwd2(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                   const float* const* g_out, const int* P, float* const* workspace, float* const* grad_flat,
+                   void* stream);
+
 /* Split-precision INFERENCE variant of scade_mlp_fwd (opt-in): every fp32 value is
  * carried as two fp16 numbers x ~= h + l*2^-11 and every product as three f16 MFMAs into two fp32
  * accumulators (~2^-21 relative error per product; requires |activations|,|weights| < 65504).
@@ -108,6 +120,17 @@ int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp, int bf16,
 long scade_mlp_bwd_lp_workspace_bytes(int P);
 int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, const void* acts,
                      const float* g_out, int P, void* workspace, float* grad_flat, void* stream);
+
+/* Two network calls in one dgrad / weight-gradient / reduce launch each (see scade_mlp_bwd2): host arrays of
+ * two entries; workspace[i] = scade_mlp_bwd_lp2_workspace_bytes(P[i], P[1-i]) bytes.  The ReLU sign words of
+ * the 16-bit workspace are indexed by the workgroups of the forward launch that wrote them, so both launches
+ * must have used the same point tiling: scade_mlp_lp_point_tiles(P[0]) == scade_mlp_lp_point_tiles(P[1])
+ * (otherwise error -3: call scade_mlp_bwd_lp twice). */
+int scade_mlp_lp_point_tiles(int P);
+long scade_mlp_bwd_lp2_workspace_bytes(int P, int P_other);
+int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,
+                      const float* const* g_out, const int* P, void* const* workspace,
+                      float* const* grad_flat, void* stream);
 
 /* Split-precision variant of scade_mlp_bwd (opt-in training mode): the dgrad chain runs on
  * f16 MFMAs with a per-point power-of-two gradient scale (exactly removed on store); the weight

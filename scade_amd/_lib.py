@@ -32,6 +32,8 @@ SIGNATURES = {
     "scade_mlp_bwd_workspace_floats": (c_long, [_I]),
     "scade_mlp_bwd_chunks": (c_int, [_I]),
     "scade_mlp_bwd": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P]),
+    "scade_mlp_bwd2_workspace_floats": (c_long, [_I, _I]),
+    "scade_mlp_bwd2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "scade_mlp_packed_f16_bytes": (c_long, []),
     "scade_mlp_pack_f16": (c_int, [_P, _P, _P]),
     "scade_mlp_fwd_f16": (c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
@@ -43,6 +45,9 @@ SIGNATURES = {
     "scade_mlp_pack_t_lp": (c_int, [_P, _P, _I, _P]),
     "scade_mlp_bwd_lp_workspace_bytes": (c_long, [_I]),
     "scade_mlp_bwd_lp": (c_int, [_P, _P, _I, _P, _P, _I, _P, _P, _P]),
+    "scade_mlp_lp_point_tiles": (c_int, [_I]),
+    "scade_mlp_bwd_lp2_workspace_bytes": (c_long, [_I, _I]),
+    "scade_mlp_bwd_lp2": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P]),
     "scade_mlp_packed_t_f16_bytes": (c_long, []),
     "scade_mlp_pack_t_f16": (c_int, [_P, _P, _P]),
     "scade_mlp_bwd_f16": (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),

@@ -62,6 +62,14 @@ struct MlpDgradArgs {
   float* dz;              // dz_floats(P)
   int P;
 };
+// One launch may walk the gradient tiles of TWO networks (the coarse and the fine NeRF of a train step: their
+// backward chains are independent, and one launch of tiles0 + tiles1 workgroups fills the rounds of two
+// workgroups per CU that two small launches leave half empty): workgroups [0, tiles0) belong to n[0], the
+// rest to n[1].  A single-network launch sets tiles0 to its whole grid.
+struct MlpDgradArgs2 {
+  MlpDgradArgs n[2];
+  int tiles0;
+};
 
 // write the wave's [2 k-tiles x 64 points] gradient block in place to LDS: optional
 // alpha-head term, optional ReLU mask from the lane-private sign bits the forward saved
@@ -99,21 +107,24 @@ __device__ __forceinline__ void dgrad_store(const f32x16 (&acc)[2][PT], int ktil
 }
 
 template <int PT>
-__global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs a) {
+__global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs2 aa) {
   constexpr int TM = tile_pts(PT);     // points of this workgroup (shadows the 64-point default)
+  const bool second = (int)blockIdx.x >= aa.tiles0;                 // wave-uniform: scalar selects
+  const MlpDgradArgs& a = second ? aa.n[1] : aa.n[0];
+  const int blk = (int)blockIdx.x - (second ? aa.tiles0 : 0);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;
   float* dal = lds + h_floats(PT);   // d alpha_pre of the tile's points
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p0 = blockIdx.x * TM;
+  const int p0 = blk * TM;
   const int P = a.P;
   const float* __restrict__ pk = a.packed;
   const float* __restrict__ pt_ = a.packedT;
   const float* __restrict__ acts = a.acts;
   float* __restrict__ dz = a.dz;
-  auto mask_of = [&](int layer) { return load_relu_words<PT>(acts, P, layer, tid); };
+  auto mask_of = [&](int layer) { return load_relu_words<PT>(acts, P, layer, tid, blk); };
 
   // ---- heads: d alpha_pre, dZ of the views layer (rgb head + ReLU mask) ----------
   {
@@ -221,7 +232,12 @@ extern "C" int scade_mlp_pack_t(const float* const* params, float* packed_t, voi
   return scade_check_launch("scade_mlp_pack_t");
 }
 
-namespace scade { int pick_chunks_v2(int P); }   // mlp_wgrad2.hip
+namespace scade {   // mlp_wgrad2.hip
+int pick_chunks_v2(int P);
+void wgrad2_joint_chunking(const int* P, int& chunk, int& gx0, int& gx1);
+}
+int scade_launch_wgrad2(const float* const* acts, const float* const* dz, const float* const* g_out, const int* P,
+                        float* const* partial, float* const* grad_flat, hipStream_t s);
 
 // chunk count of the exact weight-gradient kernel (mlp_wgrad2.hip)
 extern "C" int scade_mlp_bwd_chunks(int P) { return pick_chunks_v2(P); }
@@ -232,8 +248,19 @@ extern "C" long scade_mlp_bwd_workspace_floats(int P) {
   return dz_floats(P) + (long)nc * N_PARAM_FLOATS + 4;   // + launch-wide max slot (f16x3 mode)
 }
 
+// workspace of network 0 of a joint launch over networks of P and P_other points (scade_mlp_bwd2): its dZ
+// rows + the per-chunk partials under the JOINT chunking (never smaller than scade_mlp_bwd_workspace_floats(P),
+// so the same buffer also serves a separate launch)
+extern "C" long scade_mlp_bwd2_workspace_floats(int P, int P_other) {
+  int Ps[2] = {P, P_other}, chunk, gx0, gx1;
+  wgrad2_joint_chunking(Ps, chunk, gx0, gx1);
+  const long joint = dz_floats(P) + (long)gx0 * N_PARAM_FLOATS + 4;
+  const long alone = scade_mlp_bwd_workspace_floats(P);
+  return joint > alone ? joint : alone;
+}
+
 template <int PT>
-static int launch_dgrad(const MlpDgradArgs& d, hipStream_t s) {
+static int launch_dgrad(const MlpDgradArgs2& d, int tiles, hipStream_t s) {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_kernel<PT>),
@@ -241,8 +268,7 @@ static int launch_dgrad(const MlpDgradArgs& d, hipStream_t s) {
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(attr_set);
   }
-  hipLaunchKernelGGL(mlp_dgrad_kernel<PT>, dim3((d.P + tile_pts(PT) - 1) / tile_pts(PT)), dim3(256),
-                     mlp_lds_bytes(PT), s, d);
+  hipLaunchKernelGGL(mlp_dgrad_kernel<PT>, dim3(tiles), dim3(256), mlp_lds_bytes(PT), s, d);
   return scade_check_launch("scade_mlp_bwd(dgrad)");
 }
 
@@ -256,9 +282,37 @@ extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const f
   float* dz = workspace;
   float* partial = workspace + dz_floats(P);
 
-  MlpDgradArgs d{packed, packed_t, acts, g_out, dz, P};
   // same point tiling as the forward that wrote the ReLU words of this workspace
-  if (int e = pick_point_tiles(P) == 1 ? launch_dgrad<1>(d, s) : launch_dgrad<2>(d, s)) return e;
+  const int pt = pick_point_tiles(P);
+  const int tiles = (P + tile_pts(pt) - 1) / tile_pts(pt);
+  MlpDgradArgs2 d{{{packed, packed_t, acts, g_out, dz, P}, {}}, tiles};
+  if (int e = pt == 1 ? launch_dgrad<1>(d, tiles, s) : launch_dgrad<2>(d, tiles, s)) return e;
 
   return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
+}
+
+// The backward of TWO network calls (the coarse and the fine NeRF of one train step) as ONE dgrad launch, ONE
+// weight-gradient launch and ONE reduce: same arithmetic per network as two scade_mlp_bwd calls (bitwise - a
+// workgroup's work does not depend on its neighbours), but the joint grid fills whole rounds of two workgroups
+// per CU, which matters for the 128-ray shards of a strongly scaled batch, and three launches go.
+extern "C" int scade_mlp_bwd2(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                              const float* const* g_out, const int* P, float* const* workspace,
+                              float* const* grad_flat, void* stream) {
+  SCADE_REQUIRE(packed && packed_t && acts && g_out && P && workspace && grad_flat, -1, "scade_mlp_bwd2: null pointer");
+  for (int i = 0; i < 2; ++i) {
+    SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd2: P[%d] must be positive", i);
+    SCADE_REQUIRE(packed[i] && packed_t[i] && acts[i] && g_out[i] && workspace[i] && grad_flat[i], -1,
+                  "scade_mlp_bwd2: null pointer in entry %d", i);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  // the ReLU words are indexed by 32-point tile, not by workgroup, so the point tiling of this launch is free:
+  // it is chosen for the JOINT grid (64-point workgroups as soon as both networks together give every CU two)
+  const int pt = pick_point_tiles((long)P[0] + P[1]);
+  const int t0 = (P[0] + tile_pts(pt) - 1) / tile_pts(pt), t1 = (P[1] + tile_pts(pt) - 1) / tile_pts(pt);
+  MlpDgradArgs2 d{{{packed[0], packed_t[0], acts[0], g_out[0], workspace[0], P[0]},
+                   {packed[1], packed_t[1], acts[1], g_out[1], workspace[1], P[1]}}, t0};
+  if (int e = pt == 1 ? launch_dgrad<1>(d, t0 + t1, s) : launch_dgrad<2>(d, t0 + t1, s)) return e;
+  float* partial[2] = {workspace[0] + dz_floats(P[0]), workspace[1] + dz_floats(P[1])};
+  const float* dz[2] = {workspace[0], workspace[1]};
+  return scade_launch_wgrad2(acts, dz, g_out, P, partial, grad_flat, s);
 }

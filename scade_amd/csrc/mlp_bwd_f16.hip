@@ -117,7 +117,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   const _Float16* __restrict__ pt_ = a.packedT;
   const float* __restrict__ acts = a.acts;
   float* __restrict__ dz = a.dz;
-  auto mask_of = [&](int layer) { return load_relu_words<2>(acts, P, layer, tid); };
+  auto mask_of = [&](int layer) { return load_relu_words<2>(acts, P, layer, tid, blockIdx.x); };
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
   {

@@ -119,6 +119,13 @@ struct MlpDgradLpArgs {
   const float* gmax;
   int P;
 };
+// one launch may walk the tiles of TWO networks (see MlpDgradArgs2 in mlp_bwd.hip): workgroups [0, tiles0)
+// belong to n[0], the rest to n[1]; tiles1 = workgroups of n[1].  The sign words are indexed by the workgroup
+// of the network's OWN forward launch, so each network keeps its forward's tiling (both must use the same NPT).
+struct MlpDgradLpArgs2 {
+  MlpDgradLpArgs n[2];
+  int tiles0, tiles1;
+};
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -132,28 +139,48 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][NPT], int 
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int f = (ktile0 + t) * 32 + 8 * q + 4 * hh;
-      f32x4 wa = {0.f, 0.f, 0.f, 0.f};
-      if (ADD_ALPHA) wa = *reinterpret_cast<const f32x4*>(w_a + f);
+    for (int m = 0; m < 2; ++m) {       // row groups q = 2m, 2m + 1: two 16-byte chunks of 8 features
+      f32x4 wa[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      if (ADD_ALPHA) {
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq)
+          wa[qq] = *reinterpret_cast<const f32x4*>(w_a + (ktile0 + t) * 32 + 8 * (2 * m + qq) + 4 * hh);
+      }
 #pragma unroll
       for (int p = 0; p < NPT; ++p) {
         const int row = p * 32 + r;
-        float y[4];
+        u32x2 v[2];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          y[i] = acc[t][p][4 * q + i];
-          if (ADD_ALPHA) y[i] = y[i] + wa[i] * dal_scaled[row];
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * m + qq;
+          float y[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) {
+            y[i] = acc[t][p][4 * q + i];
+            if (ADD_ALPHA) y[i] = y[i] + wa[qq][i] * dal_scaled[row];
+          }
+          v[qq][0] = pack2<BF, false>(y[0], y[1]);
+          v[qq][1] = pack2<BF, false>(y[2], y[3]);
+          if (MASK) {   // sign words (mlp_tile_lp.h): dword d = ((t*4+q)*4+p)*2 + j
+            const int d0 = ((t * 4 + q) * 4 + p) * 2;
+            v[qq][0] = mask_pair(v[qq][0], bits[d0 >> 4], d0 & 15);
+            v[qq][1] = mask_pair(v[qq][1], bits[d0 >> 4], (d0 & 15) + 1);
+          }
         }
-        u32x2 v;
-        v[0] = pack2<BF, false>(y[0], y[1]);
-        v[1] = pack2<BF, false>(y[2], y[3]);
-        if (MASK) {   // sign words (mlp_tile_lp.h): dword d = ((t*4+q)*4+p)*2 + j
-          const int d0 = ((t * 4 + q) * 4 + p) * 2;
-          v[0] = mask_pair(v[0], bits[d0 >> 4], d0 & 15);
-          v[1] = mask_pair(v[1], bits[d0 >> 4], (d0 & 15) + 1);
+        // as in the forward's layer_store_lp: a lane holds HALF (features 8q + 4hh .. +3) of each of the two
+        // 16-byte chunks; stored as ds_write_b64 the 16 rows of a lane group share 8 slots of a bank line
+        // (2-way conflict: 30 % of this kernel's LDS cycles in round 2).  v_permlane32_swap trades the halves
+        // between lane r and lane r + 32 - the lower lane ends up with all of chunk 2m, the upper one with
+        // all of chunk 2m + 1 - and each stores one conflict-free ds_write_b128.
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned lo, hi;
+          lp_swap_halves(v[0][j], v[1][j], lo, hi);
+          w[j] = lo;
+          w[2 + j] = hi;
         }
-        *reinterpret_cast<u32x2*>(g + x_idx(row, f >> 3) + (f & 7)) = v;
+        *reinterpret_cast<u32x4*>(g + x_idx(row, (ktile0 + t) * 4 + 2 * m + hh)) = w;
       }
     }
 }
@@ -161,8 +188,12 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][NPT], int 
 constexpr int dgrad_lp_lds_bytes(int NPT) { return 32 * NPT * W * 2 + 2 * 32 * NPT * 4; }
 
 template <bool BF, int NPT>
-__global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) {
+__global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa) {
   constexpr int LM = 32 * NPT, LPT = NPT, LXPLANE = LM * W;   // this workgroup's tile (shadow the 128-point default)
+  const bool second = (int)blockIdx.x >= aa.tiles0;                 // wave-uniform: scalar selects
+  const MlpDgradLpArgs& a = second ? aa.n[1] : aa.n[0];
+  const int blk = (int)blockIdx.x - (second ? aa.tiles0 : 0);
+  const int ntiles = second ? aa.tiles1 : aa.tiles0;
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V4 V4;
   typedef typename LP<BF>::V8 V8;
@@ -173,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p0 = blockIdx.x * LM;
+  const int p0 = blk * LM;
   const int P = a.P;
   const T* __restrict__ pt_ = reinterpret_cast<const T*>(a.packedT);
   const float* __restrict__ tl = reinterpret_cast<const float*>(pt_ + PACKED_T_LP_ELEMS);
@@ -250,7 +281,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
   AFrag3<BF> A;
   const int kt0 = wave * 2;
   auto load_mask = [&](int layer) {
-    const u32x4 mw = masks[((size_t)layer * gridDim.x + blockIdx.x) * 256 + tid];
+    const u32x4 mw = masks[((size_t)layer * ntiles + blk) * 256 + tid];
     mb[0] = mw[0]; mb[1] = mw[1]; mb[2] = mw[2]; mb[3] = mw[3];
   };
   // this wave's k-tile pair of dgrad index TT: [kt][NB16][64] V8
@@ -305,6 +336,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs a) 
 struct WgradLpJob {
   long dz_off;       // element offset of the dZ matrix (row stride 256) in the dz workspace
   long in_off;       // element offset of the input matrix in the acts workspace
+                     // (both filled in by the kernel from the slots below and ITS network's point count)
+  int dz_slot;       // workspace slot of the dZ matrix
+  int in_slot;       // workspace slot of the input matrix; -1 = the embedding rows
   int in_stride;     // 256 (activation slot) or 64 (emb)
   int kw;            // tile width in k: 256 or 64
   int n_rows;        // valid output rows (256 or 128)
@@ -318,16 +352,22 @@ struct WgradLpJob {
   int aux_off;       // WF_ALPHA: offset of alpha weight (bias follows at +256)
 };
 
-struct WgradLpArgs {
-  WgradLpJob jobs[MAX_WGRAD_JOBS];
+// per-network part of a launch (one network, or the coarse and the fine NeRF of a train step: chunks
+// [0, gx0) of grid.x belong to net[0], the rest to net[1])
+struct WgradLpNet {
   const unsigned char* acts;
   const unsigned char* dz;
   const float* g_out;   // [P,4] (rgb head)
   float* partial;       // [nchunks][N_PARAM_FLOATS]
   const float* gmax;
   int P;
+};
+struct WgradLpArgs {
+  WgradLpJob jobs[MAX_WGRAD_JOBS];
+  WgradLpNet net[2];
   int chunk;            // points per chunk (multiple of WL_PT)
   int njobs;
+  int gx0;
 };
 
 constexpr int WL_PT = 32;                          // points per stage = two k16 blocks
@@ -363,7 +403,7 @@ struct WStage {
 };
 
 template <bool BF, int KW>
-__device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLpJob& jb, typename LP<BF>::T* lds,
+__device__ __forceinline__ void wgrad_lp_job(const WgradLpNet& a, const WgradLpJob& jb, typename LP<BF>::T* lds,
                                              int c0, int c1, float invS, float* __restrict__ out) {
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V8 V8;
@@ -527,7 +567,7 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpArgs& a, const WgradLp
 // A thread owns 8 columns (one 16-byte load per point) of every 32nd point, four points in flight:
 // this job is pure load latency, and as the LAST job of the table its workgroups set the kernel's end.
 template <bool BF>
-__device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpArgs& a, const WgradLpJob& jb, float* lds,
+__device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpNet& a, const WgradLpJob& jb, float* lds,
                                                  int c0, int c1, float* __restrict__ out) {
   typedef typename LP<BF>::T T;
   typedef typename LP<BF>::V8 V8;
@@ -583,13 +623,18 @@ __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpArgs& a, const Wgr
 }
 
 template <bool BF>
-__global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs a) {
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
   typedef typename LP<BF>::T T;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsw16[];
-  const WgradLpJob& jb = a.jobs[blockIdx.y];
-  const int c0 = blockIdx.x * a.chunk;
-  const int c1 = min(a.P, c0 + a.chunk);
-  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
+  const bool second = (int)blockIdx.x >= aa.gx0;                  // wave-uniform: scalar selects
+  const WgradLpNet& a = second ? aa.net[1] : aa.net[0];
+  const int bx = (int)blockIdx.x - (second ? aa.gx0 : 0);
+  WgradLpJob jb = aa.jobs[blockIdx.y];
+  jb.dz_off = acts_slot_off(a.P, jb.dz_slot);
+  jb.in_off = jb.in_slot >= 0 ? acts_slot_off(a.P, jb.in_slot) : acts_emb_off(a.P);
+  const int c0 = bx * aa.chunk;
+  const int c1 = min(a.P, c0 + aa.chunk);
+  float* out = a.partial + (size_t)bx * N_PARAM_FLOATS;
   const float invS = BF ? 1.0f : 1.0f / lp_loss_scale(a.gmax[0]);
   if (jb.flags & WF_RGB) {
     wgrad_rgb_lp_job<BF>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);
@@ -600,36 +645,67 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs a) {
   }
 }
 
-// fills the job table (13 jobs) and the chunking; returns grid.x
-static int build_wgrad_lp_jobs(WgradLpArgs& w, int P) {
+// sum of the per-chunk partials of two networks in one launch (blocks [0, WGRAD_REDUCE_BLOCKS) -> network 0);
+// the summation order of wgrad_reduce4_kernel
+struct ReduceLp2Args {
+  const float* partial[2];
+  float* grad[2];
+  int nchunks[2];
+};
+__global__ static void wgrad_lp_reduce_pair_kernel(ReduceLp2Args r) {
+  const bool second = blockIdx.x >= WGRAD_REDUCE_BLOCKS;
+  const int i = (blockIdx.x - (second ? WGRAD_REDUCE_BLOCKS : 0)) * 256 + threadIdx.x;
+  if (i >= N_PARAM_FLOATS / 4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(second ? r.partial[1] : r.partial[0]) + i;
+  const int nchunks = second ? r.nchunks[1] : r.nchunks[0];
+  constexpr size_t ST = N_PARAM_FLOATS / 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+    s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+  }
+  for (; c < nchunks; ++c) s0 += p[(size_t)c * ST];
+  reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = (s0 + s1) + (s2 + s3);
+}
+
+// fills the job table (13 jobs; identical for every network: offsets are slots)
+static void build_wgrad_lp_jobs(WgradLpArgs& w) {
   int off[N_PARAM_TENSORS + 1];
   param_offsets(off);
-  const int nchunks = pick_chunks(P, LP_CHUNK_PTS);
-  int chunk = (P + nchunks - 1) / nchunks;
-  chunk = (chunk + WL_PT - 1) / WL_PT * WL_PT;
-  w.chunk = chunk;
   int nj = 0;
-  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
-  auto add = [&](long dzo, long ino, int ins, int kw, int nrows, int woff, int ld, int kcol0, int kfirst,
+  constexpr int EMB_SLOT = -1;
+  auto add = [&](int dzs, int ins, int in_stride, int kw, int nrows, int woff, int ld, int kcol0, int kfirst,
                  int kvalid, int boff, int flags, int aux) {
     WgradLpJob& j = w.jobs[nj++];
-    j.dz_off = dzo; j.in_off = ino; j.in_stride = ins; j.kw = kw; j.n_rows = nrows; j.w_off = woff;
-    j.ld = ld; j.kcol0 = kcol0; j.kfirst = kfirst; j.kvalid = kvalid; j.b_off = boff; j.flags = flags;
+    j.dz_off = 0; j.in_off = 0; j.dz_slot = dzs; j.in_slot = ins; j.in_stride = in_stride; j.kw = kw; j.n_rows = nrows;
+    j.w_off = woff; j.ld = ld; j.kcol0 = kcol0; j.kfirst = kfirst; j.kvalid = kvalid; j.b_off = boff; j.flags = flags;
     j.aux_off = aux;
   };
   for (int l = 1; l <= 7; ++l) {
     const int ld = l == 5 ? 313 : 256, kc0 = l == 5 ? 57 : 0;
-    add(slot(l), slot(l - 1), 256, 256, 256, off[2 * l], ld, kc0, 0, 256, off[2 * l + 1], WF_BIAS, 0);
+    add(l, l - 1, 256, 256, 256, off[2 * l], ld, kc0, 0, 256, off[2 * l + 1], WF_BIAS, 0);
   }
-  add(slot(SLOT_FEAT), slot(7), 256, 256, 256, off[18], 256, 0, 0, 256, off[19], WF_BIAS | WF_ALPHA, off[20]);
-  add(slot(SLOT_VIEWS_H), slot(SLOT_FEAT), 256, 256, 128, off[16], 259, 0, 0, 256, off[17], WF_BIAS, 0);
-  add(slot(0), acts_emb_off(P), 64, 64, 256, off[0], 57, 0, 0, 57, off[1], WF_BIAS, 0);
-  add(slot(5), acts_emb_off(P), 64, 64, 256, off[10], 313, 0, 0, 57, 0, 0, 0);
+  add(SLOT_FEAT, 7, 256, 256, 256, off[18], 256, 0, 0, 256, off[19], WF_BIAS | WF_ALPHA, off[20]);
+  add(SLOT_VIEWS_H, SLOT_FEAT, 256, 256, 128, off[16], 259, 0, 0, 256, off[17], WF_BIAS, 0);
+  add(0, EMB_SLOT, 64, 64, 256, off[0], 57, 0, 0, 57, off[1], WF_BIAS, 0);
+  add(5, EMB_SLOT, 64, 64, 256, off[10], 313, 0, 0, 57, 0, 0, 0);
   // view-direction columns of views_linears.0: emb columns 60..62 -> weight columns 256..258
-  add(slot(SLOT_VIEWS_H), acts_emb_off(P), 64, 64, 128, off[16], 259, 256, 60, 63, 0, 0, 0);
-  add(0, slot(SLOT_VIEWS_H), 256, 0, 0, off[22], 128, 0, 0, 0, off[23], WF_RGB, 0);
+  add(SLOT_VIEWS_H, EMB_SLOT, 64, 64, 128, off[16], 259, 256, 60, 63, 0, 0, 0);
+  add(0, SLOT_VIEWS_H, 256, 0, 0, off[22], 128, 0, 0, 0, off[23], WF_RGB, 0);
   w.njobs = nj;
-  return (P + chunk - 1) / chunk;
+}
+// chunk length (multiple of WL_PT) for nchunks chunks over P points
+static int lp_chunk_len(long P, int nchunks) {
+  int chunk = (int)((P + nchunks - 1) / nchunks);
+  return (chunk + WL_PT - 1) / WL_PT * WL_PT;
+}
+// joint chunking of two networks: one chunk length, the joint chunk count filling whole rounds
+static void lp_joint_chunking(const int* P, int& chunk, int& gx0, int& gx1) {
+  const long Pt = (long)P[0] + P[1];
+  chunk = lp_chunk_len(Pt, pick_chunks((int)Pt, LP_CHUNK_PTS));
+  gx0 = (P[0] + chunk - 1) / chunk;
+  gx1 = (P[1] + chunk - 1) / chunk;
 }
 
 }  // namespace scade
@@ -656,8 +732,7 @@ extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp
 }
 
 template <bool BF>
-static int launch_bwd_lp(const float* packed, const void* packed_t, const unsigned char* acts, const float* g_out,
-                         int P, unsigned char* ws, float* grad_flat, hipStream_t s) {
+static int lp_bwd_set_attr() {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 4>),
@@ -671,32 +746,117 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(attr_set);
   }
+  return 0;
+}
+
+// fp16 only: the launch-wide loss scale (bf16 kernels use S = 1 and never read gmax)
+static int lp_launch_gmax(const float* g_out, int P, unsigned int* gmax, hipStream_t s) {
+  hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
+  SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
+  const long ng = 4L * P;
+  const int gblocks = (int)((ng + 256 * 16 - 1) / (256 * 16) < 256 ? (ng + 256 * 16 - 1) / (256 * 16) : 256);   // ng = 4 P
+  hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(256), 0, s, g_out, ng, gmax);
+  return scade_check_launch("scade_mlp_bwd_lp(gmax)");
+}
+
+template <bool BF>
+static int launch_bwd_lp(const float* packed, const void* packed_t, const unsigned char* acts, const float* g_out,
+                         int P, unsigned char* ws, float* grad_flat, hipStream_t s) {
+  if (int e = lp_bwd_set_attr<BF>()) return e;
   unsigned char* dz = ws;
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
-  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)pick_chunks(P, LP_CHUNK_PTS) * N_PARAM_FLOATS);
-  if (!BF) {   // fp16 only: the launch-wide loss scale (bf16 kernels use S = 1 and never read gmax)
-    hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
-    SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
-    const long ng = 4L * P;
-    const int gblocks = (int)((ng + 256 * 16 - 1) / (256 * 16) < 256 ? (ng + 256 * 16 - 1) / (256 * 16) : 256);   // ng = 4 P
-    hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(256), 0, s, g_out, ng, gmax);
-    if (int e = scade_check_launch("scade_mlp_bwd_lp(gmax)")) return e;
+  const int nchunks = pick_chunks(P, LP_CHUNK_PTS);
+  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)nchunks * N_PARAM_FLOATS);
+  if (!BF) {
+    if (int e = lp_launch_gmax(g_out, P, gmax, s)) return e;
   }
-  MlpDgradLpArgs d{packed, packed_t, acts, g_out, dz, reinterpret_cast<const float*>(gmax), P};
   // same point tiling as the forward that wrote the sign words of this workspace
-  if (lp_pick_point_tiles(P) == 2)
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2>), dim3((P + 63) / 64), dim3(256), dgrad_lp_lds_bytes(2), s, d);
+  const int npt = lp_pick_point_tiles(P);
+  const int tiles = (P + 32 * npt - 1) / (32 * npt);
+  MlpDgradLpArgs2 d{{{packed, packed_t, acts, g_out, dz, reinterpret_cast<const float*>(gmax), P}, {}}, tiles, 0};
+  if (npt == 2)
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2>), dim3(tiles), dim3(256), dgrad_lp_lds_bytes(2), s, d);
   else
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4>), dim3((P + LM - 1) / LM), dim3(256), dgrad_lp_lds_bytes(4), s, d);
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4>), dim3(tiles), dim3(256), dgrad_lp_lds_bytes(4), s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(dgrad)")) return e;
   WgradLpArgs w{};
-  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial;
-  w.gmax = reinterpret_cast<const float*>(gmax); w.P = P;
-  const int grid_x = build_wgrad_lp_jobs(w, P);
+  build_wgrad_lp_jobs(w);
+  w.net[0] = WgradLpNet{acts, dz, g_out, partial, reinterpret_cast<const float*>(gmax), P};
+  w.chunk = lp_chunk_len(P, nchunks);
+  const int grid_x = (P + w.chunk - 1) / w.chunk;
+  w.gx0 = grid_x;
   hipLaunchKernelGGL(mlp_wgrad_lp_kernel<BF>, dim3(grid_x, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(wgrad)")) return e;
   hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd_lp(reduce)");
+}
+
+// two networks: ONE dgrad launch, ONE weight-gradient launch, ONE reduce (scade_mlp_bwd_lp2)
+template <bool BF>
+static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, const float* const* g_out,
+                          const int* P, void* const* wsv, float* const* grad_flat, hipStream_t s) {
+  if (int e = lp_bwd_set_attr<BF>()) return e;
+  const int npt = lp_pick_point_tiles(P[0]);
+  SCADE_REQUIRE(lp_pick_point_tiles(P[1]) == npt, -3,
+                "scade_mlp_bwd_lp2: the forwards of the two launches tiled their points differently (P = %d, %d); "
+                "use scade_mlp_bwd_lp twice", P[0], P[1]);
+  int chunk, gx0, gx1;
+  lp_joint_chunking(P, chunk, gx0, gx1);
+  MlpDgradLpArgs2 d{};
+  WgradLpArgs w{};
+  build_wgrad_lp_jobs(w);
+  float* partial[2];
+  for (int i = 0; i < 2; ++i) {
+    unsigned char* ws = reinterpret_cast<unsigned char*>(wsv[i]);
+    const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts[i]);
+    partial[i] = reinterpret_cast<float*>(ws + lp_dz_bytes(P[i]));
+    unsigned int* gmax = reinterpret_cast<unsigned int*>(partial[i] + (size_t)(i == 0 ? gx0 : gx1) * N_PARAM_FLOATS);
+    if (!BF) {
+      if (int e = lp_launch_gmax(g_out[i], P[i], gmax, s)) return e;
+    }
+    d.n[i] = MlpDgradLpArgs{nullptr, packed_t[i], ac, g_out[i], ws, reinterpret_cast<const float*>(gmax), P[i]};
+    w.net[i] = WgradLpNet{ac, ws, g_out[i], partial[i], reinterpret_cast<const float*>(gmax), P[i]};
+  }
+  d.tiles0 = (P[0] + 32 * npt - 1) / (32 * npt);
+  d.tiles1 = (P[1] + 32 * npt - 1) / (32 * npt);
+  if (npt == 2)
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(2), s, d);
+  else
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(4), s, d);
+  if (int e = scade_check_launch("scade_mlp_bwd_lp2(dgrad)")) return e;
+  w.chunk = chunk; w.gx0 = gx0;
+  hipLaunchKernelGGL(mlp_wgrad_lp_kernel<BF>, dim3(gx0 + gx1, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
+  if (int e = scade_check_launch("scade_mlp_bwd_lp2(wgrad)")) return e;
+  ReduceLp2Args r{{partial[0], partial[1]}, {grad_flat[0], grad_flat[1]}, {gx0, gx1}};
+  hipLaunchKernelGGL(wgrad_lp_reduce_pair_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
+  return scade_check_launch("scade_mlp_bwd_lp2(reduce)");
+}
+
+// point tiles (of 32) per workgroup the 16-bit forward / dgrad use for a launch over P points
+extern "C" int scade_mlp_lp_point_tiles(int P) { return lp_pick_point_tiles(P); }
+
+// workspace of one network of a joint launch over networks of P and P_other points (scade_mlp_bwd_lp2); never
+// smaller than scade_mlp_bwd_lp_workspace_bytes(P)
+extern "C" long scade_mlp_bwd_lp2_workspace_bytes(int P, int P_other) {
+  int Ps[2] = {P, P_other}, chunk, gx0, gx1;
+  lp_joint_chunking(Ps, chunk, gx0, gx1);
+  const long joint = lp_dz_bytes(P) + (long)gx0 * N_PARAM_FLOATS * 4 + 256;
+  const long alone = scade_mlp_bwd_lp_workspace_bytes(P);
+  return joint > alone ? joint : alone;
+}
+
+extern "C" int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,
+                                 const float* const* g_out, const int* P, void* const* workspace,
+                                 float* const* grad_flat, void* stream) {
+  SCADE_REQUIRE(packed_t_lp && acts && g_out && P && workspace && grad_flat, -1, "scade_mlp_bwd_lp2: null pointer");
+  for (int i = 0; i < 2; ++i) {
+    SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd_lp2: P[%d] must be positive", i);
+    SCADE_REQUIRE(packed_t_lp[i] && acts[i] && g_out[i] && workspace[i] && grad_flat[i], -1,
+                  "scade_mlp_bwd_lp2: null pointer in entry %d", i);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  return bf16 ? launch_bwd_lp2<true>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s)
+              : launch_bwd_lp2<false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s);
 }
 
 extern "C" int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, const void* acts,

@@ -68,9 +68,10 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][NPT], int
         u32x4 w;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const auto sw = __builtin_amdgcn_permlane32_swap(v[0][j], v[1][j], false, false);
-          w[j] = sw[0];         // lower lanes: own chunk 2m low half;  upper lanes: the lower lane's chunk 2m+1 low half
-          w[2 + j] = sw[1];     // lower lanes: the upper lane's chunk 2m high half;  upper lanes: own chunk 2m+1 high half
+          unsigned lo, hi;      // (lp_swap_halves: the swap behind the wait states its asm-produced operands need)
+          lp_swap_halves(v[0][j], v[1][j], lo, hi);
+          w[j] = lo;            // lower lanes: own chunk 2m low half;  upper lanes: the lower lane's chunk 2m+1 low half
+          w[2 + j] = hi;        // lower lanes: the upper lane's chunk 2m high half;  upper lanes: own chunk 2m+1 high half
         }
         const int row = p * 32 + r;
         const int c = (ntile0 + t) * 4 + 2 * m + hh;
@@ -103,6 +104,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   const T* __restrict__ wpk = reinterpret_cast<const T*>(a.packed);
   const float* __restrict__ tail = reinterpret_cast<const float*>(wpk + PACKED_LP_ELEMS);
 #define TAIL(off) (tail + (int)CE<(off) - OFF_BIAS>::v)
+  // NaN census of the hidden layers' parameters (pack kernel; used by the heads): two wave-uniform flags
+  bool nan_trunk, nan_colour;
+  {
+    const float ft = TAIL(LP_NAN_TRUNK)[lane], fc = TAIL(LP_NAN_COLOUR)[lane];
+    nan_trunk = __builtin_amdgcn_readfirstlane(__any(ft != ft)) != 0;
+    nan_colour = __builtin_amdgcn_readfirstlane(__any(fc != fc)) != 0;
+  }
 
   // ---- prologue: embedding tile [128][64] (57 real channels, zero padded) ------------
   {
@@ -239,15 +247,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   // NaN is a negative int16 to the packed ReLU), so the pack kernel takes a census of the fp32 parameters and
   // leaves it in the tail as 0 / NaN floats (LP_NAN_TRUNK: pts_linears - the reference then returns NaN in
   // all four outputs of every point; LP_NAN_COLOUR: feature_linear / views_linears - NaN colour, finite
-  // density).  NaN head parameters need no help: the heads are fp32 arithmetic.
+  // density); nan_trunk / nan_colour were read at the top of the kernel, where registers are free.  NaN head
+  // parameters need no help: the heads are fp32 arithmetic.
   float alpha[LM / 64];
   int badf[LM / 64];
-  bool nan_trunk, nan_colour;
-  {
-    const float ft = TAIL(LP_NAN_TRUNK)[lane], fc = TAIL(LP_NAN_COLOUR)[lane];
-    nan_trunk = __any(ft != ft) != 0;
-    nan_colour = __any(fc != fc) != 0;
-  }
   {
     const float* wa = TAIL(OFF_WA);
 #pragma unroll

@@ -115,10 +115,11 @@ __device__ __forceinline__ void store_relu_words(float* acts, long P, int layer,
   w[0] = (unsigned)bits;
   if (PT > 1) w[256] = (unsigned)(bits >> 32);
 }
+// ``blk``: index of the workgroup among those of ITS network (a launch may cover two networks)
 template <int PT>
-__device__ __forceinline__ unsigned long long load_relu_words(const float* acts, long P, int layer, int tid) {
+__device__ __forceinline__ unsigned long long load_relu_words(const float* acts, long P, int layer, int tid, int blk) {
   const unsigned* w = reinterpret_cast<const unsigned*>(acts + acts_mask_off(P)) +
-                      ((size_t)layer * relu_word_tiles(P) + (size_t)blockIdx.x * PT) * 256 + tid;
+                      ((size_t)layer * relu_word_tiles(P) + (size_t)blk * PT) * 256 + tid;
   unsigned long long b = w[0];
   if (PT > 1) b |= (unsigned long long)w[256] << 32;
   return b;

@@ -117,6 +117,31 @@ __device__ __forceinline__ void save_tile_lp(const typename LP<BF>::T* x, typena
   }
 }
 
+// (row, chunk) a lane copies in wave-instruction ``it`` of a per-wave tile copy whose rows are CPR 16-byte
+// chunks wide (8: 64 columns, 4: 32 columns).  ds_read_b128 is serviced in the fixed 16-lane groups
+// {0-3,12-15,20-27}, {4-11,16-19,28-31} (+32); under the x_idx swizzle (slot = chunk ^ (row & 15)) a group is
+// conflict free when its rows differ in the row bits ABOVE the chunk bits it spans - rows r, r + 8 for eight
+// chunks, r, r + 4, r + 8, r + 12 for four.  The straight mapping (lane / CPR, lane % CPR) put rows r, r + 1
+// (.. r + 3) into one group: 2-way conflicts on every read of the tile copies (the difference between the
+// training forward's 14.7 % conflict cycles and the inference kernel's 4.7 % in round 2).  Every instruction
+// still covers whole rows, so the global stores stay 128-byte (64-byte) row segments.
+template <int CPR>
+__device__ __forceinline__ void tile_copy_map(int lane, int it, int& row, int& chunk) {
+  static_assert(CPR == 8 || CPR == 4, "tile_copy_map: 8 or 4 chunks per row");
+  const int q = (lane >> 2) & 7, up = lane >> 5;          // lane quad within the half wave, half wave
+  if (CPR == 8) {
+    // quads 0..7 of a half wave -> rows {a, b, b, a, b+8, a+8, a+8, b+8}, a = 2 up, b = a + 1
+    const int off = (0x98890110 >> (4 * q)) & 15;
+    row = 16 * (it >> 1) + 4 * (it & 1) + 2 * up + off;
+    chunk = lane & 7;
+  } else {
+    // quads 0..7 -> rows {a, b, b+4, a+4, b+8, a+8, a+12, b+12}
+    const int off = (int)((0xDC895410u >> (4 * q)) & 15u);
+    row = 16 * it + 2 * up + off;
+    chunk = lane & 3;
+  }
+}
+
 // the same copy for the NCW columns (from column c0) ONE WAVE has just written, every row of the tile: a
 // wave's LDS accesses execute in order, so it reads its own epilogue back without a barrier and its rows
 // leave for HBM while the other waves are still in their epilogues (the exact kernels' save_tile_wave)
@@ -134,15 +159,17 @@ __device__ __forceinline__ void save_tile_lp_wave(const typename LP<BF>::T* x, t
     float f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int i = lane + 64 * (it0 + j);
-      const int row = i / CPR, c = (c0 >> 3) + (i - row * CPR);
+      int row, c;
+      tile_copy_map<CPR>(lane, it0 + j, row, c);
+      c += c0 >> 3;
       v[j] = *reinterpret_cast<const V8*>(x + x_idx(row, c));
       f[j] = row_fac ? row_fac[row] : 1.f;
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int i = lane + 64 * (it0 + j);
-      const int row = i / CPR, c = (c0 >> 3) + (i - row * CPR);
+      int row, c;
+      tile_copy_map<CPR>(lane, it0 + j, row, c);
+      c += c0 >> 3;
       if (row_fac) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[j][e] = (T)((float)v[j][e] * f[j]);
@@ -314,6 +341,20 @@ __device__ __forceinline__ void load_bias16(f32x16 (&cb)[NT], const float* __res
 // -0, is a negative int16, a positive float a positive one) - one VALU op per two values.
 // Inline asm: the compiler's own lowering of the same expression converts every scalar separately
 // and merges the halves with v_perm_b32.
+// v_permlane32_swap of two dwords whose producers may be INLINE ASM (pack2, mask_pair below).  gfx950 needs two
+// wait states between a VALU write of a VGPR and a v_permlane*_swap that reads it; hipcc's hazard recognizer
+// inserts them for instructions it selected itself but cannot see into inline asm (and does not even count an
+// asm statement as a wait state), so a v_cvt_pk_bf16_f32 scheduled right in front of the swap handed it a stale
+// register: the bf16 dgrad's unmasked d-feature tile came out ~16 % wrong in round 3's first build, and the
+// forward's epilogue had only been correct by the luck of its schedule.  The s_nop rides in an asm that
+// reads both operands and "modifies" one, which orders it behind their producers and in front of the swap.
+__device__ __forceinline__ void lp_swap_halves(unsigned a, unsigned b, unsigned& lo, unsigned& hi) {
+  asm("s_nop 1" : "+v"(a) : "v"(b));      // data dependences only (not volatile): a, b ready -> nop -> swap
+  const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+  lo = sw[0];
+  hi = sw[1];
+}
+
 template <bool BF, bool RELU>
 __device__ __forceinline__ unsigned pack2(float y0, float y1) {
   unsigned w;

@@ -46,6 +46,9 @@ constexpr int W2_LDS_BYTES = W2_D * (W2_S * (128 + 256) + 64) * 4;    // 37,632
 struct Wgrad2Job {
   long dz_off;       // float offset of the dZ matrix (row stride 256) in the dz workspace, n_base included
   long in_off;       // float offset of the input matrix in the acts workspace
+                     // (both filled in by the kernel from the slots below and ITS network's point count)
+  int dz_slot;       // workspace slot of the dZ matrix
+  int in_slot;       // workspace slot of the input matrix; -1 = the embedding rows
   int in_stride;     // 256 (activation slot) or 64 (emb)
   int kw;            // k width of the tile: 256 or 64; 0 = the rgb-head job
   int n_base;        // first output row of this half (0 / 128)
@@ -53,13 +56,19 @@ struct Wgrad2Job {
   int w_off, ld, kcol0, kvalid, b_off, flags, aux_off;   // as WgradJob
 };
 constexpr int MAX_WGRAD2_JOBS = 24;
-struct Wgrad2Args {
-  Wgrad2Job jobs[MAX_WGRAD2_JOBS];
+// the per-network part of a launch: a launch covers one network or two (the coarse and the fine NeRF of a
+// train step); chunks [0, gx0) of grid.x belong to net[0], the rest to net[1]
+struct Wgrad2Net {
   const float* acts;
   const float* dz;
   const float* g_out;
   float* partial;
-  int P, chunk, njobs;
+  int P;
+};
+struct Wgrad2Args {
+  Wgrad2Job jobs[MAX_WGRAD2_JOBS];
+  Wgrad2Net net[2];
+  int chunk, njobs, gx0;
 };
 
 // workgroup barrier that orders LDS only: release/acquire fences restricted to the local address space
@@ -84,7 +93,7 @@ __device__ __forceinline__ w2_rsrc_t w2_make_rsrc(const float* base, unsigned by
 }
 
 template <int KW, int FLAGS>
-__device__ __forceinline__ void wgrad2_mfma_job(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0,
+__device__ __forceinline__ void wgrad2_mfma_job(const Wgrad2Net& a, const Wgrad2Job& jb, float* lds, int c0,
                                                 int c1, float* __restrict__ out) {
   constexpr int S = W2_S, D = W2_D;
   constexpr int NKT = KW == 256 ? 4 : 1;          // k-tiles of 32 per wave
@@ -301,7 +310,7 @@ __device__ __forceinline__ void wgrad2_mfma_job(const Wgrad2Args& a, const Wgrad
 
 // rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c].  A thread owns 4 columns
 // (one 16-byte load per point) of every 8th point, four points in flight: this job is pure load latency.
-__device__ __forceinline__ void wgrad2_rgb_job(const Wgrad2Args& a, const Wgrad2Job& jb, float* lds, int c0,
+__device__ __forceinline__ void wgrad2_rgb_job(const Wgrad2Net& a, const Wgrad2Job& jb, float* lds, int c0,
                                                int c1, float* __restrict__ out) {
   const int tid = threadIdx.x;
   const int k4 = tid & 31, pl = tid >> 5;       // 32 column groups x 8 point lanes
@@ -353,12 +362,17 @@ __device__ __forceinline__ void wgrad2_rgb_job(const Wgrad2Args& a, const Wgrad2
   }
 }
 
-__global__ __launch_bounds__(256, 2) void mlp_wgrad2_kernel(Wgrad2Args a) {
+__global__ __launch_bounds__(256, 2) void mlp_wgrad2_kernel(Wgrad2Args aa) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const Wgrad2Job& jb = a.jobs[blockIdx.y];
-  const int c0 = blockIdx.x * a.chunk;
-  const int c1 = min(a.P, c0 + a.chunk);
-  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
+  const bool second = (int)blockIdx.x >= aa.gx0;                  // wave-uniform: scalar selects
+  const Wgrad2Net& a = second ? aa.net[1] : aa.net[0];
+  const int bx = (int)blockIdx.x - (second ? aa.gx0 : 0);
+  Wgrad2Job jb = aa.jobs[blockIdx.y];
+  jb.dz_off = acts_slot_off(a.P, jb.dz_slot) + jb.n_base;
+  jb.in_off = jb.in_slot >= 0 ? acts_slot_off(a.P, jb.in_slot) : acts_emb_off(a.P);
+  const int c0 = bx * aa.chunk;
+  const int c1 = min(a.P, c0 + aa.chunk);
+  float* out = a.partial + (size_t)bx * N_PARAM_FLOATS;
   if (jb.kw == 0) {
     wgrad2_rgb_job(a, jb, lds, c0, c1, out);
   } else if (jb.kw == 256) {
@@ -368,6 +382,29 @@ __global__ __launch_bounds__(256, 2) void mlp_wgrad2_kernel(Wgrad2Args a) {
   } else {
     wgrad2_mfma_job<64, WF_BIAS>(a, jb, lds, c0, c1, out);     // (the layer-5 block has no bias: b_off checked)
   }
+}
+
+// sum of the per-chunk partials of one or two networks (blocks [0, WGRAD_REDUCE_BLOCKS) -> network 0)
+struct Reduce2Args {
+  const float* partial[2];
+  float* grad[2];
+  int nchunks[2];
+};
+__global__ static void wgrad2_reduce_pair_kernel(Reduce2Args r) {
+  const bool second = blockIdx.x >= WGRAD_REDUCE_BLOCKS;
+  const int i = (blockIdx.x - (second ? WGRAD_REDUCE_BLOCKS : 0)) * 256 + threadIdx.x;
+  if (i >= N_PARAM_FLOATS / 4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(second ? r.partial[1] : r.partial[0]) + i;
+  const int nchunks = second ? r.nchunks[1] : r.nchunks[0];
+  constexpr size_t ST = N_PARAM_FLOATS / 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;     // the order of wgrad_reduce4_kernel
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+    s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+  }
+  for (; c < nchunks; ++c) s0 += p[(size_t)c * ST];
+  reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = (s0 + s1) + (s2 + s3);
 }
 
 // Chunks of points per launch.  Two workgroups share a CU; per chunk there are 17 half-layer workgroups of
@@ -396,49 +433,54 @@ int pick_chunks_v2(int P) {
   return (int)n;
 }
 
-static int build_wgrad2_jobs(Wgrad2Args& w, const float* acts, const float* dz, const float* g_out, float* partial,
-                             int P) {
+// chunking of a joint launch over two networks: one chunk length for both, chosen so that the JOINT chunk
+// count fills whole rounds of two workgroups per CU
+void wgrad2_joint_chunking(const int* P, int& chunk, int& gx0, int& gx1) {
+  const long Pt = (long)P[0] + P[1];
+  const int nchunks = pick_chunks_v2((int)Pt);
+  chunk = (int)((Pt + nchunks - 1) / nchunks);
+  chunk = (chunk + W2_PT - 1) / W2_PT * W2_PT;
+  gx0 = (P[0] + chunk - 1) / chunk;
+  gx1 = (P[1] + chunk - 1) / chunk;
+}
+
+// fills the job table (identical for every network: offsets are slots) and returns the job count
+static int build_wgrad2_jobs(Wgrad2Args& w) {
   int off[N_PARAM_TENSORS + 1];
   param_offsets(off);
-  w.acts = acts; w.dz = dz; w.g_out = g_out; w.partial = partial; w.P = P;
-  const int nchunks = pick_chunks_v2(P);
-  int chunk = (P + nchunks - 1) / nchunks;
-  chunk = (chunk + W2_PT - 1) / W2_PT * W2_PT;
-  w.chunk = chunk;
   int nj = 0;
-  auto slot = [&](int sidx) { return acts_slot_off(P, sidx); };
-  auto add = [&](long dzo, long ino, int ins, int kw, int nbase, int nrows, int woff, int ld, int kcol0, int kvalid,
+  constexpr int EMB_SLOT = -1;
+  auto add = [&](int dzs, int ins, int in_stride, int kw, int nbase, int nrows, int woff, int ld, int kcol0, int kvalid,
                  int boff, int flags, int aux) {
     Wgrad2Job& j = w.jobs[nj++];
-    j.dz_off = dzo + nbase; j.in_off = ino; j.in_stride = ins; j.kw = kw; j.n_base = nbase; j.n_rows = nrows;
-    j.w_off = woff; j.ld = ld; j.kcol0 = kcol0; j.kvalid = kvalid; j.b_off = boff; j.flags = flags; j.aux_off = aux;
+    j.dz_off = 0; j.in_off = 0; j.dz_slot = dzs; j.in_slot = ins; j.in_stride = in_stride; j.kw = kw; j.n_base = nbase;
+    j.n_rows = nrows; j.w_off = woff; j.ld = ld; j.kcol0 = kcol0; j.kvalid = kvalid; j.b_off = boff; j.flags = flags;
+    j.aux_off = aux;
   };
   // long jobs first, short last (tail filling)
   for (int l = 1; l <= 7; ++l) {
     const int ld = l == 5 ? 313 : 256, kc0 = l == 5 ? 57 : 0;
     for (int h = 0; h < 2; ++h)
-      add(slot(l), slot(l - 1), 256, 256, 128 * h, 256, off[2 * l], ld, kc0, 256, off[2 * l + 1], WF_BIAS, 0);
+      add(l, l - 1, 256, 256, 128 * h, 256, off[2 * l], ld, kc0, 256, off[2 * l + 1], WF_BIAS, 0);
   }
   for (int h = 0; h < 2; ++h)   // the alpha head rides on ONE half only (it needs the whole input row, not dZ)
-    add(slot(SLOT_FEAT), slot(7), 256, 256, 128 * h, 256, off[18], 256, 0, 256, off[19],
+    add(SLOT_FEAT, 7, 256, 256, 128 * h, 256, off[18], 256, 0, 256, off[19],
         WF_BIAS | (h == 0 ? WF_ALPHA : 0), off[20]);
-  add(slot(SLOT_VIEWS_H), slot(SLOT_FEAT), 256, 256, 0, 128, off[16], 259, 0, 256, off[17], WF_BIAS | WF_VIEWCOLS, 0);
+  add(SLOT_VIEWS_H, SLOT_FEAT, 256, 256, 0, 128, off[16], 259, 0, 256, off[17], WF_BIAS | WF_VIEWCOLS, 0);
   for (int h = 0; h < 2; ++h) {
-    add(slot(0), acts_emb_off(P), 64, 64, 128 * h, 256, off[0], 57, 0, 57, off[1], WF_BIAS, 0);
-    add(slot(5), acts_emb_off(P), 64, 64, 128 * h, 256, off[10], 313, 0, 57, 0, 0, 0);
+    add(0, EMB_SLOT, 64, 64, 128 * h, 256, off[0], 57, 0, 57, off[1], WF_BIAS, 0);
+    add(5, EMB_SLOT, 64, 64, 128 * h, 256, off[10], 313, 0, 57, 0, 0, 0);
   }
-  add(0, slot(SLOT_VIEWS_H), 256, 0, 0, 0, off[22], 128, 0, 0, off[23], WF_RGB, 0);
+  add(0, SLOT_VIEWS_H, 256, 0, 0, 0, off[22], 128, 0, 0, off[23], WF_RGB, 0);
   w.njobs = nj;
-  return (P + chunk - 1) / chunk;
+  return nj;
 }
 
 }  // namespace scade
 
 using namespace scade;
 
-// wgrad + reduce (shared by the exact backward and the split-precision backward's exact-wgrad mode)
-int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
-                       float* grad_flat, hipStream_t s) {
+static int wgrad2_set_attr() {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad2_kernel),
@@ -446,10 +488,41 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(attr_set);
   }
+  return 0;
+}
+
+// wgrad + reduce (shared by the exact backward and the split-precision backward's exact-wgrad mode)
+int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
+                       float* grad_flat, hipStream_t s) {
+  if (int e = wgrad2_set_attr()) return e;
   Wgrad2Args w{};
-  const int grid_x = build_wgrad2_jobs(w, acts, dz, g_out, partial, P);
+  build_wgrad2_jobs(w);
+  const int nchunks = pick_chunks_v2(P);
+  int chunk = (P + nchunks - 1) / nchunks;
+  chunk = (chunk + W2_PT - 1) / W2_PT * W2_PT;
+  const int grid_x = (P + chunk - 1) / chunk;
+  w.net[0] = Wgrad2Net{acts, dz, g_out, partial, P};
+  w.chunk = chunk; w.gx0 = grid_x;
   hipLaunchKernelGGL(mlp_wgrad2_kernel, dim3(grid_x, w.njobs), dim3(256), W2_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd(wgrad)")) return e;
   hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd(reduce)");
+}
+
+// the same for TWO networks in one weight-gradient launch and one reduce launch (scade_mlp_bwd2)
+int scade_launch_wgrad2(const float* const* acts, const float* const* dz, const float* const* g_out, const int* P,
+                        float* const* partial, float* const* grad_flat, hipStream_t s) {
+  if (int e = wgrad2_set_attr()) return e;
+  Wgrad2Args w{};
+  build_wgrad2_jobs(w);
+  int chunk, gx0, gx1;     // the partial buffers are sized for this by scade_mlp_bwd2_workspace_floats
+  wgrad2_joint_chunking(P, chunk, gx0, gx1);
+  w.net[0] = Wgrad2Net{acts[0], dz[0], g_out[0], partial[0], P[0]};
+  w.net[1] = Wgrad2Net{acts[1], dz[1], g_out[1], partial[1], P[1]};
+  w.chunk = chunk; w.gx0 = gx0;
+  hipLaunchKernelGGL(mlp_wgrad2_kernel, dim3(gx0 + gx1, w.njobs), dim3(256), W2_LDS_BYTES, s, w);
+  if (int e = scade_check_launch("scade_mlp_bwd2(wgrad)")) return e;
+  Reduce2Args r{{partial[0], partial[1]}, {grad_flat[0], grad_flat[1]}, {gx0, gx1}};
+  hipLaunchKernelGGL(wgrad2_reduce_pair_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
+  return scade_check_launch("scade_mlp_bwd2(reduce)");
 }

@@ -108,6 +108,7 @@ __global__ void train_loss_fwd_kernel(TrainLossArgs a) {
       }
     }
     carve_ray = (float)(tl_wave_sum_d(acc) / (double)a.P);             // helpers:125 mean over samples
+    if (im < 0) carve_ray = __builtin_nanf("");     // device image index out of range (fminf drops the NaN distances)
   }
   if (lane == 0) {
     f32x4 o = {(float)sq_f, (float)sq_c, carve_ray, 0.f};

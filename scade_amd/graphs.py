@@ -57,7 +57,7 @@ class GraphedTrainer:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
         loss, aux = tr.forward_loss(self.rays, self.tgt, self.hyp, img_i=self.img_i, mask=self.mask,
                                     n_total=self.n_total, **kw)
-        loss.backward(tr._unit_grad(loss))
+        tr.backward(loss)
         tr.bucket.end_backward()
         tr.reduce_grads()
         tr.opt.step_dev()

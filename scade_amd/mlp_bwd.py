@@ -6,6 +6,73 @@ import math
 from . import ops
 
 
+class DeferredBackward:
+    """Joins the MLP backward of the coarse and the fine NeRF of a train step into ONE dgrad launch, ONE
+    weight-gradient launch and ONE reduce (scade_mlp_bwd2 / scade_mlp_bwd_lp2): their backward chains are
+    independent (run_scade_scannet.py:711 detaches the samples between the two networks), and the joint grid
+    fills whole rounds of two workgroups per CU where two separate launches each end in a part-filled one -
+    which is most of the time at the 128 rays per GPU of a strongly scaled batch.
+
+        with DeferredBackward() as q:        # inside: a network's FIRST backward of the step (the one that
+            loss.backward(...)               # writes its gradient sink) only queues (net, acts, g_out)
+        # on exit: two queued entries of one precision -> the pair launch; anything else -> one by one
+
+    Only backwards that write a fresh gradient sink are deferred (they return no gradients to autograd, so
+    nothing downstream waits for them); everything is launched on the stream current at exit."""
+    active = None
+
+    def __init__(self):
+        self.items = []
+
+    def __enter__(self):
+        if DeferredBackward.active is not None:
+            raise RuntimeError("DeferredBackward: already active")
+        DeferredBackward.active = self
+        return self
+
+    def __exit__(self, et, ev, tb):
+        DeferredBackward.active = None
+        items, self.items = self.items, []
+        if et is None:
+            flush_deferred(items)
+        return False
+
+
+def _pair_key(net):
+    p = net.train_precision
+    return p if p in ("f32", "f16", "bf16") else None
+
+
+def flush_deferred(items):
+    if len(items) == 2 and _pair_key(items[0][0]) is not None and _pair_key(items[0][0]) == _pair_key(items[1][0]) \
+            and items[0][0] is not items[1][0]:
+        (n0, a0, g0), (n1, a1, g1) = items
+        prec = n0.train_precision
+        sinks = [n0._grad_sink, n1._grad_sink]
+        if prec == "f32":
+            ops.mlp_bwd2([n0.packed(), n1.packed()], [n0.packed_t(), n1.packed_t()], [a0, a1], [g0, g1], sinks)
+            return
+        bf16 = prec == "bf16"
+        P0, P1 = g0.numel() // 4, g1.numel() // 4
+        if ops.lp_point_tiles(P0) == ops.lp_point_tiles(P1):
+            ops.mlp_bwd_lp2([n0.packed_t_lp(bf16), n1.packed_t_lp(bf16)], bf16, [a0, a1], [g0, g1], sinks)
+            return
+    for net, acts, g in items:
+        _backward_now(net, acts, g, net._grad_sink)
+
+
+def _backward_now(net, acts, g_out, out):
+    if net.train_precision in ("f16x3", "f16x3-dgrad"):
+        return ops.mlp_bwd_f16(net.packed(), net.packed_t_f16(), acts, g_out,
+                               wgrad_f16=net.train_precision == "f16x3", out=out)
+    if net.train_precision in ("f16", "bf16"):
+        bf16 = net.train_precision == "bf16"
+        return ops.mlp_bwd_lp(None, net.packed_t_lp(bf16), bf16, acts, g_out, out=out)
+    if net.train_precision == "f32":
+        return ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out, out=out)
+    raise ValueError("NeRF.train_precision must be one of %s" % (net.TRAIN_PRECISIONS,))
+
+
 def mlp_backward(net, acts, g_out):
     """-> list of 24 gradient tensors in ops.PARAM_ORDER (views of one flat buffer)."""
     if acts is None or acts.numel() == 0:
@@ -22,16 +89,13 @@ def mlp_backward(net, acts, g_out):
     # gradient straight into it (no zero fill before, no temporary, no add after); later ones accumulate
     direct = sink is not None and getattr(net, "_sink_fresh", False)
     out = sink if direct else None
-    if net.train_precision in ("f16x3", "f16x3-dgrad"):
-        flat = ops.mlp_bwd_f16(net.packed(), net.packed_t_f16(), acts, g_out,
-                               wgrad_f16=net.train_precision == "f16x3", out=out)
-    elif net.train_precision in ("f16", "bf16"):
-        bf16 = net.train_precision == "bf16"
-        flat = ops.mlp_bwd_lp(None, net.packed_t_lp(bf16), bf16, acts, g_out, out=out)
-    elif net.train_precision == "f32":
-        flat = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out, out=out)
-    else:
-        raise ValueError("NeRF.train_precision must be one of %s" % (net.TRAIN_PRECISIONS,))
+    q = DeferredBackward.active
+    if direct and q is not None:
+        # joined with the other network's backward when the queue is flushed (DeferredBackward.__exit__)
+        q.items.append((net, acts, g_out))
+        net._sink_fresh = False
+        return [None] * len(ops.PARAM_ORDER)
+    flat = _backward_now(net, acts, g_out, out)
     if sink is not None:
         if direct:
             net._sink_fresh = False

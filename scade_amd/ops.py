@@ -259,6 +259,49 @@ def mlp_bwd_lp(packed: Optional[Tensor], packed_t_lp: Tensor, bf16: bool, acts: 
     return grad
 
 
+def _host_ptrs(ts):
+    """HOST array of device pointers (the scade_*2 entries take two-entry host arrays)."""
+    return ctypes.cast((ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
+
+
+def mlp_bwd2(packed, packed_t, acts, g_out, outs) -> None:
+    """Exact backward of TWO network calls (coarse + fine NeRF of a train step) as one dgrad launch, one
+    weight-gradient launch and one reduce (scade_mlp_bwd2).  Every argument: a pair; ``outs`` = the two flat
+    gradient buffers [589700], OVERWRITTEN."""
+    g = [_c(check(t, "mlp_bwd2: g_out")).reshape(-1, 4) for t in g_out]
+    P = [t.shape[0] for t in g]
+    lib = _lib.load()
+    ws = [torch.empty(int(lib.scade_mlp_bwd2_workspace_floats(P[i], P[1 - i])), device=g[i].device, dtype=torch.float32)
+          for i in range(2)]
+    grads = [_grad_out(o, g[0].device) for o in outs]
+    Pa = (ctypes.c_int * 2)(*P)
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_bwd2", _host_ptrs(packed), _host_ptrs(packed_t), _host_ptrs(acts), _host_ptrs(g),
+         ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads), stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
+
+
+def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs) -> None:
+    """16-bit backward of two network calls in one launch each (scade_mlp_bwd_lp2); see mlp_bwd2."""
+    g = [_c(check(t, "mlp_bwd_lp2: g_out")).reshape(-1, 4) for t in g_out]
+    P = [t.shape[0] for t in g]
+    lib = _lib.load()
+    ws = [torch.empty(int(lib.scade_mlp_bwd_lp2_workspace_bytes(P[i], P[1 - i])), device=g[i].device, dtype=torch.uint8)
+          for i in range(2)]
+    grads = [_grad_out(o, g[0].device) for o in outs]
+    Pa = (ctypes.c_int * 2)(*P)
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_bwd_lp2", _host_ptrs(packed_t_lp), int(bf16), _host_ptrs(acts), _host_ptrs(g),
+         ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads), stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
+
+
+def lp_point_tiles(P: int) -> int:
+    return int(_lib.load().scade_mlp_lp_point_tiles(int(P)))
+
+
 def mlp_fwd_lp(packed_lp: Tensor, bf16: bool, inp: Tensor, viewdirs: Optional[Tensor],
                bb: Optional[Tensor], acts: Optional[Tensor] = None) -> Tensor:
     """16-bit-operand forward: inp [P,60] (viewdirs None) or pts [N,S,3] + viewdirs [N,3] + bb [4]."""

@@ -46,7 +46,8 @@ class Trainer:
                  space_carving_weight=0.007, N_samples=64, N_importance=128, lrate_decay_rate=0.1,
                  lrate_decay_step=400000, freeze_ss=400000, norm_p=2, space_carving_threshold=0.0,
                  is_joint=False, warm_start_nerf=0, lindisp=False, raw_noise_std=0.0, precision="f32",
-                 overlap_coarse=None, mask_mode="scannet", allreduce=None, start_iter=0, fused_loss=True):
+                 overlap_coarse=None, mask_mode="scannet", allreduce=None, start_iter=0, fused_loss=True,
+                 joint_backward=None):
         dev = next(coarse.parameters()).device
         if mask_mode not in ("scannet", "wild"):
             raise ValueError('Trainer: mask_mode must be "scannet" or "wild"')
@@ -96,6 +97,11 @@ class Trainer:
         # the three-term loss as one fused operator (ops.TrainLossFn) instead of the separate public
         # operators (same arithmetic; ``fused_loss=False`` keeps the operator-by-operator path)
         self.fused_loss = fused_loss
+        # the MLP backward of both networks as ONE dgrad / weight-gradient / reduce launch each
+        # (mlp_bwd.DeferredBackward).  Not with the side stream: there the coarse chain's own launches are the point
+        if joint_backward is None:
+            joint_backward = os.environ.get("SCADE_JOINT_BACKWARD", "1") != "0"
+        self.joint_backward = bool(joint_backward) and self.coarse_stream is None
         self._one = torch.ones((), device=dev)      # see _unit_grad (built here, never inside a graph capture)
         self.bucket.broadcast_params(0)
 
@@ -197,12 +203,21 @@ class Trainer:
         else:
             self.bucket.allreduce_grads(force=self.force_allreduce)
 
+    def backward(self, loss):
+        """loss.backward() (:985) with the two networks' MLP backwards joined into one launch sequence."""
+        if self.joint_backward:
+            from .mlp_bwd import DeferredBackward
+            with DeferredBackward():
+                loss.backward(self._unit_grad(loss))
+        else:
+            loss.backward(self._unit_grad(loss))
+
     def step(self, rays, target_s, target_hyp, img_i=0, mask=None, n_total=None, **render_kw):
         """One optimisation step on this rank's shard; returns (this rank's term of the global loss,
         aux).  ``n_total``: rays of the whole batch when the shards are uneven."""
         self.bucket.begin_step()
         loss, aux = self.forward_loss(rays, target_s, target_hyp, img_i, mask, n_total, **render_kw)
-        loss.backward(self._unit_grad(loss))                                                  # :985
+        self.backward(loss)                                                                   # :985
         self.bucket.end_backward()
         self.reduce_grads()
         lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it + 1)  # :988-991
