@@ -20,6 +20,13 @@ SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_wgrad2.hip", "mlp_fwd_
            "mlp_bwd_lp.hip", "ray_ops.hip", "train_loss.hip", "optim.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
+# kernel experiments (same-box A/B): SCADE_AB_FLAGS="-DSOMETHING" SCADE_AB_OUT=tools/scratch/ab1 python -m
+# scade_amd.build builds a VARIANT library + objects under that directory; run with SCADE_LIB=<dir>/libscade_hip.so
+if os.environ.get("SCADE_AB_OUT"):
+    CFLAGS = CFLAGS + os.environ.get("SCADE_AB_FLAGS", "").split()
+    LIBDIR = os.path.abspath(os.environ["SCADE_AB_OUT"])
+    OBJDIR = os.path.join(LIBDIR, "obj")
+    LIB = os.path.join(LIBDIR, "libscade_hip.so")
 
 
 def hipcc():

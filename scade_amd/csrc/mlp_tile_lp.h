@@ -339,15 +339,19 @@ __device__ __forceinline__ void load_bias16(f32x16 (&cb)[NT], const float* __res
 // round two fp32 values to T (RNE) and pack them into one dword; with RELU the ReLU is applied to
 // the PACKED pair as a signed 16-bit integer max with 0 (v_pk_max_i16: a negative float, including
 // -0, is a negative int16, a positive float a positive one) - one VALU op per two values.
-// Inline asm: the compiler's own lowering of the same expression converts every scalar separately
-// and merges the halves with v_perm_b32.
-// v_permlane32_swap of two dwords whose producers may be INLINE ASM (pack2, mask_pair below).  gfx950 needs two
-// wait states between a VALU write of a VGPR and a v_permlane*_swap that reads it; hipcc's hazard recognizer
-// inserts them for instructions it selected itself but cannot see into inline asm (and does not even count an
-// asm statement as a wait state), so a v_cvt_pk_bf16_f32 scheduled right in front of the swap handed it a stale
-// register: the bf16 dgrad's unmasked d-feature tile came out ~16 % wrong in round 3's first build, and the
-// forward's epilogue had only been correct by the luck of its schedule.  The s_nop rides in an asm that
-// reads both operands and "modifies" one, which orders it behind their producers and in front of the swap.
+// The conversion is a 2-vector __builtin_convertvector, which hipcc selects as ONE v_cvt_pk_{bf16,f16}_f32
+// (scalar casts get converted one by one and merged with v_perm_b32).  It must NOT be inline asm: its inputs
+// are MFMA accumulators, and a VALU read of an MFMA result needs software wait states on gfx950 (no hardware
+// interlock) that the compiler inserts only in front of instructions it selected itself - while it is free to
+// hoist an asm statement right behind the last MFMA of the k-loop.  Round 3's first dgrad epilogue order made
+// it do exactly that: the first two chunks of the LAST point tile came out stale, differently from run to
+// run, in the bf16 build only (fp16's schedule happened to differ); the round-2 epilogues had been correct by
+// the luck of their schedules.  The integer ReLU stays asm: its input is the conversion's ordinary VALU result.
+// v_permlane32_swap of two dwords whose producers may be INLINE ASM (the integer ReLU of pack2, mask_pair).
+// gfx950 needs two wait states between a VALU write of a VGPR and a v_permlane*_swap that reads it; hipcc's
+// hazard recognizer inserts them for instructions it selected itself but under-counts behind an asm statement
+// (one wait state instead of two in a minimal test).  The s_nop rides in an asm that reads both operands and
+// "modifies" one, which orders it behind their producers and in front of the swap.
 __device__ __forceinline__ void lp_swap_halves(unsigned a, unsigned b, unsigned& lo, unsigned& hi) {
   asm("s_nop 1" : "+v"(a) : "v"(b));      // data dependences only (not volatile): a, b ready -> nop -> swap
   const auto sw = __builtin_amdgcn_permlane32_swap(a, b, false, false);
@@ -355,11 +359,15 @@ __device__ __forceinline__ void lp_swap_halves(unsigned a, unsigned b, unsigned&
   hi = sw[1];
 }
 
+typedef float lp_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 lp_f16x2 __attribute__((ext_vector_type(2)));
 template <bool BF, bool RELU>
 __device__ __forceinline__ unsigned pack2(float y0, float y1) {
+  const lp_f32x2 y = {y0, y1};
   unsigned w;
-  if (BF) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(w) : "v"(y0), "v"(y1));
-  else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(w) : "v"(y0), "v"(y1));
+  if (BF) w = __builtin_bit_cast(unsigned, __builtin_convertvector(y, lp_bf16x2));
+  else w = __builtin_bit_cast(unsigned, __builtin_convertvector(y, lp_f16x2));
   if (RELU) asm("v_pk_max_i16 %0, %1, 0" : "=v"(w) : "v"(w));
   return w;
 }

@@ -462,7 +462,10 @@ def test_trainer_coarse_stream_overlap_is_bitwise_neutral(dev):
     out = {}
     for overlap in (False, True):
         coarse, fine = make_scade_nets(dev, seed=0)
-        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, overlap_coarse=overlap)
+        # (joint_backward off: the side stream needs the two chains' own launches; the joint launch chunks the
+        # point sums differently, which is compared in test_joint_backward_of_both_networks_...)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, overlap_coarse=overlap,
+                     joint_backward=False)
         assert (tr.coarse_stream is not None) == overlap
         losses = [float(tr.step(rays, tgt, hyp, t_rand=a, u_coarse=b, cached_u=c)[0]) for a, b, c in draws]
         torch.cuda.synchronize()
@@ -541,7 +544,9 @@ def _rccl_capture_worker(out_path, port):
              ("graph_overlap", True, "overlap", True), ("eager_overlap", False, "overlap", True)]
     for mode, graphed, ar, force in modes:
         coarse, fine = make_scade_nets(dev, seed=4)
-        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=2, allreduce=ar)
+        # joint_backward off in every mode: "overlap" needs the coarse chain's own launches, and the modes are
+        # compared parameter by parameter after four Adam steps (the joint launch sums the points in other chunks)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=2, allreduce=ar, joint_backward=False)
         tr.force_allreduce = force
         gt = GraphedTrainer(tr, N, K, inject_draws=True, force_allreduce=force) if graphed else None
         ls = []
