@@ -433,9 +433,9 @@ def test_bf16_backward_without_point_scale_flushes_only_negligible_gradients(dev
         (net(x.to(dev)) * g_.to(dev)).sum().backward()
         out[name] = torch.cat([q.grad.reshape(-1) for q in net.parameters()])
     assert torch.isfinite(out["mixed"]).all()
-    # the tiny rows change the bf16 weight gradients by no more than their (1e-36-sized) contribution allows;
-    # a zero output gradient is not an inert row for the BIASES' neighbours only through the sums, so compare
-    # the two bf16 runs: same rows of ordinary magnitude, same rounding -> equal to 1e-30
-    assert float((out["mixed"] - out["big_only"]).abs().max()) <= 1e-30, \
+    # the tiny rows change the bf16 weight gradients by no more than their (1e-36-sized) contribution allows:
+    # compare the two bf16 runs - same rows of ordinary magnitude, same rounding
+    # (to fp32 rounding of the sums: one ulp of a gradient entry at most, measured 4.5e-13)
+    assert float((out["mixed"] - out["big_only"]).abs().max()) <= 1e-6 * float(out["big_only"].abs().max()), \
         float((out["mixed"] - out["big_only"]).abs().max())
     assert rel_l2(out["mixed"], out["mixed_exact"]) < 0.15
