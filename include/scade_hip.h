@@ -153,6 +153,17 @@ int scade_embed(const float* x, int P, int D, int multires, float* out, void* st
  * rays rows: o(0..2) d(3..5) near(6) far(7); t_vals = linspace(0,1,S). */
 int scade_ray_points(const float* rays, int ray_stride, const float* t_vals, const float* t_rand,
                      int N, int S, int lindisp, float* z_vals, float* pts, void* stream);
+/* The same with the training step's uniform draws made INSIDE the kernel (the reference draws them with three
+ * torch.rand calls per step: run_scade_scannet.py:570, helpers:350, helpers:399): Philox4x32-10 keyed by `seed`,
+ * counter = (draw block, ray, step) - a pure function of (seed, step, ray, draw index), no generator state.
+ * step = *step_dev (a float holding the number of steps taken, e.g. the fused optimizer's device state: graph
+ * captured steps) when step_dev is given, else `step`.  Per ray the stream is [S jitter draws | Si draws of the
+ * coarse importance sampler | Si draws of the depth-hypothesis sampler], each part padded to a multiple of four;
+ * a draw is (32 random bits >> 8) * 2^-24 in [0,1).  The jitter is consumed in registers; u_a / u_b [N,Si]
+ * (nullable) receive the samplers' draws for scade_ray_tail / scade_sample_pdf_fwd. */
+int scade_ray_points_draw(const float* rays, int ray_stride, const float* t_vals, int N, int S, int lindisp,
+                          unsigned long long seed, unsigned long long step, const float* step_dev, int Si,
+                          float* z_vals, float* pts, float* u_a, float* u_b, void* stream);
 
 /* stratified jitter of an existing z tensor (perturb_z_vals :564-579), t_rand[N,S] ~ U[0,1) */
 int scade_perturb_z(const float* z_vals, const float* t_rand, int N, int S, float* out,

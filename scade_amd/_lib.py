@@ -53,6 +53,8 @@ SIGNATURES = {
     "scade_mlp_bwd_f16": (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
     "scade_embed": (c_int, [_P, _I, _I, _I, _P, _P]),
     "scade_ray_points": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
+    "scade_ray_points_draw": (c_int, [_P, _I, _P, _I, _I, _I, ctypes.c_ulonglong, ctypes.c_ulonglong, _P, _I, _P, _P, _P, _P,
+                                      _P]),
     "scade_perturb_z": (c_int, [_P, _P, _I, _I, _P, _P]),
     "scade_composite_fwd": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P]),
     "scade_composite_bwd": (c_int, [_P, _P, _P, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P]),

@@ -393,14 +393,33 @@ __global__ void mlp_pack_lp_kernel(PackLpArgs a) {
     for (int i = t0; i < 4; i += stride) tail[OFF_BR - OFF_BIAS + i] = i < 3 ? a.p[23][i] : 0.f;
     for (int i = t0; i < 2 * 64 * 8; i += stride) wpk[off_wl(NLAYER_MFMA) + i] = (T)0.f;
     // NaN census of the hidden layers' fp32 parameters (see the forward's alpha head): this block's slice of
-    // every tensor, one 0 / NaN float per block and class; gridDim.x = LP_NAN_BLOCKS
+    // every tensor, one 0 / NaN float per block and class; gridDim.x = LP_NAN_BLOCKS.  Straight-line: every
+    // thread issues its ~24 sixteen-byte loads back to back (index clamped instead of predicated - re-reading
+    // an element is harmless for a census) and only then looks at them; as twenty small loops, each waiting for
+    // its own loads, this tripled the pack kernel's time (5 -> 15 us).
     int bad_trunk = 0, bad_colour = 0;
-    for (int t = 0; t < 20; ++t) {
-      const float* __restrict__ src = a.p[t];
-      const int n = lp_param_numel(t);
-      int bad = 0;
-      for (int i = t0; i < n; i += stride) { const float v = src[i]; bad |= (v != v) ? 1 : 0; }
-      if (t < 16) bad_trunk |= bad; else bad_colour |= bad;
+    {
+      constexpr int NTHR = LP_NAN_BLOCKS * 256;
+      f32x4 v[24];
+      int n = 0;
+#pragma unroll
+      for (int t = 0; t < 20; ++t) {
+        const int n4 = lp_param_numel(t) / 4;
+        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.p[t]);
+#pragma unroll
+        for (int k = 0; k < (n4 + NTHR - 1) / NTHR; ++k) v[n++] = src[min(t0 + k * NTHR, n4 - 1)];
+      }
+      n = 0;
+#pragma unroll
+      for (int t = 0; t < 20; ++t) {
+        const int n4 = lp_param_numel(t) / 4;
+#pragma unroll
+        for (int k = 0; k < (n4 + NTHR - 1) / NTHR; ++k) {
+          const f32x4 x = v[n++];
+          const int bad = (x[0] != x[0]) | (x[1] != x[1]) | (x[2] != x[2]) | (x[3] != x[3]);
+          if (t < 16) bad_trunk |= bad; else bad_colour |= bad;
+        }
+      }
     }
     bad_trunk = __syncthreads_or(bad_trunk);
     bad_colour = __syncthreads_or(bad_colour);

@@ -67,7 +67,39 @@ struct RayPointsArgs {
   float* z_vals;         // [N,S]
   float* pts;            // [N,S,3] or null
   int N, S, ray_stride, lindisp;
+  // draw mode (scade_ray_points_draw): the step's uniform draws come from a counter-based generator inside
+  // this kernel instead of a tensor - the jitter is consumed in registers, the two samplers' draws are written
+  // out for the ray tails
+  int draw;                  // 0: t_rand as above
+  unsigned seed_lo, seed_hi; // Philox key
+  unsigned long long step;   // host step index ...
+  const float* step_dev;     // ... or the device-resident step count (FusedAdam.state[0], graph-captured steps)
+  float* u_a;                // [N,Si] draws of the coarse importance sampler (helpers:346-361), or null
+  float* u_b;                // [N,Si] draws of the depth-hypothesis sampler (helpers:395-410), or null
+  int Si;
 };
+
+// Philox4x32-10 (Salmon et al., SC'11; the generator family torch's device RNG uses): a pure function
+// (key, counter) -> 4 x 32 random bits, so every (step, ray, draw) has its value without any state to carry.
+__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
+    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+}
+// draw d of ray `ray` at step `step`: block d / 4 of the ray's stream, element d % 4; 24 random bits -> [0,1)
+// (the construction of torch.rand for float32)
+__device__ __forceinline__ void draw_block(unsigned seed_lo, unsigned seed_hi, unsigned long long step, int ray,
+                                           int block, float (&u)[4]) {
+  unsigned c[4] = {(unsigned)block, (unsigned)ray, (unsigned)step, (unsigned)(step >> 32)};
+  philox4x32_10(c, seed_lo, seed_hi);
+#pragma unroll
+  for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * 5.9604644775390625e-8f;     // 2^-24
+}
 
 __global__ void ray_points_kernel(RayPointsArgs a) {
   const int ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
@@ -83,14 +115,39 @@ __global__ void ray_points_kernel(RayPointsArgs a) {
     if (!a.lindisp) return near * om + far * t;                      // :642
     return 1.0f / (1.0f / near * om + 1.0f / far * t);               // :645
   };
+  // draw mode: the ray's stream is [jitter: S draws | sampler a: Si | sampler b: Si], every block of four
+  // padded up separately so that the arrays start on a block boundary
+  const unsigned long long step = a.draw ? (a.step_dev ? (unsigned long long)a.step_dev[0] : a.step) : 0ull;
+  const int jb = (S + 3) >> 2, sb = (a.Si + 3) >> 2;
+  if (a.draw) {
+    for (int which = 0; which < 2; ++which) {
+      float* dst = which ? a.u_b : a.u_a;
+      if (!dst) continue;
+      for (int b = lane; b < sb; b += 64) {
+        float u[4];
+        draw_block(a.seed_lo, a.seed_hi, step, ray, jb + which * sb + b, u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (4 * b + j < a.Si) dst[(size_t)ray * a.Si + 4 * b + j] = u[j];
+      }
+    }
+  }
   for (int i = lane; i < S; i += 64) {
     float z = zlin(i);
-    if (a.t_rand) {                                                  // :564-579
+    if (a.t_rand || a.draw) {                                        // :564-579
+      float t;
+      if (a.draw) {
+        float u[4];
+        draw_block(a.seed_lo, a.seed_hi, step, ray, i >> 2, u);
+        t = u[i & 3];
+      } else {
+        t = a.t_rand[(size_t)ray * S + i];
+      }
       const float zm = i > 0 ? zlin(i - 1) : z;
       const float zp = i + 1 < S ? zlin(i + 1) : z;
       const float lower = i > 0 ? 0.5f * (z + zm) : z;
       const float upper = i + 1 < S ? 0.5f * (zp + z) : z;
-      z = lower + (upper - lower) * a.t_rand[(size_t)ray * S + i];
+      z = lower + (upper - lower) * t;
     }
     a.z_vals[(size_t)ray * S + i] = z;
     if (a.pts) {
@@ -1028,9 +1085,28 @@ extern "C" int scade_ray_points(const float* rays, int ray_stride, const float* 
   if (N <= 0) return 0;
   SCADE_REQUIRE(rays && t_vals && z_vals, -1, "scade_ray_points: null pointer");
   SCADE_REQUIRE(ray_stride >= 8 && S >= 1, -2, "scade_ray_points: ray_stride >= 8 and S >= 1 required");
-  RayPointsArgs a{rays, t_vals, t_rand, z_vals, pts, N, S, ray_stride, lindisp};
+  RayPointsArgs a{};
+  a.rays = rays; a.t_vals = t_vals; a.t_rand = t_rand; a.z_vals = z_vals; a.pts = pts;
+  a.N = N; a.S = S; a.ray_stride = ray_stride; a.lindisp = lindisp;
   hipLaunchKernelGGL(ray_points_kernel, dim3(grid_rays(N)), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_ray_points");
+}
+
+extern "C" int scade_ray_points_draw(const float* rays, int ray_stride, const float* t_vals, int N, int S,
+                                     int lindisp, unsigned long long seed, unsigned long long step,
+                                     const float* step_dev, int Si, float* z_vals, float* pts, float* u_a,
+                                     float* u_b, void* stream) {
+  if (N <= 0) return 0;
+  SCADE_REQUIRE(rays && t_vals && z_vals, -1, "scade_ray_points_draw: null pointer");
+  SCADE_REQUIRE(ray_stride >= 8 && S >= 1 && Si >= 0, -2, "scade_ray_points_draw: ray_stride >= 8, S >= 1, Si >= 0 required");
+  SCADE_REQUIRE(Si > 0 || (!u_a && !u_b), -2, "scade_ray_points_draw: sampler draws requested with Si = 0");
+  RayPointsArgs a{};
+  a.rays = rays; a.t_vals = t_vals; a.z_vals = z_vals; a.pts = pts;
+  a.N = N; a.S = S; a.ray_stride = ray_stride; a.lindisp = lindisp;
+  a.draw = 1; a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.step = step; a.step_dev = step_dev;
+  a.u_a = u_a; a.u_b = u_b; a.Si = Si;
+  hipLaunchKernelGGL(ray_points_kernel, dim3(grid_rays(N)), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_ray_points_draw");
 }
 
 template <template <int> class>

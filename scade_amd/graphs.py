@@ -45,6 +45,10 @@ class GraphedTrainer:
         # optimizer state not restored, :480) has taken opt.steps = 0 steps but stands at iteration N
         tr.opt.use_device_state(c["rate"], c["step"], iter_offset=tr.it - tr.opt.steps)
         tr.opt_ss.use_device_state()
+        # in-kernel draws: the step index must live on the device too (state[0] = steps taken by this optimizer;
+        # resumed runs add their offset through the seed so that the streams do not repeat)
+        tr.draw_step_dev = tr.opt.state[0:1]
+        tr.draw_seed = (tr.draw_seed + (tr.it - tr.opt.steps) * 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
         self.graph = None
         self.loss = None
         self._captured = None     # (scale/shift update in the graph?, carving term in the graph?)

@@ -403,6 +403,36 @@ def ray_points(rays: Tensor, n_samples: int, t_rand: Optional[Tensor], lindisp: 
     return z, pts
 
 
+class Draws:
+    """Where a training step's uniform draws come from when they are made inside scade_ray_points_draw:
+    ``seed`` (Philox key), ``step`` (host step index) or ``step_dev`` (a device float holding the number of steps
+    taken - FusedAdam.state[0:1] - for graph-captured steps, where nothing may change on the host)."""
+
+    def __init__(self, seed: int, step: int = 0, step_dev: Optional[Tensor] = None):
+        self.seed, self.step, self.step_dev = int(seed) & (2 ** 64 - 1), int(step), step_dev
+
+
+def ray_points_draw(rays: Tensor, n_samples: int, lindisp: bool, draws: Draws, n_importance: int,
+                    want_a: bool = True, want_b: bool = True):
+    """ray_points with the stratified jitter drawn in the kernel -> (z, pts, u_a, u_b): u_a / u_b [N,n_importance]
+    = the draws of the coarse importance sampler / the depth-hypothesis sampler (None when not wanted)."""
+    rays, stride = _rows(rays, "ray_points_draw: rays")
+    N = rays.shape[0]
+    if rays.shape[1] < 8:
+        raise ValueError("ray_points_draw: rays need >= 8 columns (o, d, near, far)")
+    dev = rays.device
+    z = torch.empty(N, n_samples, device=dev, dtype=torch.float32)
+    pts = torch.empty(N, n_samples, 3, device=dev, dtype=torch.float32)
+    u_a = torch.empty(N, n_importance, device=dev, dtype=torch.float32) if want_a else None
+    u_b = torch.empty(N, n_importance, device=dev, dtype=torch.float32) if want_b else None
+    if draws.step_dev is not None:
+        check(draws.step_dev, "ray_points_draw: step_dev")
+    call("scade_ray_points_draw", ptr(rays), stride, ptr(linspace01(n_samples, dev)), N, n_samples,
+         int(bool(lindisp)), draws.seed, draws.step, ptr(draws.step_dev), n_importance, ptr(z), ptr(pts), ptr(u_a),
+         ptr(u_b), stream())
+    return z, pts, u_a, u_b
+
+
 def perturb_z(z_vals: Tensor, t_rand: Tensor) -> Tensor:
     z = _c(check(z_vals, "perturb_z_vals: z_vals"))
     t = _c(check(t_rand, "perturb_z_vals: t_rand"))

@@ -159,7 +159,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
                 precomputed_z_samples=None, embedded_cam=None, retraw=False, lindisp=False,
                 perturb=0., N_importance=0, network_fine=None, raw_noise_std=0., verbose=False,
                 pytest=False, is_joint=False, cached_u=None, t_rand=None, u_coarse=None,
-                coarse_stream=None, fuse_tails=True):
+                coarse_stream=None, fuse_tails=True, draws=None):
     """run_scade_scannet.py:581-751 (live branch ``N_importance > 0``).
 
     Extra keyword-only knobs beyond the reference signature: ``t_rand`` [N,N_samples]
@@ -171,7 +171,10 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     so in a train step the whole coarse backward chain (composite -> dgrad -> wgrad) runs
     CONCURRENTLY with the fine chain instead of behind it and fills the tails of its launches.
     ``fuse_tails=False`` runs the per-ray work between the MLP launches as the separate
-    raw2outputs / sample_pdf / merge operators (same bits; kept for the parity tests)."""
+    raw2outputs / sample_pdf / merge operators (same bits; kept for the parity tests).
+    ``draws`` (an ``ops.Draws``; training only, perturb > 0): the step's uniform draws that were not injected
+    are made INSIDE the first kernel of the step (scade_ray_points_draw: counter-based Philox keyed by seed,
+    step, ray and draw index) instead of by torch.rand launches."""
     if N_importance <= 0:
         raise NotImplementedError(
             "render_rays: N_importance == 0 is dead code in the reference (raises UnboundLocalError "
@@ -192,7 +195,10 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     det = (perturb == 0.)
 
     # ---- coarse: z (+jitter) and points in one launch (:638-657) -------------
-    if perturb > 0.:
+    in_kernel = perturb > 0. and t_rand is None and draws is not None and not pytest
+    if in_kernel:
+        pass                                     # jitter drawn by scade_ray_points_draw (coarse_stage)
+    elif perturb > 0.:
         if t_rand is None:
             if pytest:
                 np.random.seed(0)
@@ -207,7 +213,16 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     fused = fuse_tails and ops.ray_tail_supported(N_samples, N_importance, merge=True)
 
     def coarse_stage():
-        z, p = ops.ray_points(rays, N_samples, t_rand, lindisp)
+        nonlocal u_coarse, cached_u
+        if in_kernel:
+            # the two samplers' draws that were not injected come out of the same launch (the last sampler's
+            # stay with the host when is_joint shares ONE row among all rays, helpers:498-513)
+            z, p, ua, ub = ops.ray_points_draw(rays, N_samples, lindisp, draws, N_importance,
+                                               want_a=u_coarse is None, want_b=cached_u is None and not is_joint)
+            u_coarse = ua if u_coarse is None else u_coarse
+            cached_u = ub if cached_u is None else cached_u
+        else:
+            z, p = ops.ray_points(rays, N_samples, t_rand, lindisp)
         r = network_query_fn(p, viewdirs, embedded_cam, network_fn)
         if not fused:
             return (z, r) + tuple(raw2outputs(r, z, rays_d, raw_noise_std, pytest=pytest))

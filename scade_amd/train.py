@@ -102,6 +102,12 @@ class Trainer:
         if joint_backward is None:
             joint_backward = os.environ.get("SCADE_JOINT_BACKWARD", "1") != "0"
         self.joint_backward = bool(joint_backward) and self.coarse_stream is None
+        # the step's uniform draws inside scade_ray_points_draw (SCADE_DRAW_IN_KERNEL=0: one torch.rand launch).
+        # The Philox key comes from torch's seed of this process (parallel.seed_rank_streams gives every rank its
+        # own), the counter from the step index: reproducible under torch.manual_seed like the torch.rand path.
+        self.draw_in_kernel = os.environ.get("SCADE_DRAW_IN_KERNEL", "1") != "0"
+        self.draw_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5CADE) & (2 ** 64 - 1)
+        self.draw_step_dev = None           # GraphedTrainer: the fused optimizer's device-resident step count
         self._one = torch.ones((), device=dev)      # see _unit_grad (built here, never inside a graph capture)
         self.bucket.broadcast_params(0)
 
@@ -130,15 +136,19 @@ class Trainer:
             # (helpers:498-513): rank 0's draw.  The coarse importance sampler stays per ray (:705).
             render_kw.setdefault("cached_u", shared_uniform((c["Ni"],), rays.device))
         if not any(k in render_kw for k in ("t_rand", "u_coarse", "pytest")):
-            # the step's uniform draws (stratified jitter :564-579, the sample_pdf draws
-            # helpers:346-361) as ONE generator launch; independent streams either way
-            n, ns, ni = rays.shape[0], c["Ns"], c["Ni"]
-            need_u = "cached_u" not in render_kw and not c["joint"]
-            d = torch.rand(n * (ns + ni + (ni if need_u else 0)), device=rays.device)
-            render_kw["t_rand"] = d[:n * ns].view(n, ns)
-            render_kw["u_coarse"] = d[n * ns:n * (ns + ni)].view(n, ni)
-            if need_u:
-                render_kw["cached_u"] = d[n * (ns + ni):].view(n, ni)
+            if self.draw_in_kernel:
+                # the step's uniform draws (stratified jitter :564-579, the sample_pdf draws helpers:346-361,
+                # :395-410) are made inside the step's first kernel: no generator launch, no jitter tensor
+                render_kw["draws"] = ops.Draws(self.draw_seed, self.it, self.draw_step_dev)
+            else:
+                # ... or as ONE torch generator launch; independent streams either way
+                n, ns, ni = rays.shape[0], c["Ns"], c["Ni"]
+                need_u = "cached_u" not in render_kw and not c["joint"]
+                d = torch.rand(n * (ns + ni + (ni if need_u else 0)), device=rays.device)
+                render_kw["t_rand"] = d[:n * ns].view(n, ns)
+                render_kw["u_coarse"] = d[n * ns:n * (ns + ni)].view(n, ni)
+                if need_u:
+                    render_kw["cached_u"] = d[n * (ns + ni):].view(n, ni)
         ret = R.render_rays(rays, True, self.coarse, self.query, c["Ns"], N_importance=c["Ni"],
                             network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
                             lindisp=c["lindisp"], is_joint=c["joint"], coarse_stream=self.coarse_stream,

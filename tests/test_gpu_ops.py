@@ -479,3 +479,75 @@ def test_wrong_current_device_fails_loudly(dev):
             S.render_rays(torch.zeros(2, 11, device=dev), True, None, None, 64, N_importance=128)
     finally:
         torch.cuda.current_device = real
+
+
+def _philox4x32_10(counter, key):
+    """Reference Philox4x32-10 (Salmon et al., SC'11) on numpy uint32 arrays: counter [...,4], key (k0, k1)."""
+    import numpy as np
+    c = counter.astype(np.uint64)
+    k0, k1 = np.uint64(key[0]), np.uint64(key[1])
+    M0, M1, MASK = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0, p1 = M0 * c[..., 0], M1 * c[..., 2]
+        n0 = ((p1 >> np.uint64(32)) ^ c[..., 1] ^ k0) & MASK
+        n2 = ((p0 >> np.uint64(32)) ^ c[..., 3] ^ k1) & MASK
+        c = np.stack([n0, p1 & MASK, n2, p0 & MASK], -1)
+        k0, k1 = (k0 + np.uint64(0x9E3779B9)) & MASK, (k1 + np.uint64(0xBB67AE85)) & MASK
+    return c.astype(np.uint32)
+
+
+def test_philox_reference_known_answer():
+    """The numpy reference above against Random123's published known-answer vectors for philox4x32-10."""
+    import numpy as np
+    z = _philox4x32_10(np.zeros((1, 4), np.uint32), (0, 0))[0]
+    assert [hex(int(v)) for v in z] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    f = _philox4x32_10(np.full((1, 4), 0xFFFFFFFF, np.uint32), (0xFFFFFFFF, 0xFFFFFFFF))[0]
+    assert [hex(int(v)) for v in f] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+
+
+@pytest.mark.parametrize("S,Si", [(64, 128), (7, 5), (130, 33)])
+def test_ray_points_draw_is_philox_keyed_by_seed_step_ray(dev, S, Si):
+    """scade_ray_points_draw: the step's uniform draws made inside the kernel are Philox4x32-10 with key = seed,
+    counter = (draw block, ray, step lo, step hi); per ray [S jitter | Si | Si] with each part padded to blocks
+    of four; value = (bits >> 8) * 2^-24.  Checked bit for bit against the numpy reference: the two sampler rows
+    directly, the jitter through scade_ray_points fed with the reference draws (same z, same points).  The device
+    resident step (graph-captured steps) gives the same stream as the host step."""
+    import numpy as np
+    from scade_amd import ops
+    N = 37
+    rays = O.synthetic_rays(N, seed=3).to(dev)
+    seed, step = 0x0123456789ABCDEF, 2 ** 33 + 5
+    jb, sb = (S + 3) // 4, (Si + 3) // 4
+    nblk = jb + 2 * sb
+    ctr = np.zeros((N, nblk, 4), np.uint32)
+    ctr[..., 0] = np.arange(nblk)[None]
+    ctr[..., 1] = np.arange(N)[:, None]
+    ctr[..., 2] = step & 0xFFFFFFFF
+    ctr[..., 3] = step >> 32
+    bits = _philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32))
+    u = ((bits >> 8).astype(np.float32) * np.float32(2.0 ** -24)).reshape(N, nblk * 4)
+    want_t, want_a, want_b = u[:, :S], u[:, 4 * jb:4 * jb + Si], u[:, 4 * (jb + sb):4 * (jb + sb) + Si]
+    z, pts, ua, ub = ops.ray_points_draw(rays, S, False, ops.Draws(seed, step), Si)
+    assert torch.equal(ua.cpu(), torch.from_numpy(want_a.copy())) and torch.equal(ub.cpu(), torch.from_numpy(want_b.copy()))
+    z_ref, pts_ref = ops.ray_points(rays, S, torch.from_numpy(want_t.copy()).to(dev), False)
+    assert torch.equal(z, z_ref) and torch.equal(pts, pts_ref)
+    assert 0.0 <= float(ua.min()) and float(ua.max()) < 1.0
+    # another step / another seed: other draws; only one array wanted: the other is not touched
+    z2, _, ua2, none_b = ops.ray_points_draw(rays, S, False, ops.Draws(seed, step + 1), Si, want_b=False)
+    assert none_b is None and not torch.equal(ua2, ua) and not torch.equal(z2, z)
+    # device-resident step count (a float, as FusedAdam.state[0] holds it)
+    sd = torch.tensor([12345.0], device=dev)
+    a = ops.ray_points_draw(rays, S, False, ops.Draws(seed, 999, step_dev=sd), Si)
+    b = ops.ray_points_draw(rays, S, False, ops.Draws(seed, 12345), Si)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_in_kernel_draws_are_uniform(dev):
+    from scade_amd import ops
+    rays = O.synthetic_rays(2048, seed=4).to(dev)
+    _, _, ua, ub = ops.ray_points_draw(rays, 64, False, ops.Draws(7, 3), 128)
+    x = torch.cat([ua.flatten(), ub.flatten()]).double()
+    assert abs(float(x.mean()) - 0.5) < 2e-3 and abs(float(x.var()) - 1 / 12) < 1e-3
+    hist = torch.histc(x.float(), bins=16, min=0, max=1) / x.numel()
+    assert float((hist - 1 / 16).abs().max()) < 2e-3
+    assert abs(float(torch.corrcoef(torch.stack([ua.flatten(), ub.flatten()]))[0, 1])) < 5e-3
