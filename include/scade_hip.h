@@ -57,6 +57,15 @@ int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* v
                   int vd_stride, const float* bb, int P, int S, float* out, float* acts,
                   void* stream);
 
+/* The weight packs of a train step for one or two networks in ONE launch (instead of scade_mlp_pack +
+ * scade_mlp_pack_t, or scade_mlp_pack_lp + scade_mlp_pack_t_lp, per network).  params: n_nets x 24 pointers,
+ * network-major, each network in the scade_mlp_pack order; format 0 = exact fp32 layouts, 1 = bf16, 2 = fp16
+ * (the 16-bit forward blob includes the NaN census of the fp32 parameters); packed_fwd / packed_t: n_nets
+ * output blobs each, sized as for the stand-alone entries, NULL entries are skipped.  Same bytes as the
+ * stand-alone pack entries write. */
+int scade_mlp_pack_step(int n_nets, const float* const* params, int format, void* const* packed_fwd,
+                        void* const* packed_t, void* stream);
+
 /* Backward of scade_mlp_fwd w.r.t. the 24 parameter tensors (what autograd computes for
  * NeRF.forward in the reference).  packed_t = scade_mlp_pack_t(params) (transposed weight
  * pack, scade_mlp_packed_t_floats() floats); acts = the workspace the forward filled;
@@ -311,6 +320,15 @@ int scade_adam_step(float* params, const float* grads, float* exp_avg, float* ex
  * and the bias corrections on the device, then applies the update. */
 int scade_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
                         float* state, void* stream);
+/* Both optimizers of a train step - the networks' Adam and the depth scale / shift Adam (run_scade_scannet.py:469,
+ * :888, :993-997), which differ in learning rate and step count - in ONE update launch.  Host arrays of two
+ * entries; n[1] = 0 skips the second segment (frozen scale / shift, :996).  state[i] != NULL: that segment's
+ * scalars are device resident (scade_adam_step_dev's state layout) and one tick launch advances both first;
+ * otherwise lr / beta1 / beta2 / eps / step / grad_scale [i] are read from the host arrays. */
+int scade_adam_step2(float* const* params, const float* const* grads, float* const* exp_avg,
+                     float* const* exp_avg_sq, const long* n, const float* lr, const float* beta1,
+                     const float* beta2, const float* eps, const int* step, const float* grad_scale,
+                     float* const* state, void* stream);
 
 #ifdef __cplusplus
 }

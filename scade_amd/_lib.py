@@ -25,6 +25,7 @@ SIGNATURES = {
     "scade_mlp_packed_floats": (c_long, []),
     "scade_mlp_lds_bytes": (c_int, []),
     "scade_mlp_pack": (c_int, [_P, _P, _P]),
+    "scade_mlp_pack_step": (c_int, [_I, _P, _I, _P, _P, _P]),
     "scade_mlp_fwd": (c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "scade_mlp_acts_floats": (c_long, [c_long]),
     "scade_mlp_packed_t_floats": (c_long, []),
@@ -80,6 +81,7 @@ SIGNATURES = {
                                 _P, _P, _P, _P]),
     "scade_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, _I, c_float, _P]),
     "scade_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, _P]),
+    "scade_adam_step2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     "scade_mse_bwd": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
 }
 

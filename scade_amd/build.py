@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libscade_hip.so")
 SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_wgrad2.hip", "mlp_fwd_f16.hip", "mlp_bwd_f16.hip", "mlp_fwd_lp.hip",
-           "mlp_bwd_lp.hip", "ray_ops.hip", "train_loss.hip", "optim.hip"]
+           "mlp_bwd_lp.hip", "mlp_pack_step.hip", "ray_ops.hip", "train_loss.hip", "optim.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
 # kernel experiments (same-box A/B): SCADE_AB_FLAGS="-DSOMETHING" SCADE_AB_OUT=tools/scratch/ab1 python -m

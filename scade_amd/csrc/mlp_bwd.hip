@@ -16,6 +16,7 @@
 //      VALU.  wgrad_reduce4_kernel (mlp_wgrad.h) sums the chunk partials (deterministic order)
 //      into one flat gradient in PyTorch parameter layout.
 #include "mlp_tile.h"
+#include "mlp_pack.h"
 #include "mlp_wgrad.h"
 
 namespace scade {
@@ -28,28 +29,7 @@ struct PackTArgs {
   float* packedT;
 };
 
-__global__ void mlp_pack_t_kernel(PackTArgs a) {
-  const int t = blockIdx.y;  // dgrad index 0..8
-  const int l = dgrad_layer(t);
-  const int widx = l <= 7 ? 2 * l : (l == L_FEAT ? 18 : 16);
-  const float* __restrict__ Wsrc = a.p[widx];
-  const int N = n_out(l);
-  const int NB = N / 8;
-  const int ld = l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W);
-  const int hcol0 = l == 5 ? EMB : 0;
-  const int total = 256 * N;
-  const int off = off_wt(t);
-  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-    const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
-    const int nb = blk % NB, kt = blk / NB;
-    const int n = nb * 8 + 4 * (lane >> 5) + j;
-    const int k = kt * 32 + (lane & 31);
-    a.packedT[off + i] = Wsrc[(size_t)n * ld + hcol0 + k];
-  }
-  if (t == 0)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 256; i += gridDim.x * blockDim.x)
-      a.packedT[off_wt(NLAYER_DGRAD) + i] = 0.f;
-}
+__global__ void mlp_pack_t_kernel(PackTArgs a) { pack_t_row(a.p, a.packedT, blockIdx.y, blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------------------
 // B1: dgrad chain
@@ -228,7 +208,7 @@ extern "C" int scade_mlp_pack_t(const float* const* params, float* packed_t, voi
     a.p[i] = params[i];
   }
   a.packedT = packed_t;
-  hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(64, NLAYER_DGRAD), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_pack_t_kernel, dim3(PACK_BLOCKS, PACK_T_ROWS), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_mlp_pack_t");
 }
 

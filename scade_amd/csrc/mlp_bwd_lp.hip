@@ -16,24 +16,10 @@
 //                          HBM-bound by design: 1 KB per point-layer at the 16-bit MFMA rate.
 //   B3 wgrad_reduce        sum of the per-chunk partials, S removed.
 #include "mlp_tile_lp.h"
+#include "mlp_pack.h"
 #include "mlp_wgrad.h"
 
 namespace scade {
-
-// transposed single-plane pack: dgrad index t (mlp_layout.h), layer l = dgrad_layer(t):
-//   WTL[((kt*NB16 + nb)*64 + lane)*8 + j] = W[nb*16 + 8*(lane>>5) + j][hcol0 + kt*32 + (lane&31)]
-constexpr long wtl_elems(int t) { return 256L * n_out(dgrad_layer(t)); }
-constexpr long off_wtl(int t) {
-  long o = 0;
-  for (int i = 0; i < t; ++i) o += wtl_elems(i);
-  return o;
-}
-constexpr long PACKED_T_LP_ELEMS = off_wtl(NLAYER_DGRAD) + 2 * 64 * 8;
-// fp32 tail behind the 16-bit planes: the head weights the dgrad kernel multiplies on the VALU
-// (alpha_linear.weight [256] | rgb_linear.weight [3][128]) - so that a 16-bit training step needs no
-// fp32 forward blob at all
-constexpr int TL_WA = 0, TL_WR = 256, PACKED_T_LP_TAIL_FLOATS = 256 + 384;
-constexpr long PACKED_T_LP_BYTES = PACKED_T_LP_ELEMS * 2 + PACKED_T_LP_TAIL_FLOATS * 4;
 
 struct PackTLpArgs {
   const float* p[N_PARAM_TENSORS];
@@ -41,35 +27,7 @@ struct PackTLpArgs {
 };
 
 template <bool BF>
-__global__ void mlp_pack_t_lp_kernel(PackTLpArgs a) {
-  typedef typename LP<BF>::T T;
-  T* out = reinterpret_cast<T*>(a.packed);
-  const int t = blockIdx.y;
-  const int l = dgrad_layer(t);
-  const int widx = l <= 7 ? 2 * l : (l == L_FEAT ? 18 : 16);
-  const float* __restrict__ Wsrc = a.p[widx];
-  const int N = n_out(l);
-  const int NB = N / 16;
-  const int ld = l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W);
-  const int hcol0 = l == 5 ? EMB : 0;
-  const long total = 256L * N;
-  const long off = off_wtl(t);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    const long blk = i >> 9;
-    const int nb = (int)(blk % NB), kt = (int)(blk / NB);
-    const int n = nb * 16 + 8 * (lane >> 5) + j;
-    const int k = kt * 32 + (lane & 31);
-    out[off + i] = (T)Wsrc[(size_t)n * ld + hcol0 + k];
-  }
-  if (t == 0) {
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 64 * 8; i += gridDim.x * blockDim.x)
-      out[off_wtl(NLAYER_DGRAD) + i] = (T)0.f;
-    float* tl = reinterpret_cast<float*>(out + PACKED_T_LP_ELEMS);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PACKED_T_LP_TAIL_FLOATS; i += gridDim.x * blockDim.x)
-      tl[i] = i < TL_WR ? a.p[20][i] : a.p[22][i - TL_WR];
-  }
-}
+__global__ void mlp_pack_t_lp_kernel(PackTLpArgs a) { pack_t_lp_row<BF>(a.p, a.packed, blockIdx.y, blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------------------
 // G: launch-wide max |g_out| (finite values only) -> gmax (float bits, zeroed before the launch)
@@ -726,8 +684,8 @@ extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp
     a.p[i] = params[i];
   }
   a.packed = packed_t_lp;
-  if (bf16) hipLaunchKernelGGL(mlp_pack_t_lp_kernel<true>, dim3(64, NLAYER_DGRAD), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(mlp_pack_t_lp_kernel<false>, dim3(64, NLAYER_DGRAD), dim3(256), 0, (hipStream_t)stream, a);
+  if (bf16) hipLaunchKernelGGL(mlp_pack_t_lp_kernel<true>, dim3(PACK_BLOCKS, PACK_T_ROWS), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mlp_pack_t_lp_kernel<false>, dim3(PACK_BLOCKS, PACK_T_ROWS), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_mlp_pack_t_lp");
 }
 

@@ -20,6 +20,7 @@
 //  * skip-concat (layer 5) and view-concat are extra k-blocks, never a concat;
 //  * the 256->1 and 128->3 heads are VALU dot products.
 #include "mlp_tile.h"
+#include "mlp_pack.h"
 
 namespace scade {
 
@@ -42,7 +43,6 @@ __device__ __forceinline__ float relu_keep_nan(float x) {
   return __builtin_bit_cast(float, b > 0 ? b : 0);
 }
 // positive-signed quiet NaN for any NaN (the sign of a propagated NaN is otherwise the input's)
-__device__ __forceinline__ float canon_nan(float x) { return x != x ? __builtin_nanf("") : x; }
 // ... and for +-inf: an infinite coordinate makes the reference's whole row NaN (sin(inf) = NaN meets every
 // feature of layer 0) while inf - inf inside an MFMA yields a default NaN of either sign, which the integer
 // relu would not carry reliably - so it enters the layers as +NaN already
@@ -297,47 +297,7 @@ struct PackArgs {
   float* packed;
 };
 
-// source column of padded channel k' for layer l, or -1 for zero padding
-__device__ __forceinline__ int kmap(int l, int kp) {
-  if (l == 0) return kp < EMB ? kp : -1;
-  if (l == 5) return kp < EMB_PAD ? (kp < EMB ? kp : -1) : EMB + (kp - EMB_PAD);
-  if (l == L_VIEWS) return kp < VIEW_PAD ? (kp < 3 ? W + kp : -1) : kp - VIEW_PAD;
-  return kp;
-}
-__device__ __forceinline__ int k_real(int l) {
-  return l == 0 ? EMB : (l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W));
-}
-
-__global__ void mlp_pack_kernel(PackArgs a) {
-  const int l = blockIdx.y;  // 0..9 MFMA layers, 10 = biases + heads
-  if (l < NLAYER_MFMA) {
-    const int widx = l < 8 ? 2 * l : (l == L_FEAT ? 18 : 16);
-    const float* __restrict__ Wsrc = a.p[widx];
-    const int KB = kb_total(l);
-    const int total = w_floats(l);
-    const int kr = k_real(l);
-    const int off = off_w(l);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-      const int j = i & 3, lane = (i >> 2) & 63, blk = i >> 8;
-      const int kb = blk % KB, nt = blk / KB;
-      const int n = nt * 32 + (lane & 31);
-      const int src = kmap(l, kb * 8 + 4 * (lane >> 5) + j);
-      a.packed[off + i] = src >= 0 ? canon_nan(Wsrc[(size_t)n * kr + src]) : 0.f;   // NaN weights: positive-signed
-    }
-  } else {
-    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    for (int i = t0; i < NLAYER_MFMA * 256; i += stride) {
-      const int ll = i >> 8, f = i & 255;
-      const int bidx = ll < 8 ? 2 * ll + 1 : (ll == L_FEAT ? 19 : 17);
-      a.packed[OFF_BIAS + i] = (ll == L_VIEWS && f >= 128) ? 0.f : canon_nan(a.p[bidx][f]);
-    }
-    for (int i = t0; i < 256; i += stride) a.packed[OFF_WA + i] = a.p[20][i];
-    for (int i = t0; i < 4; i += stride) a.packed[OFF_BA + i] = i == 0 ? a.p[21][0] : 0.f;
-    for (int i = t0; i < 384; i += stride) a.packed[OFF_WR + i] = a.p[22][i];
-    for (int i = t0; i < 4; i += stride) a.packed[OFF_BR + i] = i < 3 ? a.p[23][i] : 0.f;
-    for (int i = t0; i < 256; i += stride) a.packed[OFF_BR + 4 + i] = 0.f;
-  }
-}
+__global__ void mlp_pack_kernel(PackArgs a) { pack_fwd_row(a.p, a.packed, blockIdx.y, blockIdx.x, gridDim.x); }
 
 }  // namespace scade
 
@@ -356,7 +316,7 @@ extern "C" int scade_mlp_pack(const float* const* params, float* packed, void* s
     a.p[i] = params[i];
   }
   a.packed = packed;
-  hipLaunchKernelGGL(mlp_pack_kernel, dim3(64, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
+  hipLaunchKernelGGL(mlp_pack_kernel, dim3(PACK_BLOCKS, PACK_FWD_ROWS), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_mlp_pack");
 }
 

@@ -9,6 +9,7 @@
 // precision (relative 2^-11 per operand for fp16, 2^-8 for bf16), NOT the 1e-4 parity bar:
 // the tests hold this path to a PSNR / relative-L2 bound instead and it is never the default.
 #include "mlp_tile_lp.h"
+#include "mlp_pack.h"
 
 namespace scade {
 
@@ -351,84 +352,8 @@ struct PackLpArgs {
   void* packed;
 };
 
-__device__ __forceinline__ int kmap16_lp(int l, int kp) {
-  // padded channel kp -> source column of layer l's weight, or -1 (zero)
-  if (l == 0) return kp < EMB ? kp : -1;
-  if (l == 5) return kp < 64 ? (kp < EMB ? kp : -1) : EMB + (kp - 64);
-  if (l == L_VIEWS) return kp < 16 ? (kp < 3 ? W + kp : -1) : kp - 16;
-  return kp;
-}
-
 template <bool BF>
-__global__ void mlp_pack_lp_kernel(PackLpArgs a) {
-  typedef typename LP<BF>::T T;
-  const int l = blockIdx.y;
-  T* wpk = reinterpret_cast<T*>(a.packed);
-  if (l < NLAYER_MFMA) {
-    const int widx = l < 8 ? 2 * l : (l == L_FEAT ? 18 : 16);
-    const float* __restrict__ Wsrc = a.p[widx];
-    const int KB = kb16(l);
-    const long total = wl_elems(l);
-    const int kr = l == 0 ? EMB : (l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W));
-    const long off = off_wl(l);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-      const long blk = i >> 9;                        // nt*KB + kb
-      const int kb = (int)(blk % KB), nt = (int)(blk / KB);
-      const int n = nt * 32 + (lane & 31);
-      const int src = kmap16_lp(l, kb * 16 + 8 * (lane >> 5) + j);
-      wpk[off + i] = (T)(src >= 0 ? Wsrc[(size_t)n * kr + src] : 0.f);
-    }
-  } else {
-    float* tail = reinterpret_cast<float*>(wpk + PACKED_LP_ELEMS);
-    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    for (int i = t0; i < NLAYER_MFMA * 256; i += stride) {
-      const int ll = i >> 8, f = i & 255;
-      const int bidx = ll < 8 ? 2 * ll + 1 : (ll == L_FEAT ? 19 : 17);
-      tail[i] = (ll == L_VIEWS && f >= 128) ? 0.f : a.p[bidx][f];
-    }
-    for (int i = t0; i < 256; i += stride) tail[OFF_WA - OFF_BIAS + i] = a.p[20][i];
-    for (int i = t0; i < 4; i += stride) tail[OFF_BA - OFF_BIAS + i] = i == 0 ? a.p[21][0] : 0.f;
-    for (int i = t0; i < 384; i += stride) tail[OFF_WR - OFF_BIAS + i] = a.p[22][i];
-    for (int i = t0; i < 4; i += stride) tail[OFF_BR - OFF_BIAS + i] = i < 3 ? a.p[23][i] : 0.f;
-    for (int i = t0; i < 2 * 64 * 8; i += stride) wpk[off_wl(NLAYER_MFMA) + i] = (T)0.f;
-    // NaN census of the hidden layers' fp32 parameters (see the forward's alpha head): this block's slice of
-    // every tensor, one 0 / NaN float per block and class; gridDim.x = LP_NAN_BLOCKS.  Straight-line: every
-    // thread issues its ~24 sixteen-byte loads back to back (index clamped instead of predicated - re-reading
-    // an element is harmless for a census) and only then looks at them; as twenty small loops, each waiting for
-    // its own loads, this tripled the pack kernel's time (5 -> 15 us).
-    int bad_trunk = 0, bad_colour = 0;
-    {
-      constexpr int NTHR = LP_NAN_BLOCKS * 256;
-      f32x4 v[24];
-      int n = 0;
-#pragma unroll
-      for (int t = 0; t < 20; ++t) {
-        const int n4 = lp_param_numel(t) / 4;
-        const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.p[t]);
-#pragma unroll
-        for (int k = 0; k < (n4 + NTHR - 1) / NTHR; ++k) v[n++] = src[min(t0 + k * NTHR, n4 - 1)];
-      }
-      n = 0;
-#pragma unroll
-      for (int t = 0; t < 20; ++t) {
-        const int n4 = lp_param_numel(t) / 4;
-#pragma unroll
-        for (int k = 0; k < (n4 + NTHR - 1) / NTHR; ++k) {
-          const f32x4 x = v[n++];
-          const int bad = (x[0] != x[0]) | (x[1] != x[1]) | (x[2] != x[2]) | (x[3] != x[3]);
-          if (t < 16) bad_trunk |= bad; else bad_colour |= bad;
-        }
-      }
-    }
-    bad_trunk = __syncthreads_or(bad_trunk);
-    bad_colour = __syncthreads_or(bad_colour);
-    if (threadIdx.x == 0) {
-      tail[LP_NAN_TRUNK - OFF_BIAS + blockIdx.x] = bad_trunk ? __builtin_nanf("") : 0.f;
-      tail[LP_NAN_COLOUR - OFF_BIAS + blockIdx.x] = bad_colour ? __builtin_nanf("") : 0.f;
-    }
-  }
-}
+__global__ void mlp_pack_lp_kernel(PackLpArgs a) { pack_lp_row<BF>(a.p, a.packed, blockIdx.y, blockIdx.x, gridDim.x); }
 
 }  // namespace scade
 
@@ -445,8 +370,8 @@ extern "C" int scade_mlp_pack_lp(const float* const* params, void* packed, int b
     a.p[i] = params[i];
   }
   a.packed = packed;
-  if (bf16) hipLaunchKernelGGL(mlp_pack_lp_kernel<true>, dim3(LP_NAN_BLOCKS, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(mlp_pack_lp_kernel<false>, dim3(LP_NAN_BLOCKS, NLAYER_MFMA + 1), dim3(256), 0, (hipStream_t)stream, a);
+  if (bf16) hipLaunchKernelGGL(mlp_pack_lp_kernel<true>, dim3(PACK_BLOCKS, PACK_FWD_ROWS), dim3(256), 0, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(mlp_pack_lp_kernel<false>, dim3(PACK_BLOCKS, PACK_FWD_ROWS), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_mlp_pack_lp");
 }
 

@@ -52,7 +52,88 @@ __global__ void adam_step_dev_kernel(float* __restrict__ p, const float* __restr
     p[i] = p[i] - step_size * (mi / denom);
   }
 }
+// Two optimizers in one launch (the networks' Adam and the depth scale / shift Adam of a train step, which differ
+// in learning rate and step count): blocks [0, blocks0) update segment 0, the rest segment 1.  Scalars come
+// from the launch arguments, or - st != null - from the segment's device-resident state (adam_tick2_kernel).
+struct AdamSeg {
+  float* p; const float* g; float* m; float* v;
+  long n;
+  float lr, beta1, beta2, eps, bc1, bc2_sqrt, grad_scale;
+  float* st;
+};
+struct Adam2Args {
+  AdamSeg s[2];
+  int blocks0;
+};
+__global__ void adam_step2_kernel(Adam2Args a) {
+  const bool second = (int)blockIdx.x >= a.blocks0;
+  const AdamSeg& s = second ? a.s[1] : a.s[0];
+  const long b = (long)blockIdx.x - (second ? a.blocks0 : 0);
+  const long nb = second ? (long)gridDim.x - a.blocks0 : a.blocks0;
+  float lr = s.lr, beta1 = s.beta1, beta2 = s.beta2, eps = s.eps, bc1 = s.bc1, bc2_sqrt = s.bc2_sqrt, gs = s.grad_scale;
+  if (s.st) { beta1 = s.st[4]; beta2 = s.st[5]; eps = s.st[6]; gs = s.st[7]; lr = s.st[8]; bc1 = s.st[9]; bc2_sqrt = s.st[10]; }
+  const float step_size = lr / bc1;
+  for (long i = b * 256 + threadIdx.x; i < s.n; i += nb * 256) {
+    const float gi = s.g[i] * gs;
+    const float mi = s.m[i] * beta1 + gi * (1.0f - beta1);
+    const float vi = s.v[i] * beta2 + (gi * gi) * (1.0f - beta2);
+    s.m[i] = mi;
+    s.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    s.p[i] = s.p[i] - step_size * (mi / denom);
+  }
+}
+__device__ __forceinline__ void adam_tick(float* st) {
+  const float t = st[0] + 1.0f;
+  st[0] = t;
+  const double it = (double)t + (double)st[11];
+  const double k = st[3] > 0.f ? floor(it / (double)st[3]) : 0.0;
+  st[8] = (float)((double)st[1] * pow((double)st[2], k));
+  st[9] = (float)(1.0 - pow((double)st[4], (double)t));
+  st[10] = (float)sqrt(1.0 - pow((double)st[5], (double)t));
+}
+__global__ void adam_tick2_kernel(float* st0, float* st1) {
+  if (threadIdx.x == 0 && st0) adam_tick(st0);
+  if (threadIdx.x == 64 && st1) adam_tick(st1);
+}
 }  // namespace scade
+
+static int adam_blocks(long n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
+
+// Both optimizers of a train step in ONE launch.  Arrays of two entries; n[1] = 0 skips the second segment
+// (scale / shift frozen, run_scade_scannet.py:996).  state[i] != NULL: that segment's scalars live on the device
+// (scade_adam_step_dev's layout) and are advanced by one tick launch for both before the update.
+extern "C" int scade_adam_step2(float* const* params, const float* const* grads, float* const* exp_avg,
+                                float* const* exp_avg_sq, const long* n, const float* lr, const float* beta1,
+                                const float* beta2, const float* eps, const int* step, const float* grad_scale,
+                                float* const* state, void* stream) {
+  SCADE_REQUIRE(params && grads && exp_avg && exp_avg_sq && n, -1, "scade_adam_step2: null pointer");
+  scade::Adam2Args a{};
+  bool any_state = false;
+  for (int i = 0; i < 2; ++i) {
+    scade::AdamSeg& s = a.s[i];
+    s.n = n[i];
+    if (n[i] <= 0) { s.n = 0; continue; }
+    SCADE_REQUIRE(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i], -1, "scade_adam_step2: null pointer in segment %d", i);
+    s.p = params[i]; s.g = grads[i]; s.m = exp_avg[i]; s.v = exp_avg_sq[i];
+    s.st = state ? state[i] : nullptr;
+    if (s.st) { any_state = true; continue; }
+    SCADE_REQUIRE(lr && beta1 && beta2 && eps && step && grad_scale, -1, "scade_adam_step2: host scalars missing");
+    SCADE_REQUIRE(step[i] >= 1, -2, "scade_adam_step2: step counts from 1");
+    s.lr = lr[i]; s.beta1 = beta1[i]; s.beta2 = beta2[i]; s.eps = eps[i]; s.grad_scale = grad_scale[i];
+    s.bc1 = (float)(1.0 - pow((double)beta1[i], step[i]));
+    s.bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2[i], step[i]));
+  }
+  if (a.s[0].n <= 0 && a.s[1].n <= 0) return 0;
+  hipStream_t st = (hipStream_t)stream;
+  if (any_state)
+    hipLaunchKernelGGL(scade::adam_tick2_kernel, dim3(1), dim3(128), 0, st, a.s[0].n > 0 ? a.s[0].st : nullptr,
+                       a.s[1].n > 0 ? a.s[1].st : nullptr);
+  a.blocks0 = a.s[0].n > 0 ? adam_blocks(a.s[0].n) : 0;
+  const int blocks1 = a.s[1].n > 0 ? adam_blocks(a.s[1].n) : 0;
+  hipLaunchKernelGGL(scade::adam_step2_kernel, dim3(a.blocks0 + blocks1), dim3(256), 0, st, a);
+  return scade_check_launch("scade_adam_step2");
+}
 
 extern "C" int scade_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq,
                                    long n, float* state, void* stream) {

@@ -15,6 +15,7 @@ import torch
 import torch.distributed as dist
 
 from . import ops
+from .optim import adam_step_pair
 
 
 class GraphedTrainer:
@@ -64,9 +65,7 @@ class GraphedTrainer:
         tr.backward(loss)
         tr.bucket.end_backward()
         tr.reduce_grads()
-        tr.opt.step_dev()
-        if tr.scaleshift_active():
-            tr.opt_ss.step_dev()
+        adam_step_pair(tr.opt, tr.opt_ss if tr.scaleshift_active() else None, dev=True)
         return aux["loss_report"]
 
     def _state(self):

@@ -137,6 +137,41 @@ def mlp_pack_t(params: Sequence[Tensor], out: Optional[Tensor] = None) -> Tensor
     return out
 
 
+def mlp_pack_step(nets, fmt: str) -> None:
+    """Bring the training weight packs of one or two NeRFs up to date with ONE launch (scade_mlp_pack_step): the
+    forward and the transposed layout of each network whose cached blobs are stale.  ``fmt``: "f32" (the exact
+    kernels' packs), "bf16" or "f16" (the 16-bit kernels' packs).  The blobs land in the networks' own caches
+    (NeRF.packed / packed_t / packed_lp / packed_t_lp return them without packing again)."""
+    lib = _lib.load()
+    code = {"f32": 0, "bf16": 1, "f16": 2}[fmt]
+    plist, fwd, tr, adopt = [], [], [], []
+    for net in nets:
+        ps = net.ordered_params()
+        dev = ps[0].device
+        key = net.pack_key()
+        need_f, need_t = net.pack_stale(fmt, False, key), net.pack_stale(fmt, True, key)
+        if not (need_f or need_t):
+            continue
+        keep = [_c(check(p, "mlp_pack_step").detach()) for p in ps]
+        if code == 0:
+            bf = torch.empty(int(lib.scade_mlp_packed_floats()), device=dev, dtype=torch.float32) if need_f else None
+            bt = torch.empty(int(lib.scade_mlp_packed_t_floats()), device=dev, dtype=torch.float32) if need_t else None
+        else:
+            bf = torch.empty(int(lib.scade_mlp_packed_lp_bytes()), device=dev, dtype=torch.uint8) if need_f else None
+            bt = torch.empty(int(lib.scade_mlp_packed_t_lp_bytes()), device=dev, dtype=torch.uint8) if need_t else None
+        plist += keep
+        fwd.append(bf)
+        tr.append(bt)
+        adopt.append((net, bf, bt, key))
+    if not adopt:
+        return
+    vp = lambda ts: ctypes.cast((ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts]),
+                                ctypes.c_void_p)
+    call("scade_mlp_pack_step", len(adopt), vp(plist), code, vp(fwd), vp(tr), stream())
+    for net, bf, bt, key in adopt:
+        net.adopt_packs(fmt, bf, bt, key)
+
+
 def mlp_acts_alloc(P: int, device) -> Tensor:
     return torch.empty(int(_lib.load().scade_mlp_acts_floats(P)), device=device, dtype=torch.float32)
 

@@ -2,6 +2,8 @@
 train loop (run_scade_scannet.py:469, :888, :993-997) as one kernel launch."""
 from __future__ import annotations
 
+from typing import Optional
+
 import torch
 
 from . import ops
@@ -47,3 +49,31 @@ class FusedAdam:
 
     def zero_grad(self):
         self.flat.zero_grad()
+
+
+def adam_step_pair(a: FusedAdam, b: Optional[FusedAdam], lr_a=None, dev: bool = False):
+    """``a.step(lr=lr_a)`` and (``b`` given) ``b.step()`` as ONE update launch (scade_adam_step2); ``dev``: both
+    optimizers read their scalars from their device state (``use_device_state``; graph-captured steps)."""
+    import ctypes
+    opts = [a] + ([b] if b is not None else [])
+    for o in opts:
+        o.steps += 1
+    two = lambda f, ct: (ct * 2)(*[f(o) for o in opts] + ([ct()] if len(opts) == 1 else []))
+    P = ctypes.c_void_p
+    pp = lambda f: ctypes.cast(two(lambda o: f(o).data_ptr(), ctypes.c_void_p), P)
+    n = two(lambda o: o.flat.numel, ctypes.c_long)
+    if dev:
+        st = pp(lambda o: o.state)
+        call("scade_adam_step2", pp(lambda o: o.flat.data), pp(lambda o: o.flat.grad), pp(lambda o: o.exp_avg),
+             pp(lambda o: o.exp_avg_sq), ctypes.cast(n, P), None, None, None, None, None, None, st, stream())
+    else:
+        lrs = two(lambda o: float(lr_a if (o is a and lr_a is not None) else o.lr), ctypes.c_float)
+        b1 = two(lambda o: float(o.betas[0]), ctypes.c_float)
+        b2 = two(lambda o: float(o.betas[1]), ctypes.c_float)
+        eps = two(lambda o: float(o.eps), ctypes.c_float)
+        stp = two(lambda o: int(o.steps), ctypes.c_int)
+        gs = two(lambda o: 1.0, ctypes.c_float)
+        call("scade_adam_step2", pp(lambda o: o.flat.data), pp(lambda o: o.flat.grad), pp(lambda o: o.exp_avg),
+             pp(lambda o: o.exp_avg_sq), ctypes.cast(n, P), ctypes.cast(lrs, P), ctypes.cast(b1, P),
+             ctypes.cast(b2, P), ctypes.cast(eps, P), ctypes.cast(stp, P), ctypes.cast(gs, P), None, stream())
+    ops.PARAM_EPOCH += 1

@@ -236,6 +236,36 @@ class NeRF(nn.Module):
             self._packed_t_lp_key = key
         return self._packed_t_lp
 
+    # -- the Trainer's one-launch pack of both networks (ops.mlp_pack_step) ------------------------------
+    def pack_key(self):
+        return (ops.PARAM_EPOCH,) + tuple((p.data_ptr(), p._version) for p in self.ordered_params())
+
+    def pack_stale(self, fmt, transposed, key=None):
+        """Is the cached training pack of this format stale? (fmt: "f32" | "bf16" | "f16")"""
+        key = self.pack_key() if key is None else key
+        dev = self.ordered_params()[0].device
+        if fmt == "f32":
+            blob, k = (getattr(self, "_packed_t", None), getattr(self, "_packed_t_key", None)) if transposed \
+                else (self._packed, self._packed_key)
+            return blob is None or k != key or blob.device != dev
+        blob, k = (getattr(self, "_packed_t_lp", None), getattr(self, "_packed_t_lp_key", None)) if transposed \
+            else (getattr(self, "_packed_lp", None), getattr(self, "_packed_lp_key", None))
+        return blob is None or k != (fmt == "bf16",) + key or blob.device != dev
+
+    def adopt_packs(self, fmt, fwd, transposed, key):
+        """Take over blobs ops.mlp_pack_step wrote for the parameter state ``key`` describes."""
+        if fmt == "f32":
+            if fwd is not None:
+                self._packed, self._packed_key = fwd, key
+            if transposed is not None:
+                self._packed_t, self._packed_t_key = transposed, key
+        else:
+            k = (fmt == "bf16",) + key
+            if fwd is not None:
+                self._packed_lp, self._packed_lp_key = fwd, k
+            if transposed is not None:
+                self._packed_t_lp, self._packed_t_lp_key = transposed, k
+
     def warm_packs(self):
         """Bring the weight pack of the current inference precision up to date on the CURRENT stream
         (callers that fan work out over several streams do this before forking)."""

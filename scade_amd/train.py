@@ -21,7 +21,7 @@ import torch.distributed as dist
 from . import ops
 from . import rendering as R
 from . import run_nerf_helpers as H
-from .optim import FusedAdam
+from .optim import FusedAdam, adam_step_pair
 from .parallel import FlatParams, batch_share, shared_uniform, staircase_lr
 
 
@@ -105,6 +105,7 @@ class Trainer:
         # the step's uniform draws inside scade_ray_points_draw (SCADE_DRAW_IN_KERNEL=0: one torch.rand launch).
         # The Philox key comes from torch's seed of this process (parallel.seed_rank_streams gives every rank its
         # own), the counter from the step index: reproducible under torch.manual_seed like the torch.rand path.
+        self.joint_pack = os.environ.get("SCADE_JOINT_PACK", "1") != "0"
         self.draw_in_kernel = os.environ.get("SCADE_DRAW_IN_KERNEL", "1") != "0"
         self.draw_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5CADE) & (2 ** 64 - 1)
         self.draw_step_dev = None           # GraphedTrainer: the fused optimizer's device-resident step count
@@ -130,6 +131,12 @@ class Trainer:
         is weighted by n_local / N_total (``n_total`` = rays of all ranks; None = equal shards), so the
         sum over ranks is the single-process loss and the sum-all-reduced gradient its gradient."""
         c = self.cfg
+        # the MFMA weight blobs of both networks (forward + transposed layout), rebuilt after the last
+        # optimizer step by ONE launch instead of four
+        prec = self.coarse.train_precision
+        if self.joint_pack and prec in ("f32", "bf16", "f16") and self.fine.train_precision == prec \
+                and torch.is_grad_enabled():
+            ops.mlp_pack_step([self.coarse, self.fine], prec)
         share = batch_share(rays.shape[0], n_total) if self.sharded else 1.0
         if c["joint"] and self.sharded:
             # the LAST sampler (sample_pdf_joint_return_u, :728) draws ONE u[S] for the whole batch
@@ -231,8 +238,7 @@ class Trainer:
         self.bucket.end_backward()
         self.reduce_grads()
         lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it + 1)  # :988-991
-        self.opt.step(lr=lr)                                                                  # :993
-        if self.scaleshift_active():                                                          # :996-997
-            self.opt_ss.step()
+        # optimizer.step() (:993) and, while i < freeze_ss, optimizer_ss.step() (:996-997): one launch
+        adam_step_pair(self.opt, self.opt_ss if self.scaleshift_active() else None, lr_a=lr)
         self.it += 1
         return aux["loss_report"], aux

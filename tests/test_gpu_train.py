@@ -725,3 +725,39 @@ def test_joint_backward_of_both_networks_equals_the_separate_launches(dev, prec,
         (rel_l2(gj[:n], gs[:n]), rel_l2(gj[n:2 * n], gs[n:2 * n]))
     assert torch.equal(gj[2 * n:], gs[2 * n:])          # scale / shift rows: untouched by the change
     assert float(gs[:n].abs().max()) > 0 and float(gs[n:2 * n].abs().max()) > 0
+
+
+@pytest.mark.parametrize("fmt", ["f32", "bf16", "f16"])
+def test_one_launch_pack_of_both_networks_writes_the_same_blobs(dev, fmt):
+    """ops.mlp_pack_step (scade_mlp_pack_step: forward + transposed layouts of the coarse and the fine NeRF in
+    ONE launch) against the four stand-alone pack entries: byte-identical blobs, adopted by the networks' caches
+    (no second pack), re-done only for what went stale."""
+    from scade_amd import ops
+    from scade_amd.train import make_scade_nets
+    coarse, fine = make_scade_nets(dev, seed=21)
+    bf = fmt == "bf16"
+    want = []
+    for net in (coarse, fine):
+        ps = net.ordered_params()
+        want.append((ops.mlp_pack(ps), ops.mlp_pack_t(ps)) if fmt == "f32" else
+                    (ops.mlp_pack_lp(ps, bf), ops.mlp_pack_t_lp(ps, bf)))
+    ops.mlp_pack_step([coarse, fine], fmt)
+    torch.cuda.synchronize()
+    for net, (wf, wt) in zip((coarse, fine), want):
+        got_f, got_t = (net._packed, net._packed_t) if fmt == "f32" else (net._packed_lp, net._packed_t_lp)
+        assert torch.equal(got_f.view(torch.uint8), wf.view(torch.uint8)), "forward layout differs"
+        assert torch.equal(got_t.view(torch.uint8), wt.view(torch.uint8)), "transposed layout differs"
+        # the caches are current: the accessors hand the adopted blobs back
+        acc_f, acc_t = (net.packed(), net.packed_t()) if fmt == "f32" else (net.packed_lp(bf), net.packed_t_lp(bf))
+        assert acc_f.data_ptr() == got_f.data_ptr() and acc_t.data_ptr() == got_t.data_ptr()
+    # nothing stale -> nothing launched (same blobs); one network touched -> only that one repacked
+    keep = coarse._packed if fmt == "f32" else coarse._packed_lp
+    ops.mlp_pack_step([coarse, fine], fmt)
+    assert (coarse._packed if fmt == "f32" else coarse._packed_lp) is keep
+    with torch.no_grad():
+        fine.pts_linears[2].weight.mul_(1.5)
+    ops.mlp_pack_step([coarse, fine], fmt)
+    assert (coarse._packed if fmt == "f32" else coarse._packed_lp) is keep
+    ps = fine.ordered_params()
+    ref = ops.mlp_pack(ps) if fmt == "f32" else ops.mlp_pack_lp(ps, bf)
+    assert torch.equal((fine._packed if fmt == "f32" else fine._packed_lp).view(torch.uint8), ref.view(torch.uint8))
