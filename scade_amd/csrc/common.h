@@ -44,6 +44,64 @@ __device__ __forceinline__ T wave_sum(T v) {
   return v;
 }
 
+// ---- fp64 wave scans / reductions on DPP ----------------------------------------------------------------
+// The per-ray kernels scan and reduce in fp64 (ATen's CPU cumsum / cumprod accumulate in double and round each
+// prefix).  As __shfl_up(double) every step of a scan was two ds_bpermute_b32 through the LDS crossbar plus
+// their ~100-cycle round trip in a six-step dependent chain; on the data-parallel-primitive path a step is two
+// v_mov_b32 with a DPP modifier (row_shr inside the rows of 16 lanes, row_bcast:15 / :31 across them - the
+// classic GCN scan) and the f64 operation, no LDS traffic and a handful of cycles of latency.
+// dpp_ctrl encodings (gfx9): row_shl:n 0x100+n, row_shr:n 0x110+n, wave_shl:1 0x130, wave_shr:1 0x138,
+// row_bcast:15 0x142, row_bcast:31 0x143.  With bound_ctrl = false a lane whose source lies outside its row
+// (or whose row is masked off) keeps `old` - the identity of the operation.
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ double dpp_mov_d(double old, double src) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(src), CTRL, ROW_MASK, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(src), CTRL, ROW_MASK, 0xF, false);
+  return __hiloint2double(hi, lo);
+}
+// value of one lane in every lane, through two SGPRs (wave-uniform)
+template <int LANE>
+__device__ __forceinline__ double wave_lane_d(double v) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), LANE);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), LANE);
+  return __hiloint2double(hi, lo);
+}
+struct DppSum {
+  static constexpr double identity() { return 0.0; }
+  static __device__ __forceinline__ double op(double lower, double v) { return lower + v; }
+};
+struct DppProd {
+  static constexpr double identity() { return 1.0; }
+  static __device__ __forceinline__ double op(double lower, double v) { return lower * v; }
+};
+// inclusive scan, lane 0 first
+template <typename OP>
+__device__ __forceinline__ double wave_incl_scan_d(double v) {
+  constexpr double e = OP::identity();
+  v = OP::op(dpp_mov_d<0x111>(e, v), v);
+  v = OP::op(dpp_mov_d<0x112>(e, v), v);
+  v = OP::op(dpp_mov_d<0x114>(e, v), v);
+  v = OP::op(dpp_mov_d<0x118>(e, v), v);              // every row of 16 scanned
+  v = OP::op(dpp_mov_d<0x142, 0xA>(e, v), v);         // rows 1, 3 += last lane of rows 0, 2
+  v = OP::op(dpp_mov_d<0x143, 0xC>(e, v), v);         // rows 2, 3 += lane 31
+  return v;
+}
+// the wave shifted up by one lane (lane i gets lane i-1; lane 0 gets `first`)
+__device__ __forceinline__ double wave_shr1_d(double v, double first) { return dpp_mov_d<0x138>(first, v); }
+// inclusive SUFFIX sum (lane 63 first): rows scanned with row_shl, the row totals joined through SGPRs
+__device__ __forceinline__ double wave_incl_sum_rev_d(double v) {
+  v = v + dpp_mov_d<0x101>(0.0, v);
+  v = v + dpp_mov_d<0x102>(0.0, v);
+  v = v + dpp_mov_d<0x104>(0.0, v);
+  v = v + dpp_mov_d<0x108>(0.0, v);                   // lane 16 r = sum of row r
+  const double r1 = wave_lane_d<16>(v), r2 = wave_lane_d<32>(v), r3 = wave_lane_d<48>(v);
+  const int row = lane_id() >> 4;
+  const double above = row == 0 ? r1 + (r2 + r3) : (row == 1 ? r2 + r3 : (row == 2 ? r3 : 0.0));
+  return v + above;
+}
+// sum over the wave, in every lane (wave-uniform)
+__device__ __forceinline__ double wave_sum_dpp_d(double v) { return wave_lane_d<63>(wave_incl_scan_d<DppSum>(v)); }
+
 // inclusive scan over the 64 lanes of a wave with a binary op
 template <typename T, typename Op>
 __device__ __forceinline__ T wave_scan_incl(T v, Op op) {

@@ -121,6 +121,8 @@ __device__ __forceinline__ void pack_lp_row(const float* const* p, void* packed,
     for (int i = t0; i < 384; i += stride) tail[OFF_WR - OFF_BIAS + i] = p[22][i];
     for (int i = t0; i < 4; i += stride) tail[OFF_BR - OFF_BIAS + i] = i < 3 ? p[23][i] : 0.f;
     for (int i = t0; i < 2 * 64 * 8; i += stride) wpk[off_wl(NLAYER_MFMA) + i] = (T)0.f;
+    // (the rest of the tail's slack behind the census slots: every byte of the blob is defined)
+    for (int i = LP_NAN_COLOUR + LP_NAN_BLOCKS - OFF_BIAS + t0; i < (int)F16_TAIL_FLOATS; i += stride) tail[i] = 0.f;
     // NaN census of the hidden layers' fp32 parameters (see the forward's alpha head): this block's slice of
     // every tensor, one 0 / NaN float per block and class; gridDim.x = LP_NAN_BLOCKS.  Straight-line: every
     // thread issues its ~24 sixteen-byte loads back to back (index clamped instead of predicated - re-reading

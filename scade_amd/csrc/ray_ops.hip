@@ -20,42 +20,13 @@ namespace scade {
 
 constexpr int RAYS_PER_WG = 4;
 
-__device__ __forceinline__ double shfl_up_d(double v, int o) { return __shfl_up(v, o, 64); }
-
-__device__ __forceinline__ double wave_incl_prod(double v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double n = __shfl_up(v, o, 64);
-    if (l >= o) v = n * v;
-  }
-  return v;
-}
-__device__ __forceinline__ double wave_incl_sum(double v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double n = __shfl_up(v, o, 64);
-    if (l >= o) v = n + v;
-  }
-  return v;
-}
+// fp64 scans / reductions of a ray's samples: the DPP primitives of common.h (round 3; until then
+// __shfl_up(double) = two ds_bpermute per step)
+__device__ __forceinline__ double wave_incl_prod(double v) { return wave_incl_scan_d<DppProd>(v); }
+__device__ __forceinline__ double wave_incl_sum(double v) { return wave_incl_scan_d<DppSum>(v); }
 // suffix (inclusive, from the top lane down) sum
-__device__ __forceinline__ double wave_incl_sum_rev(double v) {
-  const int l = lane_id();
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    double n = __shfl_down(v, o, 64);
-    if (l + o < 64) v = n + v;
-  }
-  return v;
-}
-__device__ __forceinline__ double wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
-__device__ __forceinline__ double bcast_d(double v, int srclane) { return __shfl(v, srclane, 64); }
+__device__ __forceinline__ double wave_incl_sum_rev(double v) { return wave_incl_sum_rev_d(v); }
+__device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_dpp_d(v); }
 
 // ---------------------------------------------------------------------------
 // ray_points: z_vals (+ stratified jitter) and sample positions
@@ -219,10 +190,9 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, int ray, i
       s.sb = 1.0f / (1.0f + expf(-rv[2]));
     }
     const double incl = wave_incl_prod(xd);
-    double excl = shfl_up_d(incl, 1);
-    if (lane == 0) excl = 1.0;
+    const double excl = wave_shr1_d(incl, 1.0);
     s.T = (float)(carry * excl);
-    carry = carry * bcast_d(incl, 63);
+    carry = carry * wave_lane_d<63>(incl);
     s.w = valid ? s.alpha * s.T : 0.f;
     if (valid) {
       s_r += (double)(s.w * s.sr);
@@ -303,7 +273,7 @@ __device__ __forceinline__ void composite_bwd_ray(const CompositeArgs& a, int ra
     const double gw = valid ? (double)G * (double)s.w : 0.0;
     const double incl = wave_incl_sum_rev(gw);
     const double after = carry + (incl - gw);                          // sum over k > i
-    carry += bcast_d(incl, 0);
+    carry += wave_lane_d<0>(incl);
     if (valid) {
       const float x = (1.0f - s.alpha) + 1e-10f;
       const float galpha = G * s.T - (float)(after / (double)x);
@@ -372,7 +342,7 @@ __device__ __forceinline__ float build_cdf_rows(const float* br, int mids, const
       if (pdf && j < M - 1) pdf[j] = p;
       const double incl = wave_incl_sum((double)p);
       if (j < M - 1) cdf[j + 1] = (float)(carry + incl);                      // helpers:342 cumsum
-      carry += bcast_d(incl, 63);
+      carry += wave_lane_d<63>(incl);
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -480,7 +450,7 @@ __device__ __forceinline__ void sample_pdf_bwd_rows(float* cdf, const float* bin
     const double v = (i < M - 1) ? (double)dcdf[i + 1] : 0.0;
     const double incl = wave_incl_sum_rev(v);
     const double dp = carry + incl;            // sum_{j >= i+1} dcdf_j
-    carry += bcast_d(incl, 0);
+    carry += wave_lane_d<0>(incl);
     if (i < M - 1) {
       cdf[i] = (float)dp;
       dot += dp * (double)pdf[i];

@@ -40,11 +40,7 @@ struct TrainLossArgs {
   int img_i, N, P, K, mse_masked, carve_on;
 };
 
-__device__ __forceinline__ double tl_wave_sum_d(double v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
-}
+__device__ __forceinline__ double tl_wave_sum_d(double v) { return wave_sum_dpp_d(v); }
 __device__ __forceinline__ float tl_bcast(float v, int src) {
   return __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(v), src));
 }
