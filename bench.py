@@ -214,7 +214,8 @@ def fast_region(args, dev, world, barrier, step, coarse, fine, precision="f16x3"
 
 
 TRAIN_PEAKS = {"f32": (FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA"), "f16x3": (F16X3_EFFECTIVE_PEAK_TFLOPS, "f16 MFMA / 3"),
-               "bf16": (LP_MFMA_PEAK_TFLOPS, "bf16 MFMA"), "f16": (LP_MFMA_PEAK_TFLOPS, "f16 MFMA")}
+               "bf16": (LP_MFMA_PEAK_TFLOPS, "bf16 MFMA"), "f16": (LP_MFMA_PEAK_TFLOPS, "f16 MFMA"),
+               "bf16-s8": (LP_MFMA_PEAK_TFLOPS, "bf16 MFMA; rows saved for the weight gradient as 8-bit e5m2")}
 
 
 def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=None, allreduce="single",
@@ -647,6 +648,8 @@ def main():
             guarded("train_step_f16x3", train_region, *tr_args, precision="f16x3")
             # mixed precision (BASELINE config 5's bf16 MFMA path): 16-bit forward, dgrad and wgrad
             guarded("train_step_bf16", train_region, *tr_args, precision="bf16")
+            # the same with the saved rows (activations, dZ) as 8-bit e5m2: half the HBM bytes of that step
+            guarded("train_step_bf16_s8", train_region, *tr_args, precision="bf16-s8")
             if use_dist:
                 guarded("train_step_bf16_overlap", train_region, *tr_args, precision="bf16", allreduce="overlap")
     if not args.no_train:
@@ -663,7 +666,9 @@ def main():
             if world == 1:
                 guarded("train_step_graph", lambda: [graph_region(args, dev, 128, "f32"),
                                                      graph_region(args, dev, 128, "bf16"),
-                                                     graph_region(args, dev, args.rays, "bf16")])
+                                                     graph_region(args, dev, args.rays, "bf16"),
+                                                     graph_region(args, dev, 128, "bf16-s8"),
+                                                     graph_region(args, dev, args.rays, "bf16-s8")])
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         state["region"] = "cpu_baseline"
         out["cpu_baseline"] = cpu_baseline(pc, pf, 1024, args.hyp)
@@ -680,13 +685,12 @@ def main():
     state["done"] = True
     emit()
     if use_dist:
-        # Every rank has passed the final barrier and the line is out.  The process group is NOT torn down:
-        # RCCL's teardown of a group whose collectives were captured in HIP graphs has been seen to abort()
-        # (once in ~60 runs), which no Python handler can catch and which would turn a measured run into a
-        # non-zero exit status.  The operating system reclaims everything at exit.
+        # (round 2 skipped the teardown here with os._exit: a process whose collectives had been graph-captured was
+        # seen to abort about once in sixty runs.  The cause was the process group's watchdog thread polling an
+        # event during a GLOBAL-mode stream capture - scade_amd/graphs.py _capture_mode - not the teardown.)
         sys.stdout.flush()
         sys.stderr.flush()
-        os._exit(0)
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -145,7 +145,9 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][NPT], int 
 
 constexpr int dgrad_lp_lds_bytes(int NPT) { return 32 * NPT * W * 2 + 2 * 32 * NPT * 4; }
 
-template <bool BF, int NPT>
+// S8: format code 2 - the saved rows (activations read, dZ written) are 8-bit e5m2 (mlp_tile_lp.h); the dZ rows
+// then carry the launch-wide loss scale like the fp16 path's (e5m2 has fp16's exponent range)
+template <bool BF, int NPT, bool S8 = false>
 __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa) {
   constexpr int LM = 32 * NPT, LPT = NPT, LXPLANE = LM * W;   // this workgroup's tile (shadow the 128-point default)
   const bool second = (int)blockIdx.x >= aa.tiles0;                 // wave-uniform: scalar selects
@@ -173,7 +175,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   const u32x4* __restrict__ masks = reinterpret_cast<const u32x4*>(a.acts + lp_acts_mask_byte(P));
   // bf16 carries fp32's exponent range: the launch-wide loss scale (and the two launches that find it) is an
   // fp16 matter; a power-of-two scale commutes with every rounding here, so S = 1 gives the same bits
-  const float S = BF ? 1.f : lp_loss_scale(a.gmax[0]);
+  const float S = (BF && !S8) ? 1.f : lp_loss_scale(a.gmax[0]);
+  unsigned char* __restrict__ dz8 = a.dz;
+  const unsigned char* __restrict__ acts8 = a.acts;
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
 #pragma unroll
@@ -219,17 +223,34 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
       V4 mk;
 #pragma unroll
       for (int j = 0; j < 4; ++j) mk[j] = (T)0.f;
-      if (ok) mk = *reinterpret_cast<const V4*>(hv + (size_t)pt * W + chunk * 4);
+      if (S8) {      // 8-bit rows: a positive e5m2 byte <-> a positive activation (sign bit clear, not zero)
+        unsigned mb8 = 0u;
+        if (ok) mb8 = *reinterpret_cast<const unsigned*>(acts8 + acts_slot_off(P, SLOT_VIEWS_H) * 2 + (size_t)pt * W + chunk * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const unsigned b = (mb8 >> (8 * j)) & 0xFFu;
+          mk[j] = (T)((b != 0u && b < 0x80u) ? 1.f : 0.f);
+        }
+      } else if (ok) {
+        mk = *reinterpret_cast<const V4*>(hv + (size_t)pt * W + chunk * 4);
+      }
       V4 vs, vS;
+      float vf[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float d = go[0] * w0[j] + go[1] * w1[j] + go[2] * w2[j];
         const float v = (float)mk[j] > 0.f ? d : 0.f;
         vs[j] = (T)(v * s);
         vS[j] = (T)(v * S);
+        vf[j] = v * S;
       }
       *reinterpret_cast<V4*>(g + x_idx(row, chunk >> 1) + (chunk & 1) * 4) = vs;
-      if (ok) *reinterpret_cast<V4*>(dzv + (size_t)pt * W + chunk * 4) = vS;
+      if (S8) {
+        if (ok) *reinterpret_cast<unsigned*>(dz8 + acts_slot_off(P, SLOT_VIEWS_H) * 2 + (size_t)pt * W + chunk * 4) =
+            lp_pack4_bf8(vf[0], vf[1], vf[2], vf[3]);
+      } else if (ok) {
+        *reinterpret_cast<V4*>(dzv + (size_t)pt * W + chunk * 4) = vS;
+      }
     }
   }
   __syncthreads();
@@ -256,7 +277,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), 3, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
-  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  if (S8) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, fac, 64 * wave, lane);
+  else save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   __syncthreads();
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
@@ -264,7 +286,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), 3, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
-  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  if (S8) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, 7) * 2, p0, P, fac, 64 * wave, lane);
+  else save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   __syncthreads();
 
 #define DGRAD_LAYER_L(L)                                                                            \
@@ -273,7 +296,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
                                                     g, g, lane, nullptr);                           \
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
-  save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
+  if (S8) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, (L)-1) * 2, p0, P, fac, 64 * wave, lane);      \
+  else save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
   __syncthreads();
 
   DGRAD_LAYER_L(7)
@@ -521,10 +545,180 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpNet& a, const WgradLpJ
   }
 }
 
+// ---- format code 2: the same job on 8-bit (e5m2) dZ / activation rows (mlp_tile_lp.h).  Only the staging
+// differs: a thread owns 16 columns of ONE row of the 32-point stage (one 16-byte load = 16 values per operand),
+// converts them to bf16 on the way into the same LDS tiles, and the MFMA part is wgrad_lp_job's.  The embedding
+// rows (KW = 64 jobs' input) stay 16-bit.
+struct WStage8 {
+  lp_u32x4 a, b;       // 16 e5m2 values of the dZ row / the input row
+  __bf16 __attribute__((ext_vector_type(8))) e;   // KW = 64: 8 embedding columns (16-bit rows)
+  float d;             // d alpha_pre of the row (WF_ALPHA job)
+};
+
+template <int KW>
+__device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLpJob& jb, __bf16* lds,
+                                              int c0, int c1, float invS, float* __restrict__ out) {
+  constexpr bool BF = true;
+  typedef __bf16 T;
+  typedef typename LP<BF>::V8 V8;
+  constexpr int NKT = KW == 256 ? 4 : 1;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int n0 = (wave >> 1) * 64;
+  const int k0 = (wave & 1) * (KW / 2);
+  const bool active = n0 < jb.n_rows;
+  const int P = a.P;
+  const unsigned char* __restrict__ dzm = a.dz + jb.dz_off * 2;       // 8-bit rows: first half of the slot region
+  const unsigned char* __restrict__ inm8 = a.acts + jb.in_off * 2;
+  const T* __restrict__ inm16 = reinterpret_cast<const T*>(a.acts) + jb.in_off;   // embedding rows
+  const float* __restrict__ dalp = reinterpret_cast<const float*>(a.dz + lp_dz_dalpha_byte(P));
+  const int cc = tid & 15, rr = tid >> 4;      // 16-column chunk cc of row rr of the stage
+  const V8 zero8 = __builtin_bit_cast(V8, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
+
+  f32x16 acc[2][NKT];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int u = 0; u < NKT; ++u)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
+  float bias_acc[16], alpha_acc[16], dal_acc = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { bias_acc[j] = 0.f; alpha_acc[j] = 0.f; }
+
+  const bool want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
+  auto issue = [&](WStage8& s, int pt0) {       // unconditional loads (see wgrad_lp_job)
+    const int pa = min(pt0 + rr, P - 1);
+    s.a = __builtin_nontemporal_load(reinterpret_cast<const lp_u32x4*>(dzm + (size_t)pa * 256 + 16 * cc));
+    if (KW == 256) {
+      s.b = __builtin_nontemporal_load(reinterpret_cast<const lp_u32x4*>(inm8 + (size_t)pa * 256 + 16 * cc));
+      s.d = dalp[want_alpha ? pa : 0];
+    } else {
+      const int pe = min(pt0 + ((tid >> 3) & 31), P - 1);
+      s.e = *reinterpret_cast<const V8*>(inm16 + (size_t)pe * 64 + 8 * (tid & 7));
+    }
+  };
+  auto widen = [&](const lp_u32x4& w, V8& lo, V8& hi) {
+    const lp_u32x2 p0 = lp_unpack4_bf8<true>(w[0]), p1 = lp_unpack4_bf8<true>(w[1]);
+    const lp_u32x2 p2 = lp_unpack4_bf8<true>(w[2]), p3 = lp_unpack4_bf8<true>(w[3]);
+    lo = __builtin_bit_cast(V8, lp_u32x4{p0[0], p0[1], p1[0], p1[1]});
+    hi = __builtin_bit_cast(V8, lp_u32x4{p2[0], p2[1], p3[0], p3[1]});
+  };
+  auto commit = [&](const WStage8& s, int pt0, int buf) {
+    T* st = lds + buf * WL_STAGE;
+    const bool va = pt0 + rr < c1;
+    V8 a0 = zero8, a1 = zero8, b0 = zero8, b1 = zero8;
+    if (va) widen(s.a, a0, a1);
+    *reinterpret_cast<V8*>(st + rr * WL_PITCH + 16 * cc) = a0;
+    *reinterpret_cast<V8*>(st + rr * WL_PITCH + 16 * cc + 8) = a1;
+    if (KW == 256) {
+      if (va) widen(s.b, b0, b1);
+      *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 16 * cc) = b0;
+      *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 16 * cc + 8) = b1;
+    } else if (tid < 256) {
+      const V8 e = pt0 + (tid >> 3) < c1 ? s.e : zero8;
+      *reinterpret_cast<V8*>(st + WL_TILE + (tid >> 3) * WL_PITCH + 8 * (tid & 7)) = e;
+    }
+    if (jb.flags & WF_BIAS) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { bias_acc[j] += (float)a0[j]; bias_acc[8 + j] += (float)a1[j]; }
+    }
+    if (want_alpha) {
+      const float d = va ? s.d : 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        alpha_acc[j] = fmaf(d, (float)b0[j], alpha_acc[j]);
+        alpha_acc[8 + j] = fmaf(d, (float)b1[j], alpha_acc[8 + j]);
+      }
+      if (cc == 0) dal_acc += d;
+    }
+  };
+  auto compute = [&](int buf) {
+    if (!active) return;
+    const T* st = lds + buf * WL_STAGE;
+#pragma unroll
+    for (int kk = 0; kk < 2; ++kk) {
+      const V8 a0 = tr_frag<BF>(st, 16 * kk, n0, lane);
+      const V8 a1 = tr_frag<BF>(st, 16 * kk, n0 + 32, lane);
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        const V8 b = tr_frag<BF>(st + WL_TILE, 16 * kk, k0 + 32 * u, lane);
+        acc[0][u] = LP<BF>::mfma(a0, b, acc[0][u]);
+        acc[1][u] = LP<BF>::mfma(a1, b, acc[1][u]);
+      }
+    }
+  };
+
+  WStage8 r0, r1, r2;
+  issue(r0, c0);
+  issue(r1, c0 + WL_PT);
+  issue(r2, c0 + 2 * WL_PT);
+  commit(r0, c0, 0);
+  issue(r0, c0 + 3 * WL_PT);
+  __syncthreads();
+#define WL_STEP(RN, BUF, BUFN, K)                                   \
+  if (pt0 + ((K) + 1) * WL_PT < c1) commit(RN, pt0 + ((K) + 1) * WL_PT, BUFN); \
+  issue(RN, pt0 + ((K) + 4) * WL_PT);                               \
+  compute(BUF);                                                     \
+  __syncthreads();                                                  \
+  if (pt0 + ((K) + 1) * WL_PT >= c1) break;
+  for (int pt0 = c0;; pt0 += 3 * WL_PT) {
+    WL_STEP(r1, 0, 1, 0)
+    WL_STEP(r2, 1, 2, 1)
+    WL_STEP(r0, 2, 0, 2)
+  }
+#undef WL_STEP
+
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        const int k = k0 + 32 * u + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (n < jb.n_rows && k >= jb.kfirst && k < jb.kvalid)
+            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + (k - jb.kfirst)] = acc[t][u][i] * invS;
+        }
+      }
+  }
+  // riders: the 32 rows of a column are combined through LDS
+  float* red = reinterpret_cast<float*>(lds);      // [32][256] (+ 32)
+  if (jb.flags & WF_BIAS) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[rr * 256 + 16 * cc + j] = bias_acc[j];
+    __syncthreads();
+    if (tid < jb.n_rows) {
+      float s = 0.f;
+      for (int g = 0; g < 32; ++g) s += red[g * 256 + tid];
+      out[jb.b_off + tid] = s * invS;
+    }
+    __syncthreads();
+  }
+  if (KW == 256 && (jb.flags & WF_ALPHA)) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[rr * 256 + 16 * cc + j] = alpha_acc[j];
+    if (cc == 0) red[32 * 256 + rr] = dal_acc;
+    __syncthreads();
+    if (tid < 256) {
+      float s = 0.f;
+      for (int g = 0; g < 32; ++g) s += red[g * 256 + tid];
+      out[jb.aux_off + tid] = s;
+    }
+    if (tid == 0) {
+      float s = 0.f;
+      for (int g = 0; g < 32; ++g) s += red[32 * 256 + g];
+      out[jb.aux_off + 256] = s;
+    }
+  }
+}
+
 // rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c].
 // A thread owns 8 columns (one 16-byte load per point) of every 32nd point, four points in flight:
 // this job is pure load latency, and as the LAST job of the table its workgroups set the kernel's end.
-template <bool BF>
+template <bool BF, bool S8 = false>
 __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpNet& a, const WgradLpJob& jb, float* lds,
                                                  int c0, int c1, float* __restrict__ out) {
   typedef typename LP<BF>::T T;
@@ -532,6 +726,7 @@ __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpNet& a, const Wgra
   const int tid = threadIdx.x;
   const int k8 = tid & 15, pl = tid >> 4;        // 16 column groups x 32 point lanes
   const T* __restrict__ hv = reinterpret_cast<const T*>(a.acts) + jb.in_off + 8 * k8;
+  const unsigned char* __restrict__ hv8 = a.acts + jb.in_off * 2 + 8 * k8;     // format code 2: 8-bit rows
   const int P = a.P;
   float s[3][8], b[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -544,7 +739,13 @@ __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpNet& a, const Wgra
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int pt = min(pt0 + 32 * q, P - 1);
-      h[q] = *reinterpret_cast<const V8*>(hv + (size_t)pt * 256);
+      if (S8) {
+        const lp_u32x2 w8 = *reinterpret_cast<const lp_u32x2*>(hv8 + (size_t)pt * 256);
+        const lp_u32x2 q0 = lp_unpack4_bf8<BF>(w8[0]), q1 = lp_unpack4_bf8<BF>(w8[1]);
+        h[q] = __builtin_bit_cast(V8, lp_u32x4{q0[0], q0[1], q1[0], q1[1]});
+      } else {
+        h[q] = *reinterpret_cast<const V8*>(hv + (size_t)pt * 256);
+      }
       g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
     }
 #pragma unroll
@@ -580,7 +781,7 @@ __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpNet& a, const Wgra
   }
 }
 
-template <bool BF>
+template <bool BF, bool S8 = false>
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
   typedef typename LP<BF>::T T;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsw16[];
@@ -593,9 +794,12 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
   const int c0 = bx * aa.chunk;
   const int c1 = min(a.P, c0 + aa.chunk);
   float* out = a.partial + (size_t)bx * N_PARAM_FLOATS;
-  const float invS = BF ? 1.0f : 1.0f / lp_loss_scale(a.gmax[0]);
+  const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(a.gmax[0]);
   if (jb.flags & WF_RGB) {
-    wgrad_rgb_lp_job<BF>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);
+    wgrad_rgb_lp_job<BF, S8>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);
+  } else if (S8) {
+    if (jb.kw == 256) wgrad_lp8_job<256>(a, jb, reinterpret_cast<__bf16*>(ldsw16), c0, c1, invS, out);
+    else wgrad_lp8_job<64>(a, jb, reinterpret_cast<__bf16*>(ldsw16), c0, c1, invS, out);
   } else if (jb.kw == 256) {
     wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
   } else {
@@ -689,17 +893,17 @@ extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp
   return scade_check_launch("scade_mlp_pack_t_lp");
 }
 
-template <bool BF>
+template <bool BF, bool S8>
 static int lp_bwd_set_attr() {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   if (scade_attr_needed(attr_set)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 4>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 4, S8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, dgrad_lp_lds_bytes(4));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 2>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_lp_kernel<BF, 2, S8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, dgrad_lp_lds_bytes(2));
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_lp_kernel<BF>),
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_lp_kernel<BF, S8>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, WGRAD_LP_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_lp: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(attr_set);
@@ -707,7 +911,8 @@ static int lp_bwd_set_attr() {
   return 0;
 }
 
-// fp16 only: the launch-wide loss scale (bf16 kernels use S = 1 and never read gmax)
+// the launch-wide loss scale (fp16 rows, and the 8-bit rows of format code 2; plain bf16 uses S = 1 and never
+// reads gmax)
 static int lp_launch_gmax(const float* g_out, int P, unsigned int* gmax, hipStream_t s) {
   hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
   SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
@@ -717,15 +922,15 @@ static int lp_launch_gmax(const float* g_out, int P, unsigned int* gmax, hipStre
   return scade_check_launch("scade_mlp_bwd_lp(gmax)");
 }
 
-template <bool BF>
+template <bool BF, bool S8>
 static int launch_bwd_lp(const float* packed, const void* packed_t, const unsigned char* acts, const float* g_out,
                          int P, unsigned char* ws, float* grad_flat, hipStream_t s) {
-  if (int e = lp_bwd_set_attr<BF>()) return e;
+  if (int e = lp_bwd_set_attr<BF, S8>()) return e;
   unsigned char* dz = ws;
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
   const int nchunks = pick_chunks(P, LP_CHUNK_PTS);
   unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)nchunks * N_PARAM_FLOATS);
-  if (!BF) {
+  if (!BF || S8) {
     if (int e = lp_launch_gmax(g_out, P, gmax, s)) return e;
   }
   // same point tiling as the forward that wrote the sign words of this workspace
@@ -733,9 +938,9 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   const int tiles = (P + 32 * npt - 1) / (32 * npt);
   MlpDgradLpArgs2 d{{{packed, packed_t, acts, g_out, dz, reinterpret_cast<const float*>(gmax), P}, {}}, tiles, 0};
   if (npt == 2)
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2>), dim3(tiles), dim3(256), dgrad_lp_lds_bytes(2), s, d);
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2, S8>), dim3(tiles), dim3(256), dgrad_lp_lds_bytes(2), s, d);
   else
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4>), dim3(tiles), dim3(256), dgrad_lp_lds_bytes(4), s, d);
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4, S8>), dim3(tiles), dim3(256), dgrad_lp_lds_bytes(4), s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(dgrad)")) return e;
   WgradLpArgs w{};
   build_wgrad_lp_jobs(w);
@@ -743,17 +948,17 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   w.chunk = lp_chunk_len(P, nchunks);
   const int grid_x = (P + w.chunk - 1) / w.chunk;
   w.gx0 = grid_x;
-  hipLaunchKernelGGL(mlp_wgrad_lp_kernel<BF>, dim3(grid_x, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
+  hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(grid_x, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(wgrad)")) return e;
   hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd_lp(reduce)");
 }
 
 // two networks: ONE dgrad launch, ONE weight-gradient launch, ONE reduce (scade_mlp_bwd_lp2)
-template <bool BF>
+template <bool BF, bool S8>
 static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, const float* const* g_out,
                           const int* P, void* const* wsv, float* const* grad_flat, hipStream_t s) {
-  if (int e = lp_bwd_set_attr<BF>()) return e;
+  if (int e = lp_bwd_set_attr<BF, S8>()) return e;
   const int npt = lp_pick_point_tiles(P[0]);
   SCADE_REQUIRE(lp_pick_point_tiles(P[1]) == npt, -3,
                 "scade_mlp_bwd_lp2: the forwards of the two launches tiled their points differently (P = %d, %d); "
@@ -769,7 +974,7 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
     const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts[i]);
     partial[i] = reinterpret_cast<float*>(ws + lp_dz_bytes(P[i]));
     unsigned int* gmax = reinterpret_cast<unsigned int*>(partial[i] + (size_t)(i == 0 ? gx0 : gx1) * N_PARAM_FLOATS);
-    if (!BF) {
+    if (!BF || S8) {
       if (int e = lp_launch_gmax(g_out[i], P[i], gmax, s)) return e;
     }
     d.n[i] = MlpDgradLpArgs{nullptr, packed_t[i], ac, g_out[i], ws, reinterpret_cast<const float*>(gmax), P[i]};
@@ -778,12 +983,12 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
   d.tiles0 = (P[0] + 32 * npt - 1) / (32 * npt);
   d.tiles1 = (P[1] + 32 * npt - 1) / (32 * npt);
   if (npt == 2)
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(2), s, d);
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2, S8>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(2), s, d);
   else
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(4), s, d);
+    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4, S8>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(4), s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_lp2(dgrad)")) return e;
   w.chunk = chunk; w.gx0 = gx0;
-  hipLaunchKernelGGL(mlp_wgrad_lp_kernel<BF>, dim3(gx0 + gx1, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
+  hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(gx0 + gx1, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd_lp2(wgrad)")) return e;
   ReduceLp2Args r{{partial[0], partial[1]}, {grad_flat[0], grad_flat[1]}, {gx0, gx1}};
   hipLaunchKernelGGL(wgrad_lp_reduce_pair_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
@@ -813,8 +1018,10 @@ extern "C" int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const
                   "scade_mlp_bwd_lp2: null pointer in entry %d", i);
   }
   hipStream_t s = (hipStream_t)stream;
-  return bf16 ? launch_bwd_lp2<true>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s)
-              : launch_bwd_lp2<false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s);
+  SCADE_REQUIRE(bf16 >= 0 && bf16 <= 2, -2, "scade_mlp_bwd_lp2: format 0 (fp16), 1 (bf16) or 2 (bf16, 8-bit saved rows)");
+  if (bf16 == 2) return launch_bwd_lp2<true, true>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s);
+  return bf16 ? launch_bwd_lp2<true, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s)
+              : launch_bwd_lp2<false, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s);
 }
 
 extern "C" int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, const void* acts,
@@ -826,6 +1033,8 @@ extern "C" int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, in
   const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts);
   unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
   hipStream_t s = (hipStream_t)stream;
-  return bf16 ? launch_bwd_lp<true>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s)
-              : launch_bwd_lp<false>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s);
+  SCADE_REQUIRE(bf16 >= 0 && bf16 <= 2, -2, "scade_mlp_bwd_lp: format 0 (fp16), 1 (bf16) or 2 (bf16, 8-bit saved rows)");
+  if (bf16 == 2) return launch_bwd_lp<true, true>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s);
+  return bf16 ? launch_bwd_lp<true, false>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s)
+              : launch_bwd_lp<false, false>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s);
 }

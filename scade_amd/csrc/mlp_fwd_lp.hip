@@ -89,7 +89,8 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][NPT], int
 
 __device__ __forceinline__ bool lp_nonfinite(float v) { return !(fabsf(v) <= 3.4028234664e38f); }   // NaN or +-inf
 
-template <bool BF, int MODE, bool SAVE, int NPT>
+// SAVE: 0 inference; 1 training, 16-bit rows saved; 2 training, 8-bit (e5m2) rows saved (format code 2)
+template <bool BF, int MODE, int SAVE, int NPT>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   constexpr int LM = 32 * NPT, LPT = NPT, LXPLANE = LM * W;   // this workgroup's tile (shadow the 128-point default)
   typedef typename LP<BF>::T T;
@@ -185,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   unsigned bits[4];
   // inference: weights fetched three k-blocks ahead; the training variant has no registers left
   // for a fourth set and stays at two
-  constexpr int NS = SAVE ? 3 : 4;
+  constexpr int NS = SAVE ? 3 : 4;   // (SAVE = 1, 2 -> 3)
   AFragN<BF, NS> A;
   const int nt0 = wave * 2;
 #define WLBASE(L) (reinterpret_cast<const V8*>(wpk + CE<off_wl(L)>::v) + ((L) == L_VIEWS ? wave : nt0) * (int)CE<kb16(L) * 64>::v)
@@ -197,13 +198,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS, NPT>(acc, A, WLBASE(L), WLBASE(LNEXT),   \
                                                         (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
     __syncthreads();                                                                            \
-    layer_store_lp<BF, 2, true, SAVE, 2, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
+    layer_store_lp<BF, 2, true, SAVE != 0, 2, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
     if (SAVE) {                                                                                 \
       u32x4 mw_ = {bits[0], bits[1], bits[2], bits[3]};                                         \
       reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[                                  \
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
     }                                                                                           \
-    if (SAVE) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
+    if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
+    if (SAVE == 2) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, L) * 2, p0, P, nullptr, 64 * wave, lane); \
     __syncthreads();                                                                            \
   }
 
@@ -291,7 +293,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS, NPT>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
   __syncthreads();
   layer_store_lp<BF, 2, false, false, 1, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
-  if (SAVE) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, 64 * wave, lane);
+  if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, 64 * wave, lane);
+  if (SAVE == 2) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, nullptr, 64 * wave, lane);
   __syncthreads();
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
@@ -300,7 +303,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
     __syncthreads();
     layer_store_lp<BF, 1, true, false, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
-    if (SAVE) save_tile_lp_wave<BF, 32, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
+    if (SAVE == 1) save_tile_lp_wave<BF, 32, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
+    if (SAVE == 2) save_tile_lp_wave8<BF, 32, NPT>(x, a.acts + acts_slot_off(P, SLOT_VIEWS_H) * 2, p0, P, nullptr, 32 * wave, lane);
     __syncthreads();
   }
 #undef WLBASE
@@ -375,7 +379,7 @@ extern "C" int scade_mlp_pack_lp(const float* const* params, void* packed, int b
   return scade_check_launch("scade_mlp_pack_lp");
 }
 
-template <bool BF, int MODE, bool SAVE, int NPT>
+template <bool BF, int MODE, int SAVE, int NPT>
 static int launch_lp_pt(const MlpLpArgs& a, hipStream_t s) {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   auto kern = mlp_fwd_lp_kernel<BF, MODE, SAVE, NPT>;
@@ -388,7 +392,7 @@ static int launch_lp_pt(const MlpLpArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(kern, dim3((a.P + 32 * NPT - 1) / (32 * NPT)), dim3(256), lp_lds_bytes(NPT), s, a);
   return scade_check_launch("scade_mlp_fwd_lp");
 }
-template <bool BF, int MODE, bool SAVE>
+template <bool BF, int MODE, int SAVE>
 static int launch_lp(const MlpLpArgs& a, hipStream_t s) {
   return lp_pick_point_tiles(a.P) == 2 ? launch_lp_pt<BF, MODE, SAVE, 2>(a, s)
                                        : launch_lp_pt<BF, MODE, SAVE, 4>(a, s);
@@ -400,21 +404,23 @@ extern "C" int scade_mlp_fwd_lp(const void* packed_lp, int bf16, int mode, const
   if (P == 0) return 0;
   SCADE_REQUIRE(packed_lp && in && out, -1, "scade_mlp_fwd_lp: null pointer");
   SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd_lp: mode must be 0 or 1");
+  SCADE_REQUIRE(bf16 >= 0 && bf16 <= 2, -2, "scade_mlp_fwd_lp: format 0 (fp16), 1 (bf16) or 2 (bf16, 8-bit saved rows)");
   if (mode == 1) {
     SCADE_REQUIRE(viewdirs && bb && vd_stride >= 3, -1, "scade_mlp_fwd_lp: mode 1 needs viewdirs and bb");
     SCADE_REQUIRE(S > 0 && P % S == 0, -2, "scade_mlp_fwd_lp: P must be a multiple of S");
   }
   MlpLpArgs a{packed_lp, in, viewdirs, bb, out, reinterpret_cast<unsigned char*>(acts), P, S, vd_stride};
   hipStream_t s = (hipStream_t)stream;
+  if (bf16 == 2 && acts) return mode ? launch_lp<true, 1, 2>(a, s) : launch_lp<true, 0, 2>(a, s);
   const int sel = (bf16 ? 4 : 0) + (mode ? 2 : 0) + (acts ? 1 : 0);
   switch (sel) {
-    case 0: return launch_lp<false, 0, false>(a, s);
-    case 1: return launch_lp<false, 0, true>(a, s);
-    case 2: return launch_lp<false, 1, false>(a, s);
-    case 3: return launch_lp<false, 1, true>(a, s);
-    case 4: return launch_lp<true, 0, false>(a, s);
-    case 5: return launch_lp<true, 0, true>(a, s);
-    case 6: return launch_lp<true, 1, false>(a, s);
-    default: return launch_lp<true, 1, true>(a, s);
+    case 0: return launch_lp<false, 0, 0>(a, s);
+    case 1: return launch_lp<false, 0, 1>(a, s);
+    case 2: return launch_lp<false, 1, 0>(a, s);
+    case 3: return launch_lp<false, 1, 1>(a, s);
+    case 4: return launch_lp<true, 0, 0>(a, s);
+    case 5: return launch_lp<true, 0, 1>(a, s);
+    case 6: return launch_lp<true, 1, 0>(a, s);
+    default: return launch_lp<true, 1, 1>(a, s);
   }
 }

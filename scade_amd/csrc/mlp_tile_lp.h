@@ -18,6 +18,9 @@ namespace scade {
 // forces compile-time evaluation of the constexpr layout helpers at their use sites (hipcc
 // otherwise emits some of them as real device functions and CALLS them from the kernel)
 template <long V> struct CE { static constexpr long v = V; };
+typedef float lp_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 lp_bf16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 lp_f16x2 __attribute__((ext_vector_type(2)));
 
 template <bool BF> struct LP;
 template <> struct LP<false> {
@@ -175,6 +178,70 @@ __device__ __forceinline__ void save_tile_lp_wave(const typename LP<BF>::T* x, t
         for (int e = 0; e < 8; ++e) v[j][e] = (T)((float)v[j][e] * f[j]);
       }
       if (p0 + row < P) __builtin_nontemporal_store(v[j], reinterpret_cast<V8*>(dst + (size_t)(p0 + row) * W + 8 * c));
+    }
+  }
+}
+
+// ---- format code 2: bf16 arithmetic, rows SAVED for the weight gradient as 8-bit e5m2 ("bf8") ------------------
+// The 16-bit training step is HBM-bound on the rows it saves (activations written by the forward, dZ rows written
+// by the dgrad chain, both read back by the weight gradient: 21 KB per point; measured roofs of this part 4.5
+// TB/s written, 6.7 TB/s read).  Format code 2 halves those bytes: the forward / dgrad arithmetic is the bf16
+// path's, bit for bit, only the COPY of a tile that leaves for HBM is rounded (RNE) to e5m2 - activations as they
+// are, dZ rows under the launch-wide power-of-two loss scale of the fp16 path (e5m2 has fp16's exponent range) -
+// and the weight gradient converts the rows back to bf16 while staging them into LDS.  What changes numerically
+// is the weight gradient's operands (2 mantissa bits, zero-mean rounding); dgrad and forward are untouched.
+// Layout: the workspaces keep the 16-bit offsets; an 8-bit row p of slot s lies at byte acts_slot_off(P, s) * 2 +
+// p * 256 (the first half of the slot's region).
+typedef unsigned lp_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned lp_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ unsigned lp_pack4_bf8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
+  return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+}
+// 4 e5m2 bytes -> 4 values of T as two packed dwords (exact: every e5m2 value is a bf16 / fp16 value)
+template <bool BF>
+__device__ __forceinline__ lp_u32x2 lp_unpack4_bf8(unsigned w) {
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  const f2 lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)w, true);
+  lp_u32x2 r;
+  if (BF) {
+    r[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, lp_bf16x2));
+    r[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, lp_bf16x2));
+  } else {
+    r[0] = __builtin_bit_cast(unsigned, __builtin_convertvector(lo, lp_f16x2));
+    r[1] = __builtin_bit_cast(unsigned, __builtin_convertvector(hi, lp_f16x2));
+  }
+  return r;
+}
+// save_tile_lp_wave with 8-bit rows: dst8 = byte base of the slot; row_fac as there
+template <bool BF, int NCW, int NPT = LPT>
+__device__ __forceinline__ void save_tile_lp_wave8(const typename LP<BF>::T* x, unsigned char* __restrict__ dst8,
+                                                   int p0, int P, const float* row_fac, int c0, int lane) {
+  typedef typename LP<BF>::V8 V8;
+  constexpr int CPR = NCW >> 3;
+  constexpr int ITERS = 32 * NPT * CPR / 64;
+  static_assert(ITERS % 4 == 0, "save_tile_lp_wave8: batches of four");
+#pragma unroll 1
+  for (int it0 = 0; it0 < ITERS; it0 += 4) {
+    V8 v[4];
+    float f[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int row, c;
+      tile_copy_map<CPR>(lane, it0 + j, row, c);
+      c += c0 >> 3;
+      v[j] = *reinterpret_cast<const V8*>(x + x_idx(row, c));
+      f[j] = row_fac ? row_fac[row] : 1.f;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      int row, c;
+      tile_copy_map<CPR>(lane, it0 + j, row, c);
+      c += c0 >> 3;
+      lp_u32x2 o;
+      o[0] = lp_pack4_bf8((float)v[j][0] * f[j], (float)v[j][1] * f[j], (float)v[j][2] * f[j], (float)v[j][3] * f[j]);
+      o[1] = lp_pack4_bf8((float)v[j][4] * f[j], (float)v[j][5] * f[j], (float)v[j][6] * f[j], (float)v[j][7] * f[j]);
+      if (p0 + row < P) __builtin_nontemporal_store(o, reinterpret_cast<lp_u32x2*>(dst8 + (size_t)(p0 + row) * W + 8 * c));
     }
   }
 }
@@ -359,9 +426,6 @@ __device__ __forceinline__ void lp_swap_halves(unsigned a, unsigned b, unsigned&
   hi = sw[1];
 }
 
-typedef float lp_f32x2 __attribute__((ext_vector_type(2)));
-typedef __bf16 lp_bf16x2 __attribute__((ext_vector_type(2)));
-typedef _Float16 lp_f16x2 __attribute__((ext_vector_type(2)));
 template <bool BF, bool RELU>
 __device__ __forceinline__ unsigned pack2(float y0, float y1) {
   const lp_f32x2 y = {y0, y1};

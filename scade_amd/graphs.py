@@ -18,6 +18,18 @@ from . import ops
 from .optim import adam_step_pair
 
 
+def _capture_mode():
+    """Capture-error mode of every stream capture of this module: "thread_local".  torch's default, "global",
+    makes a HIP call that is illegal during capture an error in EVERY thread of the process - including the NCCL
+    watchdog thread of a torch.distributed process group, which polls the events of earlier (eager) collectives
+    with hipEventQuery.  When such a poll lands inside a capture window the watchdog throws and the process
+    aborts (ProcessGroupNCCL.cpp, Watchdog::run): the "RCCL teardown abort" of round 2, seen about once in forty
+    to sixty runs and never in teardown (tools/probe_rccl_teardown.py, profiles/r03_rccl_teardown.txt).  The
+    capturing thread's own calls stay checked.  SCADE_GRAPH_CAPTURE_MODE=global restores the old behaviour."""
+    import os
+    return os.environ.get("SCADE_GRAPH_CAPTURE_MODE", "thread_local")
+
+
 class GraphedTrainer:
     """``n_total``: rays of the whole (all-rank) batch when the shards are uneven (default: equal
     shards, n_rays x world); it fixes this rank's loss weight n_rays / n_total at capture time.
@@ -90,7 +102,7 @@ class GraphedTrainer:
         ops.PARAM_EPOCH += 1
         self._captured = (tr.scaleshift_active(), tr.carving_active())
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
             self.loss = self._body()
         # the capture itself executed nothing; undo its host-side bookkeeping
         tr.opt.steps, tr.opt_ss.steps = steps
@@ -154,7 +166,7 @@ class GraphedRender:
                 self._call()
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph), torch.no_grad():
+        with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()), torch.no_grad():
             self.out = self._call()
         self._epoch = self._weights_key()
 

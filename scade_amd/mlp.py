@@ -22,13 +22,13 @@ class MlpEmbeddedFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, train, x, *params):
         acts = None
-        lp = train and net.train_precision in ("f16", "bf16")
+        lp = train and net.train_precision in ops.LP_FORMATS
         if train:
             _check_train_precision(net)
             acts = (ops.mlp_acts_lp_alloc if lp else ops.mlp_acts_alloc)(x.shape[0], x.device)
         if lp:
-            bf16 = net.train_precision == "bf16"
-            out = ops.mlp_fwd_lp(net.packed_lp(bf16), bf16, x, None, None, acts)
+            code, bf16 = ops.LP_FORMATS[net.train_precision]
+            out = ops.mlp_fwd_lp(net.packed_lp(bf16), code, x, None, None, acts)
         elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), x, None, None, acts)
         else:
@@ -51,14 +51,14 @@ class MlpPointsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, net, train, pts, viewdirs, bb, *params):
         acts = None
-        lp = train and net.train_precision in ("f16", "bf16")
+        lp = train and net.train_precision in ops.LP_FORMATS
         if train:
             _check_train_precision(net)
             P = pts.shape[0] * pts.shape[1]
             acts = (ops.mlp_acts_lp_alloc if lp else ops.mlp_acts_alloc)(P, pts.device)
         if lp:
-            bf16 = net.train_precision == "bf16"
-            out = ops.mlp_fwd_lp(net.packed_lp(bf16), bf16, pts, viewdirs, bb, acts)
+            code, bf16 = ops.LP_FORMATS[net.train_precision]
+            out = ops.mlp_fwd_lp(net.packed_lp(bf16), code, pts, viewdirs, bb, acts)
         elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
             out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts)
         else:

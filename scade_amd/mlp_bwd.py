@@ -40,7 +40,7 @@ class DeferredBackward:
 
 def _pair_key(net):
     p = net.train_precision
-    return p if p in ("f32", "f16", "bf16") else None
+    return p if (p == "f32" or p in ops.LP_FORMATS) else None
 
 
 def flush_deferred(items):
@@ -52,10 +52,10 @@ def flush_deferred(items):
         if prec == "f32":
             ops.mlp_bwd2([n0.packed(), n1.packed()], [n0.packed_t(), n1.packed_t()], [a0, a1], [g0, g1], sinks)
             return
-        bf16 = prec == "bf16"
+        code, bf16 = ops.LP_FORMATS[prec]
         P0, P1 = g0.numel() // 4, g1.numel() // 4
         if ops.lp_point_tiles(P0) == ops.lp_point_tiles(P1):
-            ops.mlp_bwd_lp2([n0.packed_t_lp(bf16), n1.packed_t_lp(bf16)], bf16, [a0, a1], [g0, g1], sinks)
+            ops.mlp_bwd_lp2([n0.packed_t_lp(bf16), n1.packed_t_lp(bf16)], code, [a0, a1], [g0, g1], sinks)
             return
     for net, acts, g in items:
         _backward_now(net, acts, g, net._grad_sink)
@@ -65,9 +65,9 @@ def _backward_now(net, acts, g_out, out):
     if net.train_precision in ("f16x3", "f16x3-dgrad"):
         return ops.mlp_bwd_f16(net.packed(), net.packed_t_f16(), acts, g_out,
                                wgrad_f16=net.train_precision == "f16x3", out=out)
-    if net.train_precision in ("f16", "bf16"):
-        bf16 = net.train_precision == "bf16"
-        return ops.mlp_bwd_lp(None, net.packed_t_lp(bf16), bf16, acts, g_out, out=out)
+    if net.train_precision in ops.LP_FORMATS:
+        code, bf16 = ops.LP_FORMATS[net.train_precision]
+        return ops.mlp_bwd_lp(None, net.packed_t_lp(bf16), code, acts, g_out, out=out)
     if net.train_precision == "f32":
         return ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out, out=out)
     raise ValueError("NeRF.train_precision must be one of %s" % (net.TRAIN_PRECISIONS,))

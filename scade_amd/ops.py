@@ -78,6 +78,9 @@ class KernelTimer:
 KERNEL_TIMER: Optional[KernelTimer] = None
 PARAM_EPOCH = 0   # bumped by optimizers that update parameters through raw pointers
 N_PARAM_FLOATS = 589700
+# 16-bit training formats: name -> (format code of the scade_mlp_*_lp entries, weight packs are bf16?)
+#   "bf16-s8": bf16 arithmetic, the rows saved for the weight gradient (activations, dZ) stored as 8-bit e5m2
+LP_FORMATS = {"f16": (0, False), "bf16": (1, True), "bf16-s8": (2, True)}
 MLP_FLOP_PER_POINT = 2 * 587264      # algorithmic, unpadded
 
 

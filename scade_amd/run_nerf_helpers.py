@@ -151,7 +151,9 @@ class NeRF(nn.Module):
         # ~1e-3 / ~1e-2 relative error: BASELINE.json config 5's "bf16 MFMA path")
         self.inference_precision = "f32"
         # "f32": exact training kernels.  "f16x3": forward, dgrad and wgrad on the split-precision
-        # kernels ("f16x3-dgrad": wgrad stays exact fp32).  "f16" / "bf16": mixed-precision training,
+        # kernels ("f16x3-dgrad": wgrad stays exact fp32).  "bf16-s8": "bf16" with the rows saved for the weight
+        # gradient (activations, dZ) kept as 8-bit e5m2 in HBM (half the bytes of the HBM-bound training step;
+        # forward and dgrad arithmetic unchanged).  "f16" / "bf16": mixed-precision training,
         # 16-bit activations / gradients / weight copies, fp32 accumulate and fp32 master weights
         self.train_precision = "f32"
 
@@ -277,7 +279,7 @@ class NeRF(nn.Module):
             self.packed()
 
     INFERENCE_PRECISIONS = ("f32", "f16x3", "f16", "bf16")
-    TRAIN_PRECISIONS = ("f32", "f16x3", "f16x3-dgrad", "f16", "bf16")
+    TRAIN_PRECISIONS = ("f32", "f16x3", "f16x3-dgrad", "f16", "bf16", "bf16-s8")
 
     def _fast(self, train):
         if self.inference_precision not in self.INFERENCE_PRECISIONS:

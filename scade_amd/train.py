@@ -134,9 +134,9 @@ class Trainer:
         # the MFMA weight blobs of both networks (forward + transposed layout), rebuilt after the last
         # optimizer step by ONE launch instead of four
         prec = self.coarse.train_precision
-        if self.joint_pack and prec in ("f32", "bf16", "f16") and self.fine.train_precision == prec \
+        if self.joint_pack and (prec == "f32" or prec in ops.LP_FORMATS) and self.fine.train_precision == prec \
                 and torch.is_grad_enabled():
-            ops.mlp_pack_step([self.coarse, self.fine], prec)
+            ops.mlp_pack_step([self.coarse, self.fine], "bf16" if prec == "bf16-s8" else prec)
         share = batch_share(rays.shape[0], n_total) if self.sharded else 1.0
         if c["joint"] and self.sharded:
             # the LAST sampler (sample_pdf_joint_return_u, :728) draws ONE u[S] for the whole batch

@@ -282,7 +282,7 @@ def test_lp_backward_power_of_two_scale_invariance_and_chunks(dev, prec):
     assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
 
 
-@pytest.mark.parametrize("prec", ["f16", "bf16"])
+@pytest.mark.parametrize("prec", ["f16", "bf16", "bf16-s8"])
 def test_lp_trainer_descends_like_the_exact_path(dev, prec):
     """Twelve optimiser steps of the full SCADE train step (render, 3-term loss with K hypotheses,
     backward, fused Adam, re-pack) in mixed precision track the exact fp32 run."""
@@ -340,7 +340,7 @@ def test_lp_full_size_properties(dev):
     assert rel_l2(grads("f16", G), exact) < 0.06
 
 
-@pytest.mark.parametrize("prec", ["bf16", "f16"])
+@pytest.mark.parametrize("prec", ["bf16", "f16", "bf16-s8"])
 def test_lp_training_curve_parity(dev, prec):
     """Loss-curve parity (the acceptance criterion for the config-5 path): a
     student pair of networks is fitted for 200 optimiser steps to a teacher's render (target colours
@@ -439,3 +439,75 @@ def test_bf16_backward_without_point_scale_flushes_only_negligible_gradients(dev
     assert float((out["mixed"] - out["big_only"]).abs().max()) <= 1e-6 * float(out["big_only"].abs().max()), \
         float((out["mixed"] - out["big_only"]).abs().max())
     assert rel_l2(out["mixed"], out["mixed_exact"]) < 0.15
+
+
+@pytest.mark.parametrize("P", [3000, 40000])
+def test_bf16_with_8bit_saved_rows(dev, P):
+    """train_precision = "bf16-s8" (format code 2 of the scade_mlp_*_lp entries): bf16 arithmetic with the rows
+    saved for the weight gradient - activations written by the forward, dZ rows written by the dgrad chain - kept
+    as 8-bit e5m2 in HBM (half the bytes of the HBM-bound 16-bit training step).  Checked here:
+      * the forward's OUTPUT is the bf16 path's, bit for bit (only the tile copies are rounded);
+      * every saved activation row IS the bf16 path's row rounded to e5m2 (RNE), bit for bit;
+      * the weight gradients equal dZ8^T In8 / S evaluated in fp64 on the kernel's OWN 8-bit rows (S = the
+        launch-wide power-of-two loss scale) to fp32-accumulation accuracy - the kernels compute exactly the
+        contraction they are given;
+      * against the plain bf16 gradient the difference is the e5m2 rounding of the operands: a few per cent
+        norm-wise, zero-mean.
+    3000 points run 64-point workgroups, 40,000 points 128-point ones."""
+    import math
+    from scade_amd import ops, _lib
+    from scade_amd._lib import call, ptr, stream
+    params = O.nerf_init(5)
+    net = make_net(params, dev)
+    x, G = lp_inputs(P, seed=11)
+    x, G = x.to(dev), G.to(dev)
+    lib = _lib.load()
+    res = {}
+    for code in (1, 2):
+        acts = ops.mlp_acts_lp_alloc(P, dev)
+        acts.zero_()
+        out = ops.mlp_fwd_lp(net.packed_lp(True), code, x, None, None, acts)
+        ws = torch.zeros(int(lib.scade_mlp_bwd_lp_workspace_bytes(P)), device=dev, dtype=torch.uint8)
+        grad = torch.empty(ops.N_PARAM_FLOATS, device=dev)
+        call("scade_mlp_bwd_lp", None, ptr(net.packed_t_lp(True)), code, ptr(acts), ptr(G), P, ptr(ws), ptr(grad), stream())
+        torch.cuda.synchronize()
+        res[code] = (out, acts, ws, grad)
+    (o16, a16, w16, g16), (o8, a8, w8, g8) = res[1], res[2]
+    assert torch.equal(o16, o8), "the forward arithmetic must not change"
+    rows16 = a16[:10 * P * 512].view(torch.bfloat16).view(10, P, 256)
+    slot8 = lambda t, s: t[s * P * 512:s * P * 512 + P * 256].view(torch.float8_e5m2).view(P, 256)
+    for s_ in range(10):
+        ncol = 128 if s_ == 8 else 256                              # slot 8: the 128-wide views hidden layer
+        want = rows16[s_][:, :ncol].to(torch.float8_e5m2)
+        assert torch.equal(slot8(a8, s_)[:, :ncol].view(torch.uint8), want.view(torch.uint8)), f"activation slot {s_}"
+    # the kernel's own rows -> the contraction in fp64
+    m = float(G.abs().max())
+    S = 2.0 ** min(6 - math.frexp(m)[1], 96)
+    off, flat = 0, {}
+    for name in ops.PARAM_ORDER:
+        n = math.prod(ops.PARAM_SHAPES[name])
+        flat[name] = (g8[off:off + n].view(ops.PARAM_SHAPES[name]), g16[off:off + n].view(ops.PARAM_SHAPES[name]))
+        off += n
+    for l in range(1, 8):
+        dz = slot8(w8, l).double()
+        inp = slot8(a8, l - 1).double()
+        ref = dz.t() @ inp / S
+        got, plain = flat[f"pts_linears.{l}.weight"]
+        got = got[:, 57:] if l == 5 else got
+        plain = plain[:, 57:] if l == 5 else plain
+        assert rel_l2(got, ref) < 2e-3, (l, rel_l2(got, ref))
+        assert rel_l2(flat[f"pts_linears.{l}.bias"][0], dz.sum(0) / S) < 2e-3
+        assert rel_l2(got, plain) < 0.08, (l, rel_l2(got, plain))       # e5m2 rounding of both operands
+    # the dgrad chain itself is the bf16 path's: its dZ rows are the bf16 rows (x S) rounded to e5m2
+    dz16 = w16[:10 * P * 512].view(torch.bfloat16).view(10, P, 256)
+    for s_ in (1, 4, 7, 9):
+        want = (dz16[s_].float() * S).to(torch.float8_e5m2).float()
+        got8 = slot8(w8, s_).float()
+        normal = want.abs() >= 2.0 ** -14
+        assert torch.equal(got8[normal], want[normal]), f"dZ slot {s_}: normal range"
+        # (e5m2's subnormal range, 2^-16 steps: the hardware conversion and torch's may treat it differently)
+        assert float((got8 - want).abs().max()) <= 2.0 ** -16, f"dZ slot {s_}: subnormal range"
+        assert float(normal.float().mean()) > 0.3
+    # all 24 tensors: finite, close to the plain bf16 gradient norm-wise
+    assert torch.isfinite(g8).all()
+    assert rel_l2(g8, g16) < 0.06, rel_l2(g8, g16)
