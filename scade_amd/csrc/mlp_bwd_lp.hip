@@ -223,17 +223,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
       V4 mk;
 #pragma unroll
       for (int j = 0; j < 4; ++j) mk[j] = (T)0.f;
-      if (S8) {      // 8-bit rows: a positive e5m2 byte <-> a positive activation (sign bit clear, not zero)
-        unsigned mb8 = 0u;
-        if (ok) mb8 = *reinterpret_cast<const unsigned*>(acts8 + acts_slot_off(P, SLOT_VIEWS_H) * 2 + (size_t)pt * W + chunk * 4);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const unsigned b = (mb8 >> (8 * j)) & 0xFFu;
-          mk[j] = (T)((b != 0u && b < 0x80u) ? 1.f : 0.f);
-        }
-      } else if (ok) {
-        mk = *reinterpret_cast<const V4*>(hv + (size_t)pt * W + chunk * 4);
-      }
+      if (ok) mk = *reinterpret_cast<const V4*>(hv + (size_t)pt * W + chunk * 4);     // (16-bit in every format)
       V4 vs, vS;
       float vf[4];
 #pragma unroll
@@ -546,21 +536,30 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpNet& a, const WgradLpJ
 }
 
 // ---- format code 2: the same job on 8-bit (e5m2) dZ / activation rows (mlp_tile_lp.h).  Only the staging
-// differs: a thread owns 16 columns of ONE row of the 32-point stage (one 16-byte load = 16 values per operand),
-// converts them to bf16 on the way into the same LDS tiles, and the MFMA part is wgrad_lp_job's.  The embedding
-// rows (KW = 64 jobs' input) stay 16-bit.
+// differs: a thread owns 16 columns of ONE row of the 32-point stage (one 16-byte load = 16 values per operand) and
+// widens them on the way into the same LDS tiles.  An e5m2 number IS the top byte of an fp16 number, so the
+// widening is one v_perm_b32 per two values (byte b -> halfword b << 8, exact) and the contraction runs on the fp16
+// MFMA (same rate as bf16; every operand value is exactly representable either way) - as bf16 the widening was
+// v_cvt_pk_f32_bf8 + v_cvt_pk_bf16_f32 per pair, four times the VALU work of the commit phase.  The embedding rows
+// (KW = 64 jobs' input) are saved as bf16 and converted to fp16 here (|gamma(x)| <= 1, |viewdir| <= 1: in range).
 struct WStage8 {
   lp_u32x4 a, b;       // 16 e5m2 values of the dZ row / the input row
-  __bf16 __attribute__((ext_vector_type(8))) e;   // KW = 64: 8 embedding columns (16-bit rows)
+  __bf16 __attribute__((ext_vector_type(8))) e;   // KW = 64: 8 embedding columns (bf16 rows)
   float d;             // d alpha_pre of the row (WF_ALPHA job)
 };
+// four e5m2 bytes of w -> two dwords of packed fp16 (v_perm_b32 selectors: 0x0c = constant zero byte)
+__device__ __forceinline__ void widen4_bf8_f16(unsigned w, unsigned& lo, unsigned& hi) {
+  lo = __builtin_amdgcn_perm(0u, w, 0x010c000cu);      // [0, b0, 0, b1]
+  hi = __builtin_amdgcn_perm(0u, w, 0x030c020cu);      // [0, b2, 0, b3]
+}
 
 template <int KW>
-__device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLpJob& jb, __bf16* lds,
+__device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLpJob& jb, _Float16* lds,
                                               int c0, int c1, float invS, float* __restrict__ out) {
-  constexpr bool BF = true;
-  typedef __bf16 T;
+  constexpr bool BF = false;                    // fp16 tiles and MFMAs (see above)
+  typedef _Float16 T;
   typedef typename LP<BF>::V8 V8;
+  typedef __bf16 __attribute__((ext_vector_type(8))) BV8;
   constexpr int NKT = KW == 256 ? 4 : 1;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -571,7 +570,7 @@ __device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLp
   const int P = a.P;
   const unsigned char* __restrict__ dzm = a.dz + jb.dz_off * 2;       // 8-bit rows: first half of the slot region
   const unsigned char* __restrict__ inm8 = a.acts + jb.in_off * 2;
-  const T* __restrict__ inm16 = reinterpret_cast<const T*>(a.acts) + jb.in_off;   // embedding rows
+  const __bf16* __restrict__ inm16 = reinterpret_cast<const __bf16*>(a.acts) + jb.in_off;   // embedding rows
   const float* __restrict__ dalp = reinterpret_cast<const float*>(a.dz + lp_dz_dalpha_byte(P));
   const int cc = tid & 15, rr = tid >> 4;      // 16-column chunk cc of row rr of the stage
   const V8 zero8 = __builtin_bit_cast(V8, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
@@ -596,28 +595,42 @@ __device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLp
       s.d = dalp[want_alpha ? pa : 0];
     } else {
       const int pe = min(pt0 + ((tid >> 3) & 31), P - 1);
-      s.e = *reinterpret_cast<const V8*>(inm16 + (size_t)pe * 64 + 8 * (tid & 7));
+      s.e = *reinterpret_cast<const BV8*>(inm16 + (size_t)pe * 64 + 8 * (tid & 7));
     }
   };
   auto widen = [&](const lp_u32x4& w, V8& lo, V8& hi) {
-    const lp_u32x2 p0 = lp_unpack4_bf8<true>(w[0]), p1 = lp_unpack4_bf8<true>(w[1]);
-    const lp_u32x2 p2 = lp_unpack4_bf8<true>(w[2]), p3 = lp_unpack4_bf8<true>(w[3]);
-    lo = __builtin_bit_cast(V8, lp_u32x4{p0[0], p0[1], p1[0], p1[1]});
-    hi = __builtin_bit_cast(V8, lp_u32x4{p2[0], p2[1], p3[0], p3[1]});
+    unsigned q[8];
+    widen4_bf8_f16(w[0], q[0], q[1]);
+    widen4_bf8_f16(w[1], q[2], q[3]);
+    widen4_bf8_f16(w[2], q[4], q[5]);
+    widen4_bf8_f16(w[3], q[6], q[7]);
+    lo = __builtin_bit_cast(V8, lp_u32x4{q[0], q[1], q[2], q[3]});
+    hi = __builtin_bit_cast(V8, lp_u32x4{q[4], q[5], q[6], q[7]});
   };
   auto commit = [&](const WStage8& s, int pt0, int buf) {
     T* st = lds + buf * WL_STAGE;
     const bool va = pt0 + rr < c1;
     V8 a0 = zero8, a1 = zero8, b0 = zero8, b1 = zero8;
     if (va) widen(s.a, a0, a1);
-    *reinterpret_cast<V8*>(st + rr * WL_PITCH + 16 * cc) = a0;
-    *reinterpret_cast<V8*>(st + rr * WL_PITCH + 16 * cc + 8) = a1;
+    // a lane's two 16-byte halves lie 16 bytes apart, the lanes of a row 32 bytes apart: written in program order
+    // the eight lanes of a ds_write_b128 group would cover 256 bytes with 16-byte holes and hit every bank group
+    // twice (measured: 29.7 % conflict cycles).  Lanes 4..7 of each group of eight write their HIGH half first:
+    // the group then covers 8 distinct 16-byte bank groups in both instructions.
+    const bool hi_first = (cc & 4) != 0;
+    T* pa_ = st + rr * WL_PITCH + 16 * cc;
+    *reinterpret_cast<V8*>(pa_ + (hi_first ? 8 : 0)) = hi_first ? a1 : a0;
+    *reinterpret_cast<V8*>(pa_ + (hi_first ? 0 : 8)) = hi_first ? a0 : a1;
     if (KW == 256) {
       if (va) widen(s.b, b0, b1);
-      *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 16 * cc) = b0;
-      *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 16 * cc + 8) = b1;
+      T* pb_ = st + WL_TILE + rr * WL_PITCH + 16 * cc;
+      *reinterpret_cast<V8*>(pb_ + (hi_first ? 8 : 0)) = hi_first ? b1 : b0;
+      *reinterpret_cast<V8*>(pb_ + (hi_first ? 0 : 8)) = hi_first ? b0 : b1;
     } else if (tid < 256) {
-      const V8 e = pt0 + (tid >> 3) < c1 ? s.e : zero8;
+      V8 e = zero8;
+      if (pt0 + (tid >> 3) < c1) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = (T)(float)s.e[j];
+      }
       *reinterpret_cast<V8*>(st + WL_TILE + (tid >> 3) * WL_PITCH + 8 * (tid & 7)) = e;
     }
     if (jb.flags & WF_BIAS) {
@@ -796,10 +809,10 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
   float* out = a.partial + (size_t)bx * N_PARAM_FLOATS;
   const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(a.gmax[0]);
   if (jb.flags & WF_RGB) {
-    wgrad_rgb_lp_job<BF, S8>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);
+    wgrad_rgb_lp_job<BF, false>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);   // (its input slot is 16-bit in every format)
   } else if (S8) {
-    if (jb.kw == 256) wgrad_lp8_job<256>(a, jb, reinterpret_cast<__bf16*>(ldsw16), c0, c1, invS, out);
-    else wgrad_lp8_job<64>(a, jb, reinterpret_cast<__bf16*>(ldsw16), c0, c1, invS, out);
+    if (jb.kw == 256) wgrad_lp8_job<256>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
+    else wgrad_lp8_job<64>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
   } else if (jb.kw == 256) {
     wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
   } else {

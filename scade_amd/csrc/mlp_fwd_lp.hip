@@ -303,8 +303,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
     __syncthreads();
     layer_store_lp<BF, 1, true, false, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
-    if (SAVE == 1) save_tile_lp_wave<BF, 32, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
-    if (SAVE == 2) save_tile_lp_wave8<BF, 32, NPT>(x, a.acts + acts_slot_off(P, SLOT_VIEWS_H) * 2, p0, P, nullptr, 32 * wave, lane);
+    // (format code 2 keeps THIS slot 16-bit: the 128-wide views hidden layer is what the dgrad kernel derives the
+    // views ReLU mask from - an activation below e5m2's range must not read as "inactive" - and 256 bytes per
+    // point either way)
+    if (SAVE) save_tile_lp_wave<BF, 32, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
     __syncthreads();
   }
 #undef WLBASE

@@ -191,7 +191,10 @@ __device__ __forceinline__ void save_tile_lp_wave(const typename LP<BF>::T* x, t
 // and the weight gradient converts the rows back to bf16 while staging them into LDS.  What changes numerically
 // is the weight gradient's operands (2 mantissa bits, zero-mean rounding); dgrad and forward are untouched.
 // Layout: the workspaces keep the 16-bit offsets; an 8-bit row p of slot s lies at byte acts_slot_off(P, s) * 2 +
-// p * 256 (the first half of the slot's region).
+// p * 256 (the first half of the slot's region).  Two parts stay 16-bit: the embedding rows (64 columns) and
+// the activation slot of the 128-wide views hidden layer - the dgrad kernel derives that layer's ReLU mask from
+// it, so rounding it could turn a tiny positive activation into "inactive"; with it 16-bit the dgrad chain of
+// format code 2 is the bf16 path's bit for bit (tests/test_gpu_lp.py).
 typedef unsigned lp_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned lp_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned lp_pack4_bf8(float a, float b, float c, float d) {

@@ -21,12 +21,20 @@ KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-siz
     (r"train_loss_bwd_kernel", "train_loss_bwd"),
     (r"mlp_fwd_f16_kernel<1, false>", "mlp_fwd_f16_kernel"), (r"mlp_fwd_f16_kernel<1, true>", "mlp_fwd_f16_kernel_train"),
     (r"mlp_dgrad_f16_kernel", "mlp_dgrad_f16_kernel"), (r"mlp_wgrad_f16_kernel", "mlp_wgrad_f16_kernel"),
-    (r"mlp_fwd_lp_kernel<true, 1, false, 4>", "mlp_fwd_lp_kernel_bf16"), (r"mlp_fwd_lp_kernel<false, 1, false, 4>", "mlp_fwd_lp_kernel_f16"),
-    (r"mlp_fwd_lp_kernel<true, 1, true, 4>", "mlp_fwd_lp_kernel_bf16_train"),
-    (r"mlp_fwd_lp_kernel<true, 1, true, 2>", "mlp_fwd_lp_kernel_bf16_train_small"),
-    (r"mlp_dgrad_lp_kernel<true, 4>", "mlp_dgrad_lp_kernel_bf16"), (r"mlp_dgrad_lp_kernel<true, 2>", "mlp_dgrad_lp_kernel_bf16_small"),
-    (r"mlp_wgrad_lp_kernel<true>", "mlp_wgrad_lp_kernel_bf16"),
-    (r"wgrad_reduce4_kernel", "wgrad_reduce4_kernel"),
+    # (round 3: the SAVE template argument of the 16-bit forward is an int - 0 inference, 1 16-bit rows, 2 8-bit rows;
+    # dgrad / wgrad carry an S8 flag; the backward kernels of a train step cover both networks in one launch)
+    (r"mlp_fwd_lp_kernel<true, 1, (false|0), 4>", "mlp_fwd_lp_kernel_bf16"), (r"mlp_fwd_lp_kernel<false, 1, (false|0), 4>", "mlp_fwd_lp_kernel_f16"),
+    (r"mlp_fwd_lp_kernel<true, 1, (true|1), 4>", "mlp_fwd_lp_kernel_bf16_train"),
+    (r"mlp_fwd_lp_kernel<true, 1, (true|1), 2>", "mlp_fwd_lp_kernel_bf16_train_small"),
+    (r"mlp_fwd_lp_kernel<true, 1, 2, 4>", "mlp_fwd_lp_kernel_bf16_s8_train"),
+    (r"mlp_fwd_lp_kernel<true, 1, 2, 2>", "mlp_fwd_lp_kernel_bf16_s8_train_small"),
+    (r"mlp_dgrad_lp_kernel<true, 4(, false)?>", "mlp_dgrad_lp_kernel_bf16"), (r"mlp_dgrad_lp_kernel<true, 2(, false)?>", "mlp_dgrad_lp_kernel_bf16_small"),
+    (r"mlp_dgrad_lp_kernel<true, 4, true>", "mlp_dgrad_lp_kernel_bf16_s8"), (r"mlp_dgrad_lp_kernel<true, 2, true>", "mlp_dgrad_lp_kernel_bf16_s8_small"),
+    (r"mlp_wgrad_lp_kernel<true(, false)?>", "mlp_wgrad_lp_kernel_bf16"), (r"mlp_wgrad_lp_kernel<true, true>", "mlp_wgrad_lp_kernel_bf16_s8"),
+    (r"wgrad_reduce4_kernel", "wgrad_reduce4_kernel"), (r"wgrad2_reduce_pair_kernel", "wgrad2_reduce_pair_kernel"),
+    (r"wgrad_lp_reduce_pair_kernel", "wgrad_lp_reduce_pair_kernel"),
+    (r"mlp_pack_step_kernel<0>", "mlp_pack_step_f32"), (r"mlp_pack_step_kernel<1>", "mlp_pack_step_bf16"),
+    (r"adam_step2_kernel", "adam_step2_kernel"), (r"ray_points_kernel", "ray_points_kernel"),
 ]
 
 

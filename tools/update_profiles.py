@@ -72,12 +72,12 @@ notes = {
                       f"launches vs HIP events {dr['roofline']['avg_launch_ms']:.4f} ms over the timed ones in the same run; "
                       f"{dr['roofline']['frac']:.3f} of the 157.3 TFLOP/s peak by timing",
     "mlp_fwd_kernel_train": "exact training forward (fp32 activation rows + one 32-bit ReLU word per lane, layer and point tile written)",
-    "mlp_dgrad_kernel": "dZ rows written",
+    "mlp_dgrad_kernel": "dZ rows written; round 3: one launch walks the tiles of BOTH networks of a step",
     "mlp_fwd_kernel_train_small": "32-point workgroups (the 128-ray launches of the graph region)",
     "mlp_dgrad_kernel_small": "32-point workgroups",
     "mlp_wgrad_kernel": "dZ and activations streamed once per layer; includes the low-MFMA embedding and rgb-head jobs",
-    "mlp_wgrad2_kernel": "round-2 weight gradient: half-layer workgroups, two per CU, point-major tiles by LDS-DMA into a 3-slot ring, output rows permuted (no transposition); "
-                         "the mean includes the 128-ray launches (one or two short workgroups per CU)",
+    "mlp_wgrad2_kernel": "exact weight gradient: half-layer workgroups, two per CU, point-major tiles by LDS-DMA into a 3-slot ring, output rows permuted (no transposition); "
+                         "round 3: ONE launch covers both networks of a step; the mean includes the 128-ray launches",
     "wgrad_reduce4_kernel": "sums the per-chunk partials",
     "mlp_fwd_f16_kernel": "opt-in f16x3 render kernel (3 f16 MFMAs per fp32-class product)",
     "mlp_fwd_f16_kernel_train": "f16x3 training forward, bound by the fp32 activation rows it writes",
@@ -86,8 +86,16 @@ notes = {
     "mlp_fwd_lp_kernel_bf16": "opt-in bf16 render kernel (config 5); round 2: the epilogue trades chunk halves between lane r and "
                               "r + 32 (v_permlane32_swap) and stores conflict-free ds_write_b128 (was 26.4 % conflict cycles)",
     "mlp_fwd_lp_kernel_f16": "same kernel, fp16 operands",
-    "mlp_fwd_lp_kernel_bf16_train": "bf16 training forward: 16-bit activation rows",
-    "mlp_dgrad_lp_kernel_bf16": "16-bit dZ rows",
+    "mlp_fwd_lp_kernel_bf16_train": "bf16 training forward: 16-bit activation rows; round 3: conflict-free lane map of the tile copies",
+    "mlp_dgrad_lp_kernel_bf16": "16-bit dZ rows, both networks in one launch; round 3: epilogue halves traded with v_permlane32_swap + ds_write_b128 (was 30.1 % conflict cycles)",
+    "mlp_fwd_lp_kernel_bf16_s8_train": "round 3, format code 2: the bf16 training forward saving 8-bit e5m2 rows",
+    "mlp_dgrad_lp_kernel_bf16_s8": "format code 2: 8-bit e5m2 dZ rows under the launch-wide loss scale",
+    "mlp_wgrad_lp_kernel_bf16_s8": "format code 2: rows converted back to bf16 while staging into LDS",
+    "wgrad2_reduce_pair_kernel": "sums the per-chunk partials of both networks",
+    "wgrad_lp_reduce_pair_kernel": "sums the per-chunk partials of both networks (16-bit path)",
+    "mlp_pack_step_f32": "round 3: the four weight packs of a step (both networks, forward + transposed layout) in one launch",
+    "mlp_pack_step_bf16": "the same for the 16-bit kernels (incl. the NaN census of the fp32 parameters)",
+    "adam_step2_kernel": "round 3: both optimizers (networks; depth scale / shift) in one update launch",
     "mlp_fwd_lp_kernel_bf16_train_small": "64-point workgroups (128-ray launches)",
     "mlp_dgrad_lp_kernel_bf16_small": "64-point workgroups",
     "mlp_wgrad_lp_kernel_bf16": "HBM-bound by design (1 KB per point-layer); 16-bit rows + fp32 partials",
