@@ -295,6 +295,17 @@ int scade_train_loss_bwd(const float* rgb, const float* rgb0, const float* targe
                          float carve_weight, float threshold, float out_scale, int N, int P, int K,
                          float* workspace, const float* g_loss, float* g_rgb, float* g_rgb0, float* g_pred,
                          float* g_scales, float* g_shifts, void* stream);
+/* Forward AND backward of that loss in ONE pair of launches, for callers that differentiate the total with a
+ * UNIT gradient (a train step does; nothing in the backward depends on the reduced loss value): the arguments of
+ * scade_train_loss_fwd + the gradient outputs of scade_train_loss_bwd; workspace [8 N] floats.  n_ss > 0: g_scales /
+ * g_shifts [n_ss] are WRITTEN (zero but for the batch's image - the caller needs no zero fill of those rows);
+ * n_ss = 0: the batch's image row is accumulated into, as scade_train_loss_bwd does. */
+int scade_train_loss_fb(const float* rgb, const float* rgb0, const float* target, const float* pred,
+                        const float* hyp, const float* scales, const float* shifts,
+                        const long long* img_i_dev, int img_i, const float* mask, int mse_masked, int carve_on,
+                        float carve_weight, float threshold, float out_scale, int N, int P, int K,
+                        float* workspace, float* loss4, float* g_rgb, float* g_rgb0, float* g_pred,
+                        float* g_scales, float* g_shifts, int n_ss, void* stream);
 
 /* ---- ray generation + training-batch gather (helpers:285-305 get_ray_dirs/get_rays; the ray
  *      rows of render()/render_hyp(), run_scade_scannet.py:122-141; the gathers of

@@ -77,6 +77,8 @@ SIGNATURES = {
                                      _I, _I, _I, _P, _P, _P]),
     "scade_train_loss_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, c_float, c_float, c_float,
                                      _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "scade_train_loss_fb": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, c_float, c_float, c_float,
+                                    _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "scade_gen_rays": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P,
                                 _P, _P, _P, _P]),
     "scade_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, _I, c_float, _P]),

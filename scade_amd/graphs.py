@@ -68,12 +68,15 @@ class GraphedTrainer:
 
     def _body(self):
         tr = self.tr
-        tr.bucket.begin_step()
+        tr.begin()
         kw = {}
         if self.draws is not None:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
         loss, aux = tr.forward_loss(self.rays, self.tgt, self.hyp, img_i=self.img_i, mask=self.mask,
                                     n_total=self.n_total, **kw)
+        if tr._unit_loss_ready:
+            tr._unit_loss_ready = False
+            tr.flat_ss.grad.zero_()
         tr.backward(loss)
         tr.bucket.end_backward()
         tr.reduce_grads()

@@ -915,6 +915,67 @@ class TrainLossFn(torch.autograd.Function):
                 None, None, None, None, None, None, None)
 
 
+class TrainLossUnitFn(torch.autograd.Function):
+    """TrainLossFn with forward AND backward in ONE pair of launches (scade_train_loss_fb) for the train step,
+    which differentiates the total with a unit gradient: the gradients w.r.t. rgb / rgb0 / pred are computed while
+    the loss terms are, the scale / shift rows of the gradient bucket are WRITTEN by the reduce (all n_images rows:
+    no zero fill of them needed), and backward() only hands the saved tensors out.  ``unit`` is the tensor the
+    caller passes to ``backward(gradient=unit)``: any other incoming gradient raises (it would need the scale /
+    shift rows re-done).  Same arithmetic as TrainLossFn."""
+
+    @staticmethod
+    def forward(ctx, rgb, rgb0, target, pred, hyp, scales, shifts, img_i, mask, mse_masked, carve_on,
+                carve_weight, threshold, out_scale, unit):
+        for t, w in ((rgb, "rgb"), (rgb0, "rgb0"), (target, "target"), (pred, "pred_hyp"), (hyp, "hypotheses")):
+            check(t, "train_loss: " + w)
+        N, P = pred.shape
+        K = hyp.shape[0]
+        if tuple(hyp.shape[1:]) not in ((N,), (N, 1)):
+            raise ValueError(f"train_loss: hypotheses must be [K,{N},1], got {tuple(hyp.shape)}")
+        if tuple(rgb.shape) != (N, 3) or tuple(rgb0.shape) != (N, 3) or tuple(target.shape) != (N, 3):
+            raise ValueError("train_loss: rgb, rgb0 and target must be [N,3]")
+        gs, gh = scales.grad, shifts.grad
+        ok = lambda g, p: g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.numel() == p.numel()
+        if not (ok(gs, scales) and ok(gh, shifts)):
+            raise RuntimeError("train_loss (unit-gradient form): scales / shifts need contiguous fp32 .grad buffers "
+                               "(the Trainer's gradient bucket)")
+        rgb_c, rgb0_c, tgt_c, pred_c, hyp_c = _c(rgb), _c(rgb0), _c(target), _c(pred), _c(hyp.reshape(K, N))
+        sc, sh = _c(scales.detach().reshape(-1)), _c(shifts.detach().reshape(-1))
+        mask_c = None if mask is None else _c(check(mask, "train_loss: mask").reshape(N))
+        idx_t = None
+        if torch.is_tensor(img_i):
+            if img_i.dtype != torch.int64 or img_i.device != pred.device or img_i.numel() != 1:
+                raise TypeError(f"train_loss: a tensor img_i must be ONE int64 on {pred.device}, got "
+                                f"{img_i.dtype} x {img_i.numel()} on {img_i.device}")
+            idx_t = _c(img_i.reshape(1))
+        idx = sc.numel() if idx_t is not None else int(img_i)
+        if idx_t is None and not 0 <= idx < sc.numel():
+            raise IndexError(f"train_loss: img_i {idx} outside [0, {sc.numel()})")
+        dev = pred.device
+        ws = torch.empty(8 * N, device=dev, dtype=torch.float32)
+        loss4 = torch.empty(4, device=dev, dtype=torch.float32)
+        g_rgb, g_rgb0, g_pred = torch.empty_like(rgb_c), torch.empty_like(rgb0_c), torch.empty_like(pred_c)
+        call("scade_train_loss_fb", ptr(rgb_c), ptr(rgb0_c), ptr(tgt_c), ptr(pred_c), ptr(hyp_c), ptr(sc), ptr(sh),
+             ptr(idx_t), idx, ptr(mask_c), int(bool(mse_masked)), int(bool(carve_on)), float(carve_weight),
+             float(threshold), float(out_scale), N, P, K, ptr(ws), ptr(loss4), ptr(g_rgb), ptr(g_rgb0), ptr(g_pred),
+             ptr(gs), ptr(gh), sc.numel(), stream())
+        ctx.save_for_backward(g_rgb, g_rgb0, g_pred)
+        ctx.unit_ptr = unit.data_ptr()
+        comps = loss4[1:]
+        ctx.mark_non_differentiable(comps)
+        ctx.set_materialize_grads(False)
+        return loss4[0], comps
+
+    @staticmethod
+    def backward(ctx, g, _unused):
+        if g is None or g.data_ptr() != ctx.unit_ptr:
+            raise RuntimeError("train_loss (unit-gradient form): backward() must be called with the unit tensor "
+                               "given to the forward (Trainer.backward does); use ops.TrainLossFn otherwise")
+        g_rgb, g_rgb0, g_pred = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        return (g_rgb if need[0] else None, g_rgb0 if need[1] else None, None, g_pred if need[3] else None) + (None,) * 11
+
+
 class MseFn(torch.autograd.Function):
     """img2mse (helpers:11), optional per-row mask (run_scade_wild.py:978-986)."""
 

@@ -79,13 +79,18 @@ class FlatParams:
             if ok:
                 self._sinks.append((net, o0))
 
-    def begin_step(self):
+    def begin_step(self, zero_outside_sinks: bool = True):
         """Start of a train step, instead of ``zero_grad()``: a network with a gradient sink gets its
         gradient WRITTEN into the sink by the first fused backward of the step (ops.mlp_bwd*(out=sink)), so
-        only what lies outside the sinks is zero-filled here.  ``end_backward()`` zero-fills the sink of a
+        only what lies outside the sinks is zero-filled here (``zero_outside_sinks=False``: not even that - the
+        caller's loss operator writes those rows itself).  ``end_backward()`` zero-fills the sink of a
         network whose backward did not run this step."""
         if not self._sinks:
             return self.zero_grad()
+        if not zero_outside_sinks:
+            for net, _ in self._sinks:
+                net._sink_fresh = True
+            return
         from . import ops
         pos = 0
         for net, o0 in sorted(self._sinks, key=lambda t: t[1]):

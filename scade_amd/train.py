@@ -106,6 +106,9 @@ class Trainer:
         # The Philox key comes from torch's seed of this process (parallel.seed_rank_streams gives every rank its
         # own), the counter from the step index: reproducible under torch.manual_seed like the torch.rand path.
         self.joint_pack = os.environ.get("SCADE_JOINT_PACK", "1") != "0"
+        # loss forward + backward as one launch pair when the step is driven by begin() / backward() below
+        self.unit_loss = os.environ.get("SCADE_UNIT_LOSS", "1") != "0"
+        self._unit_loss_ready = False
         self.draw_in_kernel = os.environ.get("SCADE_DRAW_IN_KERNEL", "1") != "0"
         self.draw_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5CADE) & (2 ** 64 - 1)
         self.draw_step_dev = None           # GraphedTrainer: the fused optimizer's device-resident step count
@@ -164,10 +167,16 @@ class Trainer:
         if self.fused_loss and not c["joint"] and hyp_per_ray:
             # the whole loss (affine map of the hypotheses :954, both photometric terms, the carving term,
             # their sum :968-983, this rank's share) in one forward / one backward entry
-            loss, comps = ops.TrainLossFn.apply(
-                ret["rgb_map"], ret["rgb0"], target_s, ret["pred_hyp"], target_hyp, self.depth_scales,
-                self.depth_shifts, img_i, mask, c["mask_mode"] == "wild", self.carving_active(), c["w"], c["thr"],
-                share)
+            largs = (ret["rgb_map"], ret["rgb0"], target_s, ret["pred_hyp"], target_hyp, self.depth_scales,
+                     self.depth_shifts, img_i, mask, c["mask_mode"] == "wild", self.carving_active(), c["w"], c["thr"],
+                     share)
+            if self._unit_loss_ready and torch.is_grad_enabled():
+                # Trainer.step / GraphedTrainer: loss forward + backward as one launch pair (the scale / shift
+                # rows of the bucket are written by it: begin_step() left them alone)
+                self._unit_loss_ready = False
+                loss, comps = ops.TrainLossUnitFn.apply(*largs, self._one)
+            else:
+                loss, comps = ops.TrainLossFn.apply(*largs)
             return loss, dict(img_loss=comps[0], carve=comps[1] if self.carving_active() else None,
                               img_loss0=comps[2], ret=ret, share=share, loss_report=loss.detach())
         if torch.is_tensor(img_i):
@@ -220,6 +229,15 @@ class Trainer:
         else:
             self.bucket.allreduce_grads(force=self.force_allreduce)
 
+    def begin(self):
+        """Start of a step driven through forward_loss() / backward(): gradient sinks armed (FlatParams.begin_step)
+        and - when the fused three-term loss will run in its unit-gradient form, which WRITES the scale / shift
+        gradient rows - without the zero fill of those rows."""
+        c = self.cfg
+        unit = self.unit_loss and self.fused_loss and not c["joint"]
+        self.bucket.begin_step(zero_outside_sinks=not unit)
+        self._unit_loss_ready = unit
+
     def backward(self, loss):
         """loss.backward() (:985) with the two networks' MLP backwards joined into one launch sequence."""
         if self.joint_backward:
@@ -232,8 +250,11 @@ class Trainer:
     def step(self, rays, target_s, target_hyp, img_i=0, mask=None, n_total=None, **render_kw):
         """One optimisation step on this rank's shard; returns (this rank's term of the global loss,
         aux).  ``n_total``: rays of the whole batch when the shards are uneven."""
-        self.bucket.begin_step()
+        self.begin()
         loss, aux = self.forward_loss(rays, target_s, target_hyp, img_i, mask, n_total, **render_kw)
+        if self._unit_loss_ready:        # the loss took another form (cached-quantile hypotheses): zero the rows now
+            self._unit_loss_ready = False
+            self.flat_ss.grad.zero_()
         self.backward(loss)                                                                   # :985
         self.bucket.end_backward()
         self.reduce_grads()

@@ -762,3 +762,55 @@ def test_one_launch_pack_of_both_networks_writes_the_same_blobs(dev, fmt):
     ps = fine.ordered_params()
     ref = ops.mlp_pack(ps) if fmt == "f32" else ops.mlp_pack_lp(ps, bf)
     assert torch.equal((fine._packed if fmt == "f32" else fine._packed_lp).view(torch.uint8), ref.view(torch.uint8))
+
+
+@pytest.mark.parametrize("variant", ["plain", "wild_mask_thr", "warm_start", "dev_index"])
+def test_unit_gradient_loss_form_equals_the_two_entry_form(dev, variant, monkeypatch):
+    """Trainer.step runs the three-term loss forward AND backward as one launch pair (ops.TrainLossUnitFn,
+    scade_train_loss_fb: the step differentiates the total with a unit gradient) and lets its reduce WRITE all
+    scale / shift gradient rows instead of zero-filling them first.  Against the forward / backward entry pair
+    (SCADE_UNIT_LOSS=0): same loss, bit-identical gradient bucket - stale contents of the scale / shift rows
+    included - and bit-identical parameters after three steps.  Any other incoming gradient is refused."""
+    from scade_amd import ops
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K = 80, 12
+    rays = O.synthetic_rays(N, seed=41).to(dev)
+    g = torch.Generator().manual_seed(42)
+    tgt = torch.rand(N, 3, generator=g).to(dev)
+    hyp = (torch.rand(K, N, 1, generator=g) * 4.9 + 0.1).to(dev)
+    mask = (torch.rand(N, generator=g) > 0.3).float().to(dev) if "mask" in variant else None
+    draws = [dict(t_rand=torch.rand(N, 64, generator=g).to(dev), u_coarse=torch.rand(N, 128, generator=g).to(dev),
+                  cached_u=torch.rand(N, 128, generator=g).to(dev)) for _ in range(3)]
+    kw = {"plain": {}, "wild_mask_thr": dict(mask_mode="wild", space_carving_threshold=0.05),
+          "warm_start": dict(warm_start_nerf=2), "dev_index": {}}[variant]
+    res = {}
+    for unit in ("1", "0"):
+        monkeypatch.setenv("SCADE_UNIT_LOSS", unit)
+        coarse, fine = make_scade_nets(dev, seed=9)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3, scaleshift_lr=1e-3, **kw)
+        assert tr.unit_loss == (unit == "1")
+        tr.bucket.grad.fill_(5.0)                     # stale gradient rows everywhere
+        losses, grads = [], []
+        for i, d in enumerate(draws):
+            img = torch.tensor([i % 3], device=dev) if variant == "dev_index" else i % 3
+            loss, aux = tr.step(rays, tgt, hyp, img_i=img, mask=mask, **d)
+            losses.append(float(loss))
+            grads.append(tr.bucket.grad.clone())
+        torch.cuda.synchronize()
+        res[unit] = (losses, grads, tr.bucket.data.clone())
+    assert res["1"][0] == res["0"][0]
+    for a, b in zip(res["1"][1], res["0"][1]):
+        assert torch.equal(a, b)
+    assert torch.equal(res["1"][2], res["0"][2])
+    n = 2 * 589700
+    ss = res["1"][1][-1][n:]
+    if variant != "warm_start":
+        assert float(ss.abs().sum()) > 0 and float(ss[[0, 1, 3, 4]].abs().sum()) == 0.0, "step 3 touches image 2 only"
+    # a non-unit incoming gradient cannot be served by the unit form
+    monkeypatch.setenv("SCADE_UNIT_LOSS", "1")
+    coarse, fine = make_scade_nets(dev, seed=9)
+    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3)
+    tr.begin()
+    loss, _ = tr.forward_loss(rays, tgt, hyp, **draws[0])
+    with pytest.raises(RuntimeError):
+        (loss * 2.0).backward()
