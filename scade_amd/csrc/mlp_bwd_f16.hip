@@ -58,13 +58,17 @@ __global__ void mlp_pack_t_f16_kernel(PackTF16Args a) {
       a.packed[off_wt16(NLAYER_DGRAD) + i] = (_Float16)0.f;
 }
 
+__global__ void zero_word_kernel(unsigned int* w) {
+  if (threadIdx.x == 0) *w = 0u;
+}
+
 struct MlpDgradF16Args {
   const float* packed;       // fp32 forward pack (rgb / alpha head weights)
   const _Float16* packedT;   // transposed two-plane pack
   const float* acts;
   const float* g_out;        // [P,4]
   float* dz;                 // dz_floats(P)
-  unsigned int* gmax;        // launch-wide max of |g_out| (float bits; zeroed before the launch)
+  unsigned int* gmax;        // launch-wide max of |g_out| (float bits; zeroed by zero_word_kernel before the launch)
   int P;
 };
 
@@ -548,8 +552,11 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   // workspace tail: [dz | partial | gmax]
   const int nchunks = pick_chunks(P);
   unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)nchunks * N_PARAM_FLOATS);
-  hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
-  SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_f16: hipMemsetAsync: %s", hipGetErrorString(me));
+  // a one-thread KERNEL, not hipMemsetAsync: inside a captured train step that is a memset node, and memset
+  // nodes of back-to-back graph replays are not ordered against their neighbouring kernels on this ROCm (the
+  // dgrad workgroups' atomicMax raced the reset: see lp_gmax_kernel in mlp_bwd_lp.hip)
+  hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(64), 0, s, gmax);
+  if (int e = scade_check_launch("scade_mlp_bwd_f16(zero)")) return e;
   MlpDgradF16Args d{packed, reinterpret_cast<const _Float16*>(packed_t_f16), acts, g_out, dz, gmax, P};
   hipLaunchKernelGGL(mlp_dgrad_f16_kernel, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(dgrad)")) return e;

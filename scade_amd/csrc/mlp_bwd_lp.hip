@@ -30,14 +30,22 @@ template <bool BF>
 __global__ void mlp_pack_t_lp_kernel(PackTLpArgs a) { pack_t_lp_row<BF>(a.p, a.packed, blockIdx.y, blockIdx.x, gridDim.x); }
 
 // ---------------------------------------------------------------------------
-// G: launch-wide max |g_out| (finite values only) -> gmax (float bits, zeroed before the launch)
+// G: launch-wide max |g_out| (finite values only) -> LP_GMAX_SLOTS per-workgroup maxima; every consumer
+// workgroup takes the max of the slots itself (lp_read_gmax, one 16-byte load per lane + a wave max).
+// No atomic and nothing to zero first: the former form (hipMemsetAsync of one word + atomicMax) put a MEMSET
+// NODE into the captured train step, and memset nodes of back-to-back graph replays are not ordered against
+// their neighbouring kernels on this ROCm - a replay queued behind another could read the word before or after
+// its own reset, i.e. take the previous step's maximum or zero (tools/soak_train.py: the fp16 / 8-bit-save
+// precisions stalled at 5x the loss of the others once the host ran far enough ahead).
 // ---------------------------------------------------------------------------
-__global__ void lp_gmax_kernel(const float* __restrict__ g, long n, unsigned int* gmax) {
-  // 16-byte loads (g_out is [P,4]), one atomic per WORKGROUP: the former one-per-wave form spent most
-  // of its 15 us serialising 1500 atomics on one address
-  __shared__ float part[4];
+constexpr int LP_GMAX_SLOTS = 256;          // == the block size of lp_gmax_kernel, >= its grid
+static_assert(N_PARAM_FLOATS % 4 == 0, "the slots sit behind the partial rows and are read as f32x4");
+
+__global__ __launch_bounds__(LP_GMAX_SLOTS) void lp_gmax_kernel(const float* __restrict__ g, long n,
+                                                                float* __restrict__ slots) {
+  __shared__ float part[LP_GMAX_SLOTS / 64];
   float m = 0.f;
-  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);
+  const f32x4* g4 = reinterpret_cast<const f32x4*>(g);        // 16-byte loads (g_out is [P,4])
   for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (long)gridDim.x * blockDim.x) {
     const f32x4 v = g4[i];
 #pragma unroll
@@ -50,10 +58,18 @@ __global__ void lp_gmax_kernel(const float* __restrict__ g, long n, unsigned int
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    m = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-    if (m > 0.f) atomicMax(gmax, __float_as_uint(m));
-  }
+  if (threadIdx.x == 0) slots[blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+  // the slots no workgroup of this grid owns
+  if (blockIdx.x == 0 && threadIdx.x >= gridDim.x) slots[threadIdx.x] = 0.f;
+}
+
+// max of the slots, wave-uniform (every wave of a consumer reads the 1 KB itself: an L2 hit, no LDS, no barrier)
+__device__ __forceinline__ float lp_read_gmax(const float* __restrict__ slots) {
+  const f32x4 v = reinterpret_cast<const f32x4*>(slots)[threadIdx.x & 63];
+  float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+  return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(m)));
 }
 
 // loss scale: max|g_out| * S in [2^5, 2^6)  (dZ entries can exceed max|g_out| by the layer gains;
@@ -175,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   const u32x4* __restrict__ masks = reinterpret_cast<const u32x4*>(a.acts + lp_acts_mask_byte(P));
   // bf16 carries fp32's exponent range: the launch-wide loss scale (and the two launches that find it) is an
   // fp16 matter; a power-of-two scale commutes with every rounding here, so S = 1 gives the same bits
-  const float S = (BF && !S8) ? 1.f : lp_loss_scale(a.gmax[0]);
+  const float S = (BF && !S8) ? 1.f : lp_loss_scale(lp_read_gmax(a.gmax));
   unsigned char* __restrict__ dz8 = a.dz;
   const unsigned char* __restrict__ acts8 = a.acts;
 
@@ -807,7 +823,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
   const int c0 = bx * aa.chunk;
   const int c1 = min(a.P, c0 + aa.chunk);
   float* out = a.partial + (size_t)bx * N_PARAM_FLOATS;
-  const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(a.gmax[0]);
+  const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(lp_read_gmax(a.gmax));
   if (jb.flags & WF_RGB) {
     wgrad_rgb_lp_job<BF, false>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);   // (its input slot is 16-bit in every format)
   } else if (S8) {
@@ -890,7 +906,7 @@ using namespace scade;
 extern "C" long scade_mlp_packed_t_lp_bytes(void) { return PACKED_T_LP_BYTES; }
 
 extern "C" long scade_mlp_bwd_lp_workspace_bytes(int P) {
-  return lp_dz_bytes(P) + (long)pick_chunks(P, LP_CHUNK_PTS) * N_PARAM_FLOATS * 4 + 256;
+  return lp_dz_bytes(P) + (long)pick_chunks(P, LP_CHUNK_PTS) * N_PARAM_FLOATS * 4 + LP_GMAX_SLOTS * 4;
 }
 
 extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp, int bf16, void* stream) {
@@ -926,12 +942,11 @@ static int lp_bwd_set_attr() {
 
 // the launch-wide loss scale (fp16 rows, and the 8-bit rows of format code 2; plain bf16 uses S = 1 and never
 // reads gmax)
-static int lp_launch_gmax(const float* g_out, int P, unsigned int* gmax, hipStream_t s) {
-  hipError_t me = hipMemsetAsync(gmax, 0, sizeof(unsigned int), s);
-  SCADE_REQUIRE(me == hipSuccess, (int)me, "scade_mlp_bwd_lp: hipMemsetAsync: %s", hipGetErrorString(me));
+static int lp_launch_gmax(const float* g_out, int P, float* gmax, hipStream_t s) {
   const long ng = 4L * P;
-  const int gblocks = (int)((ng + 256 * 16 - 1) / (256 * 16) < 256 ? (ng + 256 * 16 - 1) / (256 * 16) : 256);   // ng = 4 P
-  hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(256), 0, s, g_out, ng, gmax);
+  const long want = (ng + LP_GMAX_SLOTS * 16 - 1) / (LP_GMAX_SLOTS * 16);       // 16 values per thread
+  const int gblocks = (int)(want < LP_GMAX_SLOTS ? want : LP_GMAX_SLOTS);
+  hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(LP_GMAX_SLOTS), 0, s, g_out, ng, gmax);
   return scade_check_launch("scade_mlp_bwd_lp(gmax)");
 }
 
@@ -942,14 +957,14 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   unsigned char* dz = ws;
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
   const int nchunks = pick_chunks(P, LP_CHUNK_PTS);
-  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)nchunks * N_PARAM_FLOATS);
+  float* gmax = partial + (size_t)nchunks * N_PARAM_FLOATS;
   if (!BF || S8) {
     if (int e = lp_launch_gmax(g_out, P, gmax, s)) return e;
   }
   // same point tiling as the forward that wrote the sign words of this workspace
   const int npt = lp_pick_point_tiles(P);
   const int tiles = (P + 32 * npt - 1) / (32 * npt);
-  MlpDgradLpArgs2 d{{{packed, packed_t, acts, g_out, dz, reinterpret_cast<const float*>(gmax), P}, {}}, tiles, 0};
+  MlpDgradLpArgs2 d{{{packed, packed_t, acts, g_out, dz, gmax, P}, {}}, tiles, 0};
   if (npt == 2)
     hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2, S8>), dim3(tiles), dim3(256), dgrad_lp_lds_bytes(2), s, d);
   else
@@ -957,7 +972,7 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   if (int e = scade_check_launch("scade_mlp_bwd_lp(dgrad)")) return e;
   WgradLpArgs w{};
   build_wgrad_lp_jobs(w);
-  w.net[0] = WgradLpNet{acts, dz, g_out, partial, reinterpret_cast<const float*>(gmax), P};
+  w.net[0] = WgradLpNet{acts, dz, g_out, partial, gmax, P};
   w.chunk = lp_chunk_len(P, nchunks);
   const int grid_x = (P + w.chunk - 1) / w.chunk;
   w.gx0 = grid_x;
@@ -986,12 +1001,12 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
     unsigned char* ws = reinterpret_cast<unsigned char*>(wsv[i]);
     const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts[i]);
     partial[i] = reinterpret_cast<float*>(ws + lp_dz_bytes(P[i]));
-    unsigned int* gmax = reinterpret_cast<unsigned int*>(partial[i] + (size_t)(i == 0 ? gx0 : gx1) * N_PARAM_FLOATS);
+    float* gmax = partial[i] + (size_t)(i == 0 ? gx0 : gx1) * N_PARAM_FLOATS;
     if (!BF || S8) {
       if (int e = lp_launch_gmax(g_out[i], P[i], gmax, s)) return e;
     }
-    d.n[i] = MlpDgradLpArgs{nullptr, packed_t[i], ac, g_out[i], ws, reinterpret_cast<const float*>(gmax), P[i]};
-    w.net[i] = WgradLpNet{ac, ws, g_out[i], partial[i], reinterpret_cast<const float*>(gmax), P[i]};
+    d.n[i] = MlpDgradLpArgs{nullptr, packed_t[i], ac, g_out[i], ws, gmax, P[i]};
+    w.net[i] = WgradLpNet{ac, ws, g_out[i], partial[i], gmax, P[i]};
   }
   d.tiles0 = (P[0] + 32 * npt - 1) / (32 * npt);
   d.tiles1 = (P[1] + 32 * npt - 1) / (32 * npt);
@@ -1016,7 +1031,7 @@ extern "C" int scade_mlp_lp_point_tiles(int P) { return lp_pick_point_tiles(P); 
 extern "C" long scade_mlp_bwd_lp2_workspace_bytes(int P, int P_other) {
   int Ps[2] = {P, P_other}, chunk, gx0, gx1;
   lp_joint_chunking(Ps, chunk, gx0, gx1);
-  const long joint = lp_dz_bytes(P) + (long)gx0 * N_PARAM_FLOATS * 4 + 256;
+  const long joint = lp_dz_bytes(P) + (long)gx0 * N_PARAM_FLOATS * 4 + LP_GMAX_SLOTS * 4;
   const long alone = scade_mlp_bwd_lp_workspace_bytes(P);
   return joint > alone ? joint : alone;
 }

@@ -518,6 +518,41 @@ def test_graphed_trainer_matches_eager(dev):
     assert res["graph"][5] == 4, "scale/shift optimizer stops at the freeze point i < freeze_ss (:996)"
 
 
+@pytest.mark.parametrize("precision", ["f16", "f16x3", "bf16-s8", "bf16"])
+def test_graph_replays_queued_back_to_back_equal_eager_bitwise(dev, precision):
+    """400 graph replays queued without a host synchronisation in between leave the parameters bit-for-bit where
+    400 eager steps leave them (in-kernel draws: both runs see the same Philox stream).  Guards the loss scale of
+    the fp16 / 8-bit-save formats: its launch-wide max|g_out| word was reset by hipMemsetAsync, which a capture
+    turns into a memset NODE - and those are not ordered against the neighbouring kernels when replays queue up
+    (a replay took the previous step's maximum, or none; tools/soak_train.py stalled at 5x the loss)."""
+    from scade_amd.graphs import GraphedTrainer
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K, steps = 256, 10, 400
+    pool = O.synthetic_rays(2048, seed=81).to(dev)
+    g = torch.Generator(device=dev).manual_seed(82)
+    tgt_all = torch.rand(2048, 3, device=dev, generator=g)
+    dep_all = torch.rand(2048, device=dev, generator=g) * 3 + 1
+    res = {}
+    for mode in ("eager", "graph"):
+        coarse, fine = make_scade_nets(dev, seed=5)
+        torch.manual_seed(11)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
+        tr.draw_in_kernel = True
+        gt = GraphedTrainer(tr, N, K) if mode == "graph" else None
+        gb = torch.Generator(device=dev).manual_seed(83)
+        for it in range(steps):
+            idx = torch.randint(0, 2048, (N,), device=dev, generator=gb)
+            hyp = (dep_all[idx][None, :, None] + 0.3 * torch.randn(K, N, 1, device=dev, generator=gb)).clamp(0.1, 5.0)
+            if gt is not None:
+                gt.step(pool[idx], tgt_all[idx], hyp)
+            else:
+                tr.step(pool[idx], tgt_all[idx], hyp)
+        torch.cuda.synchronize()
+        res[mode] = tr.flat.data.clone()
+    assert bool(torch.isfinite(res["graph"]).all())
+    assert torch.equal(res["graph"], res["eager"]), float((res["graph"] - res["eager"]).abs().max())
+
+
 def _rccl_capture_worker(out_path, port):
     """Child process of the test below: a one-rank RCCL group, eager and graph-captured steps in both all-reduce
     modes; the results are on disk BEFORE the group is torn down."""

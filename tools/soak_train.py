@@ -21,6 +21,7 @@ with torch.no_grad():
 tgt_all = t["rgb_map"].clone(); depth_all = t["depth_map"].clone()
 for prec in os.environ.get("SOAK_PRECISIONS", "f32,f16x3,bf16,f16").split(","):
     coarse, fine = make_scade_nets(dev, seed=7)
+    torch.manual_seed(int(os.environ.get("SOAK_DRAW_SEED", "7")))     # the draws' stream (in-kernel key / torch.rand)
     tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=prec)
     gt = GraphedTrainer(tr, N, K)
     g = torch.Generator(device=dev).manual_seed(5)
