@@ -341,21 +341,43 @@ struct WgradLpJob {
 };
 
 // per-network part of a launch (one network, or the coarse and the fine NeRF of a train step: chunks
-// [0, gx0) of grid.x belong to net[0], the rest to net[1])
+// are two runs of entries in the launch's plan, see WgradLpPlan)
 struct WgradLpNet {
   const unsigned char* acts;
   const unsigned char* dz;
   const float* g_out;   // [P,4] (rgb head)
-  float* partial;       // [nchunks][N_PARAM_FLOATS]
+  float* partial;       // [lp_ws_rows()][N_PARAM_FLOATS]: row k = segment k of the job that owns the element
   const float* gmax;
   int P;
+};
+// Balanced persistent launch (round 3).  The work of a launch is the list of (network, job) ENTRIES, each a run of
+// 32-point stages weighted by what a stage of that job costs (bytes per stage: the kernel is bound by the memory
+// system); workgroup w of the NWG = one-per-CU workgroups owns the weighted positions [w W / NWG, (w + 1) W / NWG)
+// of the concatenated list, i.e. a contiguous stage range of one entry and, where it crosses an entry boundary, of
+// the next one or two; the boundaries are laid out on the host so that every workgroup carries the same stage cost
+// PLUS a fixed cost per segment it opens (prologue latency and the partial-row stores: ~16 stages of a 256 x 256
+// job - at 128 rays per GPU that is a third of a workgroup's whole budget).  Against the former grid of (chunk, job) workgroups handed out by the dispatcher: every CU
+// streams the same number of bytes (4.4 part-filled rounds before), and there are NWG + entries segments instead
+// of chunks x jobs workgroups - a third of the fp32 partial rows to write (their stores keep a CU's read stream
+// idle: 15 % of the kernel) and to reduce.  Segment k of an entry writes partial row k (= w - first workgroup of
+// the entry); the reduce kernel sums, per parameter, the rows of the job that owns it.
+constexpr int LP_MAX_ENTRIES = 2 * MAX_WGRAD_JOBS;
+constexpr int LP_MAX_WG = 256;
+struct WgradLpPlan {
+  int cum[LP_MAX_ENTRIES + 1];   // weighted position of entry e = net * njobs + job (cum[n] = W)
+  int bound[LP_MAX_WG + 1];      // workgroup w owns the weighted positions [bound[w], bound[w + 1])
+  short first_wg[LP_MAX_ENTRIES];   // workgroup that owns position cum[e]
+  unsigned char weight[MAX_WGRAD_JOBS];   // cost of one stage of a job
+  int nst[2];                    // stages per network
+  int nwg;
+  int chunk, gx0, gx1;           // chunk > 0: the small-launch grid instead (see lp_build_plan) - workgroup id =
+                                 // job * (gx0 + gx1) + chunk index, chunks [0, gx0) of `chunk` points are net[0]'s
 };
 struct WgradLpArgs {
   WgradLpJob jobs[MAX_WGRAD_JOBS];
   WgradLpNet net[2];
-  int chunk;            // points per chunk (multiple of WL_PT)
+  WgradLpPlan plan;
   int njobs;
-  int gx0;
 };
 
 constexpr int WL_PT = 32;                          // points per stage = two k16 blocks
@@ -363,7 +385,6 @@ constexpr int WL_PITCH = 288;                      // elements per LDS row: 256 
                                                    // rows of a transposing read land 16 banks apart)
 constexpr int WL_TILE = WL_PT * WL_PITCH;          // elements per operand tile
 constexpr int WL_STAGE = 2 * WL_TILE;              // dZ tile + input tile
-constexpr int LP_CHUNK_PTS = 3500;   // mlp_wgrad.h pick_chunks: fewer, longer chunks (fp32 partial traffic)
 constexpr int WGRAD_LP_LDS_BYTES = 3 * WL_STAGE * 2;   // triple buffered: 110592
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -762,32 +783,47 @@ __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpNet& a, const Wgra
   for (int c = 0; c < 3; ++c)
 #pragma unroll
     for (int j = 0; j < 8; ++j) s[c][j] = 0.f;
-  for (int pt0 = c0 + pl; pt0 < c1; pt0 += 128) {
-    V8 h[4];
-    f32x4 g[4];
+  // software-pipelined: the eight loads of the NEXT 128 points are in flight while this thread's four points
+  // are accumulated (one round trip per 128 points left each of these workgroups a straggler of the balanced
+  // launch: the job is pure load latency and runs beside 250 streaming workgroups)
+  struct Set { V8 h[4]; f32x4 g[4]; };
+  auto fetch = [&](Set& st, int pt0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int pt = min(pt0 + 32 * q, P - 1);
       if (S8) {
         const lp_u32x2 w8 = *reinterpret_cast<const lp_u32x2*>(hv8 + (size_t)pt * 256);
         const lp_u32x2 q0 = lp_unpack4_bf8<BF>(w8[0]), q1 = lp_unpack4_bf8<BF>(w8[1]);
-        h[q] = __builtin_bit_cast(V8, lp_u32x4{q0[0], q0[1], q1[0], q1[1]});
+        st.h[q] = __builtin_bit_cast(V8, lp_u32x4{q0[0], q0[1], q1[0], q1[1]});
       } else {
-        h[q] = *reinterpret_cast<const V8*>(hv + (size_t)pt * 256);
+        st.h[q] = *reinterpret_cast<const V8*>(hv + (size_t)pt * 256);
       }
-      g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+      st.g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
     }
+  };
+  auto accumulate = [&](const Set& st, int pt0) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       if (pt0 + 32 * q < c1) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float x = (float)h[q][j];
-          s[0][j] = fmaf(g[q][0], x, s[0][j]); s[1][j] = fmaf(g[q][1], x, s[1][j]);
-          s[2][j] = fmaf(g[q][2], x, s[2][j]);
+          const float x = (float)st.h[q][j];
+          s[0][j] = fmaf(st.g[q][0], x, s[0][j]); s[1][j] = fmaf(st.g[q][1], x, s[1][j]);
+          s[2][j] = fmaf(st.g[q][2], x, s[2][j]);
         }
-        b[0] += g[q][0]; b[1] += g[q][1]; b[2] += g[q][2];
+        b[0] += st.g[q][0]; b[1] += st.g[q][1]; b[2] += st.g[q][2];
       }
+    }
+  };
+  {
+    Set s0, s1;
+    int pt0 = c0 + pl;
+    fetch(s0, pt0);                         // (clamped rows beyond c1 are loaded and never accumulated)
+    for (; pt0 < c1; pt0 += 256) {
+      fetch(s1, pt0 + 128);
+      accumulate(s0, pt0);
+      fetch(s0, pt0 + 256);
+      accumulate(s1, pt0 + 128);
     }
   }
   float* red = lds;                               // [32 point lanes][3][128] + [32][4]
@@ -810,54 +846,175 @@ __device__ __forceinline__ void wgrad_rgb_lp_job(const WgradLpNet& a, const Wgra
   }
 }
 
+#ifdef WL_DBG
+// -DWL_DBG (a variant build: SCADE_AB_FLAGS, scade_amd/build.py): per workgroup {start, stages, entries, end} on the
+// 100 MHz wall clock, read back with scade_debug_wl - how the per-stage weights of lp_job_weights() were measured
+__device__ unsigned long long wl_dbg[4 * 512];
+#endif
 template <bool BF, bool S8 = false>
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
   typedef typename LP<BF>::T T;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsw16[];
-  const bool second = (int)blockIdx.x >= aa.gx0;                  // wave-uniform: scalar selects
-  const WgradLpNet& a = second ? aa.net[1] : aa.net[0];
-  const int bx = (int)blockIdx.x - (second ? aa.gx0 : 0);
-  WgradLpJob jb = aa.jobs[blockIdx.y];
-  jb.dz_off = acts_slot_off(a.P, jb.dz_slot);
-  jb.in_off = jb.in_slot >= 0 ? acts_slot_off(a.P, jb.in_slot) : acts_emb_off(a.P);
-  const int c0 = bx * aa.chunk;
-  const int c1 = min(a.P, c0 + aa.chunk);
-  float* out = a.partial + (size_t)bx * N_PARAM_FLOATS;
-  const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(lp_read_gmax(a.gmax));
-  if (jb.flags & WF_RGB) {
-    wgrad_rgb_lp_job<BF, false>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);   // (its input slot is 16-bit in every format)
-  } else if (S8) {
-    if (jb.kw == 256) wgrad_lp8_job<256>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
-    else wgrad_lp8_job<64>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
-  } else if (jb.kw == 256) {
-    wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
-  } else {
-    wgrad_lp_job<BF, 64>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
+  const WgradLpPlan& pl = aa.plan;
+  const int w = (int)blockIdx.x;
+#ifdef WL_DBG
+  int dbg_k = 1;
+  if (threadIdx.x == 0) { wl_dbg[4 * w] = wall_clock64(); wl_dbg[4 * w + 1] = wl_dbg[4 * w + 2] = 0; }
+#endif
+  const bool grid_mode = pl.chunk > 0;                  // small launches: one (job, chunk) per workgroup
+  const int gx = pl.gx0 + pl.gx1;
+  const int gj = grid_mode ? w / gx : 0, gb = grid_mode ? w - gj * gx : 0;
+  const long b0 = grid_mode ? 0 : pl.bound[w], b1 = grid_mode ? 0 : pl.bound[w + 1];
+  const int e_first = grid_mode ? gj + (gb >= pl.gx0 ? aa.njobs : 0) : 0;
+  const int e_last = grid_mode ? e_first + 1 : 2 * aa.njobs;
+  bool first = true;
+  for (int e = e_first; e < e_last; ++e) {
+    const int ce = pl.cum[e], ce1 = pl.cum[e + 1];
+    if (!grid_mode && (ce1 == ce || (long)ce >= b1 || (long)ce1 <= b0)) continue;      // empty entry / not this workgroup's
+    const bool second = e >= aa.njobs;                                 // wave-uniform: scalar selects
+    const WgradLpNet& a = second ? aa.net[1] : aa.net[0];
+    const int j = e - (second ? aa.njobs : 0);
+    const int wj = pl.weight[j], nst = second ? pl.nst[1] : pl.nst[0];
+    // stage(x) = clamp(floor((x - cum) / weight), 0, nst): the same function on both sides of every boundary
+    const long x0 = b0 - ce, x1 = b1 - ce;
+    const int s0 = x0 <= 0 ? 0 : (int)min((long)nst, x0 / wj);
+    const int s1 = (int)min((long)nst, x1 / wj);
+    WgradLpJob jb = aa.jobs[j];
+    jb.dz_off = acts_slot_off(a.P, jb.dz_slot);
+    jb.in_off = jb.in_slot >= 0 ? acts_slot_off(a.P, jb.in_slot) : acts_emb_off(a.P);
+    const int gc = gb - (second ? pl.gx0 : 0);          // grid mode: chunk index within the network
+    const int c0 = grid_mode ? gc * pl.chunk : s0 * WL_PT;
+    const int c1 = grid_mode ? min(a.P, c0 + pl.chunk)
+                             : min(a.P, max(s1, s0) * WL_PT);       // an empty segment (c1 == c0) still writes its zero row
+    float* out = a.partial + (size_t)(grid_mode ? gc : w - pl.first_wg[e]) * N_PARAM_FLOATS;
+    const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(lp_read_gmax(a.gmax));
+    if (!first) __syncthreads();                        // the previous segment's riders still read the LDS
+    first = false;
+    if (jb.flags & WF_RGB) {
+      wgrad_rgb_lp_job<BF, false>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);   // (its input slot is 16-bit in every format)
+    } else if (S8) {
+      if (jb.kw == 256) wgrad_lp8_job<256>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
+      else wgrad_lp8_job<64>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
+    } else if (jb.kw == 256) {
+      wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
+    } else {
+      wgrad_lp_job<BF, 64>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
+    }
+#ifdef WL_DBG
+    if (threadIdx.x == 0) { wl_dbg[4 * w + 1] += (unsigned long long)((c1 - c0 + 31) / 32); wl_dbg[4 * w + 2] = wl_dbg[4 * w + 2] * 100 + e + 1; }
+    ++dbg_k;
+#endif
   }
+#ifdef WL_DBG
+  if (threadIdx.x == 0) wl_dbg[4 * w + 3] = wall_clock64();
+#endif
+}
+#ifdef WL_DBG
+}  // namespace scade
+extern "C" int scade_debug_wl(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scade::wl_dbg), sizeof(unsigned long long) * 4 * 512);
+}
+namespace scade {
+#endif
+
+// flat-gradient offsets of the parameter tensors as compile-time constants (param_offsets() of mlp_wgrad.h)
+struct LpParamOffsets { int v[N_PARAM_TENSORS + 1]; };
+constexpr LpParamOffsets lp_make_offsets() {
+  LpParamOffsets o{};
+  int at = 0, i = 0;
+  for (int l = 0; l < 8; ++l) {
+    const int k = l == 0 ? 57 : (l == 5 ? 313 : 256);
+    o.v[i++] = at; at += 256 * k;
+    o.v[i++] = at; at += 256;
+  }
+  o.v[i++] = at; at += 128 * 259;
+  o.v[i++] = at; at += 128;
+  o.v[i++] = at; at += 256 * 256;
+  o.v[i++] = at; at += 256;
+  o.v[i++] = at; at += 256;
+  o.v[i++] = at; at += 1;
+  o.v[i++] = at; at += 3 * 128;
+  o.v[i++] = at; at += 3;
+  o.v[i] = at;
+  return o;
+}
+constexpr LpParamOffsets LP_OFF = lp_make_offsets();
+static_assert(LP_OFF.v[N_PARAM_TENSORS] == N_PARAM_FLOATS, "parameter layout");
+
+// job (index into build_wgrad_lp_jobs' table) that writes flat-gradient element x.  The offsets are immediates
+// (an unrolled compare chain): indexed from the kernel arguments every step of the search was a dependent
+// memory load per lane, which doubled the reduce kernel's time.
+__host__ __device__ inline int lp_param_job(int x) {
+  int t = 0;
+#pragma unroll
+  for (int k = 1; k < N_PARAM_TENSORS; ++k) t += x >= LP_OFF.v[k] ? 1 : 0;
+  if (t < 16) {                                   // pts_linears[l]: weight (even t), bias (odd t)
+    const int l = t >> 1;
+    if (l == 0) return 9;                         // the embedding job of layer 0
+    if (t == 10 && (x - LP_OFF.v[10]) % 313 < 57) return 10;   // skip-connection columns: embedding job
+    return l - 1;
+  }
+  if (t == 16) return (x - LP_OFF.v[16]) % 259 < 256 ? 8 : 11;   // views_linears.0: hidden | view-direction columns
+  if (t == 17) return 8;
+  if (t <= 21) return 7;                          // feature_linear + the alpha head riding on its job
+  return 12;                                      // rgb head
 }
 
-// sum of the per-chunk partials of two networks in one launch (blocks [0, WGRAD_REDUCE_BLOCKS) -> network 0);
-// the summation order of wgrad_reduce4_kernel
-struct ReduceLp2Args {
+// sum of the per-segment partial rows: element x of network n = sum over the rows [0, nseg[n][job(x)]) of
+// partial[n]; one float4 per thread (four scalar sums where a float4 straddles two jobs), four accumulators
+struct ReduceLpArgs {
   const float* partial[2];
   float* grad[2];
-  int nchunks[2];
+  unsigned char nseg[2][MAX_WGRAD_JOBS];
+  int uniform[2];      // > 0: every job of the network has this many rows (the small-launch grid): no lookup
 };
-__global__ static void wgrad_lp_reduce_pair_kernel(ReduceLp2Args r) {
+__global__ static void wgrad_lp_reduce_kernel(ReduceLpArgs r) {
   const bool second = blockIdx.x >= WGRAD_REDUCE_BLOCKS;
   const int i = (blockIdx.x - (second ? WGRAD_REDUCE_BLOCKS : 0)) * 256 + threadIdx.x;
   if (i >= N_PARAM_FLOATS / 4) return;
-  const f32x4* p = reinterpret_cast<const f32x4*>(second ? r.partial[1] : r.partial[0]) + i;
-  const int nchunks = second ? r.nchunks[1] : r.nchunks[0];
-  constexpr size_t ST = N_PARAM_FLOATS / 4;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-  int c = 0;
-  for (; c + 4 <= nchunks; c += 4) {
-    s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
-    s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+  const float* part = second ? r.partial[1] : r.partial[0];
+  const unsigned char* nseg = second ? r.nseg[1] : r.nseg[0];
+  const int uni = second ? r.uniform[1] : r.uniform[0];
+  if (uni > 0) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+    constexpr size_t ST = N_PARAM_FLOATS / 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int c = 0;
+    for (; c + 4 <= uni; c += 4) {
+      s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+      s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+    }
+    for (; c < uni; ++c) s0 += p[(size_t)c * ST];
+    reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = (s0 + s1) + (s2 + s3);
+    return;
   }
-  for (; c < nchunks; ++c) s0 += p[(size_t)c * ST];
-  reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = (s0 + s1) + (s2 + s3);
+  int job[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) job[q] = lp_param_job(4 * i + q);
+  f32x4 res;
+  if (job[0] == job[3]) {                          // (jobs own contiguous runs within a tensor row: ends equal = all equal)
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+    constexpr size_t ST = N_PARAM_FLOATS / 4;
+    const int n = nseg[job[0]];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int c = 0;
+    for (; c + 4 <= n; c += 4) {
+      s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+      s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+    }
+    for (; c < n; ++c) s0 += p[(size_t)c * ST];
+    res = (s0 + s1) + (s2 + s3);
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float* p = part + 4 * i + q;
+      const int n = nseg[job[q]];
+      float t = 0.f;
+      for (int c = 0; c < n; ++c) t += p[(size_t)c * N_PARAM_FLOATS];
+      res[q] = t;
+    }
+  }
+  reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = res;
 }
 
 // fills the job table (13 jobs; identical for every network: offsets are slots)
@@ -886,17 +1043,148 @@ static void build_wgrad_lp_jobs(WgradLpArgs& w) {
   add(0, SLOT_VIEWS_H, 256, 0, 0, off[22], 128, 0, 0, 0, off[23], WF_RGB, 0);
   w.njobs = nj;
 }
-// chunk length (multiple of WL_PT) for nchunks chunks over P points
-static int lp_chunk_len(long P, int nchunks) {
-  int chunk = (int)((P + nchunks - 1) / nchunks);
-  return (chunk + WL_PT - 1) / WL_PT * WL_PT;
+// Per-stage cost of the jobs in build_wgrad_lp_jobs' order, in 32nds of a 256 x 256 layer's: MEASURED per
+// workgroup with the kernel's own timestamps (tools/scratch: -DWL_DBG) under the running mix, 1024-ray step -
+// bf16 16 / 16.9 / 13.4 / 10.3 / 9.2 / 9.1 / 3.7 (layer, feature + alpha rider, views, the three embedding-input
+// jobs, rgb head; in 16ths), 8-bit rows 16 / 17.7 / 12.6 / 9.8 / 8.8 / 8.5 / 3.8, fp16 as bf16.  Bytes per stage
+// alone would say 16 / 16 / 16 / 10 / 10 / 10 / 8.  (SCADE_WL_WEIGHTS="l,feat,views,emb0,emb5,embv,rgb" overrides.)
+static const int* lp_job_weights() {
+  static int w[7] = {32, 35, 26, 20, 18, 17, 8};
+  static bool init = false;
+  if (!init) {
+    init = true;
+    if (const char* e = getenv("SCADE_WL_WEIGHTS")) {
+      int v[7];
+      if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == 7)
+        for (int i = 0; i < 7; ++i)
+          if (v[i] >= 1 && v[i] <= 255) w[i] = v[i];
+    }
+  }
+  return w;
 }
-// joint chunking of two networks: one chunk length, the joint chunk count filling whole rounds
-static void lp_joint_chunking(const int* P, int& chunk, int& gx0, int& gx1) {
-  const long Pt = (long)P[0] + P[1];
-  chunk = lp_chunk_len(Pt, pick_chunks((int)Pt, LP_CHUNK_PTS));
-  gx0 = (P[0] + chunk - 1) / chunk;
-  gx1 = (P[1] + chunk - 1) / chunk;
+static int lp_job_weight(int j, bool) {
+  const int* w = lp_job_weights();
+  return j < 7 ? w[0] : w[j - 6];      // jobs 0..6: layers 1..7; 7 feature, 8 views, 9..11 embedding jobs, 12 rgb
+}
+// partial rows a network's workspace holds: no entry is cut into more segments than this (its share of the
+// workgroups, rounded up, plus the two it may share with its neighbours)
+static int lp_rows_bound(bool s8) {
+  WgradLpArgs w{};
+  build_wgrad_lp_jobs(w);
+  int sum = 0, mx = 0;
+  for (int j = 0; j < w.njobs; ++j) {
+    const int v = lp_job_weight(j, s8);
+    sum += v;
+    mx = v > mx ? v : mx;
+  }
+  return (device_cus() * mx + sum - 1) / sum + 6;    // (+ slack: the fixed per-segment costs shorten the segments)
+}
+// rows every workspace holds (scade_mlp_bwd_lp_workspace_bytes): either format
+static int lp_ws_rows() {
+  const int a = lp_rows_bound(false), b = lp_rows_bound(true);
+  return a > b ? a : b;
+}
+// fixed cost of one segment of job j (its prologue round trip + the stores of its partial row), in the units of
+// lp_job_weights(): 80 + 460 x (elements written / 65536); the 90 us the partial stores cost the 1024-ray launch
+// (knock-out) were 20 us per 256 x 256 segment = 15-19 of its stages
+static int lp_job_fixed(const WgradLpJob& j) {
+  const long elems = (j.flags & WF_RGB) ? 3 * 128 + 3 : (long)j.n_rows * (j.kvalid - j.kfirst) + ((j.flags & WF_BIAS) ? j.n_rows : 0);
+  return 80 + (int)(460 * elems / 65536);
+}
+// fills w.plan for networks of P[0] and P[1] (0 = absent) points; nseg[n][j] = partial rows of job j of network n
+static int lp_build_plan(WgradLpArgs& w, const int* P, bool s8, unsigned char nseg[2][MAX_WGRAD_JOBS]) {
+  WgradLpPlan& pl = w.plan;
+  const int nj = w.njobs, ne = 2 * nj;
+  long cum = 0;
+  for (int n = 0; n < 2; ++n) {
+    pl.nst[n] = (P[n] + WL_PT - 1) / WL_PT;
+    for (int j = 0; j < nj; ++j) {
+      pl.cum[n * nj + j] = (int)cum;
+      cum += (long)pl.nst[n] * lp_job_weight(j, s8);
+      SCADE_REQUIRE(cum < (1L << 30), -2, "scade_mlp_bwd_lp: %d + %d points are more than one launch takes", P[0], P[1]);
+    }
+  }
+  pl.cum[ne] = (int)cum;
+  int fixed[MAX_WGRAD_JOBS];
+  for (int j = 0; j < nj; ++j) {
+    pl.weight[j] = (unsigned char)lp_job_weight(j, s8);
+    fixed[j] = lp_job_fixed(w.jobs[j]);
+  }
+  const long W = cum;
+  pl.chunk = pl.gx0 = pl.gx1 = 0;
+  // Small launches keep the round-2 grid of (job, chunk) workgroups handed out by the dispatcher: below ~4 stages
+  // per CU and job the stage costs are latency, not bytes (the weights above do not hold), and a third more
+  // workgroups than CUs lets one's partial-row stores overlap another's loop (128 rays per GPU: 0.325 ms graphed
+  // bf16 step against 0.333 with the balanced plan; 1024 rays: 1.45 against 1.37, 4096 rays: 5.5 against 5.2).
+  static const long grid_below = getenv("SCADE_WL_GRID_BELOW") ? atol(getenv("SCADE_WL_GRID_BELOW")) : 100000;
+  if ((long)P[0] + P[1] < grid_below) {
+    const long Pt = (long)P[0] + P[1];
+    int nchunks = pick_chunks((int)Pt, 5200);
+    const int rows_max = lp_ws_rows();
+    nchunks = nchunks > rows_max - 1 ? rows_max - 1 : nchunks;
+    int chunk = (int)((Pt + nchunks - 1) / nchunks);
+    chunk = (chunk + WL_PT - 1) / WL_PT * WL_PT;
+    pl.chunk = chunk;
+    pl.gx0 = (P[0] + chunk - 1) / chunk;
+    pl.gx1 = (P[1] + chunk - 1) / chunk;
+    SCADE_REQUIRE(pl.gx0 <= rows_max && pl.gx1 <= rows_max, -9, "scade_mlp_bwd_lp: internal: %d / %d chunks exceed the %d partial rows",
+                  pl.gx0, pl.gx1, rows_max);
+    pl.nwg = (pl.gx0 + pl.gx1) * nj;
+    for (int j = 0; j < nj; ++j) { nseg[0][j] = (unsigned char)pl.gx0; nseg[1][j] = (unsigned char)pl.gx1; }
+    return 0;
+  }
+  pl.nwg = device_cus() < LP_MAX_WG ? device_cus() : LP_MAX_WG;
+  // greedy walk with per-workgroup budget C: a segment costs its job's fixed part plus its stages; the smallest
+  // C that places all W positions (bisection: the walk is monotone in C) balances the launch
+  auto walk = [&](long C, bool store) {
+    long pos = 0;
+    int e = 0;
+    for (int g = 0; g < pl.nwg; ++g) {
+      if (store) pl.bound[g] = (int)pos;
+      long budget = C;
+      while (pos < W) {
+        while (pl.cum[e + 1] <= pos) ++e;
+        const long f = fixed[e % nj], wj = pl.weight[e % nj];
+        if (budget < f + wj) break;                       // not worth opening (or continuing into) this entry
+        budget -= f;
+        long take = pl.cum[e + 1] - pos;
+        if (take > budget) take = budget / wj * wj;       // whole stages
+        pos += take;
+        budget -= take;
+        if (pos < pl.cum[e + 1]) break;
+      }
+    }
+    if (store) pl.bound[pl.nwg] = (int)W;
+    return pos >= W;
+  };
+  // (never so small that an entry is cut into more segments than the workspace has rows: tiny launches then
+  // simply leave the last workgroups without work)
+  const int rows = lp_ws_rows();
+  long lo = 1, hi = W + 4096;
+  for (int e = 0; e < ne; ++e) {
+    const long need = fixed[e % nj] + ((long)pl.cum[e + 1] - pl.cum[e] + rows - 4) / (rows - 3) + pl.weight[e % nj];
+    lo = need > lo ? need : lo;
+  }
+  hi = hi > lo ? hi : lo;
+  while (lo < hi) {
+    const long mid = (lo + hi) / 2;
+    if (walk(mid, false)) hi = mid; else lo = mid + 1;
+  }
+  walk(lo, true);
+  for (int e = 0; e < ne; ++e) {
+    const long elo = pl.cum[e], ehi = pl.cum[e + 1];
+    if (ehi == elo) { pl.first_wg[e] = 0; nseg[e / nj][e % nj] = 0; continue; }
+    int a = 0, b = 0;
+    for (int g = 0; g < pl.nwg; ++g) {
+      if (pl.bound[g] <= elo) a = g;                      // a = max { g : bound[g] <= lo }
+      if (pl.bound[g] < ehi) b = g;                       // b = max { g : bound[g] <  hi }
+    }
+    SCADE_REQUIRE(b - a + 1 <= rows, -9, "scade_mlp_bwd_lp: internal: %d segments of entry %d exceed the %d partial rows",
+                  b - a + 1, e, rows);
+    pl.first_wg[e] = (short)a;
+    nseg[e / nj][e % nj] = (unsigned char)(b - a + 1);
+  }
+  return 0;
 }
 
 }  // namespace scade
@@ -906,7 +1194,8 @@ using namespace scade;
 extern "C" long scade_mlp_packed_t_lp_bytes(void) { return PACKED_T_LP_BYTES; }
 
 extern "C" long scade_mlp_bwd_lp_workspace_bytes(int P) {
-  return lp_dz_bytes(P) + (long)pick_chunks(P, LP_CHUNK_PTS) * N_PARAM_FLOATS * 4 + LP_GMAX_SLOTS * 4;
+  // [dz | partial rows | max|g_out| slots]; the row count covers every format and every partner network
+  return lp_dz_bytes(P) + (long)lp_ws_rows() * N_PARAM_FLOATS * 4 + LP_GMAX_SLOTS * 4;
 }
 
 extern "C" int scade_mlp_pack_t_lp(const float* const* params, void* packed_t_lp, int bf16, void* stream) {
@@ -956,8 +1245,7 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   if (int e = lp_bwd_set_attr<BF, S8>()) return e;
   unsigned char* dz = ws;
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
-  const int nchunks = pick_chunks(P, LP_CHUNK_PTS);
-  float* gmax = partial + (size_t)nchunks * N_PARAM_FLOATS;
+  float* gmax = partial + (size_t)lp_ws_rows() * N_PARAM_FLOATS;
   if (!BF || S8) {
     if (int e = lp_launch_gmax(g_out, P, gmax, s)) return e;
   }
@@ -973,12 +1261,14 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   WgradLpArgs w{};
   build_wgrad_lp_jobs(w);
   w.net[0] = WgradLpNet{acts, dz, g_out, partial, gmax, P};
-  w.chunk = lp_chunk_len(P, nchunks);
-  const int grid_x = (P + w.chunk - 1) / w.chunk;
-  w.gx0 = grid_x;
-  hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(grid_x, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
+  ReduceLpArgs r{};
+  const int Ps[2] = {P, 0};
+  if (int e = lp_build_plan(w, Ps, S8, r.nseg)) return e;
+  r.uniform[0] = w.plan.chunk > 0 ? w.plan.gx0 : 0;
+  hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(w.plan.nwg), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd_lp(wgrad)")) return e;
-  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
+  r.partial[0] = partial; r.grad[0] = grad_flat;
+  hipLaunchKernelGGL(wgrad_lp_reduce_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
   return scade_check_launch("scade_mlp_bwd_lp(reduce)");
 }
 
@@ -991,8 +1281,6 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
   SCADE_REQUIRE(lp_pick_point_tiles(P[1]) == npt, -3,
                 "scade_mlp_bwd_lp2: the forwards of the two launches tiled their points differently (P = %d, %d); "
                 "use scade_mlp_bwd_lp twice", P[0], P[1]);
-  int chunk, gx0, gx1;
-  lp_joint_chunking(P, chunk, gx0, gx1);
   MlpDgradLpArgs2 d{};
   WgradLpArgs w{};
   build_wgrad_lp_jobs(w);
@@ -1001,7 +1289,7 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
     unsigned char* ws = reinterpret_cast<unsigned char*>(wsv[i]);
     const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts[i]);
     partial[i] = reinterpret_cast<float*>(ws + lp_dz_bytes(P[i]));
-    float* gmax = partial[i] + (size_t)(i == 0 ? gx0 : gx1) * N_PARAM_FLOATS;
+    float* gmax = partial[i] + (size_t)lp_ws_rows() * N_PARAM_FLOATS;
     if (!BF || S8) {
       if (int e = lp_launch_gmax(g_out[i], P[i], gmax, s)) return e;
     }
@@ -1015,11 +1303,14 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
   else
     hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4, S8>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(4), s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_lp2(dgrad)")) return e;
-  w.chunk = chunk; w.gx0 = gx0;
-  hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(gx0 + gx1, w.njobs), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
+  ReduceLpArgs r{};
+  if (int e = lp_build_plan(w, P, S8, r.nseg)) return e;
+  r.uniform[0] = w.plan.chunk > 0 ? w.plan.gx0 : 0;
+  r.uniform[1] = w.plan.chunk > 0 ? w.plan.gx1 : 0;
+  hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(w.plan.nwg), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd_lp2(wgrad)")) return e;
-  ReduceLp2Args r{{partial[0], partial[1]}, {grad_flat[0], grad_flat[1]}, {gx0, gx1}};
-  hipLaunchKernelGGL(wgrad_lp_reduce_pair_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
+  for (int i = 0; i < 2; ++i) { r.partial[i] = partial[i]; r.grad[i] = grad_flat[i]; }
+  hipLaunchKernelGGL(wgrad_lp_reduce_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
   return scade_check_launch("scade_mlp_bwd_lp2(reduce)");
 }
 
@@ -1029,11 +1320,8 @@ extern "C" int scade_mlp_lp_point_tiles(int P) { return lp_pick_point_tiles(P); 
 // workspace of one network of a joint launch over networks of P and P_other points (scade_mlp_bwd_lp2); never
 // smaller than scade_mlp_bwd_lp_workspace_bytes(P)
 extern "C" long scade_mlp_bwd_lp2_workspace_bytes(int P, int P_other) {
-  int Ps[2] = {P, P_other}, chunk, gx0, gx1;
-  lp_joint_chunking(Ps, chunk, gx0, gx1);
-  const long joint = lp_dz_bytes(P) + (long)gx0 * N_PARAM_FLOATS * 4 + LP_GMAX_SLOTS * 4;
-  const long alone = scade_mlp_bwd_lp_workspace_bytes(P);
-  return joint > alone ? joint : alone;
+  (void)P_other;       // the partial rows of a network are bounded by the workgroup count, not by its partner
+  return scade_mlp_bwd_lp_workspace_bytes(P);
 }
 
 extern "C" int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,
