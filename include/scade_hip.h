@@ -341,6 +341,13 @@ int scade_adam_step2(float* const* params, const float* const* grads, float* con
                      const float* beta2, const float* eps, const int* step, const float* grad_scale,
                      float* const* state, void* stream);
 
+/* Batch staging for graph-captured steps: n <= 8 device-to-device copies (whole, 4-byte-aligned words) and,
+ * scalar_dst != NULL, one 8-byte scalar (the step's training-image index, run_scade_scannet.py:930) in ONE launch -
+ * what the reference's per-step batch assembly (:930-960: rays, target colours, depth hypotheses of the sampled
+ * pixels) writes into the step's input tensors. */
+int scade_stage_inputs(const void* const* src, void* const* dst, const long* bytes, int n,
+                       long long* scalar_dst, long long scalar, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

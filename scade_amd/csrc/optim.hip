@@ -96,7 +96,65 @@ __global__ void adam_tick2_kernel(float* st0, float* st1) {
   if (threadIdx.x == 0 && st0) adam_tick(st0);
   if (threadIdx.x == 64 && st1) adam_tick(st1);
 }
+// ---- batch staging: up to eight device-to-device copies (+ one 8-byte scalar) in ONE launch -------------------
+// A graph-captured train step reads its inputs from static buffers; refreshing them with tensor.copy_() is one
+// launch per tensor (rays, target, depth hypotheses, image index: 4 x 5 us in front of a 128-ray step of 0.3 ms).
+constexpr int STAGE_MAX = 8;
+struct StageArgs {
+  const unsigned char* src[STAGE_MAX];
+  unsigned char* dst[STAGE_MAX];
+  long bytes[STAGE_MAX];
+  int first_block[STAGE_MAX + 1];
+  int n;
+  long long* scalar_dst;
+  long long scalar;
+};
+__global__ void stage_inputs_kernel(StageArgs a) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && a.scalar_dst) *a.scalar_dst = a.scalar;
+  int g = 0;
+  while (g + 1 < a.n && (int)blockIdx.x >= a.first_block[g + 1]) ++g;
+  if (g >= a.n) return;
+  const unsigned char* __restrict__ src = a.src[g];
+  unsigned char* __restrict__ dst = a.dst[g];
+  const long bytes = a.bytes[g];
+  const long off = ((long)((int)blockIdx.x - a.first_block[g]) * 256 + threadIdx.x) * 16;
+  if (off >= bytes) return;
+  const bool vec = ((reinterpret_cast<unsigned long long>(src) | reinterpret_cast<unsigned long long>(dst)) & 15ull) == 0;
+  if (vec && off + 16 <= bytes) {
+    *reinterpret_cast<f32x4*>(dst + off) = *reinterpret_cast<const f32x4*>(src + off);
+  } else {
+    for (long o = off; o < bytes && o < off + 16; o += 4)      // (sizes and addresses are multiples of 4: checked on the host)
+      *reinterpret_cast<unsigned*>(dst + o) = *reinterpret_cast<const unsigned*>(src + o);
+  }
+}
 }  // namespace scade
+
+extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, const long* bytes, int n,
+                                  long long* scalar_dst, long long scalar, void* stream) {
+  SCADE_REQUIRE(n >= 0 && n <= scade::STAGE_MAX, -2, "scade_stage_inputs: 0..%d copies per launch", scade::STAGE_MAX);
+  SCADE_REQUIRE(n == 0 || (src && dst && bytes), -1, "scade_stage_inputs: null pointer");
+  scade::StageArgs a{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    SCADE_REQUIRE(src[i] && dst[i] && bytes[i] >= 0, -1, "scade_stage_inputs: null pointer / negative size in copy %d", i);
+    SCADE_REQUIRE(bytes[i] % 4 == 0 && ((unsigned long long)src[i] & 3) == 0 && ((unsigned long long)dst[i] & 3) == 0, -2,
+                  "scade_stage_inputs: copy %d is not a whole number of aligned 4-byte words", i);
+    a.src[i] = static_cast<const unsigned char*>(src[i]);
+    a.dst[i] = static_cast<unsigned char*>(dst[i]);
+    a.bytes[i] = bytes[i];
+    a.first_block[i] = blocks;
+    const long nb = (bytes[i] + 256 * 16 - 1) / (256 * 16);
+    SCADE_REQUIRE(blocks + nb < (1L << 30), -2, "scade_stage_inputs: too large");
+    blocks += (int)nb;
+  }
+  a.first_block[n] = blocks;
+  a.n = n;
+  a.scalar_dst = scalar_dst;
+  a.scalar = scalar;
+  if (blocks == 0 && !scalar_dst) return 0;
+  hipLaunchKernelGGL(scade::stage_inputs_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a);
+  return scade_check_launch("scade_stage_inputs");
+}
 
 static int adam_blocks(long n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
 

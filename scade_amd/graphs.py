@@ -113,23 +113,23 @@ class GraphedTrainer:
     def step(self, rays, target_s, target_hyp, t_rand=None, u_coarse=None, cached_u=None, img_i=0, mask=None):
         """One optimisation step; returns the loss tensor of the step (a static buffer)."""
         tr = self.tr
-        self.rays.copy_(rays)
-        self.tgt.copy_(target_s)
-        self.hyp.copy_(target_hyp)
+        if (mask is None) != (self.mask is None):
+            raise ValueError("GraphedTrainer.step: pass mask= exactly when built with with_mask=True")
+        # the step's inputs -> the static buffers, in ONE launch (ops.stage_inputs; a caller that assembled its
+        # batch in ``self.rays`` / ``self.tgt`` / ``self.hyp`` directly pays nothing)
+        pairs = [(rays, self.rays), (target_s, self.tgt), (target_hyp, self.hyp)]
+        scalar = None
         if torch.is_tensor(img_i):
-            self.img_i.copy_(img_i.reshape(1))
+            pairs.append((img_i.reshape(1), self.img_i))
         else:
             if not 0 <= int(img_i) < tr.n_images:
                 raise IndexError(f"GraphedTrainer.step: img_i {img_i} outside [0, {tr.n_images})")
-            self.img_i.fill_(int(img_i))
-        if (mask is None) != (self.mask is None):
-            raise ValueError("GraphedTrainer.step: pass mask= exactly when built with with_mask=True")
+            scalar = (self.img_i, int(img_i))
         if mask is not None:
-            self.mask.copy_(mask)
+            pairs.append((mask, self.mask))
         if self.draws is not None:
-            self.draws[0].copy_(t_rand)
-            self.draws[1].copy_(u_coarse)
-            self.draws[2].copy_(cached_u)
+            pairs += [(t_rand, self.draws[0]), (u_coarse, self.draws[1]), (cached_u, self.draws[2])]
+        ops.stage_inputs(pairs, scalar)
         with_ss = tr.scaleshift_active()
         if self.graph is None or (with_ss, tr.carving_active()) != self._captured:
             self._capture()      # first step, or the warm-start (:973) / scale-shift freeze point (:996) was crossed

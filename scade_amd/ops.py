@@ -336,6 +336,32 @@ def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs) -> None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
 
 
+def stage_inputs(pairs, scalar=None) -> None:
+    """``dst.copy_(src)`` for up to eight (src, dst) pairs - and ``scalar = (int64 tensor, value)``: one 8-byte
+    store - in ONE launch (scade_stage_inputs): the static input buffers of a graph-captured step.  Pairs that the
+    kernel does not take as they are (other dtype / shape / layout / device) fall back to ``copy_``."""
+    src_p, dst_p, nbytes = [], [], []
+    for src, dst in pairs:
+        if src.data_ptr() == dst.data_ptr() and src.shape == dst.shape:
+            continue                                  # the caller filled the static buffer itself
+        ok = (src.is_cuda and src.device == dst.device and src.dtype == dst.dtype and src.shape == dst.shape
+              and src.is_contiguous() and dst.is_contiguous() and (src.numel() * src.element_size()) % 4 == 0
+              and src.data_ptr() % 4 == 0 and dst.data_ptr() % 4 == 0 and len(src_p) < 8)
+        if not ok:
+            dst.copy_(src)
+            continue
+        src_p.append(src.data_ptr()); dst_p.append(dst.data_ptr()); nbytes.append(src.numel() * src.element_size())
+    sd, sv = (scalar[0].data_ptr(), int(scalar[1])) if scalar is not None else (None, 0)
+    if scalar is not None and (scalar[0].dtype != torch.int64 or not scalar[0].is_cuda):
+        raise ValueError("stage_inputs: the scalar destination must be an int64 device tensor")
+    if not src_p and sd is None:
+        return
+    n = len(src_p)
+    vp = lambda v: ctypes.cast((ctypes.c_void_p * max(n, 1))(*v), ctypes.c_void_p)
+    call("scade_stage_inputs", vp(src_p), vp(dst_p), ctypes.cast((ctypes.c_long * max(n, 1))(*nbytes), ctypes.c_void_p), n,
+         sd, sv, stream())
+
+
 def lp_point_tiles(P: int) -> int:
     return int(_lib.load().scade_mlp_lp_point_tiles(int(P)))
 

@@ -551,3 +551,23 @@ def test_in_kernel_draws_are_uniform(dev):
     hist = torch.histc(x.float(), bins=16, min=0, max=1) / x.numel()
     assert float((hist - 1 / 16).abs().max()) < 2e-3
     assert abs(float(torch.corrcoef(torch.stack([ua.flatten(), ub.flatten()]))[0, 1])) < 5e-3
+
+
+def test_stage_inputs_copies_every_pair_and_the_scalar_in_one_launch(dev):
+    """scade_stage_inputs: up to eight device copies + one int64 scalar; 16-byte fast path and the 4-byte path for
+    a destination that is not 16-byte aligned; unsupported pairs fall back to copy_."""
+    from scade_amd import ops
+    g = torch.Generator().manual_seed(3)
+    srcs = [torch.rand(n, generator=g).to(dev) for n in (1, 5, 1024 * 11 + 3, 4096, 7)]
+    big = torch.zeros(1024 * 11 + 3 + 1, device=dev)
+    dsts = [torch.zeros_like(srcs[0]), torch.zeros_like(srcs[1]), big[1:], torch.zeros_like(srcs[3]), torch.zeros(7, device=dev, dtype=torch.float64)]
+    idx = torch.zeros(1, device=dev, dtype=torch.long)
+    ops.stage_inputs(list(zip(srcs, dsts)), scalar=(idx, 41))
+    torch.cuda.synchronize()
+    for s, d in zip(srcs, dsts):
+        assert torch.equal(d.float(), s)
+    assert float(big[0]) == 0.0 and int(idx) == 41
+    # a pair that already is the destination costs nothing; nothing to do at all is fine too
+    ops.stage_inputs([(dsts[0], dsts[0])])
+    ops.stage_inputs([], scalar=(idx, 7))
+    assert int(idx) == 7
