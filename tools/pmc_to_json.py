@@ -32,7 +32,8 @@ KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-siz
     (r"mlp_dgrad_lp_kernel<true, 4, true>", "mlp_dgrad_lp_kernel_bf16_s8"), (r"mlp_dgrad_lp_kernel<true, 2, true>", "mlp_dgrad_lp_kernel_bf16_s8_small"),
     (r"mlp_wgrad_lp_kernel<true(, false)?>", "mlp_wgrad_lp_kernel_bf16"), (r"mlp_wgrad_lp_kernel<true, true>", "mlp_wgrad_lp_kernel_bf16_s8"),
     (r"wgrad_reduce4_kernel", "wgrad_reduce4_kernel"), (r"wgrad2_reduce_pair_kernel", "wgrad2_reduce_pair_kernel"),
-    (r"wgrad_lp_reduce_pair_kernel", "wgrad_lp_reduce_pair_kernel"),
+    (r"wgrad_lp_reduce_pair_kernel", "wgrad_lp_reduce_pair_kernel"), (r"wgrad_lp_reduce_kernel", "wgrad_lp_reduce_kernel"),
+    (r"stage_inputs_kernel", "stage_inputs_kernel"),
     (r"mlp_pack_step_kernel<0>", "mlp_pack_step_f32"), (r"mlp_pack_step_kernel<1>", "mlp_pack_step_bf16"),
     (r"adam_step2_kernel", "adam_step2_kernel"), (r"ray_points_kernel", "ray_points_kernel"),
 ]

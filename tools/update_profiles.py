@@ -90,15 +90,17 @@ notes = {
     "mlp_dgrad_lp_kernel_bf16": "16-bit dZ rows, both networks in one launch; round 3: epilogue halves traded with v_permlane32_swap + ds_write_b128 (was 30.1 % conflict cycles)",
     "mlp_fwd_lp_kernel_bf16_s8_train": "round 3, format code 2: the bf16 training forward saving 8-bit e5m2 rows",
     "mlp_dgrad_lp_kernel_bf16_s8": "format code 2: 8-bit e5m2 dZ rows under the launch-wide loss scale",
-    "mlp_wgrad_lp_kernel_bf16_s8": "format code 2: rows converted back to bf16 while staging into LDS",
+    "mlp_wgrad_lp_kernel_bf16_s8": "format code 2: e5m2 rows widened to fp16 (one v_perm_b32 per two values) while staging into LDS; balanced persistent launch",
     "wgrad2_reduce_pair_kernel": "sums the per-chunk partials of both networks",
     "wgrad_lp_reduce_pair_kernel": "sums the per-chunk partials of both networks (16-bit path)",
+    "wgrad_lp_reduce_kernel": "round 3: sums, per parameter, the partial rows of the job that owns it (balanced launch: one row per segment)",
+    "stage_inputs_kernel": "round 3: the inputs of a graph-captured step copied into its static buffers in one launch",
     "mlp_pack_step_f32": "round 3: the four weight packs of a step (both networks, forward + transposed layout) in one launch",
     "mlp_pack_step_bf16": "the same for the 16-bit kernels (incl. the NaN census of the fp32 parameters)",
     "adam_step2_kernel": "round 3: both optimizers (networks; depth scale / shift) in one update launch",
     "mlp_fwd_lp_kernel_bf16_train_small": "64-point workgroups (128-ray launches)",
     "mlp_dgrad_lp_kernel_bf16_small": "64-point workgroups",
-    "mlp_wgrad_lp_kernel_bf16": "HBM-bound by design (1 KB per point-layer); 16-bit rows + fp32 partials",
+    "mlp_wgrad_lp_kernel_bf16": "HBM-bound (11.7 KB read per point over the 13 jobs; ~5.6 TB/s); round 3: balanced persistent launch, one workgroup per CU with host-planned stage ranges",
     "ray_tail_coarse": "per-ray work between the coarse and the fine MLP launch (composite, sampler, sort-merge, points)",
     "ray_tail_fine": "fine composite + depth-hypothesis sampler + z_std",
     "ray_tail_bwd_fine": "round 2: backward of the fine tail in one launch (sampler backward + compositing backward)",
