@@ -341,6 +341,22 @@ int scade_adam_step2(float* const* params, const float* const* grads, float* con
                      const float* beta2, const float* eps, const int* step, const float* grad_scale,
                      float* const* state, void* stream);
 
+/* The fine tail, the train loss and the backward of both tails of a TRAIN step in one launch (+ the loss's
+ * one-workgroup reduce): scade_ray_tail (fine form, run_scade_scannet.py:720-730) -> scade_train_loss_fb (:954,
+ * :968-983) -> scade_ray_tail_bwd, and - raw0 != NULL - scade_composite_bwd of the coarse ray; same arithmetic, same
+ * bits.  Outputs: the tail's (rgb_map .. depth_map, samples = the depth hypotheses, z_std), loss4, the scale / shift
+ * gradient rows (n_ss as in scade_train_loss_fb), g_raw [N,S,4] and g_raw0 [N,S0,4].  workspace: 8 N floats. */
+int scade_ray_tail_train(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                         const float* noise, int N, int S, const float* u, int u_stride, int Si,
+                         float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
+                         float* samples, float* z_std,
+                         const float* rgb0, const float* target, const float* hyp, const float* scales,
+                         const float* shifts, const long long* img_i_dev, int img_i, const float* mask,
+                         int mse_masked, int carve_on, float carve_weight, float threshold, float out_scale,
+                         int K, float* workspace, float* loss4, float* g_scales, float* g_shifts, int n_ss,
+                         float* g_raw, const float* raw0, const float* z0, const float* noise0, int S0,
+                         float* g_raw0, void* stream);
+
 /* Batch staging for graph-captured steps: n <= 8 device-to-device copies (whole, 4-byte-aligned words) and,
  * scalar_dst != NULL, one 8-byte scalar (the step's training-image index, run_scade_scannet.py:930) in ONE launch -
  * what the reference's per-step batch assembly (:930-960: rays, target colours, depth hypotheses of the sampled

@@ -15,6 +15,7 @@
 // (cumprod / cumsum) accumulated in fp64 and rounded per prefix, as ATen's CPU
 // cumsum/cumprod kernels do.
 #include "common.h"
+#include "train_loss_dev.h"
 
 namespace scade {
 
@@ -236,12 +237,14 @@ __global__ void composite_fwd_kernel(CompositeArgs a) {
 // gradient w.r.t. weights[1 .. S-2] (the fine sampler's, scade_ray_tail_bwd)
 template <int NC>
 __device__ __forceinline__ void composite_bwd_ray(const CompositeArgs& a, int ray, int lane, const SampleState (&st)[NC],
-                                                  double sd, double sa, const float* gw_inner) {
+                                                  double sd, double sa, const float* gw_inner,
+                                                  bool reg_g = false, float rg_r = 0.f, float rg_g = 0.f, float rg_b = 0.f) {
   const int S = a.S;
   const float depth = (float)sd, acc = (float)sa;
-  const float gr = a.g_rgb ? a.g_rgb[ray * 3 + 0] : 0.f;
-  const float gg = a.g_rgb ? a.g_rgb[ray * 3 + 1] : 0.f;
-  const float gb = a.g_rgb ? a.g_rgb[ray * 3 + 2] : 0.f;
+  // (reg_g: the colour gradient is handed over in registers - the fused tail + loss kernel below)
+  const float gr = reg_g ? rg_r : a.g_rgb ? a.g_rgb[ray * 3 + 0] : 0.f;
+  const float gg = reg_g ? rg_g : a.g_rgb ? a.g_rgb[ray * 3 + 1] : 0.f;
+  const float gb = reg_g ? rg_b : a.g_rgb ? a.g_rgb[ray * 3 + 2] : 0.f;
   float gdepth = a.g_depth ? a.g_depth[ray] : 0.f;
   float gacc = a.g_acc ? a.g_acc[ray] : 0.f;
   if (a.g_disp) {
@@ -755,6 +758,108 @@ __global__ void ray_tail_bwd_kernel(TailBwdArgs a) {
   composite_bwd_ray<NC>(a.c, ray, lane, st, sd, sa, gwi);
 }
 
+// The fine tail, the three-term train loss (forward AND backward, unit gradient) and the backward of both tails
+// of a TRAIN step in ONE launch: one wave per ray runs ray_tail_body's forward, the per-ray loss functions of
+// train_loss_dev.h on the colour it still holds in registers and the depth hypotheses it just wrote to LDS,
+// the sampler's backward, the fine compositing backward on the forward state still in registers (nothing is
+// recomputed) and - c0.raw given - the coarse ray's compositing backward.  Same device functions and operation
+// order as scade_ray_tail -> scade_train_loss_fb -> scade_ray_tail_bwd (+ scade_composite_bwd for the coarse
+// ray) => the same bits; four launches of ~10 us become one (a 128-ray graph step is 0.31 ms).
+struct TailTrainArgs {
+  TailArgs t;              // fine tail, merge-less form (z_out = pts = null)
+  TrainLossArgs l;         // rgb / pred / g_rgb / g_pred unused (registers, LDS); g_rgb0 optional
+  float* g_raw;            // [N,S,4] fine
+  CompositeArgs c0;        // coarse ray: raw, z, rays_d, noise, g_raw (S0 <= 64), or raw = null
+};
+template <int NC>
+__global__ void ray_tail_train_kernel(TailTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int wv = threadIdx.x >> 6, lane = lane_id();
+  const int ray = blockIdx.x * RAYS_PER_WG + wv;
+  if (ray >= a.t.c.N) return;
+  const int S = a.t.c.S, M = S - 1, Si = a.t.Si;
+  float* w = smem + (size_t)wv * (7 * S + 2 * Si);   // w[S] | cat[S+Si] | cdf[S] | bins[S] | pdf[S] | dcdf[S] | gwi[S] | gs[Si]
+  float* cat = w + S;
+  float* cdf = cat + S + Si;
+  float* bins = cdf + S;
+  float* pdf = bins + S;
+  float* dcdf = pdf + S;
+  float* gwi = dcdf + S;
+  float* gs = gwi + S;
+
+  // ---- forward (ray_tail_body<NC, 0>) ----
+  SampleState st[NC];
+  double sr, sg, sb, sd, sa;
+  composite_ray<NC>(a.t.c, ray, lane, st, sr, sg, sb, sd, sa);
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    const int i = c * 64 + lane;
+    if (i < S) {
+      a.t.c.weights[(size_t)ray * S + i] = st[c].w;
+      w[i] = st[c].w;
+      cat[i] = st[c].z;
+    }
+  }
+  if (lane == 0) {
+    const float depth = (float)sd, acc = (float)sa;
+    a.t.c.rgb_map[ray * 3 + 0] = (float)sr;
+    a.t.c.rgb_map[ray * 3 + 1] = (float)sg;
+    a.t.c.rgb_map[ray * 3 + 2] = (float)sb;
+    a.t.c.depth_map[ray] = depth;
+    a.t.c.acc_map[ray] = acc;
+    const float q = depth / acc;                                      // :559
+    a.t.c.disp_map[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+  }
+  __builtin_amdgcn_wave_barrier();
+  const float total = build_cdf_rows(cat, 1, w + 1, nullptr, M, lane, cdf, bins, pdf);   // z_mid, weights[1:-1]
+  const float* ur = a.t.u + (size_t)ray * a.t.u_stride;
+  double s1 = 0.0;
+  for (int s = lane; s < Si; s += 64) {
+    int ind;
+    const float smp = inverse_cdf(cdf, bins, M, ur[s], ind);
+    if (a.t.samples) a.t.samples[(size_t)ray * Si + s] = smp;
+    cat[S + s] = smp;
+    s1 += (double)smp;
+  }
+  if (a.t.z_std) {                                 // torch.std(unbiased=False), :744
+    const double mean = wave_sum_d(s1) / (double)Si;
+    double s2 = 0.0;
+    for (int s = lane; s < Si; s += 64) {
+      const double dlt = (double)cat[S + s] - mean;
+      s2 += dlt * dlt;
+    }
+    s2 = wave_sum_d(s2);
+    if (lane == 0) a.t.z_std[ray] = (float)sqrt(s2 / (double)Si);
+  }
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- loss, forward and backward (train_loss_fb_kernel) ----
+  TlRayIo io;
+  io.pred_row = cat + S; io.g_pred_row = gs; io.have_rgb = true;
+  io.r = (float)sr; io.g = (float)sg; io.b = (float)sb;
+  tl_fwd_ray(a.l, ray, lane, io);
+  const float gx = tl_bwd_ray(a.l, ray, lane, 1.0f, a.l.partial + 4 * (size_t)a.l.N, io);
+  const float g_r = tl_bcast(gx, 0), g_g = tl_bcast(gx, 1), g_b = tl_bcast(gx, 2);
+  const float g0_r = tl_bcast(gx, 3), g0_g = tl_bcast(gx, 4), g0_b = tl_bcast(gx, 5);
+  __builtin_amdgcn_wave_barrier();
+
+  // ---- backward of the fine tail (ray_tail_bwd_kernel; the forward state is still here) ----
+  sample_pdf_bwd_rows(cdf, bins, pdf, dcdf, total, ur, gs, M, Si, lane, gwi);
+  __builtin_amdgcn_wave_barrier();
+  CompositeArgs cb = a.t.c;
+  cb.g_rgb = nullptr; cb.g_disp = nullptr; cb.g_acc = nullptr; cb.g_w = nullptr; cb.g_depth = nullptr;
+  cb.g_raw = a.g_raw;
+  composite_bwd_ray<NC>(cb, ray, lane, st, sd, sa, gwi, true, g_r, g_g, g_b);
+
+  // ---- backward of the coarse ray's compositing (composite_bwd_kernel<1>) ----
+  if (a.c0.raw) {
+    SampleState s0[1];
+    double r0, g0, b0, d0, a0;
+    composite_ray<1>(a.c0, ray, lane, s0, r0, g0, b0, d0, a0);
+    composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // space-carving loss
 // ---------------------------------------------------------------------------
@@ -1255,6 +1360,54 @@ extern "C" int scade_ray_tail_bwd(const float* raw, const float* z_vals, const f
   const size_t lds = (size_t)RAYS_PER_WG * 6 * S * sizeof(float);
   DISPATCH_NC(ray_tail_bwd_kernel, S, dim3(grid_rays(N)), dim3(256), lds, (hipStream_t)stream, a);
   return scade_check_launch("scade_ray_tail_bwd");
+}
+
+// scade_ray_tail (fine form) + scade_train_loss_fb + scade_ray_tail_bwd (+ scade_composite_bwd of the coarse
+// ray, raw0 != NULL) in ONE launch + the loss's reduce: see ray_tail_train_kernel.  The loss differentiates the
+// total with a UNIT gradient (scade_train_loss_fb's contract); gradients w.r.t. the five compositing outputs
+// other than the colour are zero by construction of the train loss.
+extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                                    const float* noise, int N, int S, const float* u, int u_stride, int Si,
+                                    float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
+                                    float* samples, float* z_std,
+                                    const float* rgb0, const float* target, const float* hyp, const float* scales,
+                                    const float* shifts, const long long* img_i_dev, int img_i, const float* mask,
+                                    int mse_masked, int carve_on, float carve_weight, float threshold, float out_scale,
+                                    int K, float* workspace, float* loss4, float* g_scales, float* g_shifts, int n_ss,
+                                    float* g_raw, const float* raw0, const float* z0, const float* noise0, int S0,
+                                    float* g_raw0, void* stream) {
+  SCADE_REQUIRE(N > 0, -2, "scade_ray_tail_train: empty batch");
+  SCADE_REQUIRE(raw && z_vals && rays && u && rgb_map && disp_map && acc_map && weights && depth_map && g_raw, -1,
+                "scade_ray_tail_train: null pointer");
+  SCADE_REQUIRE(rgb0 && target && workspace && loss4, -1, "scade_ray_tail_train: null pointer (loss)");
+  SCADE_REQUIRE(!carve_on || (hyp && scales && shifts && g_scales && g_shifts && K > 0), -1,
+                "scade_ray_tail_train: the carving term needs hyp, scales, shifts and their gradient buffers");
+  SCADE_REQUIRE(ray_stride >= 6, -2, "scade_ray_tail_train: ray rows need o and d");
+  SCADE_REQUIRE(S >= 3 && S <= 256 && Si >= 1 && Si <= 1024, -2,
+                "scade_ray_tail_train: S=%d outside [3,256] or Si=%d outside [1,1024]", S, Si);
+  SCADE_REQUIRE(img_i_dev ? img_i > 0 : img_i >= 0, -2, "scade_ray_tail_train: img_i (host index, or n_images beside a device index)");
+  SCADE_REQUIRE(n_ss >= 0 && (n_ss == 0 || (g_scales && g_shifts)), -2, "scade_ray_tail_train: n_ss rows need g_scales / g_shifts");
+  SCADE_REQUIRE(!raw0 || (z0 && g_raw0 && S0 >= 1 && S0 <= 64), -2, "scade_ray_tail_train: the coarse ray needs z0, g_raw0 and S0 <= 64");
+  TailTrainArgs a{};
+  a.t.c.raw = raw; a.t.c.z = z_vals; a.t.c.rays_d = rays + 3; a.t.c.noise = noise; a.t.c.rgb_map = rgb_map;
+  a.t.c.disp_map = disp_map; a.t.c.acc_map = acc_map; a.t.c.weights = weights; a.t.c.depth_map = depth_map;
+  a.t.c.N = N; a.t.c.S = S; a.t.c.d_stride = ray_stride;
+  a.t.rays = rays; a.t.u = u; a.t.samples = samples; a.t.z_std = z_std;
+  a.t.ray_stride = ray_stride; a.t.u_stride = u_stride; a.t.Si = Si;
+  a.l.rgb0 = rgb0; a.l.target = target; a.l.hyp = hyp; a.l.scales = scales; a.l.shifts = shifts;
+  a.l.img_i_dev = img_i_dev; a.l.img_i = img_i; a.l.mask = mask; a.l.mse_masked = mse_masked; a.l.carve_on = carve_on;
+  a.l.carve_weight = carve_weight; a.l.threshold = threshold; a.l.out_scale = out_scale; a.l.N = N; a.l.P = Si; a.l.K = K;
+  a.l.partial = workspace; a.l.loss = loss4; a.l.g_scales = g_scales; a.l.g_shifts = g_shifts;
+  a.g_raw = g_raw;
+  if (raw0) {
+    a.c0.raw = raw0; a.c0.z = z0; a.c0.rays_d = rays + 3; a.c0.noise = noise0; a.c0.d_stride = ray_stride;
+    a.c0.g_raw = g_raw0; a.c0.N = N; a.c0.S = S0;
+  }
+  const size_t lds = (size_t)RAYS_PER_WG * (7 * S + 2 * Si) * sizeof(float);
+  hipStream_t s = (hipStream_t)stream;
+  DISPATCH_NC(ray_tail_train_kernel, S, dim3(grid_rays(N)), dim3(256), lds, s, a);
+  if (int e = scade_check_launch("scade_ray_tail_train")) return e;
+  return scade_launch_train_loss_fb_reduce(a.l, n_ss, s);
 }
 
 extern "C" long scade_carve_workspace_floats(int N, int P, int K, int is_joint) {

@@ -1002,6 +1002,81 @@ class TrainLossUnitFn(torch.autograd.Function):
         return (g_rgb if need[0] else None, g_rgb0 if need[1] else None, None, g_pred if need[3] else None) + (None,) * 11
 
 
+class FineTailLossFn(torch.autograd.Function):
+    """The fine tail (FineTailFn), the unit-gradient train loss (TrainLossUnitFn) and the backward of BOTH tails of a
+    train step as ONE launch + the loss's reduce (scade_ray_tail_train): everything - the loss terms, the scale /
+    shift rows of the gradient bucket, d loss / d raw of the fine AND the coarse network - is computed in forward();
+    backward() hands the two gradients to the MLP backward.  Same device functions, same bits as the separate
+    operators.  ``rgb0`` is the coarse colour as a VALUE (pass it detached: its gradient is applied here, through
+    ``raw0``); ``unit`` as in TrainLossUnitFn."""
+
+    @staticmethod
+    def forward(ctx, raw, z_vals, rays, u, n_samples, raw0, z0, rgb0, target, hyp, scales, shifts, img_i, mask,
+                mse_masked, carve_on, carve_weight, threshold, out_scale, unit):
+        for t, w in ((raw, "raw"), (z_vals, "z_vals"), (raw0, "raw0"), (z0, "z_vals0"), (rgb0, "rgb0"),
+                     (target, "target"), (hyp, "hypotheses")):
+            check(t, "ray_tail_train: " + w)
+        N, S = z_vals.shape
+        S0 = z0.shape[1]
+        K = hyp.shape[0]
+        if tuple(raw.shape) != (N, S, 4) or tuple(raw0.shape) != (N, S0, 4) or tuple(z0.shape) != (N, S0):
+            raise ValueError("ray_tail_train: raw [N,S,4], raw0 [N,S0,4], z_vals0 [N,S0] expected")
+        if tuple(hyp.shape[1:]) not in ((N,), (N, 1)):
+            raise ValueError(f"ray_tail_train: hypotheses must be [K,{N},1], got {tuple(hyp.shape)}")
+        if tuple(rgb0.shape) != (N, 3) or tuple(target.shape) != (N, 3):
+            raise ValueError("ray_tail_train: rgb0 and target must be [N,3]")
+        gs, gh = scales.grad, shifts.grad
+        ok = lambda g, p: g is not None and g.is_contiguous() and g.dtype == torch.float32 and g.numel() == p.numel()
+        if not (ok(gs, scales) and ok(gh, shifts)):
+            raise RuntimeError("ray_tail_train: scales / shifts need contiguous fp32 .grad buffers (the Trainer's "
+                               "gradient bucket)")
+        raw_c, z_c, raw0_c, z0_c = _c(raw.detach()), _c(z_vals), _c(raw0.detach()), _c(z0)
+        rays_c, rstride = _rows(rays, "ray_tail_train: rays")
+        u_c, ustride = _u_arg(u, N, n_samples)
+        rgb0_c, tgt_c, hyp_c = _c(rgb0), _c(target), _c(hyp.reshape(K, N))
+        sc, sh = _c(scales.detach().reshape(-1)), _c(shifts.detach().reshape(-1))
+        mask_c = None if mask is None else _c(check(mask, "ray_tail_train: mask").reshape(N))
+        idx_t = None
+        if torch.is_tensor(img_i):
+            if img_i.dtype != torch.int64 or img_i.device != raw.device or img_i.numel() != 1:
+                raise TypeError(f"ray_tail_train: a tensor img_i must be ONE int64 on {raw.device}, got "
+                                f"{img_i.dtype} x {img_i.numel()} on {img_i.device}")
+            idx_t = _c(img_i.reshape(1))
+        idx = sc.numel() if idx_t is not None else int(img_i)
+        if idx_t is None and not 0 <= idx < sc.numel():
+            raise IndexError(f"ray_tail_train: img_i {idx} outside [0, {sc.numel()})")
+        dev = raw.device
+        f = lambda *shape: torch.empty(*shape, device=dev, dtype=torch.float32)
+        rgb, disp, acc, w, depth = f(N, 3), f(N), f(N), f(N, S), f(N)
+        samples, std = f(N, n_samples), f(N)
+        ws, loss4 = f(8 * N), f(4)
+        g_raw, g_raw0 = f(N, S, 4), f(N, S0, 4)
+        t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+        call("scade_ray_tail_train", ptr(raw_c), ptr(z_c), ptr(rays_c), rstride, None, N, S, ptr(u_c), ustride,
+             n_samples, ptr(rgb), ptr(disp), ptr(acc), ptr(w), ptr(depth), ptr(samples), ptr(std),
+             ptr(rgb0_c), ptr(tgt_c), ptr(hyp_c), ptr(sc), ptr(sh), ptr(idx_t), idx, ptr(mask_c),
+             int(bool(mse_masked)), int(bool(carve_on)), float(carve_weight), float(threshold), float(out_scale),
+             K, ptr(ws), ptr(loss4), ptr(gs), ptr(gh), sc.numel(), ptr(g_raw), ptr(raw0_c), ptr(z0_c), None, S0,
+             ptr(g_raw0), stream())
+        if t0 is not None:
+            KERNEL_TIMER.stop("ray_tail_train", t0, 0.0)
+        ctx.save_for_backward(g_raw, g_raw0)
+        ctx.unit_ptr = unit.data_ptr()
+        comps = loss4[1:]
+        ctx.mark_non_differentiable(comps, rgb, disp, acc, w, depth, samples, std)
+        ctx.set_materialize_grads(False)
+        return loss4[0], comps, rgb, disp, acc, w, depth, samples, std
+
+    @staticmethod
+    def backward(ctx, g, *_unused):
+        if g is None or g.data_ptr() != ctx.unit_ptr:
+            raise RuntimeError("ray_tail_train: backward() must be called with the unit tensor given to the forward "
+                               "(Trainer.backward does)")
+        g_raw, g_raw0 = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        return (g_raw if need[0] else None, None, None, None, None, g_raw0 if need[5] else None) + (None,) * 14
+
+
 class MseFn(torch.autograd.Function):
     """img2mse (helpers:11), optional per-row mask (run_scade_wild.py:978-986)."""
 

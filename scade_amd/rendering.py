@@ -159,7 +159,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
                 precomputed_z_samples=None, embedded_cam=None, retraw=False, lindisp=False,
                 perturb=0., N_importance=0, network_fine=None, raw_noise_std=0., verbose=False,
                 pytest=False, is_joint=False, cached_u=None, t_rand=None, u_coarse=None,
-                coarse_stream=None, fuse_tails=True, draws=None):
+                coarse_stream=None, fuse_tails=True, draws=None, _stop_before_fine_tail=False):
     """run_scade_scannet.py:581-751 (live branch ``N_importance > 0``).
 
     Extra keyword-only knobs beyond the reference signature: ``t_rand`` [N,N_samples]
@@ -174,7 +174,10 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     raw2outputs / sample_pdf / merge operators (same bits; kept for the parity tests).
     ``draws`` (an ``ops.Draws``; training only, perturb > 0): the step's uniform draws that were not injected
     are made INSIDE the first kernel of the step (scade_ray_points_draw: counter-based Philox keyed by seed,
-    step, ray and draw index) instead of by torch.rand launches."""
+    step, ray and draw index) instead of by torch.rand launches.
+    ``_stop_before_fine_tail`` (Trainer only): return after the fine MLP with ``raw`` / ``raw0`` / ``u`` and
+    ``'_fine_tail_pending': True`` - the caller runs the fine tail, the loss and both tails' backward as ONE launch
+    (ops.FineTailLossFn); ignored (a complete result is returned) when that launch cannot take the case."""
     if N_importance <= 0:
         raise NotImplementedError(
             "render_rays: N_importance == 0 is dead code in the reference (raises UnboundLocalError "
@@ -243,6 +246,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
         for t in outs:                      # allocated on the side stream, consumed on this one
             t.record_stream(main)
     z_vals_0, raw, rgb_map_0, disp_map_0, acc_map_0, weights_0, depth_map_0 = outs[:7]
+    raw_0 = raw
 
     if fused:
         z_vals, pts = outs[7:]
@@ -259,6 +263,12 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     # ---- fine stage: raw2outputs + depth hypotheses from the fine pdf (:720-730): one launch; when a
     # gradient is recorded also ONE backward launch (ops.FineTailFn)
     fusable = fuse_tails and ops.ray_tail_supported(z_vals.shape[1], N_importance, merge=False)
+    if (_stop_before_fine_tail and fusable and torch.is_grad_enabled() and raw.requires_grad and raw_noise_std == 0.
+            and z_vals.shape[1] <= 256 and z_vals_0.shape[1] <= 64):
+        u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)
+        return {'_fine_tail_pending': True, 'raw': raw, 'raw0': raw_0, 'z_vals': z_vals, 'u': u, 'rgb0': rgb_map_0,
+                'disp0': disp_map_0, 'acc0': acc_map_0, 'depth0': depth_map_0, 'z_vals0': z_vals_0,
+                'weights0': weights_0}
     if fusable and not (torch.is_grad_enabled() and raw.requires_grad):
         noise = _raw_noise(raw, raw_noise_std, pytest)
         u = cached_u if cached_u is not None else _draw_u(z_vals, N_importance, det, pytest, is_joint)

@@ -110,6 +110,9 @@ class Trainer:
         self.unit_loss = os.environ.get("SCADE_UNIT_LOSS", "1") != "0"
         self._unit_loss_ready = False
         self.draw_in_kernel = os.environ.get("SCADE_DRAW_IN_KERNEL", "1") != "0"
+        # fine tail + loss + both tails' backward in one launch (forward_loss); SCADE_FUSED_TAIL_LOSS=0: the
+        # separate operators (same bits: the equality is a test)
+        self.fused_tail_loss = os.environ.get("SCADE_FUSED_TAIL_LOSS", "1") != "0"
         self.draw_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5CADE) & (2 ** 64 - 1)
         self.draw_step_dev = None           # GraphedTrainer: the fused optimizer's device-resident step count
         self._one = torch.ones((), device=dev)      # see _unit_grad (built here, never inside a graph capture)
@@ -159,11 +162,28 @@ class Trainer:
                 render_kw["u_coarse"] = d[n * ns:n * (ns + ni)].view(n, ni)
                 if need_u:
                     render_kw["cached_u"] = d[n * (ns + ni):].view(n, ni)
+        hyp_per_ray = target_hyp.dim() == 3 and target_hyp.shape[-1] == 1
+        # the fine tail, the loss and the backward of both tails as ONE launch (ops.FineTailLossFn) where the step
+        # allows it: unit-gradient loss, per-ray hypotheses, no raw noise, coarse stage on this stream
+        one_launch = (self.fused_tail_loss and self.fused_loss and not c["joint"] and hyp_per_ray
+                      and self._unit_loss_ready and torch.is_grad_enabled() and c["noise"] == 0.
+                      and self.coarse_stream is None and "pytest" not in render_kw)
         ret = R.render_rays(rays, True, self.coarse, self.query, c["Ns"], N_importance=c["Ni"],
                             network_fine=self.fine, perturb=1., raw_noise_std=c["noise"],
                             lindisp=c["lindisp"], is_joint=c["joint"], coarse_stream=self.coarse_stream,
-                            **render_kw)
-        hyp_per_ray = target_hyp.dim() == 3 and target_hyp.shape[-1] == 1
+                            _stop_before_fine_tail=one_launch, **render_kw)
+        if ret.pop("_fine_tail_pending", False):
+            self._unit_loss_ready = False
+            raw, raw0, u = ret.pop("raw"), ret.pop("raw0"), ret["u"]
+            loss, comps, rgb, disp, acc, w, depth, pred, std = ops.FineTailLossFn.apply(
+                raw, ret["z_vals"], rays, u, c["Ni"], raw0, ret["z_vals0"], ret["rgb0"].detach(), target_s, target_hyp,
+                self.depth_scales, self.depth_shifts, img_i, mask, c["mask_mode"] == "wild", self.carving_active(),
+                c["w"], c["thr"], share, self._one)
+            if u.dim() == 1 or u.stride(0) == 0:
+                u = u.expand(rays.shape[0], c["Ni"])
+            ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, weights=w, pred_hyp=pred, u=u, z_std=std)
+            return loss, dict(img_loss=comps[0], carve=comps[1] if self.carving_active() else None,
+                              img_loss0=comps[2], ret=ret, share=share, loss_report=loss.detach())
         if self.fused_loss and not c["joint"] and hyp_per_ray:
             # the whole loss (affine map of the hypotheses :954, both photometric terms, the carving term,
             # their sum :968-983, this rank's share) in one forward / one backward entry

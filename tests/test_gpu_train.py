@@ -553,6 +553,41 @@ def test_graph_replays_queued_back_to_back_equal_eager_bitwise(dev, precision):
     assert torch.equal(res["graph"], res["eager"]), float((res["graph"] - res["eager"]).abs().max())
 
 
+@pytest.mark.parametrize("precision,mask_mode", [("f32", "scannet"), ("bf16", "scannet"), ("f32", "wild")])
+def test_one_launch_tail_loss_backward_equals_the_separate_operators(dev, precision, mask_mode):
+    """scade_ray_tail_train (fine tail + train loss + the backward of both tails in one launch, ops.FineTailLossFn)
+    leaves the loss, every gradient of the bucket (networks, depth scale / shift) and the parameters after four
+    Adam steps bit-for-bit where FineTailFn -> TrainLossUnitFn -> their backwards leave them; the auxiliary outputs
+    (colour, depth hypotheses, z_std ...) are the same tensors too."""
+    from scade_amd.train import Trainer, make_scade_nets
+    N, K, steps = 96, 10, 4
+    g = torch.Generator().manual_seed(17)
+    batches = [(O.synthetic_rays(N, seed=90 + i).to(dev), torch.rand(N, 3, generator=g).to(dev),
+                (torch.rand(K, N, 1, generator=g) * 4.9 + 0.1).to(dev), (torch.rand(N, generator=g) > 0.3).float().to(dev))
+               for i in range(steps)]
+    res = {}
+    for fused in (False, True):
+        coarse, fine = make_scade_nets(dev, seed=6)
+        torch.manual_seed(23)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3, precision=precision, mask_mode=mask_mode,
+                     scaleshift_lr=1e-3)
+        tr.fused_tail_loss = fused
+        out = []
+        for i, (rays, tgt, hyp, m) in enumerate(batches):
+            loss, aux = tr.step(rays, tgt, hyp, img_i=i % 3, mask=m if mask_mode == "wild" else None)
+            r = aux["ret"]
+            out.append((loss.detach().clone(), tr.flat.grad.clone(), tr.flat_ss.grad.clone(), r["rgb_map"].clone(),
+                        r["pred_hyp"].clone(), r["z_std"].clone(), r["depth_map"].clone(), r["weights"].clone(),
+                        aux["img_loss"].clone(), aux["img_loss0"].clone()))
+        torch.cuda.synchronize()
+        res[fused] = (out, tr.flat.data.clone(), tr.flat_ss.data.clone())
+    for a, b in zip(res[False][0], res[True][0]):
+        for x, y in zip(a, b):
+            assert torch.equal(x, y), float((x - y).abs().max())
+    assert torch.equal(res[False][1], res[True][1]) and torch.equal(res[False][2], res[True][2])
+    assert bool((res[True][2][:3] != 1).any()), "the depth scales were trained"
+
+
 def _rccl_capture_worker(out_path, port):
     """Child process of the test below: a one-rank RCCL group, eager and graph-captured steps in both all-reduce
     modes; the results are on disk BEFORE the group is torn down."""
