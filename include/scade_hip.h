@@ -136,6 +136,14 @@ int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, con
  * must have used the same point tiling: scade_mlp_lp_point_tiles(P[0]) == scade_mlp_lp_point_tiles(P[1])
  * (otherwise error -3: call scade_mlp_bwd_lp twice). */
 int scade_mlp_lp_point_tiles(int P);
+/* The launch plan of the 16-bit weight gradient (scade_mlp_bwd_lp / _lp2) for networks of P[0], P[1] (0 = absent)
+ * points, host code only (tests, tools): the work is the list of (network, job) entries, each a run of 32-point
+ * stages weighted by the job's measured per-stage cost; workgroup w owns the weighted positions [bound[w],
+ * bound[w + 1]) (one workgroup per CU), segment k of an entry writes partial row k.  info[7] = {workgroups, jobs per
+ * network, points per stage, partial rows per workspace, chunk, gx0, gx1} (chunk > 0: launches below 100k points
+ * use a (job, chunk) grid instead); bound[257], cum[33], first_wg[32], nseg[32], weight[16]. */
+int scade_mlp_wgrad_lp_plan(const int* P, int s8, int* info, int* bound, int* cum, int* first_wg, int* nseg,
+                            int* weight);
 long scade_mlp_bwd_lp2_workspace_bytes(int P, int P_other);
 int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,
                       const float* const* g_out, const int* P, void* const* workspace,

@@ -1318,6 +1318,31 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
   return scade_check_launch("scade_mlp_bwd_lp2(reduce)");
 }
 
+// The launch plan of the 16-bit weight gradient for networks of P[0] and P[1] (0 = absent) points, as the kernel
+// receives it (host code only: no device needed) - for tests and tools.  Outputs: info[0] = workgroups, info[1] =
+// jobs per network, info[2] = points per stage, info[3] = partial rows of a workspace, info[4..6] = chunk, gx0,
+// gx1 of the small-launch grid (chunk = 0: the balanced plan); bound[257], cum[33], first_wg[32], nseg[32],
+// weight[16] (unused entries zero).
+extern "C" int scade_mlp_wgrad_lp_plan(const int* P, int s8, int* info, int* bound, int* cum, int* first_wg,
+                                       int* nseg, int* weight) {
+  SCADE_REQUIRE(P && info && bound && cum && first_wg && nseg && weight, -1, "scade_mlp_wgrad_lp_plan: null pointer");
+  SCADE_REQUIRE(P[0] > 0 && P[1] >= 0, -2, "scade_mlp_wgrad_lp_plan: P[0] must be positive, P[1] non-negative");
+  WgradLpArgs w{};
+  build_wgrad_lp_jobs(w);
+  unsigned char ns[2][MAX_WGRAD_JOBS] = {};
+  if (int e = lp_build_plan(w, P, s8 != 0, ns)) return e;
+  info[0] = w.plan.nwg; info[1] = w.njobs; info[2] = WL_PT; info[3] = lp_ws_rows();
+  info[4] = w.plan.chunk; info[5] = w.plan.gx0; info[6] = w.plan.gx1;
+  for (int i = 0; i <= LP_MAX_WG; ++i) bound[i] = w.plan.chunk > 0 ? 0 : (i <= w.plan.nwg ? w.plan.bound[i] : 0);
+  for (int i = 0; i <= LP_MAX_ENTRIES; ++i) cum[i] = i <= 2 * w.njobs ? w.plan.cum[i] : 0;
+  for (int i = 0; i < LP_MAX_ENTRIES; ++i) {
+    first_wg[i] = i < 2 * w.njobs ? w.plan.first_wg[i] : 0;
+    nseg[i] = i < 2 * w.njobs ? ns[i / w.njobs][i % w.njobs] : 0;
+  }
+  for (int j = 0; j < MAX_WGRAD_JOBS; ++j) weight[j] = j < w.njobs ? w.plan.weight[j] : 0;
+  return 0;
+}
+
 // point tiles (of 32) per workgroup the 16-bit forward / dgrad use for a launch over P points
 extern "C" int scade_mlp_lp_point_tiles(int P) { return lp_pick_point_tiles(P); }
 
