@@ -41,26 +41,37 @@ __global__ void mlp_pack_t_lp_kernel(PackTLpArgs a) { pack_t_lp_row<BF>(a.p, a.p
 constexpr int LP_GMAX_SLOTS = 256;          // == the block size of lp_gmax_kernel, >= its grid
 static_assert(N_PARAM_FLOATS % 4 == 0, "the slots sit behind the partial rows and are read as f32x4");
 
-__global__ __launch_bounds__(LP_GMAX_SLOTS) void lp_gmax_kernel(const float* __restrict__ g, long n,
-                                                                float* __restrict__ slots) {
+struct LpGmaxArgs {
+  const float* g[2];      // [P,4] of one network, or of the two networks of a joint launch
+  long n[2];              // floats
+  float* slots[2];
+  int blocks0;            // workgroups [0, blocks0) take g[0], the rest g[1]
+};
+__global__ __launch_bounds__(LP_GMAX_SLOTS) void lp_gmax_kernel(LpGmaxArgs a) {
   __shared__ float part[LP_GMAX_SLOTS / 64];
+  const bool second = (int)blockIdx.x >= a.blocks0;                  // wave-uniform
+  const float* __restrict__ g = second ? a.g[1] : a.g[0];
+  const long n = second ? a.n[1] : a.n[0];
+  float* __restrict__ slots = second ? a.slots[1] : a.slots[0];
+  const int bx = (int)blockIdx.x - (second ? a.blocks0 : 0);
+  const int nb = second ? (int)gridDim.x - a.blocks0 : a.blocks0;
   float m = 0.f;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);        // 16-byte loads (g_out is [P,4])
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n / 4; i += (long)gridDim.x * blockDim.x) {
+  for (long i = (long)bx * blockDim.x + threadIdx.x; i < n / 4; i += (long)nb * blockDim.x) {
     const f32x4 v = g4[i];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float a = fabsf(v[j]);
-      if (a < 3.0e38f) m = fmaxf(m, a);
+      const float x = fabsf(v[j]);
+      if (x < 3.0e38f) m = fmaxf(m, x);
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
   if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) slots[blockIdx.x] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
-  // the slots no workgroup of this grid owns
-  if (blockIdx.x == 0 && threadIdx.x >= gridDim.x) slots[threadIdx.x] = 0.f;
+  if (threadIdx.x == 0) slots[bx] = fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]));
+  // the slots no workgroup of this network owns
+  if (bx == 0 && (int)threadIdx.x >= nb) slots[threadIdx.x] = 0.f;
 }
 
 // max of the slots, wave-uniform (every wave of a consumer reads the 1 KB itself: an L2 hit, no LDS, no barrier)
@@ -1235,11 +1246,20 @@ static int lp_bwd_set_attr() {
 
 // the launch-wide loss scale (fp16 rows, and the 8-bit rows of format code 2; plain bf16 uses S = 1 and never
 // reads gmax)
-static int lp_launch_gmax(const float* g_out, int P, float* gmax, hipStream_t s) {
-  const long ng = 4L * P;
-  const long want = (ng + LP_GMAX_SLOTS * 16 - 1) / (LP_GMAX_SLOTS * 16);       // 16 values per thread
-  const int gblocks = (int)(want < LP_GMAX_SLOTS ? want : LP_GMAX_SLOTS);
-  hipLaunchKernelGGL(lp_gmax_kernel, dim3(gblocks), dim3(LP_GMAX_SLOTS), 0, s, g_out, ng, gmax);
+static int lp_gmax_blocks(int P) {
+  const long want = (4L * P + LP_GMAX_SLOTS * 16 - 1) / (LP_GMAX_SLOTS * 16);       // 16 values per thread
+  return (int)(want < LP_GMAX_SLOTS ? want : LP_GMAX_SLOTS);
+}
+// one launch for one network (P[1] = 0) or for both networks of a joint launch
+static int lp_launch_gmax(const float* const* g_out, const int* P, float* const* gmax, hipStream_t s) {
+  LpGmaxArgs a{};
+  int blocks = 0;
+  for (int i = 0; i < 2 && P[i] > 0; ++i) {
+    a.g[i] = g_out[i]; a.n[i] = 4L * P[i]; a.slots[i] = gmax[i];
+    if (i == 0) a.blocks0 = lp_gmax_blocks(P[0]);
+    blocks += lp_gmax_blocks(P[i]);
+  }
+  hipLaunchKernelGGL(lp_gmax_kernel, dim3(blocks), dim3(LP_GMAX_SLOTS), 0, s, a);
   return scade_check_launch("scade_mlp_bwd_lp(gmax)");
 }
 
@@ -1251,7 +1271,10 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
   float* partial = reinterpret_cast<float*>(ws + lp_dz_bytes(P));
   float* gmax = partial + (size_t)lp_ws_rows() * N_PARAM_FLOATS;
   if (!BF || S8) {
-    if (int e = lp_launch_gmax(g_out, P, gmax, s)) return e;
+    const float* gs[2] = {g_out, nullptr};
+    const int Pg[2] = {P, 0};
+    float* gm[2] = {gmax, nullptr};
+    if (int e = lp_launch_gmax(gs, Pg, gm, s)) return e;
   }
   // same point tiling as the forward that wrote the sign words of this workspace
   const int npt = lp_pick_point_tiles(P);
@@ -1289,16 +1312,18 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
   WgradLpArgs w{};
   build_wgrad_lp_jobs(w);
   float* partial[2];
+  float* gmaxs[2];
   for (int i = 0; i < 2; ++i) {
     unsigned char* ws = reinterpret_cast<unsigned char*>(wsv[i]);
     const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts[i]);
     partial[i] = reinterpret_cast<float*>(ws + lp_dz_bytes(P[i]));
     float* gmax = partial[i] + (size_t)lp_ws_rows() * N_PARAM_FLOATS;
-    if (!BF || S8) {
-      if (int e = lp_launch_gmax(g_out[i], P[i], gmax, s)) return e;
-    }
+    gmaxs[i] = gmax;
     d.n[i] = MlpDgradLpArgs{nullptr, packed_t[i], ac, g_out[i], ws, gmax, P[i]};
     w.net[i] = WgradLpNet{ac, ws, g_out[i], partial[i], gmax, P[i]};
+  }
+  if (!BF || S8) {                          // both networks' maxima in one launch
+    if (int e = lp_launch_gmax(g_out, P, gmaxs, s)) return e;
   }
   d.tiles0 = (P[0] + 32 * npt - 1) / (32 * npt);
   d.tiles1 = (P[1] + 32 * npt - 1) / (32 * npt);

@@ -18,7 +18,8 @@ KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-siz
     (r"wgrad2_reduce_kernel", "wgrad2_reduce_kernel"), (r"wgrad2_rgb_kernel", "wgrad2_rgb_kernel"),
     (r"ray_tail_kernel<1, 4>", "ray_tail_coarse"), (r"ray_tail_kernel0<3>", "ray_tail_fine"),
     (r"ray_tail_bwd_kernel<3>", "ray_tail_bwd_fine"), (r"train_loss_fwd_kernel", "train_loss_fwd"),
-    (r"train_loss_bwd_kernel", "train_loss_bwd"),
+    (r"train_loss_bwd_kernel", "train_loss_bwd"), (r"ray_tail_train_kernel<3>", "ray_tail_train"),
+    (r"train_loss_fb_reduce_kernel", "train_loss_fb_reduce"),
     (r"mlp_fwd_f16_kernel<1, false>", "mlp_fwd_f16_kernel"), (r"mlp_fwd_f16_kernel<1, true>", "mlp_fwd_f16_kernel_train"),
     (r"mlp_dgrad_f16_kernel", "mlp_dgrad_f16_kernel"), (r"mlp_wgrad_f16_kernel", "mlp_wgrad_f16_kernel"),
     # (round 3: the SAVE template argument of the 16-bit forward is an int - 0 inference, 1 16-bit rows, 2 8-bit rows;

@@ -106,6 +106,8 @@ notes = {
     "ray_tail_bwd_fine": "round 2: backward of the fine tail in one launch (sampler backward + compositing backward)",
     "train_loss_fwd": "round 2: the three-term train loss as one kernel (+ a one-wave reduce)",
     "train_loss_bwd": "its backward (+ a one-wave scale/shift reduce)",
+    "ray_tail_train": "round 3: fine tail + three-term loss (forward and backward) + the backward of both tails, one wave per ray, ONE launch (was four)",
+    "train_loss_fb_reduce": "the loss's one-workgroup reduce (loss terms, depth scale / shift gradient rows)",
 }
 rows = []
 for k in notes:
