@@ -473,13 +473,17 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpNet& a, const WgradLpJ
   };
   auto commit = [&](const WStage<BF>& s, int pt0, int buf) {
     T* st = lds + buf * WL_STAGE;
-    const bool va = pt0 + rr < c1, vb = pt0 + rr + 16 < c1;
-    const V8 a0 = va ? s.a0 : zero8, a1 = vb ? s.a1 : zero8;
+    // whole stages (all but a segment's last) skip the row-validity selects: a wave-uniform branch
+    const bool full = pt0 + WL_PT <= c1;
+    const bool va = full || pt0 + rr < c1, vb = full || pt0 + rr + 16 < c1;
+    V8 a0 = s.a0, a1 = s.a1;
+    if (!full) { a0 = va ? s.a0 : zero8; a1 = vb ? s.a1 : zero8; }
     *reinterpret_cast<V8*>(st + rr * WL_PITCH + 8 * cc) = a0;
     *reinterpret_cast<V8*>(st + (rr + 16) * WL_PITCH + 8 * cc) = a1;
     V8 b0 = zero8, b1 = zero8;
     if (KW == 256) {
-      b0 = va ? s.b0 : zero8; b1 = vb ? s.b1 : zero8;
+      b0 = s.b0; b1 = s.b1;
+      if (!full) { b0 = va ? s.b0 : zero8; b1 = vb ? s.b1 : zero8; }
       *reinterpret_cast<V8*>(st + WL_TILE + rr * WL_PITCH + 8 * cc) = b0;
       *reinterpret_cast<V8*>(st + WL_TILE + (rr + 16) * WL_PITCH + 8 * cc) = b1;
     } else if (tid < 256) {
@@ -657,9 +661,12 @@ __device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLp
   };
   auto commit = [&](const WStage8& s, int pt0, int buf) {
     T* st = lds + buf * WL_STAGE;
-    const bool va = pt0 + rr < c1;
+    // whole stages (all but a segment's last) skip the row-validity selects: a wave-uniform branch
+    const bool full = pt0 + WL_PT <= c1;
+    const bool va = full || pt0 + rr < c1;
     V8 a0 = zero8, a1 = zero8, b0 = zero8, b1 = zero8;
-    if (va) widen(s.a, a0, a1);
+    if (full) widen(s.a, a0, a1);
+    else if (va) widen(s.a, a0, a1);
     // a lane's two 16-byte halves lie 16 bytes apart, the lanes of a row 32 bytes apart: written in program order
     // the eight lanes of a ds_write_b128 group would cover 256 bytes with 16-byte holes and hit every bank group
     // twice (measured: 29.7 % conflict cycles).  Lanes 4..7 of each group of eight write their HIGH half first:
@@ -669,7 +676,8 @@ __device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLp
     *reinterpret_cast<V8*>(pa_ + (hi_first ? 8 : 0)) = hi_first ? a1 : a0;
     *reinterpret_cast<V8*>(pa_ + (hi_first ? 0 : 8)) = hi_first ? a0 : a1;
     if (KW == 256) {
-      if (va) widen(s.b, b0, b1);
+      if (full) widen(s.b, b0, b1);
+      else if (va) widen(s.b, b0, b1);
       T* pb_ = st + WL_TILE + rr * WL_PITCH + 16 * cc;
       *reinterpret_cast<V8*>(pb_ + (hi_first ? 8 : 0)) = hi_first ? b1 : b0;
       *reinterpret_cast<V8*>(pb_ + (hi_first ? 0 : 8)) = hi_first ? b0 : b1;
