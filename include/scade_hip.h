@@ -334,7 +334,8 @@ int scade_adam_step(float* params, const float* grads, float* exp_avg, float* ex
                     float lr, float beta1, float beta2, float eps, int step, float grad_scale,
                     void* stream);
 /* The same update with every per-step quantity on the device (for train steps captured in a HIP
- * graph): state = float[16] {t, lr0, decay_rate, decay_step, beta1, beta2, eps, grad_scale, ...};
+ * graph): state = float[16] {t, lr0, decay_rate, decay_step, beta1, beta2, eps, grad_scale, ...; [13] = t before
+ * the last tick = the index of the step in flight (scade_ray_points_draw's step_dev)};
  * each call first advances t and derives the staircase learning rate (hyperparameter_update.py:8-13)
  * and the bias corrections on the device, then applies the update. */
 int scade_adam_step_dev(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long n,
@@ -342,12 +343,13 @@ int scade_adam_step_dev(float* params, const float* grads, float* exp_avg, float
 /* Both optimizers of a train step - the networks' Adam and the depth scale / shift Adam (run_scade_scannet.py:469,
  * :888, :993-997), which differ in learning rate and step count - in ONE update launch.  Host arrays of two
  * entries; n[1] = 0 skips the second segment (frozen scale / shift, :996).  state[i] != NULL: that segment's
- * scalars are device resident (scade_adam_step_dev's state layout) and one tick launch advances both first;
+ * scalars are device resident (scade_adam_step_dev's state layout) and one tick launch advances both first
+ * (ticked != 0: the caller already advanced them, scade_stage_inputs);
  * otherwise lr / beta1 / beta2 / eps / step / grad_scale [i] are read from the host arrays. */
 int scade_adam_step2(float* const* params, const float* const* grads, float* const* exp_avg,
                      float* const* exp_avg_sq, const long* n, const float* lr, const float* beta1,
                      const float* beta2, const float* eps, const int* step, const float* grad_scale,
-                     float* const* state, void* stream);
+                     float* const* state, int ticked, void* stream);
 
 /* The fine tail, the train loss and the backward of both tails of a TRAIN step in one launch (+ the loss's
  * one-workgroup reduce): scade_ray_tail (fine form, run_scade_scannet.py:720-730) -> scade_train_loss_fb (:954,
@@ -368,9 +370,11 @@ int scade_ray_tail_train(const float* raw, const float* z_vals, const float* ray
 /* Batch staging for graph-captured steps: n <= 8 device-to-device copies (whole, 4-byte-aligned words) and,
  * scalar_dst != NULL, one 8-byte scalar (the step's training-image index, run_scade_scannet.py:930) in ONE launch -
  * what the reference's per-step batch assembly (:930-960: rays, target colours, depth hypotheses of the sampled
- * pixels) writes into the step's input tensors. */
+ * pixels) writes into the step's input tensors.  tick_states != NULL: two device-resident optimizer states (or NULL
+ * entries) are advanced by one step here (the tick of scade_adam_step_dev; pass ticked = 1 to scade_adam_step2 then):
+ * the step's prologue is one launch. */
 int scade_stage_inputs(const void* const* src, void* const* dst, const long* bytes, int n,
-                       long long* scalar_dst, long long scalar, void* stream);
+                       long long* scalar_dst, long long scalar, float* const* tick_states, void* stream);
 
 #ifdef __cplusplus
 }

@@ -84,6 +84,7 @@ __global__ void adam_step2_kernel(Adam2Args a) {
   }
 }
 __device__ __forceinline__ void adam_tick(float* st) {
+  st[13] = st[0];                      // steps taken BEFORE this one: the step's index for in-kernel draws
   const float t = st[0] + 1.0f;
   st[0] = t;
   const double it = (double)t + (double)st[11];
@@ -108,9 +109,12 @@ struct StageArgs {
   int n;
   long long* scalar_dst;
   long long scalar;
+  float* tick[2];        // device-resident optimizer scalars to advance (scade_adam_step_dev's layout), or null
 };
 __global__ void stage_inputs_kernel(StageArgs a) {
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.scalar_dst) *a.scalar_dst = a.scalar;
+  if (blockIdx.x == 0 && threadIdx.x == 64 && a.tick[0]) adam_tick(a.tick[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 128 && a.tick[1]) adam_tick(a.tick[1]);
   int g = 0;
   while (g + 1 < a.n && (int)blockIdx.x >= a.first_block[g + 1]) ++g;
   if (g >= a.n) return;
@@ -130,7 +134,7 @@ __global__ void stage_inputs_kernel(StageArgs a) {
 }  // namespace scade
 
 extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, const long* bytes, int n,
-                                  long long* scalar_dst, long long scalar, void* stream) {
+                                  long long* scalar_dst, long long scalar, float* const* tick_states, void* stream) {
   SCADE_REQUIRE(n >= 0 && n <= scade::STAGE_MAX, -2, "scade_stage_inputs: 0..%d copies per launch", scade::STAGE_MAX);
   SCADE_REQUIRE(n == 0 || (src && dst && bytes), -1, "scade_stage_inputs: null pointer");
   scade::StageArgs a{};
@@ -151,7 +155,8 @@ extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, cons
   a.n = n;
   a.scalar_dst = scalar_dst;
   a.scalar = scalar;
-  if (blocks == 0 && !scalar_dst) return 0;
+  if (tick_states) { a.tick[0] = tick_states[0]; a.tick[1] = tick_states[1]; }
+  if (blocks == 0 && !scalar_dst && !a.tick[0] && !a.tick[1]) return 0;
   hipLaunchKernelGGL(scade::stage_inputs_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_stage_inputs");
 }
@@ -164,7 +169,7 @@ static int adam_blocks(long n) { return (int)((n + 255) / 256 < 2048 ? (n + 255)
 extern "C" int scade_adam_step2(float* const* params, const float* const* grads, float* const* exp_avg,
                                 float* const* exp_avg_sq, const long* n, const float* lr, const float* beta1,
                                 const float* beta2, const float* eps, const int* step, const float* grad_scale,
-                                float* const* state, void* stream) {
+                                float* const* state, int ticked, void* stream) {
   SCADE_REQUIRE(params && grads && exp_avg && exp_avg_sq && n, -1, "scade_adam_step2: null pointer");
   scade::Adam2Args a{};
   bool any_state = false;
@@ -184,7 +189,7 @@ extern "C" int scade_adam_step2(float* const* params, const float* const* grads,
   }
   if (a.s[0].n <= 0 && a.s[1].n <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
-  if (any_state)
+  if (any_state && !ticked)
     hipLaunchKernelGGL(scade::adam_tick2_kernel, dim3(1), dim3(128), 0, st, a.s[0].n > 0 ? a.s[0].st : nullptr,
                        a.s[1].n > 0 ? a.s[1].st : nullptr);
   a.blocks0 = a.s[0].n > 0 ? adam_blocks(a.s[0].n) : 0;

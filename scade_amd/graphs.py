@@ -58,9 +58,10 @@ class GraphedTrainer:
         # optimizer state not restored, :480) has taken opt.steps = 0 steps but stands at iteration N
         tr.opt.use_device_state(c["rate"], c["step"], iter_offset=tr.it - tr.opt.steps)
         tr.opt_ss.use_device_state()
-        # in-kernel draws: the step index must live on the device too (state[0] = steps taken by this optimizer;
+        # in-kernel draws: the step index must live on the device too (state[13] = steps taken BEFORE the step in flight:
+        # the tick that opens the step, ops.stage_inputs below, records it;
         # resumed runs add their offset through the seed so that the streams do not repeat)
-        tr.draw_step_dev = tr.opt.state[0:1]
+        tr.draw_step_dev = tr.opt.state[13:14]
         tr.draw_seed = (tr.draw_seed + (tr.it - tr.opt.steps) * 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
         self.graph = None
         self.loss = None
@@ -80,7 +81,7 @@ class GraphedTrainer:
         tr.backward(loss)
         tr.bucket.end_backward()
         tr.reduce_grads()
-        adam_step_pair(tr.opt, tr.opt_ss if tr.scaleshift_active() else None, dev=True)
+        adam_step_pair(tr.opt, tr.opt_ss if tr.scaleshift_active() else None, dev=True, ticked=True)
         return aux["loss_report"]
 
     def _state(self):
@@ -129,7 +130,8 @@ class GraphedTrainer:
             pairs.append((mask, self.mask))
         if self.draws is not None:
             pairs += [(t_rand, self.draws[0]), (u_coarse, self.draws[1]), (cached_u, self.draws[2])]
-        ops.stage_inputs(pairs, scalar)
+        # ... and the optimizers' device-resident step scalars advance in the same launch (no tick launch in the graph)
+        ops.stage_inputs(pairs, scalar, tick=[tr.opt.state, tr.opt_ss.state if tr.scaleshift_active() else None])
         with_ss = tr.scaleshift_active()
         if self.graph is None or (with_ss, tr.carving_active()) != self._captured:
             self._capture()      # first step, or the warm-start (:973) / scale-shift freeze point (:996) was crossed

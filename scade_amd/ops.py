@@ -336,9 +336,10 @@ def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs) -> None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
 
 
-def stage_inputs(pairs, scalar=None) -> None:
+def stage_inputs(pairs, scalar=None, tick=None) -> None:
     """``dst.copy_(src)`` for up to eight (src, dst) pairs - and ``scalar = (int64 tensor, value)``: one 8-byte
-    store - in ONE launch (scade_stage_inputs): the static input buffers of a graph-captured step.  Pairs that the
+    store; ``tick = [state, state | None]``: the device-resident scalars of up to two fused optimizers advanced by
+    one step - in ONE launch (scade_stage_inputs): the prologue of a graph-captured step.  Pairs that the
     kernel does not take as they are (other dtype / shape / layout / device) fall back to ``copy_``."""
     src_p, dst_p, nbytes = [], [], []
     for src, dst in pairs:
@@ -354,12 +355,19 @@ def stage_inputs(pairs, scalar=None) -> None:
     sd, sv = (scalar[0].data_ptr(), int(scalar[1])) if scalar is not None else (None, 0)
     if scalar is not None and (scalar[0].dtype != torch.int64 or not scalar[0].is_cuda):
         raise ValueError("stage_inputs: the scalar destination must be an int64 device tensor")
-    if not src_p and sd is None:
+    ticks = None
+    if tick is not None and any(t is not None for t in tick):
+        for t in tick:
+            if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() >= 16 and t.is_contiguous()):
+                raise ValueError("stage_inputs: tick entries are the float32[16] device states of FusedAdam")
+        t2 = (list(tick) + [None])[:2]
+        ticks = ctypes.cast((ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in t2]), ctypes.c_void_p)
+    if not src_p and sd is None and ticks is None:
         return
     n = len(src_p)
     vp = lambda v: ctypes.cast((ctypes.c_void_p * max(n, 1))(*v), ctypes.c_void_p)
     call("scade_stage_inputs", vp(src_p), vp(dst_p), ctypes.cast((ctypes.c_long * max(n, 1))(*nbytes), ctypes.c_void_p), n,
-         sd, sv, stream())
+         sd, sv, ticks, stream())
 
 
 def lp_point_tiles(P: int) -> int:

@@ -51,9 +51,10 @@ class FusedAdam:
         self.flat.zero_grad()
 
 
-def adam_step_pair(a: FusedAdam, b: Optional[FusedAdam], lr_a=None, dev: bool = False):
+def adam_step_pair(a: FusedAdam, b: Optional[FusedAdam], lr_a=None, dev: bool = False, ticked: bool = False):
     """``a.step(lr=lr_a)`` and (``b`` given) ``b.step()`` as ONE update launch (scade_adam_step2); ``dev``: both
-    optimizers read their scalars from their device state (``use_device_state``; graph-captured steps)."""
+    optimizers read their scalars from their device state (``use_device_state``; graph-captured steps);
+    ``ticked``: that state was already advanced for this step (``ops.stage_inputs(tick=...)``)."""
     import ctypes
     opts = [a] + ([b] if b is not None else [])
     for o in opts:
@@ -65,7 +66,7 @@ def adam_step_pair(a: FusedAdam, b: Optional[FusedAdam], lr_a=None, dev: bool = 
     if dev:
         st = pp(lambda o: o.state)
         call("scade_adam_step2", pp(lambda o: o.flat.data), pp(lambda o: o.flat.grad), pp(lambda o: o.exp_avg),
-             pp(lambda o: o.exp_avg_sq), ctypes.cast(n, P), None, None, None, None, None, None, st, stream())
+             pp(lambda o: o.exp_avg_sq), ctypes.cast(n, P), None, None, None, None, None, None, st, int(bool(ticked)), stream())
     else:
         lrs = two(lambda o: float(lr_a if (o is a and lr_a is not None) else o.lr), ctypes.c_float)
         b1 = two(lambda o: float(o.betas[0]), ctypes.c_float)
@@ -75,5 +76,5 @@ def adam_step_pair(a: FusedAdam, b: Optional[FusedAdam], lr_a=None, dev: bool = 
         gs = two(lambda o: 1.0, ctypes.c_float)
         call("scade_adam_step2", pp(lambda o: o.flat.data), pp(lambda o: o.flat.grad), pp(lambda o: o.exp_avg),
              pp(lambda o: o.exp_avg_sq), ctypes.cast(n, P), ctypes.cast(lrs, P), ctypes.cast(b1, P),
-             ctypes.cast(b2, P), ctypes.cast(eps, P), ctypes.cast(stp, P), ctypes.cast(gs, P), None, stream())
+             ctypes.cast(b2, P), ctypes.cast(eps, P), ctypes.cast(stp, P), ctypes.cast(gs, P), None, 0, stream())
     ops.PARAM_EPOCH += 1
