@@ -1066,24 +1066,10 @@ static void build_wgrad_lp_jobs(WgradLpArgs& w) {
 // workgroup with the kernel's own timestamps (tools/scratch: -DWL_DBG) under the running mix, 1024-ray step -
 // bf16 16 / 16.9 / 13.4 / 10.3 / 9.2 / 9.1 / 3.7 (layer, feature + alpha rider, views, the three embedding-input
 // jobs, rgb head; in 16ths), 8-bit rows 16 / 17.7 / 12.6 / 9.8 / 8.8 / 8.5 / 3.8, fp16 as bf16.  Bytes per stage
-// alone would say 16 / 16 / 16 / 10 / 10 / 10 / 8.  (SCADE_WL_WEIGHTS="l,feat,views,emb0,emb5,embv,rgb" overrides.)
-static const int* lp_job_weights() {
-  static int w[7] = {32, 35, 26, 20, 18, 17, 8};
-  static bool init = false;
-  if (!init) {
-    init = true;
-    if (const char* e = getenv("SCADE_WL_WEIGHTS")) {
-      int v[7];
-      if (sscanf(e, "%d,%d,%d,%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3], &v[4], &v[5], &v[6]) == 7)
-        for (int i = 0; i < 7; ++i)
-          if (v[i] >= 1 && v[i] <= 255) w[i] = v[i];
-    }
-  }
-  return w;
-}
+// alone would say 16 / 16 / 16 / 10 / 10 / 10 / 8.
+static constexpr int LP_JOB_WEIGHTS[7] = {32, 35, 26, 20, 18, 17, 8};
 static int lp_job_weight(int j, bool) {
-  const int* w = lp_job_weights();
-  return j < 7 ? w[0] : w[j - 6];      // jobs 0..6: layers 1..7; 7 feature, 8 views, 9..11 embedding jobs, 12 rgb
+  return j < 7 ? LP_JOB_WEIGHTS[0] : LP_JOB_WEIGHTS[j - 6];      // jobs 0..6: layers 1..7; 7 feature, 8 views, 9..11 embedding jobs, 12 rgb
 }
 // partial rows a network's workspace holds: no entry is cut into more segments than this (its share of the
 // workgroups, rounded up, plus the two it may share with its neighbours)
@@ -1135,8 +1121,8 @@ static int lp_build_plan(WgradLpArgs& w, const int* P, bool s8, unsigned char ns
   // per CU and job the stage costs are latency, not bytes (the weights above do not hold), and a third more
   // workgroups than CUs lets one's partial-row stores overlap another's loop (128 rays per GPU: 0.325 ms graphed
   // bf16 step against 0.333 with the balanced plan; 1024 rays: 1.45 against 1.37, 4096 rays: 5.5 against 5.2).
-  static const long grid_below = getenv("SCADE_WL_GRID_BELOW") ? atol(getenv("SCADE_WL_GRID_BELOW")) : 100000;
-  if ((long)P[0] + P[1] < grid_below) {
+  constexpr long LP_GRID_BELOW = 100000;
+  if ((long)P[0] + P[1] < LP_GRID_BELOW) {
     const long Pt = (long)P[0] + P[1];
     // ONE round: chunks x jobs <= CUs (19 chunks on 256 CUs; 28 chunks = 1.4 rounds measured 3 % slower on the
     // 128- and 256-ray graph steps, 14 chunks 3 % slower too), chunks never shorter than 512 points

@@ -89,16 +89,13 @@ constexpr int N_PARAM_FLOATS = 589700;
 // compute units of the current device (256 on MI355X); 256 when no device is visible (CPU-side
 // size queries in the build container)
 inline int device_cus() {
-  static int n = 0;
-  if (n == 0) {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) == hipSuccess &&
-        hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
-      n = v;
-    else
-      n = 256;
-  }
-  return n;
+  // asked every time (a property lookup, no driver round trip): the library keeps no per-process copy, so a
+  // process that drives devices of different sizes sizes every workspace and plan for the CURRENT one
+  int dev = 0, v = 0;
+  if (hipGetDevice(&dev) == hipSuccess &&
+      hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0)
+    return v;
+  return 256;
 }
 
 // ReLU sign words of the fp32-layout workspace: ONE 32-bit word per (pts layer, 32-point tile, thread

@@ -69,8 +69,7 @@ inline int pick_chunks(int P, int target_pts = 2400) {
   long n = ncu * k / 9;
   // a launch of ONE round: all twelve jobs of a chunk in it (21 chunks on 256 CUs), not nine heavy ones filling the
   // CUs and the three light ones behind them (28 chunks = 1.3 rounds: the coarse pass of a 1024-ray step 362 us)
-  static const bool one_round = !(getenv("SCADE_WGRAD_ONE_ROUND") && getenv("SCADE_WGRAD_ONE_ROUND")[0] == '0');
-  if (k == 1 && one_round) n = ncu / 12;
+  if (k == 1) n = ncu / 12;
   const long nmax = P / 512 > 1 ? P / 512 : 1;
   if (n > nmax) n = nmax;
   if (n < 1) n = 1;

@@ -410,19 +410,11 @@ __global__ static void wgrad2_reduce_pair_kernel(Reduce2Args r) {
 // Chunks of points per launch.  Two workgroups share a CU; per chunk there are 17 half-layer workgroups of
 // equal length (8 layers x 2 halves + the 128-row views layer) plus five short ones (four embedding
 // columns blocks, the rgb head) worth about 1.5 more.  The chunk count fills k whole "rounds" of the
-// 2 x CUs slots with chunks near `target_pts` points (SCADE_WGRAD_PTS overrides it for experiments).
-static int w2_target_pts() {
-  static int v = 0;
-  if (v == 0) {
-    const char* e = getenv("SCADE_WGRAD_PTS");
-    v = e ? atoi(e) : 0;
-    if (v < 64) v = 2400;
-  }
-  return v;
-}
+// 2 x CUs slots with chunks near `target_pts` points.
+static constexpr int W2_TARGET_PTS = 2400;   // ring depth 2..6 and chunks of 1,600..3,600 points measure within 1 %
 int pick_chunks_v2(int P) {
   const double slots = 2.0 * device_cus(), per_chunk = 18.5;
-  const int target = w2_target_pts();
+  const int target = W2_TARGET_PTS;
   long k = (long)((double)P * per_chunk / (slots * target) + 0.5);
   if (k < 1) k = 1;
   long n = (long)(slots * k / per_chunk);

@@ -18,6 +18,9 @@ from . import ops
 from .optim import adam_step_pair
 
 
+CAPTURE_ERROR_MODE = "thread_local"
+
+
 def _capture_mode():
     """Capture-error mode of every stream capture of this module: "thread_local".  torch's default, "global",
     makes a HIP call that is illegal during capture an error in EVERY thread of the process - including the NCCL
@@ -25,9 +28,9 @@ def _capture_mode():
     with hipEventQuery.  When such a poll lands inside a capture window the watchdog throws and the process
     aborts (ProcessGroupNCCL.cpp, Watchdog::run): the "RCCL teardown abort" of round 2, seen about once in forty
     to sixty runs and never in teardown (tools/probe_rccl_teardown.py, profiles/r03_rccl_teardown.txt).  The
-    capturing thread's own calls stay checked.  SCADE_GRAPH_CAPTURE_MODE=global restores the old behaviour."""
-    import os
-    return os.environ.get("SCADE_GRAPH_CAPTURE_MODE", "thread_local")
+    capturing thread's own calls stay checked.  (``graphs.CAPTURE_ERROR_MODE = "global"`` restores the old behaviour:
+    the probe tool's variant G.)"""
+    return CAPTURE_ERROR_MODE
 
 
 class GraphedTrainer:
@@ -61,8 +64,10 @@ class GraphedTrainer:
         # in-kernel draws: the step index must live on the device too (state[13] = steps taken BEFORE the step in flight:
         # the tick that opens the step, ops.stage_inputs below, records it;
         # resumed runs add their offset through the seed so that the streams do not repeat)
-        tr.draw_step_dev = tr.opt.state[13:14]
-        tr.draw_seed = (tr.draw_seed + (tr.it - tr.opt.steps) * 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
+        # Kept HERE, not on the Trainer: eager Trainer.step calls on the same trainer keep drawing by their host
+        # step index, and a second GraphedTrainer on it does not apply the offset twice.
+        self._resume_offset = tr.it - tr.opt.steps
+        self._step_dev = tr.opt.state[13:14]
         self.graph = None
         self.loss = None
         self._captured = None     # (scale/shift update in the graph?, carving term in the graph?)
@@ -73,6 +78,9 @@ class GraphedTrainer:
         kw = {}
         if self.draws is not None:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
+        else:
+            key = (tr.draw_key() + self._resume_offset * 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
+            kw = dict(draws=ops.Draws(key, 0, self._step_dev))
         loss, aux = tr.forward_loss(self.rays, self.tgt, self.hyp, img_i=self.img_i, mask=self.mask,
                                     n_total=self.n_total, **kw)
         if tr._unit_loss_ready:

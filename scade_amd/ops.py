@@ -994,7 +994,7 @@ class TrainLossUnitFn(torch.autograd.Function):
              float(threshold), float(out_scale), N, P, K, ptr(ws), ptr(loss4), ptr(g_rgb), ptr(g_rgb0), ptr(g_pred),
              ptr(gs), ptr(gh), sc.numel(), stream())
         ctx.save_for_backward(g_rgb, g_rgb0, g_pred)
-        ctx.unit_ptr = unit.data_ptr()
+        ctx.unit_ptr, ctx.unit_version = unit.data_ptr(), unit._version
         comps = loss4[1:]
         ctx.mark_non_differentiable(comps)
         ctx.set_materialize_grads(False)
@@ -1002,7 +1002,7 @@ class TrainLossUnitFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, _unused):
-        if g is None or g.data_ptr() != ctx.unit_ptr:
+        if g is None or g.data_ptr() != ctx.unit_ptr or g.numel() != 1 or g._version != ctx.unit_version:
             raise RuntimeError("train_loss (unit-gradient form): backward() must be called with the unit tensor "
                                "given to the forward (Trainer.backward does); use ops.TrainLossFn otherwise")
         g_rgb, g_rgb0, g_pred = ctx.saved_tensors
@@ -1069,7 +1069,7 @@ class FineTailLossFn(torch.autograd.Function):
         if t0 is not None:
             KERNEL_TIMER.stop("ray_tail_train", t0, 0.0)
         ctx.save_for_backward(g_raw, g_raw0)
-        ctx.unit_ptr = unit.data_ptr()
+        ctx.unit_ptr, ctx.unit_version = unit.data_ptr(), unit._version
         comps = loss4[1:]
         ctx.mark_non_differentiable(comps, rgb, disp, acc, w, depth, samples, std)
         ctx.set_materialize_grads(False)
@@ -1077,7 +1077,7 @@ class FineTailLossFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g, *_unused):
-        if g is None or g.data_ptr() != ctx.unit_ptr:
+        if g is None or g.data_ptr() != ctx.unit_ptr or g.numel() != 1 or g._version != ctx.unit_version:
             raise RuntimeError("ray_tail_train: backward() must be called with the unit tensor given to the forward "
                                "(Trainer.backward does)")
         g_raw, g_raw0 = ctx.saved_tensors

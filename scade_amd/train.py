@@ -12,7 +12,6 @@ Not a port of train_nerf (data loading, logging, checkpoints stay with the calle
 """
 from __future__ import annotations
 
-import os
 from typing import Optional
 
 import torch
@@ -81,7 +80,7 @@ class Trainer:
         # rays are sharded over the ranks of the default process group (one process per GPU)
         self.sharded = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         if allreduce is None:
-            allreduce = os.environ.get("SCADE_ALLREDUCE", "single")
+            allreduce = "single"
         if allreduce not in ("single", "overlap"):
             raise ValueError('Trainer: allreduce must be "single" or "overlap"')
         self.allreduce = allreduce
@@ -89,9 +88,9 @@ class Trainer:
         # since round 2: with two weight-gradient workgroups per CU, two kernels sharing the chip no longer
         # beat the same two back to back (measured 1024 rays, on / off: exact 7.28 / 7.17 ms, bf16 1.55 /
         # 1.50 ms, f16x3 3.47 / 3.43 ms).  The two-piece overlapped all-reduce needs the side stream and
-        # turns it on; SCADE_OVERLAP_COARSE=1/0 forces it.
+        # turns it on; ``overlap_coarse=True / False`` forces it.
         if overlap_coarse is None:
-            overlap_coarse = os.environ.get("SCADE_OVERLAP_COARSE", "0") != "0" or allreduce == "overlap"
+            overlap_coarse = allreduce == "overlap"
         self.coarse_stream = torch.cuda.Stream(device=dev) if overlap_coarse and dev.type == "cuda" else None
         self.force_allreduce = False        # self-tests: issue the collective on a one-rank group too
         # the three-term loss as one fused operator (ops.TrainLossFn) instead of the separate public
@@ -100,23 +99,33 @@ class Trainer:
         # the MLP backward of both networks as ONE dgrad / weight-gradient / reduce launch each
         # (mlp_bwd.DeferredBackward).  Not with the side stream: there the coarse chain's own launches are the point
         if joint_backward is None:
-            joint_backward = os.environ.get("SCADE_JOINT_BACKWARD", "1") != "0"
+            joint_backward = True
         self.joint_backward = bool(joint_backward) and self.coarse_stream is None
-        # the step's uniform draws inside scade_ray_points_draw (SCADE_DRAW_IN_KERNEL=0: one torch.rand launch).
-        # The Philox key comes from torch's seed of this process (parallel.seed_rank_streams gives every rank its
-        # own), the counter from the step index: reproducible under torch.manual_seed like the torch.rand path.
-        self.joint_pack = os.environ.get("SCADE_JOINT_PACK", "1") != "0"
-        # loss forward + backward as one launch pair when the step is driven by begin() / backward() below
-        self.unit_loss = os.environ.get("SCADE_UNIT_LOSS", "1") != "0"
         self._unit_loss_ready = False
-        self.draw_in_kernel = os.environ.get("SCADE_DRAW_IN_KERNEL", "1") != "0"
-        # fine tail + loss + both tails' backward in one launch (forward_loss); SCADE_FUSED_TAIL_LOSS=0: the
-        # separate operators (same bits: the equality is a test)
-        self.fused_tail_loss = os.environ.get("SCADE_FUSED_TAIL_LOSS", "1") != "0"
-        self.draw_seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5CADE) & (2 ** 64 - 1)
-        self.draw_step_dev = None           # GraphedTrainer: the fused optimizer's device-resident step count
-        self._one = torch.ones((), device=dev)      # see _unit_grad (built here, never inside a graph capture)
+        # fine tail + loss + both tails' backward in one launch (forward_loss) where the step's mode allows it;
+        # ``fused_tail_loss = False``: the separate operators (same bits: the equality is a test)
+        self.fused_tail_loss = True
+        self._draw_key = None               # Philox key of the in-kernel draws: draw_key(), derived at first use
+        # d loss / d loss = 1 (see _unit_grad; built here, never inside a graph capture).  Private and IMMUTABLE: the
+        # one-launch loss forms bake the factor 1.0 in and recognise this tensor by address and version
+        self._one = torch.ones((), device=dev)
         self.bucket.broadcast_params(0)
+
+    def draw_key(self) -> int:
+        """Philox key of this rank's in-kernel draws.  Derived at the FIRST step, not at construction, from torch's
+        seed of this process at that moment (so ``torch.manual_seed`` / ``parallel.seed_rank_streams`` called after
+        the Trainer was built still select the stream, as they did for the ``torch.rand`` path) AND the rank: the
+        Philox counter is (draw block, local ray, step), so two ranks with one key would draw the same jitter and
+        the same u for their k-th ray (per-rank distinct u / jitter streams)."""
+        if self._draw_key is None:
+            rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+            self._draw_key = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x5CADE
+                              + rank * 0xD1B54A32D192ED03) & (2 ** 64 - 1)
+        return self._draw_key
+
+    def reseed_draws(self):
+        """Forget the key: the next step derives it again from torch's current seed."""
+        self._draw_key = None
 
     def _unit_grad(self, loss):
         """d loss / d loss = 1 from a cached tensor (autograd would launch a fill for it every step)."""
@@ -140,7 +149,7 @@ class Trainer:
         # the MFMA weight blobs of both networks (forward + transposed layout), rebuilt after the last
         # optimizer step by ONE launch instead of four
         prec = self.coarse.train_precision
-        if self.joint_pack and (prec == "f32" or prec in ops.LP_FORMATS) and self.fine.train_precision == prec \
+        if (prec == "f32" or prec in ops.LP_FORMATS) and self.fine.train_precision == prec \
                 and torch.is_grad_enabled():
             ops.mlp_pack_step([self.coarse, self.fine], "bf16" if prec == "bf16-s8" else prec)
         share = batch_share(rays.shape[0], n_total) if self.sharded else 1.0
@@ -148,20 +157,11 @@ class Trainer:
             # the LAST sampler (sample_pdf_joint_return_u, :728) draws ONE u[S] for the whole batch
             # (helpers:498-513): rank 0's draw.  The coarse importance sampler stays per ray (:705).
             render_kw.setdefault("cached_u", shared_uniform((c["Ni"],), rays.device))
-        if not any(k in render_kw for k in ("t_rand", "u_coarse", "pytest")):
-            if self.draw_in_kernel:
-                # the step's uniform draws (stratified jitter :564-579, the sample_pdf draws helpers:346-361,
-                # :395-410) are made inside the step's first kernel: no generator launch, no jitter tensor
-                render_kw["draws"] = ops.Draws(self.draw_seed, self.it, self.draw_step_dev)
-            else:
-                # ... or as ONE torch generator launch; independent streams either way
-                n, ns, ni = rays.shape[0], c["Ns"], c["Ni"]
-                need_u = "cached_u" not in render_kw and not c["joint"]
-                d = torch.rand(n * (ns + ni + (ni if need_u else 0)), device=rays.device)
-                render_kw["t_rand"] = d[:n * ns].view(n, ns)
-                render_kw["u_coarse"] = d[n * ns:n * (ns + ni)].view(n, ni)
-                if need_u:
-                    render_kw["cached_u"] = d[n * (ns + ni):].view(n, ni)
+        if not any(k in render_kw for k in ("t_rand", "u_coarse", "pytest", "draws")):
+            # the step's uniform draws (stratified jitter :564-579, the sample_pdf draws helpers:346-361,
+            # :395-410) are made inside the step's first kernel: no generator launch, no jitter tensor.
+            # Injected draws (parity tests, the reference's pytest=True streams) take precedence.
+            render_kw["draws"] = ops.Draws(self.draw_key(), self.it)
         hyp_per_ray = target_hyp.dim() == 3 and target_hyp.shape[-1] == 1
         # the fine tail, the loss and the backward of both tails as ONE launch (ops.FineTailLossFn) where the step
         # allows it: unit-gradient loss, per-ray hypotheses, no raw noise, coarse stage on this stream
@@ -254,7 +254,8 @@ class Trainer:
         and - when the fused three-term loss will run in its unit-gradient form, which WRITES the scale / shift
         gradient rows - without the zero fill of those rows."""
         c = self.cfg
-        unit = self.unit_loss and self.fused_loss and not c["joint"]
+        # (needs both networks' gradient regions covered by sinks: what lies outside them is not zero-filled then)
+        unit = self.fused_loss and not c["joint"] and len(self.bucket._sinks) == 2
         self.bucket.begin_step(zero_outside_sinks=not unit)
         self._unit_loss_ready = unit
 

@@ -114,6 +114,13 @@ def _worker(rank, world, port, out_dir, backend):
     out = {}
     for name, kw, use_mask in CASES:
         out[name] = _run_case(dev, kw, use_mask, a, b, N_RAYS)
+    # in-kernel draws (no injection): both ranks step on the SAME rays, built under the SAME torch seed
+    from scade_amd.train import Trainer, make_scade_nets
+    coarse, fine = make_scade_nets(dev, seed=5)
+    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3)
+    rays_, tgt_, hyp_ = _problem()[:3]
+    aux = tr.step(rays_[:16].to(dev), tgt_[:16].to(dev), hyp_[:, :16].to(dev), n_total=32)[1]
+    out["own_draws"] = (aux["ret"]["z_vals0"].cpu(), aux["ret"]["u"].cpu())
     torch.manual_seed(100 + rank)
     out["shared_u"] = shared_uniform((NI,), dev).cpu()
     out["render"] = _render_image(dev, shard=True)          # test render sharded over the ranks
@@ -158,6 +165,10 @@ def test_sharded_trainer_two_ranks_matches_single_process(dev, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), backend), nprocs=world, join=True)
     outs = [torch.load(os.path.join(tmp_path, f"r{r}.pt")) for r in range(world)]
     assert torch.equal(outs[0]["shared_u"], outs[1]["shared_u"]), "sample_pdf_joint's u is one draw for all ranks"
+    # per-rank distinct jitter / u streams - the Philox key carries the rank (Trainer.draw_key)
+    (z0, u0), (z1, u1) = outs[0]["own_draws"], outs[1]["own_draws"]
+    assert float((u0 == u1).float().mean()) < 0.01 and float((z0 == z1).float().mean()) < 0.05, "ranks drew the same stream"
+    assert float(u0.min()) >= 0 and float(u0.max()) < 1 and abs(float(u1.mean()) - 0.5) < 0.05
     for name, kw, use_mask in CASES:
         g0, p0, l0 = outs[0][name]
         g1, p1, l1 = outs[1][name]

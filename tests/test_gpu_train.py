@@ -537,7 +537,6 @@ def test_graph_replays_queued_back_to_back_equal_eager_bitwise(dev, precision):
         coarse, fine = make_scade_nets(dev, seed=5)
         torch.manual_seed(11)
         tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
-        tr.draw_in_kernel = True
         gt = GraphedTrainer(tr, N, K) if mode == "graph" else None
         gb = torch.Generator(device=dev).manual_seed(83)
         for it in range(steps):
@@ -835,13 +834,16 @@ def test_one_launch_pack_of_both_networks_writes_the_same_blobs(dev, fmt):
 
 
 @pytest.mark.parametrize("variant", ["plain", "wild_mask_thr", "warm_start", "dev_index"])
-def test_unit_gradient_loss_form_equals_the_two_entry_form(dev, variant, monkeypatch):
+def test_unit_gradient_loss_form_equals_the_two_entry_form(dev, variant):
     """Trainer.step runs the three-term loss forward AND backward as one launch pair (ops.TrainLossUnitFn,
     scade_train_loss_fb: the step differentiates the total with a unit gradient) and lets its reduce WRITE all
-    scale / shift gradient rows instead of zero-filling them first.  Against the forward / backward entry pair
-    (SCADE_UNIT_LOSS=0): same loss, bit-identical gradient bucket - stale contents of the scale / shift rows
-    included - and bit-identical parameters after three steps.  Any other incoming gradient is refused."""
-    from scade_amd import ops
+    scale / shift gradient rows instead of zero-filling them first.  Against the same step composed by hand from
+    the forward / backward entry pair (forward_loss() without begin() takes ops.TrainLossFn; plain
+    FlatParams.begin_step() zero-fills the rows): same loss, bit-identical gradient bucket - stale contents of the
+    scale / shift rows included - and bit-identical parameters after three steps.  Any other incoming gradient is
+    refused."""
+    from scade_amd.optim import adam_step_pair
+    from scade_amd.parallel import staircase_lr
     from scade_amd.train import Trainer, make_scade_nets
     N, K = 80, 12
     rays = O.synthetic_rays(N, seed=41).to(dev)
@@ -853,34 +855,85 @@ def test_unit_gradient_loss_form_equals_the_two_entry_form(dev, variant, monkeyp
                   cached_u=torch.rand(N, 128, generator=g).to(dev)) for _ in range(3)]
     kw = {"plain": {}, "wild_mask_thr": dict(mask_mode="wild", space_carving_threshold=0.05),
           "warm_start": dict(warm_start_nerf=2), "dev_index": {}}[variant]
+
+    def two_entry_step(tr, img, d):
+        tr.bucket.begin_step()                        # zero fill of the scale / shift rows; unit form NOT armed
+        loss, aux = tr.forward_loss(rays, tgt, hyp, img, mask, **d)
+        tr.backward(loss)
+        tr.bucket.end_backward()
+        lr = staircase_lr(tr.cfg["lrate"], tr.cfg["rate"], tr.cfg["step"], tr.it + 1)
+        adam_step_pair(tr.opt, tr.opt_ss if tr.scaleshift_active() else None, lr_a=lr)
+        tr.it += 1
+        return aux["loss_report"]
+
     res = {}
-    for unit in ("1", "0"):
-        monkeypatch.setenv("SCADE_UNIT_LOSS", unit)
+    for unit in (True, False):
         coarse, fine = make_scade_nets(dev, seed=9)
         tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3, scaleshift_lr=1e-3, **kw)
-        assert tr.unit_loss == (unit == "1")
+        tr.fused_tail_loss = False                    # the loss as its own operator (the one-launch tail has its own test)
         tr.bucket.grad.fill_(5.0)                     # stale gradient rows everywhere
         losses, grads = [], []
         for i, d in enumerate(draws):
             img = torch.tensor([i % 3], device=dev) if variant == "dev_index" else i % 3
-            loss, aux = tr.step(rays, tgt, hyp, img_i=img, mask=mask, **d)
+            loss = tr.step(rays, tgt, hyp, img_i=img, mask=mask, **d)[0] if unit else two_entry_step(tr, img, d)
             losses.append(float(loss))
             grads.append(tr.bucket.grad.clone())
         torch.cuda.synchronize()
         res[unit] = (losses, grads, tr.bucket.data.clone())
-    assert res["1"][0] == res["0"][0]
-    for a, b in zip(res["1"][1], res["0"][1]):
+    assert res[True][0] == res[False][0]
+    for a, b in zip(res[True][1], res[False][1]):
         assert torch.equal(a, b)
-    assert torch.equal(res["1"][2], res["0"][2])
+    assert torch.equal(res[True][2], res[False][2])
     n = 2 * 589700
-    ss = res["1"][1][-1][n:]
+    ss = res[True][1][-1][n:]
     if variant != "warm_start":
         assert float(ss.abs().sum()) > 0 and float(ss[[0, 1, 3, 4]].abs().sum()) == 0.0, "step 3 touches image 2 only"
     # a non-unit incoming gradient cannot be served by the unit form
-    monkeypatch.setenv("SCADE_UNIT_LOSS", "1")
     coarse, fine = make_scade_nets(dev, seed=9)
     tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=3)
     tr.begin()
     loss, _ = tr.forward_loss(rays, tgt, hyp, **draws[0])
     with pytest.raises(RuntimeError):
         (loss * 2.0).backward()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_default_trainer_step_gradient_bucket_vs_golden(dev, precision):
+    """ONE hop from the shipped train step to the reference: the DEFAULT ``Trainer.step`` (one-launch packs, in-step
+    loss forms, fine tail + loss + both tails' backward in one launch, joint backward of both networks, gradient
+    sinks) on the f6 fixture's rays / parameters with the reference's own pytest=True draws injected, its gradient
+    BUCKET against ``grad_coarse/*``, ``grad_fine/*``, ``train/grad_scale|shift`` captured from the real
+    reference (run_scade_scannet.py:963-985) - at test_train_step_golden's bars, which differentiates the separate
+    public operators instead."""
+    from scade_amd.train import Trainer
+    g = load_golden("f6_render")
+    pc, pf = f6_params(g)
+    coarse, fine, _ = build(dev, pc, pf, g["bb_center"], g["bb_scale"])
+    tr = Trainer(coarse, fine, g["bb_center"], g["bb_scale"], n_images=1, precision=precision)
+    assert tr.fused_loss and tr.fused_tail_loss and tr.joint_backward and tr.coarse_stream is None, "the default modes"
+    u = g["train/u"].to(dev)                          # pytest=True: every sampler draws np.random.seed(0) rand(N, 128)
+    loss, aux = tr.step(g["rays"].to(dev), g["target_s"].to(dev), g["hyp"].to(dev), img_i=0,
+                        t_rand=g["train/t_rand"].to(dev), u_coarse=u, cached_u=u)
+    torch.cuda.synchronize()
+    assert "_fine_tail_pending" not in aux["ret"] and aux["ret"]["pred_hyp"].shape == (g["rays"].shape[0], 128)
+    assert_close(loss, g["train/loss"], rtol=1e-4, atol=1e-7, what="loss")
+    assert_close(aux["img_loss"], g["train/img_loss"], rtol=1e-4, atol=1e-7, what="img_loss")
+    assert_close(aux["carve"], g["train/carve"], rtol=1e-4, atol=1e-7, what="carve")
+    assert_close(aux["img_loss0"], g["train/img_loss0"], rtol=1e-4, atol=1e-7, what="img_loss0")
+    bucket = tr.bucket.grad
+    o = 0
+    for net, name in ((coarse, "coarse"), (fine, "fine")):
+        for k, p in net.named_parameters():
+            assert p.grad is not None and p.grad.data_ptr() == bucket[o:].data_ptr(), f"{name}.{k}: .grad is its bucket slice"
+            got, want = bucket[o:o + p.numel()].view(p.shape), g[f"grad_{name}/{k}"]
+            o += p.numel()
+            if float(want.abs().max()) == 0.0:
+                assert float(got.abs().max()) == 0.0, f"{name}.{k} must receive exactly zero gradient"
+            elif name == "coarse":
+                grad_close(sub(got), sub(want), f"grad coarse.{k}", rtol=2e-4, scale_atol=5e-5)
+            else:
+                e = rel_l2(got, want)
+                assert e < 2e-2, f"grad fine.{k}: rel-L2 {e:.3e}"
+    assert_close(bucket[o:o + 1], g["train/grad_scale"].reshape(1), rtol=5e-3, atol=1e-9, what="d scale")
+    assert_close(bucket[o + 1:o + 2], g["train/grad_shift"].reshape(1), rtol=5e-3, atol=1e-9, what="d shift")
+    assert o + 2 == bucket.numel()

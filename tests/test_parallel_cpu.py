@@ -92,7 +92,20 @@ def _worker(rank, world, port, out_dir, n_rays, pieces):
         flat.wait_all(works)
     else:
         assert flat.allreduce_grads() == 1.0 / world                  # legacy factor, unused here
-    torch.save((flat.grad.clone(), loss.detach()), os.path.join(out_dir, f"g{rank}.pt"))
+    # the Philox key of the Trainer's in-kernel draws (host logic): every rank builds its Trainer under the SAME
+    # torch seed (identical weight init), so the key must carry the rank; it is derived at first use, so a later
+    # seed_rank_streams / manual_seed still selects the stream
+    import types
+    from scade_amd.train import Trainer
+    torch.manual_seed(7)
+    keys = []
+    for reseed in (None, 8):
+        stub = types.SimpleNamespace(_draw_key=None)
+        if reseed is not None:
+            torch.manual_seed(reseed)
+        keys.append(Trainer.draw_key(stub))
+        assert Trainer.draw_key(stub) == keys[-1], "stable once derived"
+    torch.save((flat.grad.clone(), loss.detach(), keys), os.path.join(out_dir, f"g{rank}.pt"))
     dist.destroy_process_group()
 
 
@@ -101,8 +114,9 @@ def test_sharded_gradients_match_single_process(tmp_path, n_rays, pieces):
     """8 + 8 and 9 + 8 rays: the summed share-weighted gradients are the single-process ones."""
     world = 2
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_rays, pieces), nprocs=world, join=True)
-    g0, l0 = torch.load(os.path.join(tmp_path, "g0.pt"))
-    g1, l1 = torch.load(os.path.join(tmp_path, "g1.pt"))
+    g0, l0, k0 = torch.load(os.path.join(tmp_path, "g0.pt"))
+    g1, l1, k1 = torch.load(os.path.join(tmp_path, "g1.pt"))
+    assert len({k0[0], k0[1], k1[0], k1[1]}) == 4, "in-kernel draw keys: distinct per rank AND per torch seed at first use"
     assert torch.equal(g0, g1), "all ranks must hold identical reduced gradients"
     rays, tgt, hyp, t_rand, u = _problem(n_rays)
     tensors, pc, pf, scale, shift = _params()

@@ -9,7 +9,7 @@ all-reduce forced, then the variant's teardown.
   C  no graph capture at all: eager all-reduces only, then destroy_process_group()
   D  graphs alive, NO destroy_process_group(): plain interpreter exit
   E  as B, then os._exit(0) right after destroy_process_group() (skip interpreter finalisation)
-  G  SIX captures per run in torch's default GLOBAL capture-error mode (SCADE_GRAPH_CAPTURE_MODE=global), each
+  G  SIX captures per run in torch's default GLOBAL capture-error mode (graphs.CAPTURE_ERROR_MODE = "global"), each
      behind eager all-reduces whose events the process group's watchdog thread is still polling
   T  the same six captures in THREAD-LOCAL capture-error mode (GraphedTrainer's default since round 3)
 Round-3 finding (profiles/r03_rccl_teardown.txt): the abort is not in teardown at all.  It is the NCCL watchdog
@@ -44,7 +44,8 @@ def child(variant, port):
         tr.step(rays, tgt, hyp)
     gt = None
     if variant in ("G", "T"):
-        os.environ["SCADE_GRAPH_CAPTURE_MODE"] = "global" if variant == "G" else "thread_local"
+        from scade_amd import graphs
+        graphs.CAPTURE_ERROR_MODE = "global" if variant == "G" else "thread_local"
         for rep in range(6):
             for _ in range(4):                  # eager collectives: work objects for the watchdog to poll
                 tr.step(rays, tgt, hyp)

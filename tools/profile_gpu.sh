@@ -12,7 +12,6 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 # per-kernel durations and counters are only meaningful when the kernels do not overlap: keep the
 # Trainer's coarse stage on the main stream while profiling (the default since round 2)
-export SCADE_OVERLAP_COARSE=0
 STEPS=100
 # the headline region only; 12 setup + 20 warm-up steps precede the 100 timed ones (bench.py), and the
 # statistics below are taken over the LAST 100 launches of each launch size, i.e. the timed steps alone
