@@ -925,15 +925,17 @@ def test_default_trainer_step_gradient_bucket_vs_golden(dev, precision):
     for net, name in ((coarse, "coarse"), (fine, "fine")):
         for k, p in net.named_parameters():
             assert p.grad is not None and p.grad.data_ptr() == bucket[o:].data_ptr(), f"{name}.{k}: .grad is its bucket slice"
-            got, want = bucket[o:o + p.numel()].view(p.shape), g[f"grad_{name}/{k}"]
+            got, want = sub(bucket[o:o + p.numel()].view(p.shape)), g[f"grad_{name}/{k}"]     # (the fixture holds sub())
             o += p.numel()
             if float(want.abs().max()) == 0.0:
                 assert float(got.abs().max()) == 0.0, f"{name}.{k} must receive exactly zero gradient"
-            elif name == "coarse":
-                grad_close(sub(got), sub(want), f"grad coarse.{k}", rtol=2e-4, scale_atol=5e-5)
+            elif name == "coarse" and precision == "f32":
+                grad_close(got, want, f"grad coarse.{k}", rtol=2e-4, scale_atol=5e-5)
             else:
+                # norm-wise: the fine net sits behind the resampling (test_train_step_golden); in split precision a
+                # forward that differs by 1e-7 flips the sign of a handful of ReLU units (test_f16x3_train_step_golden)
                 e = rel_l2(got, want)
-                assert e < 2e-2, f"grad fine.{k}: rel-L2 {e:.3e}"
+                assert e < (2e-2 if precision == "f32" else 3e-2), f"grad {name}.{k}: rel-L2 {e:.3e}"
     assert_close(bucket[o:o + 1], g["train/grad_scale"].reshape(1), rtol=5e-3, atol=1e-9, what="d scale")
     assert_close(bucket[o + 1:o + 2], g["train/grad_shift"].reshape(1), rtol=5e-3, atol=1e-9, what="d shift")
     assert o + 2 == bucket.numel()
