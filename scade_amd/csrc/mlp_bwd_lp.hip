@@ -396,7 +396,14 @@ constexpr int WL_PITCH = 288;                      // elements per LDS row: 256 
                                                    // rows of a transposing read land 16 banks apart)
 constexpr int WL_TILE = WL_PT * WL_PITCH;          // elements per operand tile
 constexpr int WL_STAGE = 2 * WL_TILE;              // dZ tile + input tile
-constexpr int WGRAD_LP_LDS_BYTES = 3 * WL_STAGE * 2;   // triple buffered: 110592
+constexpr int WL_LDS_BYTES = 3 * WL_STAGE * 2;         // triple buffered: 110592
+#ifndef W8_D_VALUE
+#define W8_D_VALUE 3
+#endif
+constexpr int W8_S = 64;                               // format code 2 (wgrad_lp8_dma_job): points per ring slot,
+constexpr int W8_D = W8_D_VALUE;                       // ring slots,
+constexpr int W8_SLOT = 2 * W8_S * 256 + 256;          // bytes per slot: dZ [64][256] | input [64][256] | d alpha [64] fp32
+constexpr int WGRAD_LP_LDS_BYTES = W8_D * W8_SLOT > WL_LDS_BYTES ? W8_D * W8_SLOT : WL_LDS_BYTES;
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -784,6 +791,370 @@ __device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLp
   }
 }
 
+// ---- format code 2, round 4: the 256-wide jobs contract the e5m2 rows AS THEY LIE IN HBM, on the fp8-family MFMA.
+// The commit design above passes every byte through registers (load -> v_perm widening to fp16 -> ds_write ->
+// transposing 16-bit read -> fp16 MFMA) and runs commit (830 cycles, VALU) | MFMA (950) | barrier (500) in series per
+// 32-point stage.  Here:
+//  * the rows go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), 1 KiB = four 256-byte rows per wave
+//    instruction: no staging registers, no commit phase, no VALU work at all; rows past the segment end arrive as
+//    zeros through the descriptor's range check;
+//  * the MFMA operands are gathered straight from the byte rows with gfx950's ds_read_b64_tr_b8 (a 16-lane group
+//    reads an [8 points][16 columns] block, lane j receives column j's eight bytes; lane map probed on the part) -
+//    half the LDS bytes of the 16-bit image, no widening;
+//  * the contraction is v_mfma_scale_f32_32x32x64_f8f6f4 on bf8 (e5m2) operands with unit block scales (E8M0 127):
+//    64 points per instruction at TWICE the rate of the 16-bit / plain fp8 MFMAs (measured 4.5-4.9 PFLOP/s against
+//    2.0-2.3; bit-exact products - every e5m2 x e5m2 product and the fp32 accumulation are what the fp16 MFMA gave).
+//    A lane's 32 k-values are points 32 (lane >> 5) .. + 31 of the stage (any k order works as long as both
+//    operands use the same one).  The first ring version contracted 32-point stages on v_mfma_f32_32x32x16_bf8_bf8
+//    and sat at 0.73-0.77 us per stage where the memory side alone gives 0.52-0.57 (knock-outs: without MFMAs 0.52,
+//    without fragment reads 0.71, with the MFMAs replaced by s_sleep of their length 0.66): a stage's MFMA time
+//    (1152 cycles per SIMD) plus ~600 cycles around the barrier were as long as the stage's memory time, and two
+//    bottlenecks of equal length behind one barrier add up.  At twice the rate and half the barriers per point the
+//    MFMA side is 40 % of the memory time;
+//  * LDS-DMA writes a lane-linear image (no row padding possible inside an instruction), and rows 256 bytes apart
+//    share their banks, so the SOURCE is swizzled instead: the lane that fills 16-byte slot c of row r fetches
+//    logical chunk c ^ 2 (r & 7).  A transposing read's eight rows then sit in eight different slots, and the two
+//    column chunks of a 32-lane pass in the odd / even ones: SQ_LDS_BANK_CONFLICT 0.2 %;
+//  * the bias rider is one more MFMA per stage against a constant all-ones operand (every column of its tile is the
+//    row sum; wave (m, kw) does n-tile kw of its 64 features); the alpha-head rider (one job) reads the published
+//    input rows, two 16-byte pieces per thread and stage, its d alpha scalars ride the ring as 4-byte DMAs;
+//  * ring of W8_D slots of 64 points, one barrier per stage in the MIDDLE of the stage's MFMAs: the B fragments
+//    of k-tiles 2, 3 are read in front of it (under the MFMAs of k-tiles 0, 1), the next stage's B 0, 1 fragments
+//    behind it (under the MFMAs of k-tiles 2, 3) and its A fragments last, into the registers those MFMAs free: 48
+//    fragment registers beside the 144 accumulators (a second A set spilled), the A reads' latency is the only
+//    one exposed - on a pipe that is 40 % busy.
+// What the memory system gives this access pattern through LDS-DMA, no compute (tools/probe_dma.hip): 6.8-7.0 TB/s
+// with 256 workgroups, swizzle and nt included, any ring depth from 3 slots - a CU does not keep more than ~2 slots
+// of this size in flight however many are queued, which is why deeper rings measured the same.
+static_assert(W8_D * W8_SLOT <= WGRAD_LP_LDS_BYTES && WGRAD_LP_LDS_BYTES <= 160 * 1024, "the ring lives in the kernel's LDS allocation");
+static_assert(33 * 256 * 4 <= WGRAD_LP_LDS_BYTES, "alpha rider's reduction scratch");
+
+#ifdef WL_DBG
+__device__ unsigned long long wl_dbg2[4 * 512];     // per workgroup, its LAST ring job: {loop start, loop end, stages, after epilogue}
+#endif
+typedef __amdgpu_buffer_rsrc_t lp_rsrc_t;
+__device__ __forceinline__ lp_rsrc_t lp_make_rsrc(const void* base, unsigned bytes) {
+  const unsigned long long p = reinterpret_cast<unsigned long long>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
+  void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+// workgroup barrier that orders LDS only (lgkmcnt(0), never vmcnt(0): the ring stays in flight)
+__device__ __forceinline__ void lp_lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <bool ALPHA>
+__device__ __forceinline__ void wgrad_lp8_dma_job(const WgradLpNet& a, const WgradLpJob& jb, unsigned char* lds,
+                                                  int c0, int c1, float invS, float* __restrict__ out) {
+  constexpr int S = W8_S, D = W8_D;
+  constexpr int NI = ALPHA ? 5 : 4;                     // LDS-DMA instructions per wave and stage
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef i32x2 __attribute__((address_space(3))) * tr_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int m = wave >> 1, kw = wave & 1;
+  const int n0 = m * 64, k0 = kw * 128;
+  const bool active = n0 < jb.n_rows;
+  const int P = a.P;
+  const int npts = c1 - c0;
+  const lp_rsrc_t ra = lp_make_rsrc(a.dz + jb.dz_off * 2 + (size_t)c0 * 256, (unsigned)npts * 256u);
+  const lp_rsrc_t rb = lp_make_rsrc(a.acts + jb.in_off * 2 + (size_t)c0 * 256, (unsigned)npts * 256u);
+  const lp_rsrc_t rd = lp_make_rsrc(a.dz + lp_dz_dalpha_byte(P) + (size_t)c0 * 4, (unsigned)npts * 4u);
+
+  f32x16 acc[2][4], accb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    accb[i] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[t][u][i] = 0.f;
+  }
+
+  // ---- LDS-DMA of stage st into slot sl: wave w moves rows 8w .. 8w+7 of both tiles (two instructions each; lane L
+  // of instruction e fills slot L & 15 of row 8w + 4e + (L >> 4) with the row's logical chunk (L & 15) ^ 2 (row & 7)).
+  // Read once: nt.
+  const int voff0 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (lane >> 4))) << 4);              // rows 8w + 0..3
+  const int voff1 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (4 + (lane >> 4)))) << 4);        // rows 8w + 4..7
+  auto issue = [&](int st, int sl) {
+    unsigned char* slot = lds + sl * W8_SLOT;
+    const int grow = st * S + 8 * wave;                 // row of the segment (past its end: zeros)
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + 8 * wave * 256), 16, voff0, grow * 256, 0, 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + (8 * wave + 4) * 256), 16, voff1, (grow + 4) * 256, 0, 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 256 + 8 * wave * 256), 16, voff0, grow * 256, 0, 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 256 + (8 * wave + 4) * 256), 16, voff1, (grow + 4) * 256, 0, 2);
+    if (ALPHA) {
+      if (lane < 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(slot + 2 * S * 256 + 8 * wave * 4), 4, lane * 4, grow * 4, 0, 0);
+    }
+  };
+
+  // ---- fragments: lane (group g = lane >> 4, i = lane & 15) supplies the address of 8 bytes of row 32 (lane >> 5) +
+  // 8 q + (i >> 1) - half (i & 1) of the 16-column chunk (g & 1) of its tile - and receives, in registers 2q, 2q+1 of
+  // the operand, column lane & 31 of the tile at those eight points
+  struct AF { i32x8 t[2]; };      // A (dZ) fragments of the wave's two n-tiles
+  struct BF2 { i32x8 u[2]; };     // B (input) fragments of two of its four k-tiles
+  const int fj = (lane & 15) >> 1, gb = (lane >> 4) & 1;
+  const int lane_row = (32 * hh + fj) * 256 + (lane & 1) * 8;
+  // (fragment t of wave (m, kw) is n-tile t ^ kw of its 64 features: the tile whose bias it sums is always t = 0)
+  const int fa = lane_row + (((4 * m + 2 * kw + gb) ^ (2 * fj)) << 4);        // fragment 0 (fragment 1: ^ 32)
+  const int fb = S * 256 + lane_row + (((8 * kw + gb) ^ (2 * fj)) << 4);      // k-tile 0 (k-tile u: ^ 32 u)
+  auto read8 = [&](i32x8& f, const unsigned char* p) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const i32x2 v = __builtin_amdgcn_ds_read_tr8_b64_v2i32((tr_ptr_t)(p + q * 8 * 256));
+      f[2 * q] = v[0];
+      f[2 * q + 1] = v[1];
+    }
+  };
+  auto read_A = [&](AF& f, int sl) {
+    if (!active) return;
+    const unsigned char* slot = lds + sl * W8_SLOT;
+    read8(f.t[0], slot + fa);
+    read8(f.t[1], slot + (fa ^ 32));
+  };
+  auto read_B = [&](BF2& f, int sl, int pair) {
+    if (!active) return;
+    const unsigned char* slot = lds + sl * W8_SLOT;
+    read8(f.u[0], slot + (fb ^ (64 * pair)));
+    read8(f.u[1], slot + (fb ^ (64 * pair + 32)));
+  };
+  constexpr int UNIT = 0x7F7F7F7F;                      // E8M0 block scales 2^0
+  const i32x8 ones = {0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C};   // e5m2 1.0
+#define W8_MFMA(A_, B_, C_) C_ = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A_, B_, C_, 1, 1, 0, UNIT, 0, UNIT)
+  auto mfma_pair = [&](const AF& A, const BF2& B, int pair) {
+    if (!active) return;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) W8_MFMA(A.t[t], B.u[j], acc[t][2 * pair + j]);
+    if (pair == 0) W8_MFMA(A.t[0], ones, accb);
+  };
+#undef W8_MFMA
+
+  // ---- alpha-head rider: thread (rows rr, rr + 32; slot pc) holds the 16 columns of logical chunk pc ^ 2 (rr & 7)
+  const int rr = tid >> 4, pc = tid & 15;
+  float alpha_acc[16], dal_acc = 0.f, rd_d[2] = {0.f, 0.f};
+  lp_u32x4 rd_w[2] = {{0u, 0u, 0u, 0u}, {0u, 0u, 0u, 0u}};
+#pragma unroll
+  for (int j = 0; j < 16; ++j) alpha_acc[j] = 0.f;
+  auto riders_read = [&](int sl) {
+    if (!ALPHA) return;
+    const unsigned char* slot = lds + sl * W8_SLOT;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      rd_w[h] = *reinterpret_cast<const lp_u32x4*>(slot + S * 256 + (rr + 32 * h) * 256 + pc * 16);
+      rd_d[h] = *reinterpret_cast<const float*>(slot + 2 * S * 256 + (rr + 32 * h) * 4);
+    }
+  };
+  auto riders_add = [&]() {
+    if (!ALPHA) return;
+    typedef float f2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f2 lo = __builtin_amdgcn_cvt_pk_f32_bf8((int)rd_w[h][q], false), hi = __builtin_amdgcn_cvt_pk_f32_bf8((int)rd_w[h][q], true);
+        alpha_acc[4 * q + 0] = fmaf(rd_d[h], lo[0], alpha_acc[4 * q + 0]);
+        alpha_acc[4 * q + 1] = fmaf(rd_d[h], lo[1], alpha_acc[4 * q + 1]);
+        alpha_acc[4 * q + 2] = fmaf(rd_d[h], hi[0], alpha_acc[4 * q + 2]);
+        alpha_acc[4 * q + 3] = fmaf(rd_d[h], hi[1], alpha_acc[4 * q + 3]);
+      }
+      if (pc == 0) dal_acc += rd_d[h];
+    }
+  };
+
+  // ---- pipeline.  Stages past the segment are issued too (zeros, no memory traffic): the vmcnt stays a constant.
+  const int ns = (npts + S - 1) / S;
+#pragma unroll
+  for (int st = 0; st < D; ++st) issue(st, st);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
+  lp_lds_barrier();
+  AF A = {};
+  BF2 B01 = {}, B23 = {};
+  read_A(A, 0);
+  read_B(B01, 0, 0);
+  int sl = 0;
+#ifdef WL_DBG
+  if (tid == 0) { wl_dbg2[4 * blockIdx.x] = wall_clock64(); wl_dbg2[4 * blockIdx.x + 2] = (unsigned long long)ns; }
+#endif
+  for (int st = 0; st < ns; ++st) {
+    const int sl1 = sl + 1 == D ? 0 : sl + 1;
+    read_B(B23, sl, 1);
+    riders_read(sl);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_pair(A, B01, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    riders_add();
+    // stage st+1: this wave's pieces have landed (D-2 younger stages stay in flight) ...
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NI) : "memory");
+    lp_lds_barrier();                             // ... and so have everybody's; slot sl is read out
+    issue(st + D, sl);
+    read_B(B01, sl1, 0);                          // (its registers are free; A's are not until the MFMAs below are out)
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_pair(A, B23, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    read_A(A, sl1);
+    sl = sl1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land on the scratch below / after the job
+#ifdef WL_DBG
+  if (tid == 0) wl_dbg2[4 * blockIdx.x + 1] = wall_clock64();
+#endif
+
+  // ---- write the partial (loss scale removed)
+  if (active) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int k = k0 + 32 * u + r;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          const int n = n0 + 32 * (t ^ kw) + (i & 3) + 8 * (i >> 2) + 4 * hh;
+          if (n < jb.n_rows && k >= jb.kfirst && k < jb.kvalid)
+            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + (k - jb.kfirst)] = acc[t][u][i] * invS;
+        }
+      }
+    if (r == 0) {                                 // every column of the bias tile holds the row sums
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + 32 * kw + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (n < jb.n_rows) out[jb.b_off + n] = accb[i] * invS;
+      }
+    }
+  }
+#ifdef WL_DBG
+  __syncthreads();
+  if (tid == 0) wl_dbg2[4 * blockIdx.x + 3] = wall_clock64();
+#endif
+  if (ALPHA) {
+    __syncthreads();                              // every wave is through its reads and its DMAs: the ring is free
+    float* red = reinterpret_cast<float*>(lds);   // [32 rows][256] (+ 32)
+    const int lc = pc ^ (2 * (rr & 7));
+#pragma unroll
+    for (int j = 0; j < 16; ++j) red[rr * 256 + 16 * lc + j] = alpha_acc[j];
+    if (pc == 0) red[32 * 256 + rr] = dal_acc;
+    __syncthreads();
+    if (tid < 256) {
+      float sum = 0.f;
+      for (int g = 0; g < 32; ++g) sum += red[g * 256 + tid];
+      out[jb.aux_off + tid] = sum;
+    }
+    if (tid == 0) {
+      float sum = 0.f;
+      for (int g = 0; g < 32; ++g) sum += red[32 * 256 + g];
+      out[jb.aux_off + 256] = sum;
+    }
+  }
+}
+
+// The embedding-input jobs (layer 0, the skip block of layer 5, the view-direction columns of the views layer:
+// 256 or 128 features x 64 embedding columns) on the same ring: dZ rows as above, the fp8 e4m3 embedding rows (64
+// bytes per point, mlp_tile_lp.h) as the B operand of the same MFMA (mixed bf8 x fp8).  Wave (m, kw) owns 64 features
+// x embedding columns 32 kw .. + 31: two accumulators, two MFMAs per stage (+ the bias rider of layer 0), so the
+// fragments are simply read behind the barrier - the job is all memory (20 KB per 64-point stage).  The 64-byte rows
+// need their own source swizzle: rows 4 apart share their banks, so rows 4..7 of every eight fetch their chunks
+// c ^ 2 - a transposing read's 8 rows x 2 chunks then cover 256 different bytes of the bank line.
+__device__ __forceinline__ void wgrad_lp8_dma_emb_job(const WgradLpNet& a, const WgradLpJob& jb, unsigned char* lds,
+                                                      int c0, int c1, float invS, float* __restrict__ out) {
+  constexpr int S = W8_S, D = W8_D, NI = 3;
+  typedef __attribute__((address_space(3))) void* lds_ptr_t;
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef int i32x8 __attribute__((ext_vector_type(8)));
+  typedef i32x2 __attribute__((address_space(3))) * tr_ptr_t;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, hh = lane >> 5;
+  const int m = wave >> 1, kw = wave & 1;
+  const int n0 = m * 64;
+  const bool active = n0 < jb.n_rows;
+  const int P = a.P;
+  const int npts = c1 - c0;
+  const lp_rsrc_t ra = lp_make_rsrc(a.dz + jb.dz_off * 2 + (size_t)c0 * 256, (unsigned)npts * 256u);
+  const lp_rsrc_t rb = lp_make_rsrc(a.acts + acts_emb_off(P) * 2 + (size_t)c0 * 64, (unsigned)npts * 64u);
+
+  f32x16 acc[2], accb;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accb[i] = 0.f; }
+
+  const int voff0 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (lane >> 4))) << 4);
+  const int voff1 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (4 + (lane >> 4)))) << 4);
+  // embedding rows 8w .. 8w+7 (lanes 0-31: row 8w + (L >> 2), slot L & 3 <- chunk (L & 3) ^ 2 ((row >> 2) & 1))
+  const int voffe = (lane >> 2) * 64 + (((lane & 3) ^ (2 * ((lane >> 4) & 1))) << 4);
+  auto issue = [&](int st, int sl) {
+    unsigned char* slot = lds + sl * W8_SLOT;
+    const int grow = st * S + 8 * wave;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + 8 * wave * 256), 16, voff0, grow * 256, 0, 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + (8 * wave + 4) * 256), 16, voff1, (grow + 4) * 256, 0, 2);
+    if (lane < 32)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 256 + 8 * wave * 64), 16, voffe, grow * 64, 0, 2);
+  };
+  const int fj = (lane & 15) >> 1, gb = (lane >> 4) & 1;
+  const int fa = (32 * hh + fj) * 256 + (lane & 1) * 8 + (((4 * m + 2 * kw + gb) ^ (2 * fj)) << 4);   // fragment 0 = n-tile kw
+  const int fe = S * 256 + (32 * hh + fj) * 64 + (lane & 1) * 8 + (((2 * kw + gb) ^ (2 * (fj >> 2))) << 4);
+  constexpr int UNIT = 0x7F7F7F7F;
+  const i32x8 ones = {0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C, 0x3C3C3C3C};
+  const bool want_bias = (jb.flags & WF_BIAS) != 0;
+
+  const int ns = (npts + S - 1) / S;
+#pragma unroll
+  for (int st = 0; st < D; ++st) issue(st, st);
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * NI) : "memory");
+  lp_lds_barrier();
+  int sl = 0;
+  for (int st = 0; st < ns; ++st) {
+    if (active) {
+      const unsigned char* slot = lds + sl * W8_SLOT;
+      i32x8 a0, a1, b;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const i32x2 v0 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((tr_ptr_t)(slot + fa + q * 8 * 256));
+        const i32x2 v1 = __builtin_amdgcn_ds_read_tr8_b64_v2i32((tr_ptr_t)(slot + (fa ^ 32) + q * 8 * 256));
+        const i32x2 vb = __builtin_amdgcn_ds_read_tr8_b64_v2i32((tr_ptr_t)(slot + fe + q * 8 * 64));
+        a0[2 * q] = v0[0]; a0[2 * q + 1] = v0[1];
+        a1[2 * q] = v1[0]; a1[2 * q + 1] = v1[1];
+        b[2 * q] = vb[0]; b[2 * q + 1] = vb[1];
+      }
+      acc[0] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, b, acc[0], 1, 0, 0, UNIT, 0, UNIT);    // bf8 x fp8
+      acc[1] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a1, b, acc[1], 1, 0, 0, UNIT, 0, UNIT);
+      if (want_bias) accb = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a0, ones, accb, 1, 1, 0, UNIT, 0, UNIT);
+    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NI) : "memory");
+    lp_lds_barrier();
+    issue(st + D, sl);
+    sl = sl + 1 == D ? 0 : sl + 1;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+  if (active) {
+    const int k = 32 * kw + r;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + 32 * (t ^ kw) + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (n < jb.n_rows && k >= jb.kfirst && k < jb.kvalid)
+          out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + (k - jb.kfirst)] = acc[t][i] * invS;
+      }
+    if (want_bias && r == 0) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int n = n0 + 32 * kw + (i & 3) + 8 * (i >> 2) + 4 * hh;
+        if (n < jb.n_rows) out[jb.b_off + n] = accb[i] * invS;
+      }
+    }
+  }
+}
+
 // rgb head: dW_r[c][k] = sum_pt g[pt][c] * hv[pt][k], db_r[c] = sum_pt g[pt][c].
 // A thread owns 8 columns (one 16-byte load per point) of every 32nd point, four points in flight:
 // this job is pure load latency, and as the LAST job of the table its workgroups set the kernel's end.
@@ -903,8 +1274,11 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
     jb.in_off = jb.in_slot >= 0 ? acts_slot_off(a.P, jb.in_slot) : acts_emb_off(a.P);
     const int gc = gb - (second ? pl.gx0 : 0);          // grid mode: chunk index within the network
     const int c0 = grid_mode ? gc * pl.chunk : s0 * WL_PT;
-    const int c1 = grid_mode ? min(a.P, c0 + pl.chunk)
-                             : min(a.P, max(s1, s0) * WL_PT);       // an empty segment (c1 == c0) still writes its zero row
+    int c1 = grid_mode ? min(a.P, c0 + pl.chunk)
+                       : min(a.P, max(s1, s0) * WL_PT);       // an empty segment (c1 == c0) still writes its zero row
+#ifdef W8_KO_OTHER      // (experiment: only the ring jobs stream, the others write their zero rows)
+    if (S8 && ((jb.flags & WF_RGB) || jb.kw != 256)) c1 = c0;
+#endif
     float* out = a.partial + (size_t)(grid_mode ? gc : w - pl.first_wg[e]) * N_PARAM_FLOATS;
     const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(lp_read_gmax(a.gmax));
     if (!first) __syncthreads();                        // the previous segment's riders still read the LDS
@@ -912,8 +1286,21 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
     if (jb.flags & WF_RGB) {
       wgrad_rgb_lp_job<BF, false>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);   // (its input slot is 16-bit in every format)
     } else if (S8) {
-      if (jb.kw == 256) wgrad_lp8_job<256>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
-      else wgrad_lp8_job<64>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
+#ifdef LP8_COMMIT_PATH      // (A/B variant builds only: the round-3 register-staged job)
+      if (jb.kw == 256) {
+        wgrad_lp8_job<256>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
+      } else
+#endif
+      if (jb.kw == 256) {
+        if (jb.flags & WF_ALPHA) wgrad_lp8_dma_job<true>(a, jb, reinterpret_cast<unsigned char*>(ldsw16), c0, c1, invS, out);
+        else wgrad_lp8_dma_job<false>(a, jb, reinterpret_cast<unsigned char*>(ldsw16), c0, c1, invS, out);
+      } else {
+#ifdef LP8_COMMIT_EMB       // (A/B variant builds only; needs 16-bit embedding rows: the forward of this build saves fp8)
+        wgrad_lp8_job<64>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
+#else
+        wgrad_lp8_dma_emb_job(a, jb, reinterpret_cast<unsigned char*>(ldsw16), c0, c1, invS, out);
+#endif
+      }
     } else if (jb.kw == 256) {
       wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);
     } else {
@@ -931,6 +1318,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
 #ifdef WL_DBG
 }  // namespace scade
 extern "C" int scade_debug_wl(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out + 4 * 512, HIP_SYMBOL(scade::wl_dbg2), sizeof(unsigned long long) * 4 * 512) != hipSuccess) return -1;
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scade::wl_dbg), sizeof(unsigned long long) * 4 * 512);
 }
 namespace scade {
@@ -1068,8 +1456,15 @@ static void build_wgrad_lp_jobs(WgradLpArgs& w) {
 // jobs, rgb head; in 16ths), 8-bit rows 16 / 17.7 / 12.6 / 9.8 / 8.8 / 8.5 / 3.8, fp16 as bf16.  Bytes per stage
 // alone would say 16 / 16 / 16 / 10 / 10 / 10 / 8.
 static constexpr int LP_JOB_WEIGHTS[7] = {32, 35, 26, 20, 18, 17, 8};
-static int lp_job_weight(int j, bool) {
-  return j < 7 ? LP_JOB_WEIGHTS[0] : LP_JOB_WEIGHTS[j - 6];      // jobs 0..6: layers 1..7; 7 feature, 8 views, 9..11 embedding jobs, 12 rgb
+// format code 2 since round 4: every job but the rgb head runs on the LDS-DMA ring at the memory system's rate for
+// one workgroup per CU (~25 GB/s per CU with all 256 streaming), and so does the rgb head's register pipeline - a
+// stage costs its BYTES: 16 KB per 32 points for a layer, + the d alpha scalars, 16 KB at half the MFMA work for the
+// 128-row views layer (measured 14.6 / 16), 10 KB for the embedding-input jobs (8 KB of dZ + 2 KB of fp8 embedding
+// rows: measured 10.4 / 16), 8.7 KB for the rgb head (16-bit views rows + g_out: measured 8.5 - 10.4 / 16).
+static constexpr int LP8_JOB_WEIGHTS[7] = {32, 34, 29, 21, 21, 21, 19};
+static int lp_job_weight(int j, bool s8) {
+  const int* w = s8 ? LP8_JOB_WEIGHTS : LP_JOB_WEIGHTS;
+  return j < 7 ? w[0] : w[j - 6];      // jobs 0..6: layers 1..7; 7 feature, 8 views, 9..11 embedding jobs, 12 rgb
 }
 // partial rows a network's workspace holds: no entry is cut into more segments than this (its share of the
 // workgroups, rounded up, plus the two it may share with its neighbours)

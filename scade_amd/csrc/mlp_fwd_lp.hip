@@ -165,6 +165,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   T* actsT = reinterpret_cast<T*>(a.acts);
   if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0 - one 16-byte chunk per item
     T* eo = actsT + acts_emb_off(P);
+    unsigned char* eo8 = a.acts + acts_emb_off(P) * 2;        // format code 2: fp8 e4m3 rows, 64 bytes per point
     for (int i = tid; i < LM * 8; i += 256) {
       const int row = i >> 3, ch = i & 7;
       const int pt = p0 + row;
@@ -176,7 +177,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
             v[4 + c] = (T)(MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c]
                                      : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c]);
         }
-        __builtin_nontemporal_store(v, reinterpret_cast<V8*>(eo + (size_t)pt * 64 + 8 * ch));
+        if (SAVE == 2) {
+          lp_u32x2 o;
+          o[0] = lp_pack4_fp8((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
+          o[1] = lp_pack4_fp8((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
+          __builtin_nontemporal_store(o, reinterpret_cast<lp_u32x2*>(eo8 + (size_t)pt * 64 + 8 * ch));
+        } else {
+          __builtin_nontemporal_store(v, reinterpret_cast<V8*>(eo + (size_t)pt * 64 + 8 * ch));
+        }
       }
     }
   }

@@ -191,15 +191,23 @@ __device__ __forceinline__ void save_tile_lp_wave(const typename LP<BF>::T* x, t
 // and the weight gradient converts the rows back to bf16 while staging them into LDS.  What changes numerically
 // is the weight gradient's operands (2 mantissa bits, zero-mean rounding); dgrad and forward are untouched.
 // Layout: the workspaces keep the 16-bit offsets; an 8-bit row p of slot s lies at byte acts_slot_off(P, s) * 2 +
-// p * 256 (the first half of the slot's region).  Two parts stay 16-bit: the embedding rows (64 columns) and
-// the activation slot of the 128-wide views hidden layer - the dgrad kernel derives that layer's ReLU mask from
-// it, so rounding it could turn a tiny positive activation into "inactive"; with it 16-bit the dgrad chain of
-// format code 2 is the bf16 path's bit for bit (tests/test_gpu_lp.py).
+// p * 256 (the first half of the slot's region).  One part stays 16-bit: the activation slot of the 128-wide views
+// hidden layer - the dgrad kernel derives that layer's ReLU mask from it, so rounding it could turn a tiny positive
+// activation into "inactive"; with it 16-bit the dgrad chain of format code 2 is the bf16 path's bit for bit
+// (tests/test_gpu_lp.py).  The embedding rows (64 columns; read by the weight gradient only) are saved as fp8 e4m3
+// since round 4 - |gamma(x)| <= 1 needs no exponent range, so the byte goes to a third mantissa bit - at byte
+// acts_emb_off(P) * 2 + p * 64: the weight gradient's embedding-input jobs contract them on the fp8 MFMA as they
+// lie (mixed bf8 x fp8 operands), like the 256-wide jobs.
 typedef unsigned lp_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned lp_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ unsigned lp_pack4_bf8(float a, float b, float c, float d) {
   int w = __builtin_amdgcn_cvt_pk_bf8_f32(a, b, 0, false);
   return (unsigned)__builtin_amdgcn_cvt_pk_bf8_f32(c, d, w, true);
+}
+// fp8 e4m3 (OCP): the embedding rows of format code 2 (|gamma(x)|, |viewdir| <= 1; 3 mantissa bits)
+__device__ __forceinline__ unsigned lp_pack4_fp8(float a, float b, float c, float d) {
+  int w = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+  return (unsigned)__builtin_amdgcn_cvt_pk_fp8_f32(c, d, w, true);
 }
 // 4 e5m2 bytes -> 4 values of T as two packed dwords (exact: every e5m2 value is a bf16 / fp16 value)
 template <bool BF>

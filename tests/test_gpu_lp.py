@@ -483,6 +483,12 @@ def test_bf16_with_8bit_saved_rows(dev, P):
             continue
         want = rows16[s_].to(torch.float8_e5m2)
         assert torch.equal(slot8(a8, s_).view(torch.uint8), want.view(torch.uint8)), f"activation slot {s_}"
+    # the embedding rows (read by the weight gradient only): fp8 e4m3 in format code 2, 64 bytes per point
+    e0 = 10 * P * 512
+    emb16 = a16[e0:e0 + P * 128].view(torch.bfloat16).view(P, 64)
+    emb8 = a8[e0:e0 + P * 64].view(torch.float8_e4m3fn).view(P, 64)
+    assert torch.equal(emb8.view(torch.uint8), emb16.to(torch.float8_e4m3fn).view(torch.uint8)), "embedding rows"
+    assert rel_l2(emb8.float(), emb16.float()) < 0.04 and float(emb16.float().abs().max()) <= 1.0
     # the kernel's own rows -> the contraction in fp64
     m = float(G.abs().max())
     S = 2.0 ** min(6 - math.frexp(m)[1], 96)
@@ -501,6 +507,28 @@ def test_bf16_with_8bit_saved_rows(dev, P):
         assert rel_l2(got, ref) < 2e-3, (l, rel_l2(got, ref))
         assert rel_l2(flat[f"pts_linears.{l}.bias"][0], dz.sum(0) / S) < 2e-3
         assert rel_l2(got, plain) < 0.08, (l, rel_l2(got, plain))       # e5m2 rounding of both operands
+    # the embedding-input jobs (bf8 x fp8 operands): layer 0, the skip block of layer 5, the view columns of the views layer
+    e8 = emb8.double()
+    for name, dslot, cols, kcols in (("pts_linears.0.weight", 0, slice(0, 57), slice(0, 57)),
+                                     ("pts_linears.5.weight", 5, slice(0, 57), slice(0, 57)),
+                                     ("views_linears.0.weight", 8, slice(256, 259), slice(60, 63))):
+        dz = slot8(w8, dslot).double()
+        dz = dz[:, :128] if dslot == 8 else dz
+        ref = dz.t() @ e8[:, kcols] / S
+        got, plain = flat[name]
+        assert rel_l2(got[:, cols], ref) < 2e-3, (name, rel_l2(got[:, cols], ref))
+        assert rel_l2(got[:, cols], plain[:, cols]) < 0.08, (name, rel_l2(got[:, cols], plain[:, cols]))
+    assert rel_l2(flat["pts_linears.0.bias"][0], slot8(w8, 0).double().sum(0) / S) < 2e-3
+    # the feature layer's job with the alpha-head rider (d alpha_pre fp32 x the 8-bit rows of slot 7), and the views layer
+    dzf, h7 = slot8(w8, 9).double(), slot8(a8, 7).double()
+    assert rel_l2(flat["feature_linear.weight"][0], dzf.t() @ h7 / S) < 2e-3
+    assert rel_l2(flat["feature_linear.bias"][0], dzf.sum(0) / S) < 2e-3
+    dal = w8[10 * P * 512:].view(torch.float32)[:P].double()          # lp_dz_dalpha_byte(P): 256-byte aligned already
+    assert rel_l2(flat["alpha_linear.weight"][0].reshape(-1), dal @ h7) < 2e-3
+    assert rel_l2(flat["alpha_linear.bias"][0].reshape(-1), dal.sum().reshape(1)) < 2e-3
+    dzv = slot8(w8, 8).double()[:, :128]
+    assert rel_l2(flat["views_linears.0.weight"][0][:, :256], dzv.t() @ slot8(a8, 9).double() / S) < 2e-3
+    assert rel_l2(flat["views_linears.0.bias"][0], dzv.sum(0) / S) < 2e-3
     # the dgrad chain itself is the bf16 path's: its dZ rows are the bf16 rows (x S) rounded to e5m2
     dz16 = w16[:10 * P * 512].view(torch.bfloat16).view(10, P, 256)
     for s_ in (1, 4, 7, 9):

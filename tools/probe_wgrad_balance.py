@@ -34,11 +34,12 @@ torch.cuda.synchronize()
 lib = _lib.load()
 if not hasattr(lib, "scade_debug_wl"):
     sys.exit("this library was not built with -DWL_DBG (see the docstring)")
-buf = (ctypes.c_ulonglong * 2048)()
+buf = (ctypes.c_ulonglong * 4096)()
 lib.scade_debug_wl.argtypes = [ctypes.c_void_p]
 lib.scade_debug_wl.restype = ctypes.c_int
 assert lib.scade_debug_wl(buf) == 0
-a = np.array(buf[:], dtype=np.int64).reshape(512, 4)
+a2 = np.array(buf[2048:], dtype=np.int64).reshape(512, 4)
+a = np.array(buf[:2048], dtype=np.int64).reshape(512, 4)
 a = a[a[:, 3] > 0]
 t0 = a[:, 0].min()
 start, end = (a[:, 0] - t0) / 100.0, (a[:, 3] - t0) / 100.0          # us (100 MHz wall clock)
@@ -57,3 +58,12 @@ if cost:
     print("  relative to a layer = 16:", {names[j]: round(float(16 * np.mean(v) / heavy), 1) for j, v in sorted(cost.items())})
 order = np.argsort(dur)
 print("  slowest (workgroup, us, stages, entries):", [(int(i), int(dur[i]), int(a[i, 1]), int(a[i, 2])) for i in order[-8:]])
+
+# format code 2's ring jobs: loop time per stage without prologue / epilogue, and the epilogue (partial-row stores)
+b = a2[(a2[:, 2] > 20) & (a2[:, 1] > a2[:, 0])]
+if len(b):
+    per = (b[:, 1] - b[:, 0]) / 100.0 / b[:, 2]
+    epi = (b[:, 3] - b[:, 1]) / 100.0
+    print(f"  ring jobs (last one per workgroup, {len(b)} workgroups): loop us per stage min {per.min():.3f} median {np.median(per):.3f} "
+          f"max {per.max():.3f};  epilogue us median {np.median(epi):.1f} max {epi.max():.1f}")
+
