@@ -250,8 +250,23 @@ __device__ __forceinline__ void save_tile_lp_wave8(const typename LP<BF>::T* x, 
       tile_copy_map<CPR>(lane, it0 + j, row, c);
       c += c0 >> 3;
       lp_u32x2 o;
-      o[0] = lp_pack4_bf8((float)v[j][0] * f[j], (float)v[j][1] * f[j], (float)v[j][2] * f[j], (float)v[j][3] * f[j]);
-      o[1] = lp_pack4_bf8((float)v[j][4] * f[j], (float)v[j][5] * f[j], (float)v[j][6] * f[j], (float)v[j][7] * f[j]);
+      if constexpr (BF) {
+        // v_cvt_scalef32_pk_bf8_bf16: two packed bf16 -> two e5m2 bytes of (x / scale), RNE - ONE op per pair where
+        // bf16 -> fp32, the factor and v_cvt_pk_bf8_f32 took five; bit-identical for the power-of-two factors of
+        // this path (probed on the part over all bf16 encodings: saturation, subnormals, NaN included)
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        const float inv = __builtin_amdgcn_rcpf(f[j]);        // (exact for the powers of two of this path)
+        s16x2 q0 = {0, 0}, q1 = {0, 0};
+        q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v[j], v[j], 0, 1), inv, false);
+        q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v[j], v[j], 2, 3), inv, true);
+        q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 4, 5), inv, false);
+        q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 6, 7), inv, true);
+        o[0] = __builtin_bit_cast(unsigned, q0);
+        o[1] = __builtin_bit_cast(unsigned, q1);
+      } else {
+        o[0] = lp_pack4_bf8((float)v[j][0] * f[j], (float)v[j][1] * f[j], (float)v[j][2] * f[j], (float)v[j][3] * f[j]);
+        o[1] = lp_pack4_bf8((float)v[j][4] * f[j], (float)v[j][5] * f[j], (float)v[j][6] * f[j], (float)v[j][7] * f[j]);
+      }
       if (p0 + row < P) __builtin_nontemporal_store(o, reinterpret_cast<lp_u32x2*>(dst8 + (size_t)(p0 + row) * W + 8 * c));
     }
   }
