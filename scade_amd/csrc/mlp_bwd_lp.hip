@@ -170,6 +170,11 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][NPT], int 
     }
 }
 
+#ifdef DGRAD_KO_SAVE    // (knock-out experiment, variant builds only)
+constexpr bool DG_KO = true;
+#else
+constexpr bool DG_KO = false;
+#endif
 constexpr int dgrad_lp_lds_bytes(int NPT) { return 32 * NPT * W * 2 + 2 * 32 * NPT * 4; }
 
 // S8: format code 2 - the saved rows (activations read, dZ written) are 8-bit e5m2 (mlp_tile_lp.h); the dZ rows
@@ -294,8 +299,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), 3, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
-  if (S8) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, fac, 64 * wave, lane);
-  else save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, fac, 64 * wave, lane);
+  else if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   __syncthreads();
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
@@ -303,8 +308,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), 3, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
-  if (S8) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, 7) * 2, p0, P, fac, 64 * wave, lane);
-  else save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, 7) * 2, p0, P, fac, 64 * wave, lane);
+  else if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   __syncthreads();
 
 #define DGRAD_LAYER_L(L)                                                                            \
@@ -313,8 +318,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
                                                     g, g, lane, nullptr);                           \
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
-  if (S8) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, (L)-1) * 2, p0, P, fac, 64 * wave, lane);      \
-  else save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
+  if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, (L)-1) * 2, p0, P, fac, 64 * wave, lane);      \
+  else if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
   __syncthreads();
 
   DGRAD_LAYER_L(7)

@@ -89,6 +89,16 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][NPT], int
 
 __device__ __forceinline__ bool lp_nonfinite(float v) { return !(fabsf(v) <= 3.4028234664e38f); }   // NaN or +-inf
 
+#ifdef FWD_KO_SAVE      // (knock-out experiments, variant builds only)
+constexpr bool KO_SAVE = true;
+#else
+constexpr bool KO_SAVE = false;
+#endif
+#ifdef FWD_KO_SIGN
+constexpr bool KO_SIGN = true;
+#else
+constexpr bool KO_SIGN = false;
+#endif
 // SAVE: 0 inference; 1 training, 16-bit rows saved; 2 training, 8-bit (e5m2) rows saved (format code 2)
 template <bool BF, int MODE, int SAVE, int NPT>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
@@ -207,13 +217,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
                                                         (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
     __syncthreads();                                                                            \
     layer_store_lp<BF, 2, true, SAVE != 0, 2, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
-    if (SAVE) {                                                                                 \
+    if (SAVE && !KO_SIGN) {                                                                     \
       u32x4 mw_ = {bits[0], bits[1], bits[2], bits[3]};                                         \
       reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[                                  \
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
     }                                                                                           \
     if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
-    if (SAVE == 2) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, L) * 2, p0, P, nullptr, 64 * wave, lane); \
+    if (SAVE == 2 && !KO_SAVE) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, L) * 2, p0, P, nullptr, 64 * wave, lane); \
     __syncthreads();                                                                            \
   }
 

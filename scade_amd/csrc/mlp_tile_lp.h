@@ -224,51 +224,58 @@ __device__ __forceinline__ lp_u32x2 lp_unpack4_bf8(unsigned w) {
   }
   return r;
 }
-// save_tile_lp_wave with 8-bit rows: dst8 = byte base of the slot; row_fac as there
+// save_tile_lp_wave with 8-bit rows: dst8 = byte base of the slot (row pitch 256 bytes), ``fac`` = the ONE
+// power-of-two factor of every row (format code 2 runs bf16 arithmetic: no per-point scale; nullptr = 1).
+// Round 4: the knock-out of this copy was worth 19 % of the training forward and 25 % of the dgrad chain at 1.3
+// TB/s of stores - instruction overhead, not bytes: per 16-byte chunk the compiler recomputed the lane map, the
+// swizzled LDS index and a 64-bit row address, and wrapped every store in an exec-mask branch for the ragged
+// last tile.  Now a lane's sixteen chunks are two LDS base addresses + immediate offsets (rows 16 apart share
+// their swizzle; rows 4 apart differ in one address bit), the stores are buffer stores whose descriptor ends at
+// row P (rows past the end are dropped by the range check: no branch) with the lane part of the address fixed
+// and the rest in the scalar offset, and the conversion is v_cvt_scalef32_pk_bf8_bf16 (two packed bf16 -> two
+// e5m2 bytes of x / scale, RNE: one op per pair where bf16 -> fp32, the factor and v_cvt_pk_bf8_f32 took five;
+// bit-identical for power-of-two factors - probed on the part over all bf16 encodings).
 template <bool BF, int NCW, int NPT = LPT>
 __device__ __forceinline__ void save_tile_lp_wave8(const typename LP<BF>::T* x, unsigned char* __restrict__ dst8,
-                                                   int p0, int P, const float* row_fac, int c0, int lane) {
-  typedef typename LP<BF>::V8 V8;
-  constexpr int CPR = NCW >> 3;
-  constexpr int ITERS = 32 * NPT * CPR / 64;
-  static_assert(ITERS % 4 == 0, "save_tile_lp_wave8: batches of four");
-#pragma unroll 1
-  for (int it0 = 0; it0 < ITERS; it0 += 4) {
+                                                   int p0, int P, const float* fac, int c0, int lane) {
+  static_assert(NCW == 64, "a wave owns 64 columns");
+  if constexpr (!BF) return;                          // (format code 2 is bf16 arithmetic; never reached)
+  typedef __bf16 V8 __attribute__((ext_vector_type(8)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  constexpr int ITERS = 4 * NPT;                      // 16-byte chunks per lane
+  int rl, c;
+  tile_copy_map<8>(lane, 0, rl, c);                   // rl in {0..3, 8..11}: rows rl + 4 (it & 1) + 16 (it >> 1)
+  c += c0 >> 3;
+  const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
+  const unsigned char* a0 = xb + 2 * (rl * W + ((c ^ rl) << 3));            // it even
+  const unsigned char* a1 = xb + 2 * ((rl + 4) * W + ((c ^ rl ^ 4) << 3));  // it odd (row & 15 = rl | 4)
+  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8);
+  const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0, __builtin_amdgcn_readfirstlane((unsigned)P * 256u), 0x00020000);
+  const int voff = rl * 256 + 8 * c;
+  const int soff = __builtin_amdgcn_readfirstlane(p0 * 256);
+  const float inv = fac ? __builtin_amdgcn_rcpf(fac[0]) : 1.0f;
+#pragma unroll
+  for (int it0 = 0; it0 < ITERS; it0 += 4) {          // batches of four chunks in flight (all sixteen would spill)
     V8 v[4];
-    float f[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int row, c;
-      tile_copy_map<CPR>(lane, it0 + j, row, c);
-      c += c0 >> 3;
-      v[j] = *reinterpret_cast<const V8*>(x + x_idx(row, c));
-      f[j] = row_fac ? row_fac[row] : 1.f;
+      const int it = it0 + j;
+      v[j] = *reinterpret_cast<const V8*>(((it & 1) ? a1 : a0) + (it >> 1) * 16 * W * 2);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      int row, c;
-      tile_copy_map<CPR>(lane, it0 + j, row, c);
-      c += c0 >> 3;
-      lp_u32x2 o;
-      if constexpr (BF) {
-        // v_cvt_scalef32_pk_bf8_bf16: two packed bf16 -> two e5m2 bytes of (x / scale), RNE - ONE op per pair where
-        // bf16 -> fp32, the factor and v_cvt_pk_bf8_f32 took five; bit-identical for the power-of-two factors of
-        // this path (probed on the part over all bf16 encodings: saturation, subnormals, NaN included)
-        typedef short s16x2 __attribute__((ext_vector_type(2)));
-        const float inv = __builtin_amdgcn_rcpf(f[j]);        // (exact for the powers of two of this path)
-        s16x2 q0 = {0, 0}, q1 = {0, 0};
-        q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v[j], v[j], 0, 1), inv, false);
-        q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v[j], v[j], 2, 3), inv, true);
-        q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 4, 5), inv, false);
-        q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 6, 7), inv, true);
-        o[0] = __builtin_bit_cast(unsigned, q0);
-        o[1] = __builtin_bit_cast(unsigned, q1);
-      } else {
-        o[0] = lp_pack4_bf8((float)v[j][0] * f[j], (float)v[j][1] * f[j], (float)v[j][2] * f[j], (float)v[j][3] * f[j]);
-        o[1] = lp_pack4_bf8((float)v[j][4] * f[j], (float)v[j][5] * f[j], (float)v[j][6] * f[j], (float)v[j][7] * f[j]);
-      }
-      if (p0 + row < P) __builtin_nontemporal_store(o, reinterpret_cast<lp_u32x2*>(dst8 + (size_t)(p0 + row) * W + 8 * c));
+      const int it = it0 + j;
+      s16x2 q0 = {0, 0}, q1 = {0, 0};
+      q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v[j], v[j], 0, 1), inv, false);
+      q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v[j], v[j], 2, 3), inv, true);
+      q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 4, 5), inv, false);
+      q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 6, 7), inv, true);
+      const lp_u32x2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
+      __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff + (it & 1) * 4 * 256, soff + (it >> 1) * 16 * 256, 2);    // nt
     }
+    __builtin_amdgcn_sched_barrier(0);                // keep the batches apart
   }
 }
 
