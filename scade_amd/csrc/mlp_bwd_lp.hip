@@ -887,15 +887,20 @@ __device__ __forceinline__ void wgrad_lp8_dma_job(const WgradLpNet& a, const Wgr
   // ---- LDS-DMA of stage st into slot sl: wave w moves rows 8w .. 8w+7 of both tiles (two instructions each; lane L
   // of instruction e fills slot L & 15 of row 8w + 4e + (L >> 4) with the row's logical chunk (L & 15) ^ 2 (row & 7)).
   // Read once: nt.
-  const int voff0 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (lane >> 4))) << 4);              // rows 8w + 0..3
-  const int voff1 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (4 + (lane >> 4)))) << 4);        // rows 8w + 4..7
+  // (the 128-row views layer's dZ rows are 128 bytes wide: the lanes of the upper column chunks point past the
+  // descriptor's end - zeros, no memory traffic)
+  const int lc0 = (lane & 15) ^ (2 * (lane >> 4)), lc1 = (lane & 15) ^ (2 * (4 + (lane >> 4)));
+  const bool narrow = jb.n_rows <= 128;
+  const int voff0 = narrow && lc0 >= 8 ? 0x40000000 : (lane >> 4) * 256 + (lc0 << 4);          // rows 8w + 0..3
+  const int voff1 = narrow && lc1 >= 8 ? 0x40000000 : (lane >> 4) * 256 + (lc1 << 4);          // rows 8w + 4..7
+  const int voffb0 = (lane >> 4) * 256 + (lc0 << 4), voffb1 = (lane >> 4) * 256 + (lc1 << 4);   // the input rows: all 256 bytes
   auto issue = [&](int st, int sl) {
     unsigned char* slot = lds + sl * W8_SLOT;
     const int grow = st * S + 8 * wave;                 // row of the segment (past its end: zeros)
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + 8 * wave * 256), 16, voff0, grow * 256, 0, 2);
     __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + (8 * wave + 4) * 256), 16, voff1, (grow + 4) * 256, 0, 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 256 + 8 * wave * 256), 16, voff0, grow * 256, 0, 2);
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 256 + (8 * wave + 4) * 256), 16, voff1, (grow + 4) * 256, 0, 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 256 + 8 * wave * 256), 16, voffb0, grow * 256, 0, 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + S * 256 + (8 * wave + 4) * 256), 16, voffb1, (grow + 4) * 256, 0, 2);
     if (ALPHA) {
       if (lane < 8)
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(slot + 2 * S * 256 + 8 * wave * 4), 4, lane * 4, grow * 4, 0, 0);
@@ -1091,8 +1096,10 @@ __device__ __forceinline__ void wgrad_lp8_dma_emb_job(const WgradLpNet& a, const
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; accb[i] = 0.f; }
 
-  const int voff0 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (lane >> 4))) << 4);
-  const int voff1 = (lane >> 4) * 256 + (((lane & 15) ^ (2 * (4 + (lane >> 4)))) << 4);
+  const int lc0 = (lane & 15) ^ (2 * (lane >> 4)), lc1 = (lane & 15) ^ (2 * (4 + (lane >> 4)));
+  const bool narrow = jb.n_rows <= 128;            // (the views layer's dZ rows: 128 bytes wide, see wgrad_lp8_dma_job)
+  const int voff0 = narrow && lc0 >= 8 ? 0x40000000 : (lane >> 4) * 256 + (lc0 << 4);
+  const int voff1 = narrow && lc1 >= 8 ? 0x40000000 : (lane >> 4) * 256 + (lc1 << 4);
   // embedding rows 8w .. 8w+7 (lanes 0-31: row 8w + (L >> 2), slot L & 3 <- chunk (L & 3) ^ 2 ((row >> 2) & 1))
   const int voffe = (lane >> 2) * 64 + (((lane & 3) ^ (2 * ((lane >> 4) & 1))) << 4);
   auto issue = [&](int st, int sl) {
@@ -1463,10 +1470,10 @@ static void build_wgrad_lp_jobs(WgradLpArgs& w) {
 static constexpr int LP_JOB_WEIGHTS[7] = {32, 35, 26, 20, 18, 17, 8};
 // format code 2 since round 4: every job but the rgb head runs on the LDS-DMA ring at the memory system's rate for
 // one workgroup per CU (~25 GB/s per CU with all 256 streaming), and so does the rgb head's register pipeline - a
-// stage costs its BYTES: 16 KB per 32 points for a layer, + the d alpha scalars, 16 KB at half the MFMA work for the
-// 128-row views layer (measured 14.6 / 16), 10 KB for the embedding-input jobs (8 KB of dZ + 2 KB of fp8 embedding
+// stage costs its BYTES: 16 KB per 32 points for a layer, + the d alpha scalars, 12 KB for the 128-row views
+// layer (its dZ rows are 128 bytes wide), 10 KB for the embedding-input jobs (8 KB of dZ + 2 KB of fp8 embedding
 // rows: measured 10.4 / 16), 8.7 KB for the rgb head (16-bit views rows + g_out: measured 8.5 - 10.4 / 16).
-static constexpr int LP8_JOB_WEIGHTS[7] = {32, 34, 29, 21, 21, 21, 19};
+static constexpr int LP8_JOB_WEIGHTS[7] = {32, 34, 24, 21, 21, 14, 19};
 static int lp_job_weight(int j, bool s8) {
   const int* w = s8 ? LP8_JOB_WEIGHTS : LP_JOB_WEIGHTS;
   return j < 7 ? w[0] : w[j - 6];      // jobs 0..6: layers 1..7; 7 feature, 8 views, 9..11 embedding jobs, 12 rgb
