@@ -366,37 +366,64 @@ def rayops_region(dev, n_rays=16384, n_hyp=20, iters=20):
     return {"rays": n_rays, "note": "algorithmic bytes / HIP-event time per launch; peak 8 TB/s", "kernels": table}
 
 
+def interleaved_ab(fns, steps, reps, warmup):
+    """Same-process A/B harness: the variants in ``fns`` (name -> callable doing ONE step) are warmed up together and
+    then timed in ALTERNATING blocks of ``steps`` steps, ``reps`` times each (A B A B ...), so that clock / thermal
+    drift and allocator state hit every variant alike.  -> {name: {"median_ms", "min_ms", "max_ms", "blocks"}}.
+    A difference between two variants is resolved when it exceeds their spreads; one block each (what the
+    regions above time) is not evidence for anything below ~5 % (VERDICT r3 #4)."""
+    for _ in range(warmup):
+        for f in fns.values():
+            f()
+    torch.cuda.synchronize()
+    blocks = {k: [] for k in fns}
+    for _ in range(reps):
+        for k, f in fns.items():
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                f()
+            torch.cuda.synchronize()
+            blocks[k].append((time.perf_counter() - t0) / steps * 1e3)
+    out = {}
+    for k, v in blocks.items():
+        sv = sorted(v)
+        out[k] = {"median_ms": sv[len(sv) // 2], "min_ms": sv[0], "max_ms": sv[-1], "blocks": len(sv)}
+    return out
+
+
 def graph_region(args, dev, n_rays, precision):
-    """Secondary measurement (single process): the same train step at ``n_rays`` rays, eager vs
-    captured in one HIP graph (scade_amd/graphs.py).  128 rays = the per-GPU shard of a strongly-
-    scaled 1024-ray batch on 8 GPUs (BASELINE.json configs[3]), where the host work of an eager step
-    (27-31 launches + the autograd engine, ~0.6 ms) is the limit.  Steady state: 20 warm-up and >= 100 timed
-    steps per mode (these steps are ~1 ms; three warm-up steps still carried allocator start-up)."""
+    """Secondary measurement (single process): the same train step at ``n_rays`` rays, eager vs captured in one
+    HIP graph (scade_amd/graphs.py), as an INTERLEAVED A/B (interleaved_ab: 7 alternating blocks of >= 40 steps per
+    mode after a common warm-up; median and spread reported).  128 rays = the per-GPU shard of a strongly-scaled
+    1024-ray batch on 8 GPUs (BASELINE.json configs[3]), where the host work of an eager step is the limit and the
+    graph wins; at 1024 rays both modes are GPU-bound and the replay carries one launch more than the eager step
+    (the input-staging kernel, ~5 us) plus a ~9 us bubble at every replay boundary - the graph's first node waits
+    for the previous replay's completion signal, where eager launches queue behind each other without a gap
+    (rocprofv3 timelines of both: profiles/r04_graph_vs_eager.txt) - so there the replay is 1-2 % SLOWER."""
     from scade_amd.graphs import GraphedTrainer
     from scade_amd.synthetic import synthetic_rays
     from scade_amd.train import Trainer, make_scade_nets
-    out = {}
+    rays = synthetic_rays(n_rays, seed=4000).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(4001)
+    tgt = torch.rand(n_rays, 3, generator=g).to(dev)
+    hyp = (torch.rand(args.hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
+    fns, last = {}, {}
     for mode in ("eager", "graph"):
         coarse, fine = make_scade_nets(dev, seed=0)
         tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
-        rays = synthetic_rays(n_rays, seed=4000).to(dev)
-        g = torch.Generator(device="cpu").manual_seed(4001)
-        tgt = torch.rand(n_rays, 3, generator=g).to(dev)
-        hyp = (torch.rand(args.hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
-        gt = GraphedTrainer(tr, n_rays, args.hyp) if mode == "graph" else None
-        f = (lambda: gt.step(rays, tgt, hyp)) if gt else (lambda: tr.step(rays, tgt, hyp)[0])
-        nsteps = max(100, args.steps)
-        for _ in range(max(20, args.warmup)):
-            f()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(nsteps):
-            loss = f()
-        torch.cuda.synchronize()
-        out[f"ms_per_step_{mode}"] = (time.perf_counter() - t0) / nsteps * 1e3
-        assert bool(torch.isfinite(loss))
-    out["rays"] = n_rays
-    out["precision"] = precision
+        if mode == "graph":
+            gt = GraphedTrainer(tr, n_rays, args.hyp)
+            fns[mode] = lambda gt=gt: last.__setitem__("graph", gt.step(rays, tgt, hyp))
+        else:
+            fns[mode] = lambda tr=tr: last.__setitem__("eager", tr.step(rays, tgt, hyp)[0])
+    res = interleaved_ab(fns, steps=max(40, args.steps), reps=7, warmup=max(20, args.warmup))
+    assert all(bool(torch.isfinite(v)) for v in last.values())
+    out = {"rays": n_rays, "precision": precision, "harness": "interleaved A/B, 7 alternating blocks per mode, median"}
+    for mode, r in res.items():
+        out[f"ms_per_step_{mode}"] = r["median_ms"]
+        out[f"spread_{mode}_ms"] = [r["min_ms"], r["max_ms"]]
+    out["graph_over_eager"] = res["graph"]["median_ms"] / res["eager"]["median_ms"]
     return out
 
 
