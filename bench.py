@@ -252,12 +252,23 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
     nwarm, nsteps = max(10, args.warmup) + (10 if dist.is_initialized() else 0), max(40, args.steps)
     for _ in range(nwarm):
         one()
+    # the figure is the whole timed span between two barriers (as before); device events at the boundaries of five
+    # blocks (no host synchronisation in between) give its spread - box clock / power state moves these regions by
+    # a few per cent inside one run
+    nblk = 5
+    per = (nsteps + nblk - 1) // nblk
+    nsteps = per * nblk
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(nblk + 1)]
     barrier()
     t0 = time.perf_counter()
-    for _ in range(nsteps):
-        loss = one()
+    ev[0].record()
+    for b in range(nblk):
+        for _ in range(per):
+            loss = one()
+        ev[b + 1].record()
     barrier()
     elapsed = time.perf_counter() - t0
+    blk = [ev[b].elapsed_time(ev[b + 1]) / per for b in range(nblk)]
     assert bool(torch.isfinite(loss))
     timer = ops.KernelTimer()        # per-kernel events in a few EXTRA steps (they cost ~1 % of a step)
     if not graphed:
@@ -274,7 +285,8 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
     peak, peak_name = TRAIN_PEAKS[precision]
     tfl = flops / (elapsed / nsteps) / 1e12
     out = {"value": n * world * nsteps / elapsed, "unit": "rays/s", "precision": precision,
-           "ms_per_step": elapsed / nsteps * 1e3, "steps_timed": nsteps, "rays_per_gpu": n, "global_rays": n * world,
+           "ms_per_step": elapsed / nsteps * 1e3, "ms_per_step_blocks": {"median": sorted(blk)[nblk // 2], "min": min(blk), "max": max(blk), "blocks": nblk},
+           "steps_timed": nsteps, "rays_per_gpu": n, "global_rays": n * world,
            "scaling": scaling, "hypotheses": args.hyp, "graphed": graphed,
            "collective": (f"RCCL all-reduce(sum, fp32) of ONE bucket of {tr.bucket.numel} floats per step over "
                           f"{world} ranks, mode={allreduce}" if world > 1 else "none (1 GPU)"),

@@ -159,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs2 aa) {
   layer_gemm<2, 0, 16, EMB_STRIDE, PT>(acc, an, WTBASE(8, 16), WTBASE(7, 32), 32, hbuf, hbuf, lane);
   __syncthreads();
   dgrad_store<false, false, PT>(acc, kt0, hbuf, 0ull, nullptr, dal, lane);
-  save_tile_wave(hbuf, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, 64, lane, TM);
+  save_tile_wave<64, PT>(hbuf, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, lane);
   __syncthreads();
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 -----
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs2 aa) {
   layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WTBASE(7, 32), WTBASE(6, 32), 32, hbuf, hbuf, lane);
   __syncthreads();
   dgrad_store<true, true, PT>(acc, kt0, hbuf, mbits, pk + OFF_WA, dal, lane);
-  save_tile_wave(hbuf, dz + acts_slot_off(P, 7), p0, P, 64 * wave, 64, lane, TM);
+  save_tile_wave<64, PT>(hbuf, dz + acts_slot_off(P, 7), p0, P, 64 * wave, lane);
   __syncthreads();
 
   // ---- pts layers 7..1: dZ_{l-1} = (W_l^T dZ_l) masked by h_{l-1} > 0 -------------
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs2 aa) {
                                    32, hbuf, hbuf, lane);                                      \
   __syncthreads();                                                                             \
   dgrad_store<true, false, PT>(acc, kt0, hbuf, mbits, nullptr, dal, lane);                         \
-  save_tile_wave(hbuf, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, 64, lane, TM);             \
+  save_tile_wave<64, PT>(hbuf, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, lane);             \
   __syncthreads();
 
   DGRAD_LAYER(7)

@@ -95,6 +95,14 @@ __device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT
   return bits;
 }
 
+#ifdef FWD_TRACE
+__device__ unsigned long long fwd_trace[4 * 4 * 24];   // [inference wg 0/1, training wg 0/1][wave][layer 1..4][6 stamps]
+__device__ unsigned long long fwd_sect[4 * 16];        // [kernel x wg]: wave 0's stamps at the section boundaries
+#define FS_STAMP(I) if (PT == 2 && (blockIdx.x == 1300 || blockIdx.x == 1301) && threadIdx.x == 0) \
+    fwd_sect[((SAVE ? 2 : 0) + (blockIdx.x - 1300)) * 16 + (I)] = clock64();
+#else
+#define FS_STAMP(I)
+#endif
 template <int MODE, bool SAVE, int PT>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   constexpr int TM = tile_pts(PT);     // points of this workgroup (shadows the 64-point default)
@@ -107,7 +115,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   const int p0 = blockIdx.x * TM;
   const int P = a.P;
   const float* __restrict__ pk = a.packed;
+#ifdef MLP_PRIO
+  __builtin_amdgcn_s_setprio(MLP_PRIO);
+#endif
 
+  FS_STAMP(0)
   // ---------------- prologue: embedding tile [64][60] (+ zeroed tail pad) ----
   if (tid < 4) ebuf[TM * EMB_STRIDE + tid] = 0.f;
   if (MODE == 0) {
@@ -175,26 +187,49 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 #define WBASE(L) (reinterpret_cast<const f32x4*>(pk + off_w(L)) + \
                   ((L) == L_VIEWS ? wave : nt0) * kb_total(L) * 64)
 
+  // -DFWD_TRACE (a variant build: SCADE_AB_FLAGS, scade_amd/build.py; tools/probe_fwd_trace.py): core-clock stamps of
+  // two workgroups of the launch's third round at the phase boundaries of layers 1..4 -
+  // {k-loop start, k-loop end, barrier passed, epilogue done, tile copy issued, second barrier passed}
+#ifdef FWD_TRACE
+#define FT_STAMP(L, I)                                                                                      \
+  if (PT == 2 && (L) >= 1 && (L) <= 4 && (blockIdx.x == 1300 || blockIdx.x == 1301) && lane == 0)              \
+    fwd_trace[(((SAVE ? 2 : 0) + (blockIdx.x - 1300)) * 4 + wave) * 24 + ((L) - 1) * 6 + (I)] = clock64();
+#else
+#define FT_STAMP(L, I)
+#endif
 #define PTS_LAYER(L, LNEXT, KBP, PRE)                                                              \
   {                                                                                                \
     load_bias<2>(bias, pk + off_b(L), nt0, lane);                                                  \
+    FT_STAMP(L, 0)                                                                                 \
     layer_gemm<2, KBP, kb_h(L), EMB_STRIDE, PT>(acc, an, WBASE(L), WBASE(LNEXT), kb_total(LNEXT),  \
                                                 PRE, hbuf, lane);                                  \
+    FT_STAMP(L, 1)                                                                                 \
     __syncthreads();                                                                               \
+    FT_STAMP(L, 2)                                                                                 \
     const unsigned long long bits_ = layer_store<2, true, PT>(acc, bias, nt0, hbuf, lane);         \
+    FT_STAMP(L, 3)                                                                                 \
     if (SAVE) store_relu_words<PT>(a.acts, P, L, tid, bits_);                                      \
-    if (SAVE) save_tile_wave(hbuf, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, 64, lane, TM);    \
+    if (SAVE) save_tile_wave<64, PT>(hbuf, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, lane);    \
+    FT_STAMP(L, 4)                                                                                 \
     __syncthreads();                                                                               \
+    FT_STAMP(L, 5)                                                                                 \
   }
 
+  FS_STAMP(1)
   an[0] = WBASE(0)[lane];
   an[1] = WBASE(0)[kb_total(0) * 64 + lane];
   PTS_LAYER(0, 1, 8, ebuf)
+  FS_STAMP(2)
   PTS_LAYER(1, 2, 0, ebuf)
+  FS_STAMP(3)
   PTS_LAYER(2, 3, 0, ebuf)
+  FS_STAMP(4)
   PTS_LAYER(3, 4, 0, ebuf)
+  FS_STAMP(5)
   PTS_LAYER(4, 5, 0, ebuf)
+  FS_STAMP(6)
   PTS_LAYER(5, 6, 8, ebuf)
+  FS_STAMP(7)
 
   // embedding tile is dead now: reuse its head as the view pad [64][8]
   {
@@ -210,7 +245,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   // (visibility of the view pad is covered by the barriers of layers 6/7)
 
   PTS_LAYER(6, 7, 0, ebuf)
+  FS_STAMP(8)
   PTS_LAYER(7, L_FEAT, 0, ebuf)
+  FS_STAMP(9)
 #undef PTS_LAYER
 
   // ---------------- alpha head: 256 -> 1 on the VALU -------------------------
@@ -235,14 +272,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     if (SAVE && sub == 0 && head_store && p0 + row < P) a.acts[acts_alpha_off(P) + p0 + row] = alpha;
   }
 
+  FS_STAMP(10)
   // ---------------- feature_linear: 256 -> 256, no activation ----------------
   load_bias<2>(bias, pk + off_b(L_FEAT), nt0, lane);
   layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
   __syncthreads();
   layer_store<2, false, PT>(acc, bias, nt0, hbuf, lane);
-  if (SAVE) save_tile_wave(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, 64, lane, TM);
+  if (SAVE) save_tile_wave<64, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, lane);
   __syncthreads();
 
+  FS_STAMP(11)
   // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
   {
     f32x16 accv[1][PT];
@@ -252,11 +291,12 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     layer_gemm<1, 1, 32, VIEW_PAD, PT>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
     __syncthreads();
     layer_store<1, true, PT>(accv, biasv, wave, hbuf, lane);
-    if (SAVE) save_tile_wave(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, 32, lane, TM);
+    if (SAVE) save_tile_wave<32, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, lane);
     __syncthreads();
   }
 
 #undef WBASE
+  FS_STAMP(12)
   // ---------------- rgb head 128 -> 3, softplus(alpha, beta=10) --------------
   {
     const int row = PT == 2 ? tid >> 2 : (tid >> 2) & 31, sub = tid & 3;
@@ -287,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
       *reinterpret_cast<f32x4*>(a.out + (size_t)(p0 + row) * 4) = o;
     }
   }
+  FS_STAMP(13)
 }
 
 // ---------------------------------------------------------------------------
@@ -305,6 +346,12 @@ __global__ void mlp_pack_kernel(PackArgs a) { pack_fwd_row(a.p, a.packed, blockI
 // C ABI
 // ---------------------------------------------------------------------------
 using namespace scade;
+#ifdef FWD_TRACE
+extern "C" int scade_debug_fwd_trace(unsigned long long* out) {
+  if (hipMemcpyFromSymbol(out + 4 * 4 * 24, HIP_SYMBOL(scade::fwd_sect), sizeof(unsigned long long) * 4 * 16) != hipSuccess) return -1;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scade::fwd_trace), sizeof(unsigned long long) * 4 * 4 * 24);
+}
+#endif
 
 extern "C" long scade_mlp_packed_floats(void) { return PACKED_FWD_FLOATS; }
 

@@ -38,6 +38,9 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2]
                                            const float* pre, const float* hbuf, int lane) {
   constexpr int KB = KBP + KBH;
   const int r = lane & 31, hh = lane >> 5;
+#ifdef MLP_PRIO
+  __builtin_amdgcn_s_setprio(0);       // the k-loop yields to the CU's other workgroup's epilogue / copy / prologue
+#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -93,6 +96,10 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2]
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(a, b);
   }
+#ifdef MLP_PRIO
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_setprio(MLP_PRIO);
+#endif
 }
 
 // coalesced copy of the h tile (first ncols columns) to dst[P][256] (full 1-KiB rows)
@@ -107,17 +114,52 @@ __device__ __forceinline__ void save_tile(const float* hbuf, float* __restrict__
   }
 }
 
-// the same copy for the columns ONE WAVE has just written (ncw columns from column c0, every row of the tile):
+// the same copy for the columns ONE WAVE has just written (NCW columns from column c0, every row of the tile):
 // a wave's LDS accesses execute in order, so it may read its own layer_store back without a barrier and its
-// rows leave for HBM while the other waves are still in their epilogues
-__device__ __forceinline__ void save_tile_wave(const float* hbuf, float* __restrict__ dst, int p0, int P,
-                                               int c0, int ncw, int lane, int tm = TM) {
-  const int cpr = ncw >> 2;                      // 16-byte chunks per row of this wave's columns: 16 or 8
-  for (int i = lane; i < tm * cpr; i += 64) {
-    const int row = i / cpr, c = (c0 >> 2) + (i - row * cpr);
-    if (p0 + row < P)
-      __builtin_nontemporal_store(*reinterpret_cast<const f32x4*>(hbuf + h_idx(row, c)),
-                                  reinterpret_cast<f32x4*>(dst + (size_t)(p0 + row) * W + 4 * c));
+// rows leave for HBM while the other waves are still in their epilogues.
+// Round 4 (the stamp trace of profiles/r04_fwd_layer_trace.txt): fp32 MFMAs execute on the SIMD's fp32 lanes, so every
+// VALU instruction of either workgroup of a CU is time the matrix stream does not get - and this copy spent ~10 of
+// them per 16-byte chunk (lane map, swizzle, 64-bit row address, bounds compare + exec-mask branch) plus a full LDS
+// round trip per chunk.  Now: the lane's chunks are 4 (2) LDS base addresses + immediate offsets (rows 16 apart
+// share their swizzle), the stores are buffer stores with a fixed lane offset, the row part in the scalar offset and
+// the ragged last tile left to the descriptor's range check (rows >= P are dropped) - no VALU work in the loop, and
+// BATCH chunks in flight (the training forward has 16 registers to spare, not 32).
+template <int NCW, int PT, int BATCH = 2>
+__device__ __forceinline__ void save_tile_wave(const float* hbuf, float* __restrict__ dst, int p0, int P, int c0, int lane) {
+  static_assert(NCW == 64 || NCW == 32, "a wave owns 64 columns (32 in the views layer)");
+  constexpr int CPR = NCW / 4;                   // 16-byte chunks per row of this wave's columns: 16 or 8
+  constexpr int RPI = 64 / CPR;                  // rows per wave instruction: 4 or 8
+  constexpr int NB = 16 / RPI;                   // swizzle classes (instructions per 16 rows): 4 or 2
+  constexpr int ITERS = 32 * PT / RPI;           // instructions per tile
+  // (the lane's addresses are recomputed per call - a dozen VALU instructions - instead of living in registers across
+  // the whole kernel, where the compiler would hoist them to: the training forward has none to spare)
+  asm volatile("" : "+v"(lane));
+  const int lr = lane / CPR, c = (c0 >> 2) + lane % CPR;
+  const unsigned char* hb = reinterpret_cast<const unsigned char*>(hbuf);
+  const unsigned char* base[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) base[b] = hb + (RPI * b + lr) * (W * 4) + ((c ^ (RPI * b + lr)) << 4);
+  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst);
+  const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0, __builtin_amdgcn_readfirstlane((unsigned)P * 1024u), 0x00020000);
+  const int voff = lr * 1024 + c * 16;
+  const int soff = __builtin_amdgcn_readfirstlane(p0 * 1024);
+  typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
+#pragma unroll
+  for (int it0 = 0; it0 < ITERS; it0 += BATCH) {
+    u32x4_ v[BATCH];
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int it = it0 + j;
+      v[j] = *reinterpret_cast<const u32x4_*>(base[it % NB] + (it / NB) * 16 * W * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < BATCH; ++j) {
+      const int it = it0 + j;
+      __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, voff, soff + it * RPI * 1024, 2);     // streamed once: nt
+    }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
