@@ -62,8 +62,7 @@ __device__ __forceinline__ void load_bias(f32x4 (&bv)[NT][4], const float* __res
 // returns this lane's ReLU sign bits: bit p*32+(t*4+q)*4+i <-> value (t,q,p,i) > 0, the
 // same (t,q,p,i) -> (feature, point) map the dgrad kernel uses for its output fragment
 template <int NT, bool RELU, int PT = 2>
-__device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT][PT],
-                                                          const f32x4 (&bias)[NT][4], int ntile0,
+__device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT][PT], int ntile0,
                                                           float* hbuf, int lane) {
   const int r = lane & 31, hh = lane >> 5;
   unsigned long long bits = 0ull;
@@ -72,13 +71,12 @@ __device__ __forceinline__ unsigned long long layer_store(const f32x16 (&acc)[NT
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int f = (ntile0 + t) * 32 + 8 * q + 4 * hh;
-      const f32x4 bv = bias[t][q];
 #pragma unroll
       for (int p = 0; p < PT; ++p) {
         f32x4 v;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          float x = acc[t][p][4 * q + i] + bv[i];
+          float x = acc[t][p][4 * q + i];         // (the accumulator started from the bias: layer_gemm)
           // relu that PROPAGATES NaN like torch.relu (v_max_f32 would return 0 for a NaN input and
           // hide a poisoned point from the reference's isnan/isinf scan, run_scade_scannet.py:747-749):
           // ONE integer max on the float's bits - negative floats (and -0) are negative integers and
@@ -199,14 +197,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 #endif
 #define PTS_LAYER(L, LNEXT, KBP, PRE)                                                              \
   {                                                                                                \
-    load_bias<2>(bias, pk + off_b(L), nt0, lane);                                                  \
     FT_STAMP(L, 0)                                                                                 \
     layer_gemm<2, KBP, kb_h(L), EMB_STRIDE, PT>(acc, an, WBASE(L), WBASE(LNEXT), kb_total(LNEXT),  \
-                                                PRE, hbuf, lane);                                  \
+                                                PRE, hbuf, lane, bias);                            \
+    /* the NEXT layer's bias: its registers are free since the accumulators took this layer's, and an */ \
+    /* epilogue, a copy and two barriers hide the fetch */                                         \
+    load_bias<2>(bias, pk + off_b(LNEXT), nt0, lane);                                              \
     FT_STAMP(L, 1)                                                                                 \
     __syncthreads();                                                                               \
     FT_STAMP(L, 2)                                                                                 \
-    const unsigned long long bits_ = layer_store<2, true, PT>(acc, bias, nt0, hbuf, lane);         \
+    const unsigned long long bits_ = layer_store<2, true, PT>(acc, nt0, hbuf, lane);               \
     FT_STAMP(L, 3)                                                                                 \
     if (SAVE) store_relu_words<PT>(a.acts, P, L, tid, bits_);                                      \
     if (SAVE) save_tile_wave<64, PT>(hbuf, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, lane);    \
@@ -218,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   FS_STAMP(1)
   an[0] = WBASE(0)[lane];
   an[1] = WBASE(0)[kb_total(0) * 64 + lane];
+  load_bias<2>(bias, pk + off_b(0), nt0, lane);
   PTS_LAYER(0, 1, 8, ebuf)
   FS_STAMP(2)
   PTS_LAYER(1, 2, 0, ebuf)
@@ -274,10 +275,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 
   FS_STAMP(10)
   // ---------------- feature_linear: 256 -> 256, no activation ----------------
-  load_bias<2>(bias, pk + off_b(L_FEAT), nt0, lane);
-  layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
+  layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane, bias);
+  f32x4 biasv[1][4];
+  load_bias<1>(biasv, pk + off_b(L_VIEWS), wave, lane);
   __syncthreads();
-  layer_store<2, false, PT>(acc, bias, nt0, hbuf, lane);
+  layer_store<2, false, PT>(acc, nt0, hbuf, lane);
   if (SAVE) save_tile_wave<64, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, lane);
   __syncthreads();
 
@@ -285,12 +287,10 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
   {
     f32x16 accv[1][PT];
-    f32x4 biasv[1][4];
-    load_bias<1>(biasv, pk + off_b(L_VIEWS), wave, lane);
     // (an[1] is unused by the one-tile views layer; the trailing prefetch re-reads block 0)
-    layer_gemm<1, 1, 32, VIEW_PAD, PT>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane);
+    layer_gemm<1, 1, 32, VIEW_PAD, PT>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane, biasv);
     __syncthreads();
-    layer_store<1, true, PT>(accv, biasv, wave, hbuf, lane);
+    layer_store<1, true, PT>(accv, wave, hbuf, lane);
     if (SAVE) save_tile_wave<32, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, lane);
     __syncthreads();
   }

@@ -31,11 +31,16 @@ __device__ __forceinline__ int h_idx(int row, int chunk) {
 //   pre     : LDS region for the first KBP k-blocks (row stride PRE_STRIDE floats)
 //   hbuf    : swizzled h tile for the remaining KBH k-blocks
 // ---------------------------------------------------------------------------
-template <int NT, int KBP, int KBH, int PRE_STRIDE, int PT = 2>
-__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2],
-                                           const f32x4* __restrict__ wp,
-                                           const f32x4* __restrict__ wp_next, int kb_next,
-                                           const float* pre, const float* hbuf, int lane) {
+//   binit   : this lane's bias values in accumulator order (load_bias); BINIT = false: start from zero.  The
+//             accumulators START from the bias (the same 128 v_mov the zero fill costs) instead of adding it in
+//             the epilogue: fp32 MFMAs run on the SIMD's fp32 lanes, so the 128 v_add per layer and wave were
+//             1.5 % of the matrix time (round 4)
+template <int NT, int KBP, int KBH, int PRE_STRIDE, int PT, bool BINIT>
+__device__ __forceinline__ void layer_gemm_b(f32x16 (&acc)[NT][PT], f32x4 (&an)[2],
+                                             const f32x4* __restrict__ wp,
+                                             const f32x4* __restrict__ wp_next, int kb_next,
+                                             const float* pre, const float* hbuf, int lane,
+                                             const f32x4 (&binit)[NT][4]) {
   constexpr int KB = KBP + KBH;
   const int r = lane & 31, hh = lane >> 5;
 #ifdef MLP_PRIO
@@ -46,7 +51,7 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2]
 #pragma unroll
     for (int p = 0; p < PT; ++p)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][p][i] = 0.f;
+      for (int i = 0; i < 16; ++i) acc[t][p][i] = BINIT ? binit[t][i >> 2][i & 3] : 0.f;
 
   auto load_b = [&](int kb, f32x4& b0, f32x4& b1) {   // b1: rows 32.. (PT == 2 only)
     if (KBP > 0 && kb < KBP) {
@@ -100,6 +105,19 @@ __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2]
   __builtin_amdgcn_sched_barrier(0);
   __builtin_amdgcn_s_setprio(MLP_PRIO);
 #endif
+}
+template <int NT, int KBP, int KBH, int PRE_STRIDE, int PT = 2>
+__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2], const f32x4* __restrict__ wp,
+                                           const f32x4* __restrict__ wp_next, int kb_next, const float* pre,
+                                           const float* hbuf, int lane) {
+  const f32x4 none[NT][4] = {};
+  layer_gemm_b<NT, KBP, KBH, PRE_STRIDE, PT, false>(acc, an, wp, wp_next, kb_next, pre, hbuf, lane, none);
+}
+template <int NT, int KBP, int KBH, int PRE_STRIDE, int PT = 2>
+__device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2], const f32x4* __restrict__ wp,
+                                           const f32x4* __restrict__ wp_next, int kb_next, const float* pre,
+                                           const float* hbuf, int lane, const f32x4 (&binit)[NT][4]) {
+  layer_gemm_b<NT, KBP, KBH, PRE_STRIDE, PT, true>(acc, an, wp, wp_next, kb_next, pre, hbuf, lane, binit);
 }
 
 // coalesced copy of the h tile (first ncols columns) to dst[P][256] (full 1-KiB rows)
