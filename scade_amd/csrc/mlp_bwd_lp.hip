@@ -1473,7 +1473,7 @@ static constexpr int LP_JOB_WEIGHTS[7] = {32, 35, 26, 20, 18, 17, 8};
 // stage costs its BYTES: 16 KB per 32 points for a layer, + the d alpha scalars, 12 KB for the 128-row views
 // layer (its dZ rows are 128 bytes wide), 10 KB for the embedding-input jobs (8 KB of dZ + 2 KB of fp8 embedding
 // rows: measured 10.4 / 16), 8.7 KB for the rgb head (16-bit views rows + g_out: measured 8.5 - 10.4 / 16).
-static constexpr int LP8_JOB_WEIGHTS[7] = {32, 34, 24, 21, 21, 14, 19};
+static constexpr int LP8_JOB_WEIGHTS[7] = {32, 34, 24, 21, 21, 17, 21};
 static int lp_job_weight(int j, bool s8) {
   const int* w = s8 ? LP8_JOB_WEIGHTS : LP_JOB_WEIGHTS;
   return j < 7 ? w[0] : w[j - 6];      // jobs 0..6: layers 1..7; 7 feature, 8 views, 9..11 embedding jobs, 12 rgb
