@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--no-image", action="store_true", help="skip the secondary 16-chunk image-render measurement")
     ap.add_argument("--hyp", type=int, default=20, help="depth hypotheses per ray (train step)")
     ap.add_argument("--no-rayops", action="store_true", help="skip the per-ray kernels' GB/s table")
+    ap.add_argument("--no-graph", action="store_true", help="skip the eager-vs-graph A/B regions (profiling passes)")
     ap.add_argument("--secondary-budget", type=float, default=420.0,
                     help="seconds the secondary regions may take in total before the line is printed without the rest")
     return ap.parse_args()
@@ -702,7 +703,7 @@ def main():
             if strong:
                 guarded("train_step_bf16_strong_graph", train_region, *tr_args, precision="bf16",
                         rays_per_gpu=args.rays // world, graphed=True, scaling="strong")
-            if world == 1:
+            if world == 1 and not args.no_graph:
                 guarded("train_step_graph", lambda: [graph_region(args, dev, 128, "f32"),
                                                      graph_region(args, dev, 128, "bf16"),
                                                      graph_region(args, dev, args.rays, "bf16"),

@@ -4,7 +4,7 @@
 # under the profiler, so only same-box figures are comparable).
 # Usage: tools/profile_gpu.sh <round-tag> [render-only]   (outputs under gpurun_out/prof_<tag>/)
 set -u
-TAG=${1:-r03}
+TAG=${1:-r04}
 MODE=${2:-all}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
@@ -16,7 +16,7 @@ STEPS=100
 # the headline region only; 12 setup + 20 warm-up steps precede the 100 timed ones (bench.py), and the
 # statistics below are taken over the LAST 100 launches of each launch size, i.e. the timed steps alone
 CMD="python $ROOT/bench.py --no-cpu-baseline --no-train --no-image --no-fast --no-rayops --steps $STEPS --warmup 20"
-TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --no-rayops --steps 10 --warmup 2"   # render + f16x3 + train regions
+TRAIN_CMD="python $ROOT/bench.py --no-cpu-baseline --no-image --no-rayops --no-graph --steps 10 --warmup 2"   # render + f16x3 + train regions
 
 # 0. the same command un-profiled, same box, right before the profiled runs
 $CMD > $OUT/unprofiled.log 2>&1
