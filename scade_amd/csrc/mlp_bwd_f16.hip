@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   layer_gemm_h<2, 0, 8, false>(acc0, acc1, an, WT16(8, 8), WT16(7, 16), 16, gh, gl, gh, gl, lane);
   __syncthreads();
   dgrad_store_h<false, false>(acc0, acc1, kt0, gh, gl, 0ull, nullptr, dal, lane);
-  save_tile_h_wave(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, 64, inv_s, lane);
+  save_tile_h_wave<64>(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, inv_s, lane);
   __syncthreads();
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16(7, 16), WT16(6, 16), 16, gh, gl, gh, gl, lane);
   __syncthreads();
   dgrad_store_h<true, true>(acc0, acc1, kt0, gh, gl, mbits, pk + OFF_WA, dal, lane);
-  save_tile_h_wave(gh, gl, dz + acts_slot_off(P, 7), p0, P, 64 * wave, 64, inv_s, lane);
+  save_tile_h_wave<64>(gh, gl, dz + acts_slot_off(P, 7), p0, P, 64 * wave, inv_s, lane);
   __syncthreads();
 
 #define DGRAD_LAYER_H(L)                                                                         \
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
                                 gh, gl, gh, gl, lane);                                           \
   __syncthreads();                                                                               \
   dgrad_store_h<true, false>(acc0, acc1, kt0, gh, gl, mbits, nullptr, dal, lane);                \
-  save_tile_h_wave(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, 64, inv_s, lane);     \
+  save_tile_h_wave<64>(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, inv_s, lane);     \
   __syncthreads();
 
   DGRAD_LAYER_H(7)

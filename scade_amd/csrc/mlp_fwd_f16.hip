@@ -184,7 +184,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     const unsigned long long bits_ =                                                             \
         layer_store_h<2, true, 2>(acc0, acc1, nt0, xh, xl, lane, cb, TAIL(off_b(LNEXT)), nt0);   \
     if (SAVE) store_relu_words<2>(a.acts, P, L, tid, bits_);                                     \
-    if (SAVE) save_tile_h_wave(xh, xl, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, 64, nullptr, lane); \
+    if (SAVE) save_tile_h_wave<64>(xh, xl, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, nullptr, lane); \
     __syncthreads();                                                                             \
   }
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WHBASE(L_FEAT), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane, cb);
   __syncthreads();
   layer_store_h<2, false, 1>(acc0, acc1, nt0, xh, xl, lane, cb, TAIL(off_b(L_VIEWS)), wave);
-  if (SAVE) save_tile_h_wave(xh, xl, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, 64, nullptr, lane);
+  if (SAVE) save_tile_h_wave<64>(xh, xl, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, nullptr, lane);
   __syncthreads();
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
@@ -250,7 +250,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     layer_gemm_h<1, 1, 16, true>(av0, av1, an, WHBASE(L_VIEWS), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane, cb);
     __syncthreads();
     layer_store_h<1, true, 0>(av0, av1, wave, xh, xl, lane, cb, nullptr, 0);
-    if (SAVE) save_tile_h_wave(xh, xl, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, 32, nullptr, lane);
+    if (SAVE) save_tile_h_wave<32>(xh, xl, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, nullptr, lane);
     __syncthreads();
   }
 #undef WHBASE

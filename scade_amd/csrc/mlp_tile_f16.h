@@ -217,25 +217,53 @@ __device__ __forceinline__ void save_tile_h(const _Float16* xh, const _Float16* 
   }
 }
 
-// the same copy for the ncw columns (from column c0) ONE WAVE has just written (see save_tile_wave in mlp_tile.h)
+// the same copy for the NCW columns (from column c0) ONE WAVE has just written (see save_tile_wave in mlp_tile.h), in
+// its round-4 form: the lane's chunks are two LDS base addresses + immediates (rows 16 apart share their swizzle),
+// the stores are buffer stores with a fixed lane offset, the row part in the scalar offset and the ragged last tile
+// left to the descriptor's range check - no address arithmetic, no exec-mask branch per chunk; two chunks in flight
+template <int NCW>
 __device__ __forceinline__ void save_tile_h_wave(const _Float16* xh, const _Float16* xl, float* __restrict__ dst,
-                                                 int p0, int P, int c0, int ncw, const float* row_scale, int lane) {
-  const int cpr = ncw >> 3;                             // 8-half chunks per row of this wave's columns
-  for (int i = lane; i < HM * cpr; i += 64) {
-    const int row = i / cpr, c = (c0 >> 3) + (i - row * cpr);
-    if (p0 + row < P) {
-      typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-      const u32x4 vh = *reinterpret_cast<const u32x4*>(xh + x_idx(row, c));
-      const u32x4 vl = *reinterpret_cast<const u32x4*>(xl + x_idx(row, c));
-      const float sc = row_scale ? row_scale[row] : 1.0f;
+                                                 int p0, int P, int c0, const float* row_scale, int lane) {
+  static_assert(NCW == 64 || NCW == 32, "a wave owns 64 columns (32 in the views layer)");
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  constexpr int CPR = NCW >> 3;                         // 8-half chunks per row of this wave's columns: 8 or 4
+  constexpr int RPI = 64 / CPR;                         // rows per wave instruction: 8 or 16
+  constexpr int NB = 16 / RPI;                          // swizzle classes: 2 or 1
+  constexpr int ITERS = HM / RPI;
+  asm volatile("" : "+v"(lane));                        // (addresses recomputed per call, not kept live across the kernel)
+  const int lr = lane / CPR, c = (c0 >> 3) + lane % CPR;
+  int off[NB];
+#pragma unroll
+  for (int b = 0; b < NB; ++b) off[b] = (RPI * b + lr) * W + ((c ^ (RPI * b + lr)) << 3);      // x_idx(row, c) in halves
+  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst);
+  const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0, __builtin_amdgcn_readfirstlane((unsigned)P * 1024u), 0x00020000);
+  const int voff = lr * 1024 + c * 32;
+  const int soff = __builtin_amdgcn_readfirstlane(p0 * 1024);
+#pragma unroll
+  for (int it0 = 0; it0 < ITERS; it0 += 2) {
+    u32x4 vh[2], vl[2];
+    float sc[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int it = it0 + j, o = off[it % NB] + (it / NB) * 16 * W;
+      vh[j] = *reinterpret_cast<const u32x4*>(xh + o);
+      vl[j] = *reinterpret_cast<const u32x4*>(xl + o);
+      sc[j] = row_scale ? row_scale[it * RPI + lr] : 1.0f;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int it = it0 + j;
       float x[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) join2(vh[k], vl[k], x[2 * k], x[2 * k + 1]);
-      const f32x4 o0 = {x[0] * sc, x[1] * sc, x[2] * sc, x[3] * sc}, o1 = {x[4] * sc, x[5] * sc, x[6] * sc, x[7] * sc};
-      float* o = dst + (size_t)(p0 + row) * W + 8 * c;
-      __builtin_nontemporal_store(o0, reinterpret_cast<f32x4*>(o));
-      __builtin_nontemporal_store(o1, reinterpret_cast<f32x4*>(o + 4));
+      for (int k = 0; k < 4; ++k) join2(vh[j][k], vl[j][k], x[2 * k], x[2 * k + 1]);
+      const u32x4 o0 = {__float_as_uint(x[0] * sc[j]), __float_as_uint(x[1] * sc[j]), __float_as_uint(x[2] * sc[j]), __float_as_uint(x[3] * sc[j])};
+      const u32x4 o1 = {__float_as_uint(x[4] * sc[j]), __float_as_uint(x[5] * sc[j]), __float_as_uint(x[6] * sc[j]), __float_as_uint(x[7] * sc[j])};
+      __builtin_amdgcn_raw_buffer_store_b128(o0, rs, voff, soff + it * RPI * 1024, 2);          // streamed once: nt
+      __builtin_amdgcn_raw_buffer_store_b128(o1, rs, voff + 16, soff + it * RPI * 1024, 2);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
