@@ -279,7 +279,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 
   f32x16 acc[2][LPT];
   unsigned mb[4] = {0u, 0u, 0u, 0u};
-  AFrag3<BF> A;
+  constexpr int DNS = 4;          // A register sets: weights fetched three k-blocks ahead (round 4: the dgrad has the registers)
+  AFragN<BF, DNS> A;
   const int kt0 = wave * 2;
   auto load_mask = [&](int layer) {
     const u32x4 mw = masks[((size_t)layer * ntiles + blk) * 256 + tid];
@@ -291,12 +292,16 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   A.s[0].t1 = WTL(8, 8)[8 * 64 + lane];
   A.s[1].t0 = WTL(8, 8)[64 + lane];
   A.s[1].t1 = WTL(8, 8)[9 * 64 + lane];
+  if constexpr (DNS == 4) {
+    A.s[2].t0 = WTL(8, 8)[128 + lane];
+    A.s[2].t1 = WTL(8, 8)[10 * 64 + lane];
+  }
   // rotation of the A register sets on entry of the n-th gemm of the chain: views (8 k-blocks),
   // feature (16), then layers 7..1 (16 each)
-#define DROT(N) ((N) == 0 ? 0 : (8 + 16 * ((N)-1)) % 3)
+#define DROT(N) ((N) == 0 ? 0 : (8 + 16 * ((N)-1)) % DNS)
 
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
-  layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), 3, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
+  layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), DNS, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
   if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, fac, 64 * wave, lane);
@@ -305,7 +310,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
-  layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), 3, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
+  layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), DNS, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
   __syncthreads();
   dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
   if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, 7) * 2, p0, P, fac, 64 * wave, lane);
@@ -314,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 
 #define DGRAD_LAYER_L(L)                                                                            \
   load_mask((L)-1);                                                                                 \
-  layer_gemm_lp<BF, 2, 0, 16, false, DROT(9 - (L)), 3, NPT>(acc, A, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, \
+  layer_gemm_lp<BF, 2, 0, 16, false, DROT(9 - (L)), DNS, NPT>(acc, A, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, \
                                                     g, g, lane, nullptr);                           \
   __syncthreads();                                                                                  \
   dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
