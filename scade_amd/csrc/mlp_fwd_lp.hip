@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   unsigned bits[4];
   // inference: weights fetched three k-blocks ahead; the training variant has no registers left
   // for a fourth set and stays at two
-  constexpr int NS = SAVE ? 3 : 4;   // (SAVE = 1, 2 -> 3)
+  constexpr int NS = 4;
   AFragN<BF, NS> A;
   const int nt0 = wave * 2;
 #define WLBASE(L) (reinterpret_cast<const V8*>(wpk + CE<off_wl(L)>::v) + ((L) == L_VIEWS ? wave : nt0) * (int)CE<kb16(L) * 64>::v)
