@@ -279,7 +279,10 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 
   f32x16 acc[2][LPT];
   unsigned mb[4] = {0u, 0u, 0u, 0u};
-  constexpr int DNS = 4;          // A register sets: weights fetched three k-blocks ahead (round 4: the dgrad has the registers)
+#ifndef LP_DNS
+#define LP_DNS 4
+#endif
+  constexpr int DNS = LP_DNS;          // A register sets: weights fetched three k-blocks ahead (round 4: the dgrad has the registers)
   AFragN<BF, DNS> A;
   const int kt0 = wave * 2;
   auto load_mask = [&](int layer) {
@@ -288,13 +291,10 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   };
   // this wave's k-tile pair of dgrad index TT: [kt][NB16][64] V8
 #define WTL(TT, NB) (reinterpret_cast<const V8*>(pt_ + CE<off_wtl(TT)>::v) + kt0 * (NB) * 64)
-  A.s[0].t0 = WTL(8, 8)[lane];
-  A.s[0].t1 = WTL(8, 8)[8 * 64 + lane];
-  A.s[1].t0 = WTL(8, 8)[64 + lane];
-  A.s[1].t1 = WTL(8, 8)[9 * 64 + lane];
-  if constexpr (DNS == 4) {
-    A.s[2].t0 = WTL(8, 8)[128 + lane];
-    A.s[2].t1 = WTL(8, 8)[10 * 64 + lane];
+#pragma unroll
+  for (int j = 0; j < DNS - 1; ++j) {
+    A.s[j].t0 = WTL(8, 8)[j * 64 + lane];
+    A.s[j].t1 = WTL(8, 8)[(8 + j) * 64 + lane];
   }
   // rotation of the A register sets on entry of the n-th gemm of the chain: views (8 k-blocks),
   // feature (16), then layers 7..1 (16 each)

@@ -392,29 +392,23 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF,
   }
   // a real loop over groups of NS k-blocks (one body per register set); never fully unrolled: ten
   // layers of straight-line k-loops would not fit the instruction cache
-  static_assert(NS == 3 || NS == 4, "layer_gemm_lp: three or four A sets");
+  static_assert(NS >= 3 && NS <= 6, "layer_gemm_lp: three to six A sets");
   int kb = 1;
-  if constexpr (NS == 3) {
 #pragma unroll 1
-    for (; kb + 2 < KB; kb += 3) {
-      KBLOCK(kb, (ROT + 1) % 3)
-      KBLOCK(kb + 1, (ROT + 2) % 3)
-      KBLOCK(kb + 2, ROT)
-    }
-    if ((KB - 1) % 3 >= 1) KBLOCK(kb, (ROT + 1) % 3)
-    if ((KB - 1) % 3 == 2) KBLOCK(kb + 1, (ROT + 2) % 3)
-  } else {
-#pragma unroll 1
-    for (; kb + 3 < KB; kb += 4) {
-      KBLOCK(kb, (ROT + 1) % 4)
-      KBLOCK(kb + 1, (ROT + 2) % 4)
-      KBLOCK(kb + 2, (ROT + 3) % 4)
-      KBLOCK(kb + 3, ROT)
-    }
-    if ((KB - 1) % 4 >= 1) KBLOCK(kb, (ROT + 1) % 4)
-    if ((KB - 1) % 4 >= 2) KBLOCK(kb + 1, (ROT + 2) % 4)
-    if ((KB - 1) % 4 == 3) KBLOCK(kb + 2, (ROT + 3) % 4)
+  for (; kb + NS - 1 < KB; kb += NS) {
+    KBLOCK(kb, (ROT + 1) % NS)
+    KBLOCK(kb + 1, (ROT + 2) % NS)
+    KBLOCK(kb + 2, (ROT + 3) % NS)
+    if constexpr (NS > 3) KBLOCK(kb + 3, (ROT + 4) % NS)
+    if constexpr (NS > 4) KBLOCK(kb + 4, (ROT + 5) % NS)
+    if constexpr (NS > 5) KBLOCK(kb + 5, (ROT + 6) % NS)
   }
+  constexpr int REM = (KB - 1) % NS;
+  if constexpr (REM >= 1) KBLOCK(kb, (ROT + 1) % NS)
+  if constexpr (REM >= 2) KBLOCK(kb + 1, (ROT + 2) % NS)
+  if constexpr (REM >= 3) KBLOCK(kb + 2, (ROT + 3) % NS)
+  if constexpr (REM >= 4) KBLOCK(kb + 3, (ROT + 4) % NS)
+  if constexpr (REM >= 5) KBLOCK(kb + 4, (ROT + 5) % NS)
 #undef KBLOCK
 #undef FETCH_A
 #undef LOAD_BL
