@@ -177,6 +177,22 @@ constexpr bool DG_KO = false;
 #endif
 constexpr int dgrad_lp_lds_bytes(int NPT) { return 32 * NPT * W * 2 + 2 * 32 * NPT * 4; }
 
+// -DDG_TRACE (variant build; tools/probe_dgrad_trace.py): core-clock stamps of sixteen consecutive workgroups of the
+// launch's third round at the phase boundaries of every gemm of the chain, + their HW_ID / XCC_ID words
+#ifdef DG_TRACE
+__device__ unsigned long long dg_trace[16 * 4 * 9 * 6];
+__device__ unsigned dg_hwid[16 * 2];
+__device__ unsigned long long dg_heads[16 * 4 * 6];
+#define DH_STAMP(I)                                                                                \
+  if (S8 && NPT == 4 && blockIdx.x >= 1300 && blockIdx.x < 1316 && lane == 0)                       \
+    dg_heads[((blockIdx.x - 1300) * 4 + wave) * 6 + (I)] = clock64();
+#define DT_STAMP(G, I)                                                                             \
+  if (S8 && NPT == 4 && blockIdx.x >= 1300 && blockIdx.x < 1316 && lane == 0)                       \
+    dg_trace[(((blockIdx.x - 1300) * 4 + wave) * 9 + (G)) * 6 + (I)] = clock64();
+#else
+#define DT_STAMP(G, I)
+#define DH_STAMP(I)
+#endif
 // S8: format code 2 - the saved rows (activations read, dZ written) are 8-bit e5m2 (mlp_tile_lp.h); the dZ rows
 // then carry the launch-wide loss scale like the fp16 path's (e5m2 has fp16's exponent range)
 template <bool BF, int NPT, bool S8 = false>
@@ -196,6 +212,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  DT_STAMP(0, 4)          // (kernel entry)
+  DH_STAMP(0)
   const int p0 = blk * LM;
   const int P = a.P;
   const T* __restrict__ pt_ = reinterpret_cast<const T*>(a.packedT);
@@ -210,72 +228,119 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   const float S = (BF && !S8) ? 1.f : lp_loss_scale(lp_read_gmax(a.gmax));
   unsigned char* __restrict__ dz8 = a.dz;
   const unsigned char* __restrict__ acts8 = a.acts;
+  DH_STAMP(1)
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
-#pragma unroll
-  for (int rb = 0; rb < LM / 64; ++rb) {
-    const int row = rb * 64 + (tid >> 2), sub = tid & 3;
-    const int pt = p0 + row;
-    const bool ok = pt < P;
-    f32x4 go = {0.f, 0.f, 0.f, 0.f};
-    if (ok) go = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
-    float da = 0.f;
-    if (ok) {
-      const float bx = alpha_pre[pt] * 10.f;
-      da = bx > 20.f ? go[3] : go[3] / (1.f + expf(-bx));
-    }
-    const float m = fmaxf(fmaxf(fabsf(go[0]), fabsf(go[1])), fmaxf(fabsf(go[2]), fabsf(da)));
-    // per-point power-of-two scale: an fp16 matter like S (bf16 carries fp32's exponent range and a power of
-    // two commutes with every rounding of the chain: s = 1 gives the same bits, and the dZ rows then leave
-    // LDS as plain copies - no un-scaling multiply, i.e. no bf16 -> fp32 -> bf16 round trip per element).
-    // CAVEAT: "same bits" holds while every value of the chain stays in bf16's NORMAL range.  A point whose
-    // output gradient is below ~1e-30 produces dZ values under 2^-126: those flush to bf16 subnormals / zero
-    // here, where the per-point scale would have kept them normal.  Such gradients are 22 decades under
-    // Adam's eps (1e-8) and change no update; tests/test_gpu_lp.py pins the behaviour (finite, -> 0).
-    float s = 1.f;
-    if (!BF && m > 0.f && m < 3.0e38f) {
-      int e;
-      frexpf(m, &e);
-      s = ldexpf(1.f, min(-4 - e, 96));    // denormal gradients: keep the scale finite
-    }
-    if (sub == 0) {
-      if (ok) dalpha[pt] = da;
-      dal[row] = da * s;
-      fac[row] = S / s;
-    }
+  // Round 4 (the phase trace, tools/probe_dgrad_trace.py, showed this section at 32 k cycles = 23 % of a
+  // workgroup's life: 4-column chunks per lane - 8-byte loads of the saved rows and 4-byte stores 256 bytes apart,
+  // three weight loads per chunk, one chunk's loads waiting for the previous chunk's stores).  Now a lane owns ONE
+  // 8-column chunk of the 128 columns for all its rows (the 24 head weights stay in registers), a wave instruction
+  // covers four whole 256-byte rows, and every load of the section is issued before the first use.
+  {
+    constexpr int HIT = LM / 16;                          // rows per lane: row = 16 it + (tid >> 4)
+    const int chunk = tid & 15, r16 = tid >> 4;
     const float* wr = tl + TL_WR;
+    f32x4 w0[2], w1[2], w2[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      w0[h] = *reinterpret_cast<const f32x4*>(wr + chunk * 8 + 4 * h);
+      w1[h] = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 8 + 4 * h);
+      w2[h] = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 8 + 4 * h);
+    }
     const T* hv = actsT + acts_slot_off(P, SLOT_VIEWS_H);
     T* dzv = dzT + acts_slot_off(P, SLOT_VIEWS_H);
+    V8 mk[HIT];
+    f32x4 go[HIT];
+    float ap[HIT];
+    // bf16 formats: d alpha_pre (an exp and a division) once per row - lane `tid` owns row `tid` - instead of in
+    // each of the row's sixteen chunk lanes
+    float go3r = 0.f, apr = 0.f;
+    if (BF && tid < LM) {
+      const int pt = min(p0 + tid, P - 1);
+      go3r = a.g_out[(size_t)pt * 4 + 3];
+      apr = alpha_pre[pt];
+    }
+    // (no `if (ok)` around the loads: the compiler closes every divergent block with a wait for its loads, which
+    // chained eight HBM latencies - 30 k cycles; rows past P read row P - 1 and are zeroed by a select)
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int chunk = i * 4 + sub;                       // 4-column chunk of the 128 columns
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
-      const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
-      V4 mk;
+    for (int it = 0; it < HIT; ++it) {
+      const int pt = min(p0 + it * 16 + r16, P - 1);
+#ifdef DGH_HOT   // (experiment: every tile reads tile 0's rows - cache-hot)
+      const int pth = (DGH_HOT & 1) ? it * 16 + r16 : pt, ptg = (DGH_HOT & 2) ? it * 16 + r16 : pt;
+      mk[it] = *reinterpret_cast<const V8*>(hv + (size_t)pth * W + chunk * 8);
+      go[it] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)ptg * 4);
+      ap[it] = alpha_pre[ptg];
+#else
+      mk[it] = *reinterpret_cast<const V8*>(hv + (size_t)pt * W + chunk * 8);      // (16-bit in every format)
+      go[it] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+      if (!BF) ap[it] = alpha_pre[pt];
+#endif
+    }
+    DH_STAMP(2)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) mk[j] = (T)0.f;
-      if (ok) mk = *reinterpret_cast<const V4*>(hv + (size_t)pt * W + chunk * 4);     // (16-bit in every format)
-      V4 vs, vS;
-      float vf[4];
+    for (int it = 0; it < HIT; ++it) {
+      const int row = it * 16 + r16, pt = p0 + row;
+      const bool ok = pt < P;
+      if (!ok) {                                           // rows past P: zero gradient, zero mask
+        go[it] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float d = go[0] * w0[j] + go[1] * w1[j] + go[2] * w2[j];
-        const float v = (float)mk[j] > 0.f ? d : 0.f;
+        for (int j = 0; j < 8; ++j) mk[it][j] = (T)0.f;
+      }
+      // per-point power-of-two scale: an fp16 matter like S (bf16 carries fp32's exponent range and a power of
+      // two commutes with every rounding of the chain: s = 1 gives the same bits, and the dZ rows then leave
+      // LDS as plain copies - no un-scaling multiply, i.e. no bf16 -> fp32 -> bf16 round trip per element).
+      // CAVEAT: "same bits" holds while every value of the chain stays in bf16's NORMAL range.  A point whose
+      // output gradient is below ~1e-30 produces dZ values under 2^-126: those flush to bf16 subnormals / zero
+      // here, where the per-point scale would have kept them normal.  Such gradients are 22 decades under
+      // Adam's eps (1e-8) and change no update; tests/test_gpu_lp.py pins the behaviour (finite, -> 0).
+      float s = 1.f;
+      if constexpr (!BF) {                                 // (bf16: d alpha_pre is one row per lane, below)
+        const float bx = ap[it] * 10.f;
+        float da = bx > 20.f ? go[it][3] : go[it][3] / (1.f + expf(-bx));
+        if (!ok) da = 0.f;
+        const float m = fmaxf(fmaxf(fabsf(go[it][0]), fabsf(go[it][1])), fmaxf(fabsf(go[it][2]), fabsf(da)));
+        if (m > 0.f && m < 3.0e38f) {
+          int e;
+          frexpf(m, &e);
+          s = ldexpf(1.f, min(-4 - e, 96));    // denormal gradients: keep the scale finite
+        }
+        if (chunk == 0) {
+          if (ok) dalpha[pt] = da;
+          dal[row] = da * s;
+          fac[row] = S / s;
+        }
+      }
+      V8 vs, vS;
+      float vf[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        // (fused: three ops per value instead of five; the result is rounded to 16 / 8 bit right below)
+        const float d = __builtin_fmaf(go[it][2], w2[j >> 2][j & 3], __builtin_fmaf(go[it][1], w1[j >> 2][j & 3], go[it][0] * w0[j >> 2][j & 3]));
+        const float v = (float)mk[it][j] > 0.f ? d : 0.f;
         vs[j] = (T)(v * s);
         vS[j] = (T)(v * S);
         vf[j] = v * S;
       }
-      *reinterpret_cast<V4*>(g + x_idx(row, chunk >> 1) + (chunk & 1) * 4) = vs;
+      *reinterpret_cast<V8*>(g + x_idx(row, chunk)) = vs;
       if (S8) {
-        if (ok) *reinterpret_cast<unsigned*>(dz8 + acts_slot_off(P, SLOT_VIEWS_H) * 2 + (size_t)pt * W + chunk * 4) =
-            lp_pack4_bf8(vf[0], vf[1], vf[2], vf[3]);
+        const lp_u32x2 o = {lp_pack4_bf8(vf[0], vf[1], vf[2], vf[3]), lp_pack4_bf8(vf[4], vf[5], vf[6], vf[7])};
+        if (ok) *reinterpret_cast<lp_u32x2*>(dz8 + acts_slot_off(P, SLOT_VIEWS_H) * 2 + (size_t)pt * W + chunk * 8) = o;
       } else if (ok) {
-        *reinterpret_cast<V4*>(dzv + (size_t)pt * W + chunk * 4) = vS;
+        *reinterpret_cast<V8*>(dzv + (size_t)pt * W + chunk * 8) = vS;
       }
     }
+    if (BF && tid < LM) {
+      const int pt = p0 + tid;
+      const float bx = apr * 10.f;
+      float da = bx > 20.f ? go3r : go3r / (1.f + expf(-bx));
+      if (pt < P) dalpha[pt] = da; else da = 0.f;
+      dal[tid] = da;
+      fac[tid] = S;
+    }
+    DH_STAMP(3)
   }
-  __syncthreads();
+  LP_SYNC();
+  DH_STAMP(4)
 
   f32x16 acc[2][LPT];
   unsigned mb[4] = {0u, 0u, 0u, 0u};
@@ -301,31 +366,54 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 #define DROT(N) ((N) == 0 ? 0 : (8 + 16 * ((N)-1)) % DNS)
 
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
+#ifdef DG_TRACE
+  if (S8 && NPT == 4 && blockIdx.x >= 1300 && blockIdx.x < 1316 && tid == 0) {
+    dg_hwid[(blockIdx.x - 1300) * 2] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+    dg_hwid[(blockIdx.x - 1300) * 2 + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+  }
+#endif
+  DT_STAMP(0, 0)
   layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), DNS, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
-  __syncthreads();
+  DT_STAMP(0, 1)
+  LP_SYNC();
+  DT_STAMP(0, 2)
   dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
-  if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, fac, 64 * wave, lane);
-  else if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
-  __syncthreads();
+  DT_STAMP(0, 3)
+  if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  LP_SYNC();
+
+  // format code 2: the 8-bit copy of the tile just written leaves as a rider of the NEXT gemm's k-loop
+  // (SaveRider8, mlp_tile_lp.h); only the last tile of the chain is saved as a burst
+  typename std::conditional<S8 && BF, SaveRider8<NPT>, NoRider>::type rid;
+#define RID_INIT(SLOT) if constexpr (S8 && BF) rid.init(g, dz8 + acts_slot_off(P, SLOT) * 2, p0, P, fac, 64 * wave, lane);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
-  layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), DNS, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr);
-  __syncthreads();
+  RID_INIT(SLOT_FEAT)
+  DT_STAMP(0, 5) DT_STAMP(1, 0)
+  layer_gemm_lp<BF, 2, 0, 16, false, DROT(1), DNS, NPT>(acc, A, WTL(7, 16), WTL(6, 16), 16, g, g, lane, nullptr, rid);
+  DT_STAMP(1, 1)
+  LP_SYNC();
+  DT_STAMP(1, 2)
   dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
-  if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, 7) * 2, p0, P, fac, 64 * wave, lane);
-  else if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
-  __syncthreads();
+  DT_STAMP(1, 3)
+  if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  LP_SYNC();
 
 #define DGRAD_LAYER_L(L)                                                                            \
   load_mask((L)-1);                                                                                 \
+  RID_INIT(L)                                                                                       \
+  DT_STAMP(8 - (L), 5) DT_STAMP(9 - (L), 0)                                                         \
   layer_gemm_lp<BF, 2, 0, 16, false, DROT(9 - (L)), DNS, NPT>(acc, A, WTL((L)-1, 16), WTL((L) > 1 ? (L)-2 : 0, 16), 16, \
-                                                    g, g, lane, nullptr);                           \
-  __syncthreads();                                                                                  \
+                                                    g, g, lane, nullptr, rid);                      \
+  DT_STAMP(9 - (L), 1)                                                                              \
+  LP_SYNC();                                                                                  \
+  DT_STAMP(9 - (L), 2)                                                                              \
   dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
-  if (S8 && !DG_KO) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, (L)-1) * 2, p0, P, fac, 64 * wave, lane);      \
+  DT_STAMP(9 - (L), 3)                                                                              \
+  if (S8 && (L) == 1) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, 0) * 2, p0, P, fac, 64 * wave, lane);      \
   else if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
-  __syncthreads();
+  LP_SYNC();
 
   DGRAD_LAYER_L(7)
   DGRAD_LAYER_L(6)
@@ -334,7 +422,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   DGRAD_LAYER_L(3)
   DGRAD_LAYER_L(2)
   DGRAD_LAYER_L(1)
+  DT_STAMP(8, 5)
 #undef DGRAD_LAYER_L
+#undef RID_INIT
 #undef DROT
 #undef WTL
 }
@@ -848,14 +938,6 @@ __device__ __forceinline__ lp_rsrc_t lp_make_rsrc(const void* base, unsigned byt
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)p), hi = __builtin_amdgcn_readfirstlane((unsigned)(p >> 32));
   void* q = reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo);
   return __builtin_amdgcn_make_buffer_rsrc(q, 0, __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-// workgroup barrier that orders LDS only (lgkmcnt(0), never vmcnt(0): the ring stays in flight)
-__device__ __forceinline__ void lp_lds_barrier() {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
 }
 
 template <bool ALPHA>
@@ -1814,3 +1896,13 @@ extern "C" int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, in
   return bf16 ? launch_bwd_lp<true, false>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s)
               : launch_bwd_lp<false, false>(packed, packed_t_lp, ac, g_out, P, ws, grad_flat, s);
 }
+
+#ifdef DG_TRACE
+extern "C" int scade_debug_dg_heads(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scade::dg_heads), sizeof(unsigned long long) * 16 * 4 * 6);
+}
+extern "C" int scade_debug_dg_trace(unsigned long long* out, unsigned* hwid) {
+  if (hipMemcpyFromSymbol(hwid, HIP_SYMBOL(scade::dg_hwid), sizeof(unsigned) * 32) != hipSuccess) return -1;
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scade::dg_trace), sizeof(unsigned long long) * 16 * 4 * 9 * 6);
+}
+#endif

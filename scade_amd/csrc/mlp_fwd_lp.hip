@@ -171,7 +171,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       }
     }
   }
-  __syncthreads();
+  LP_SYNC();
   T* actsT = reinterpret_cast<T*>(a.acts);
   if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0 - one 16-byte chunk per item
     T* eo = actsT + acts_emb_off(P);
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   {                                                                                             \
     layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS, NPT>(acc, A, WLBASE(L), WLBASE(LNEXT),   \
                                                         (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
-    __syncthreads();                                                                            \
+    LP_SYNC();                                                                            \
     layer_store_lp<BF, 2, true, SAVE != 0, 2, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
     if (SAVE && !KO_SIGN) {                                                                     \
       u32x4 mw_ = {bits[0], bits[1], bits[2], bits[3]};                                         \
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     }                                                                                           \
     if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
     if (SAVE == 2 && !KO_SAVE) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, L) * 2, p0, P, nullptr, 64 * wave, lane); \
-    __syncthreads();                                                                            \
+    LP_SYNC();                                                                            \
   }
 
   A.s[0].t0 = WLBASE(0)[lane];
@@ -309,23 +309,23 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 
   // ---- feature_linear ------------------------------------------------------------------
   layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS, NPT>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
-  __syncthreads();
+  LP_SYNC();
   layer_store_lp<BF, 2, false, false, 1, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
   if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, 64 * wave, lane);
   if (SAVE == 2) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, nullptr, 64 * wave, lane);
-  __syncthreads();
+  LP_SYNC();
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av[1][LPT];
     layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
-    __syncthreads();
+    LP_SYNC();
     layer_store_lp<BF, 1, true, false, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
     // (format code 2 keeps THIS slot 16-bit: the 128-wide views hidden layer is what the dgrad kernel derives the
     // views ReLU mask from - an activation below e5m2's range must not read as "inactive" - and 256 bytes per
     // point either way)
     if (SAVE) save_tile_lp_wave<BF, 32, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
-    __syncthreads();
+    LP_SYNC();
   }
 #undef WLBASE
 

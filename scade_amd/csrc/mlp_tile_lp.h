@@ -273,11 +273,84 @@ __device__ __forceinline__ void save_tile_lp_wave8(const typename LP<BF>::T* x, 
       q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 4, 5), inv, false);
       q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 6, 7), inv, true);
       const lp_u32x2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
+#ifdef SAVE8_KO_STORE   // (knock-out experiment: the conversions stay live through a never-true store)
+      if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u)
+#endif
       __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff + (it & 1) * 4 * 256, soff + (it >> 1) * 16 * 256, 2);    // nt
     }
     __builtin_amdgcn_sched_barrier(0);                // keep the batches apart
   }
 }
+
+// workgroup barrier that orders LDS only (lgkmcnt(0), never vmcnt(0)): tiles are exchanged through LDS and nothing a
+// workgroup stores to HBM is read back by it, so the stores of a tile copy and the weight fragments fetched ahead
+// across a layer boundary stay in flight over the barrier (__syncthreads() drains both: its release fence is
+// s_waitcnt vmcnt(0))
+__device__ __forceinline__ void lp_lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+#ifdef LP_SYNC_FULL
+#define LP_SYNC() __syncthreads()
+#else
+#define LP_SYNC() lp_lds_barrier()
+#endif
+
+// The same copy as a RIDER of the next layer's k-loop (round 4): the tile that was just written stays in LDS as the
+// B operand of the next gemm, so its sixteen chunks per lane leave one per k-block - read in block kb, converted
+// and stored in block kb + 1 - instead of as a burst of 32 KiB per workgroup in front of the weight fetches of the
+// next layer (the stores and the A-fragment loads share the CU's vector-memory path and its in-order counter).
+struct NoRider {
+  static constexpr bool ON = false;
+  static constexpr int NCH = 0;
+  __device__ __forceinline__ void read(int) {}
+  __device__ __forceinline__ void emit() {}
+};
+template <int NPT = LPT>
+struct SaveRider8 {
+  static constexpr bool ON = true;
+  static constexpr int NCH = 4 * NPT;                 // chunks per lane
+  typedef __bf16 V8 __attribute__((ext_vector_type(8)));
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  const unsigned char *a0, *a1;
+  __amdgpu_buffer_rsrc_t rs;
+  int voff, soff0, soff_p;
+  float inv;
+  V8 v;
+  __device__ __forceinline__ void init(const __bf16* x, unsigned char* __restrict__ dst8, int p0, int P, const float* fac, int c0, int lane) {
+    int rl, c;
+    tile_copy_map<8>(lane, 0, rl, c);
+    c += c0 >> 3;
+    const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
+    a0 = xb + 2 * (rl * W + ((c ^ rl) << 3));
+    a1 = xb + 2 * ((rl + 4) * W + ((c ^ rl ^ 4) << 3));
+    const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8);
+    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+    rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
+                                           __builtin_amdgcn_readfirstlane((unsigned)P * 256u), 0x00020000);
+    voff = rl * 256 + 8 * c;
+    soff0 = __builtin_amdgcn_readfirstlane(p0 * 256);
+    inv = fac ? __builtin_amdgcn_rcpf(fac[0]) : 1.0f;
+  }
+  __device__ __forceinline__ void read(int it) {     // it: wave-uniform chunk index
+    if (it < NCH) {
+      v = *reinterpret_cast<const V8*>(((it & 1) ? a1 : a0) + (it >> 1) * 16 * W * 2);
+      soff_p = soff0 + (it >> 1) * 16 * 256 + (it & 1) * 4 * 256;
+    }
+  }
+  __device__ __forceinline__ void emit() {
+    s16x2 q0 = {0, 0}, q1 = {0, 0};
+    q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v, v, 0, 1), inv, false);
+    q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(v, v, 2, 3), inv, true);
+    q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v, v, 4, 5), inv, false);
+    q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v, v, 6, 7), inv, true);
+    const lp_u32x2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
+    __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff_p, 2);    // nt
+  }
+};
 
 // ReLU sign bits of one layer: 4 x 32-bit words per lane.  The 64 packed dwords a lane produces
 // per layer are numbered d = ((t*4 + q)*4 + p)*2 + j (n-tile t, row group q, point tile p, value
@@ -313,12 +386,12 @@ using AFrag3 = AFragN<BF, 3>;
 // layer boundary too (the last NS-1 blocks prefetch blocks 0 .. NS-2 of the next layer; the caller
 // enters the next layer with rotation (ROT + KB) % NS).  B (activations, LDS): every fragment is
 // reloaded in place for the next block right after the two MFMAs that consume it were issued.
-template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT, int NS = 3, int NPT = LPT>
+template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT, int NS = 3, int NPT = LPT, class RID = NoRider>
 __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF, NS>& A,
                                               const typename LP<BF>::V8* __restrict__ wp,
                                               const typename LP<BF>::V8* __restrict__ wp_next, int kb_next,
                                               const typename LP<BF>::T* e, const typename LP<BF>::T* x,
-                                              int lane, const f32x16* cinit) {
+                                              int lane, const f32x16* cinit, RID& rid) {
   typedef typename LP<BF>::V8 V8;
   constexpr int KB = KBP + KBH;
   const int r = lane & 31, hh = lane >> 5;
@@ -357,8 +430,10 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF,
     const int kn = (KBX) + 1 < KB ? (KBX) + 1 : (KBX);                  \
     __builtin_amdgcn_sched_barrier(0);                                  \
     MFMA2(0, A.s[R], b0) LOAD_BL(kn, 0, b0)                             \
+    if constexpr (RID::ON) { if ((KBX) <= RID::NCH) rid.emit(); }       \
     __builtin_amdgcn_sched_barrier(0);                                  \
     MFMA2(1, A.s[R], b1) LOAD_BL(kn, 1, b1)                             \
+    if constexpr (RID::ON) rid.read(KBX);                               \
     __builtin_amdgcn_sched_barrier(0);                                  \
     if constexpr (NPT > 2) {                                            \
       MFMA2(2, A.s[R], b2) LOAD_BL(kn, 2, b2)                           \
@@ -388,6 +463,7 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF,
       __builtin_amdgcn_sched_barrier(0);
     }
     MFMA2_FIRST(0, A.s[ROT], b0) LOAD_BL(kn, 0, b0)
+    if constexpr (RID::ON) rid.read(0);
     __builtin_amdgcn_sched_barrier(0);
   }
   // a real loop over groups of NS k-blocks (one body per register set); never fully unrolled: ten
@@ -409,11 +485,22 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF,
   if constexpr (REM >= 3) KBLOCK(kb + 2, (ROT + 3) % NS)
   if constexpr (REM >= 4) KBLOCK(kb + 3, (ROT + 4) % NS)
   if constexpr (REM >= 5) KBLOCK(kb + 4, (ROT + 5) % NS)
+  if constexpr (RID::ON && KB <= RID::NCH) rid.emit();        // the chunk read in the last k-block
 #undef KBLOCK
 #undef FETCH_A
 #undef LOAD_BL
 #undef MFMA2
 #undef MFMA2_FIRST
+}
+
+template <bool BF, int NT, int KBP, int KBH, bool PRE_VIEW, int ROT, int NS = 3, int NPT = LPT>
+__device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF, NS>& A,
+                                              const typename LP<BF>::V8* __restrict__ wp,
+                                              const typename LP<BF>::V8* __restrict__ wp_next, int kb_next,
+                                              const typename LP<BF>::T* e, const typename LP<BF>::T* x,
+                                              int lane, const f32x16* cinit) {
+  NoRider none;
+  layer_gemm_lp<BF, NT, KBP, KBH, PRE_VIEW, ROT, NS, NPT, NoRider>(acc, A, wp, wp_next, kb_next, e, x, lane, cinit, none);
 }
 
 // this lane's bias values in accumulator order: cb[t][4q+i] = bias[(ntile0+t)*32 + 8q + 4*(lane>>5) + i]
