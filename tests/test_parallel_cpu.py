@@ -250,7 +250,10 @@ def _render_worker(rank, world, port, q):
     img = render_rays_sharded(rays, _fake_render)             # default keys: per-pixel maps only
     everything = render_rays_sharded(rays, _fake_render, keys=None)
     seed_rank_streams(5)
-    q.put((rank, full, img, everything, torch.rand(4)))
+    # by value (numpy), not as shared-memory tensors: a tensor travels as a file descriptor that the parent must
+    # fetch from this process while it is still alive - a worker that exits first resets the connection
+    npd = lambda d: {k: v.numpy() for k, v in d.items()}
+    q.put((rank, full.numpy(), npd(img), npd(everything), torch.rand(4).numpy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -270,6 +273,9 @@ def test_sharded_test_render_gathers_whole_image_on_every_rank():
     want = _fake_render(rays)
     draws = {}
     for rank, full, img, everything, draw in res:
+        full, draw = torch.from_numpy(full), torch.from_numpy(draw)
+        img = {k: torch.from_numpy(v) for k, v in img.items()}
+        everything = {k: torch.from_numpy(v) for k, v in everything.items()}
         draws[rank] = draw
         assert torch.equal(draw, torch.rand(4, generator=torch.Generator().manual_seed(5 + rank))), "seed + rank"
         assert torch.equal(full, rays), f"rank {rank}: gather_rows"
