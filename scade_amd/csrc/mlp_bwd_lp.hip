@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   // format code 2: the 8-bit copy of the tile just written leaves as a rider of the NEXT gemm's k-loop
   // (SaveRider8, mlp_tile_lp.h); only the last tile of the chain is saved as a burst
   typename std::conditional<S8 && BF, SaveRider8<NPT>, NoRider>::type rid;
-#define RID_INIT(SLOT) if constexpr (S8 && BF) rid.init(g, dz8 + acts_slot_off(P, SLOT) * 2, p0, P, fac, 64 * wave, lane);
+#define RID_INIT(SLOT) if constexpr (S8 && BF) rid.init(g, dz8 + acts_slot_off(P, SLOT) * 2, p0, P, fac, wave);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);

@@ -99,6 +99,16 @@ constexpr bool KO_SIGN = true;
 #else
 constexpr bool KO_SIGN = false;
 #endif
+// -DFL_TRACE (variant build; tools/probe_dgrad_trace.py --fwd): core-clock stamps of sixteen consecutive workgroups of a
+// 1536-tile launch's third round at the phase boundaries of the format-code-2 training forward
+#ifdef FL_TRACE
+__device__ unsigned long long fl_trace[16 * 4 * 48];
+#define FL_STAMP(I)                                                                                        \
+  if (SAVE == 2 && NPT == 4 && gridDim.x == 1536 && blockIdx.x >= 1100 && blockIdx.x < 1116 && lane == 0)  \
+    fl_trace[((blockIdx.x - 1100) * 4 + wave) * 48 + (I)] = clock64();
+#else
+#define FL_STAMP(I)
+#endif
 // SAVE: 0 inference; 1 training, 16-bit rows saved; 2 training, 8-bit (e5m2) rows saved (format code 2)
 template <bool BF, int MODE, int SAVE, int NPT>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
@@ -111,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  FL_STAMP(0)
   const int p0 = blockIdx.x * LM;
   const int P = a.P;
   const T* __restrict__ wpk = reinterpret_cast<const T*>(a.packed);
@@ -172,6 +183,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     }
   }
   LP_SYNC();
+  FL_STAMP(1)
   T* actsT = reinterpret_cast<T*>(a.acts);
   if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0 - one 16-byte chunk per item
     T* eo = actsT + acts_emb_off(P);
@@ -211,20 +223,30 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 
   // rotation of the A register sets on entry of layer L = (k-blocks of all earlier layers) % 3
 #define FROT(L) ((int)CE<fwd_rot(L, NS)>::v)
+  typename std::conditional<SAVE == 2 && BF, SaveRider8<NPT>, NoRider>::type rid;
 #define PTS_LAYER_L(L, LNEXT, KBP)                                                              \
   {                                                                                             \
-    layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS, NPT>(acc, A, WLBASE(L), WLBASE(LNEXT),   \
-                                                        (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
+    if constexpr (SAVE == 2 && (L) > 0) {   /* the 8-bit copy of layer L-1's tile rides in this k-loop (SaveRider8) */ \
+      rid.init(x, a.acts + acts_slot_off(P, (L) > 0 ? (L)-1 : 0) * 2, p0, P, nullptr, wave);   \
+      layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS, NPT>(acc, A, WLBASE(L), WLBASE(LNEXT), \
+                                                          (int)CE<kb16(LNEXT)>::v, e, x, lane, cb, rid); \
+    } else {                                                                                    \
+      layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS, NPT>(acc, A, WLBASE(L), WLBASE(LNEXT), \
+                                                          (int)CE<kb16(LNEXT)>::v, e, x, lane, cb); \
+    }                                                                                           \
+    FL_STAMP(3 + 4 * (L))                                                                 \
     LP_SYNC();                                                                            \
+    FL_STAMP(4 + 4 * (L))                                                                 \
     layer_store_lp<BF, 2, true, SAVE != 0, 2, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
     if (SAVE && !KO_SIGN) {                                                                     \
       u32x4 mw_ = {bits[0], bits[1], bits[2], bits[3]};                                         \
       reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[                                  \
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
     }                                                                                           \
+    FL_STAMP(5 + 4 * (L))                                                                       \
     if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
-    if (SAVE == 2 && !KO_SAVE) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, L) * 2, p0, P, nullptr, 64 * wave, lane); \
     LP_SYNC();                                                                            \
+    FL_STAMP(6 + 4 * (L))                                                                 \
   }
 
   A.s[0].t0 = WLBASE(0)[lane];
@@ -236,6 +258,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     A.s[2].t1 = WLBASE(0)[(int)CE<kb16(0) * 64>::v + 128 + lane];
   }
   load_bias16<2>(cb, TAIL(off_b(0)), nt0, lane);
+  FL_STAMP(2)
   PTS_LAYER_L(0, 1, 4)
   PTS_LAYER_L(1, 2, 0)
   PTS_LAYER_L(2, 3, 0)
@@ -253,6 +276,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 #pragma unroll
     for (int j = 1; j < 4; ++j) e[row * 16 + 4 * j + c] = (T)0.f;
   }
+  FL_STAMP(35)
 
   PTS_LAYER_L(6, 7, 0)
   PTS_LAYER_L(7, L_FEAT, 0)
@@ -308,24 +332,34 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   }
 
   // ---- feature_linear ------------------------------------------------------------------
-  layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS, NPT>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+  FL_STAMP(36)
+  if constexpr (SAVE == 2) rid.init(x, a.acts + acts_slot_off(P, 7) * 2, p0, P, nullptr, wave);
+  layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS, NPT>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb, rid);
+  FL_STAMP(37)
   LP_SYNC();
+  FL_STAMP(38)
   layer_store_lp<BF, 2, false, false, 1, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
+  FL_STAMP(39)
   if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, 64 * wave, lane);
-  if (SAVE == 2) save_tile_lp_wave8<BF, 64, NPT>(x, a.acts + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, nullptr, 64 * wave, lane);
   LP_SYNC();
+  FL_STAMP(40)
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
   {
     f32x16 av[1][LPT];
-    layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb);
+    if constexpr (SAVE == 2) rid.init(x, a.acts + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, nullptr, wave);
+    layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb, rid);
+    FL_STAMP(41)
     LP_SYNC();
+    FL_STAMP(42)
     layer_store_lp<BF, 1, true, false, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
+    FL_STAMP(43)
     // (format code 2 keeps THIS slot 16-bit: the 128-wide views hidden layer is what the dgrad kernel derives the
     // views ReLU mask from - an activation below e5m2's range must not read as "inactive" - and 256 bytes per
     // point either way)
     if (SAVE) save_tile_lp_wave<BF, 32, NPT>(x, actsT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
     LP_SYNC();
+    FL_STAMP(44)
   }
 #undef WLBASE
 
@@ -365,6 +399,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       }
     }
   }
+  FL_STAMP(45)
 #undef TAIL
 }
 
@@ -383,6 +418,11 @@ __global__ void mlp_pack_lp_kernel(PackLpArgs a) { pack_lp_row<BF>(a.p, a.packed
 
 using namespace scade;
 
+#ifdef FL_TRACE
+extern "C" int scade_debug_fl_trace(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scade::fl_trace), sizeof(unsigned long long) * 16 * 4 * 48);
+}
+#endif
 extern "C" long scade_mlp_packed_lp_bytes(void) { return PACKED_LP_BYTES; }
 extern "C" long scade_mlp_acts_lp_bytes(long P) { return lp_acts_bytes(P); }
 

@@ -306,39 +306,48 @@ __device__ __forceinline__ void lp_lds_barrier() {
 struct NoRider {
   static constexpr bool ON = false;
   static constexpr int NCH = 0;
+  __device__ __forceinline__ void begin(int) {}
   __device__ __forceinline__ void read(int) {}
   __device__ __forceinline__ void emit() {}
 };
+// Whole rows per wave: behind the barrier that precedes the k-loop a wave may read any column of the tile, so wave w
+// takes rows [8 NPT w, 8 NPT (w + 1)) with all 256 columns - a store instruction writes two complete 256-byte rows
+// (512 contiguous bytes) where the per-wave column slices of the burst copy write 64-byte quarters of eight rows.
+// init() keeps wave-uniform state only (SGPRs); begin() derives the lane's part - the gemm calls it behind its
+// peeled first k-block, where the registers of the initial accumulator value (the bias vector) have just died.
 template <int NPT = LPT>
 struct SaveRider8 {
   static constexpr bool ON = true;
-  static constexpr int NCH = 4 * NPT;                 // chunks per lane
+  static constexpr int NCH = 4 * NPT;                 // chunks per lane = row pairs per wave
   typedef __bf16 V8 __attribute__((ext_vector_type(8)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
-  const unsigned char *a0, *a1;
+  const unsigned char* xb;
+  int row0;                                           // first row of this wave
   __amdgpu_buffer_rsrc_t rs;
-  int voff, soff0, soff_p;
+  int voff, soff0, soff_p, c, rlo;
   float inv;
   V8 v;
-  __device__ __forceinline__ void init(const __bf16* x, unsigned char* __restrict__ dst8, int p0, int P, const float* fac, int c0, int lane) {
-    int rl, c;
-    tile_copy_map<8>(lane, 0, rl, c);
-    c += c0 >> 3;
-    const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
-    a0 = xb + 2 * (rl * W + ((c ^ rl) << 3));
-    a1 = xb + 2 * ((rl + 4) * W + ((c ^ rl ^ 4) << 3));
+  __device__ __forceinline__ void init(const __bf16* x, unsigned char* __restrict__ dst8, int p0, int P, const float* fac, int wave) {
+    row0 = 2 * NCH * wave;
+    xb = reinterpret_cast<const unsigned char*>(x) + row0 * W * 2;
     const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8);
     const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
     rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
                                            __builtin_amdgcn_readfirstlane((unsigned)P * 256u), 0x00020000);
-    voff = rl * 256 + 8 * c;
-    soff0 = __builtin_amdgcn_readfirstlane(p0 * 256);
+    soff0 = __builtin_amdgcn_readfirstlane((p0 + row0) * 256);
     inv = fac ? __builtin_amdgcn_rcpf(fac[0]) : 1.0f;
   }
-  __device__ __forceinline__ void read(int it) {     // it: wave-uniform chunk index
+  __device__ __forceinline__ void begin(int lane) {
+    asm volatile("" : "+v"(lane));                    // (not hoisted above the caller's first k-block)
+    c = lane & 31;
+    rlo = lane >> 5;
+    voff = lane * 8;
+  }
+  __device__ __forceinline__ void read(int it) {     // it: wave-uniform chunk index; rows row0 + 2 it + {0, 1}
     if (it < NCH) {
-      v = *reinterpret_cast<const V8*>(((it & 1) ? a1 : a0) + (it >> 1) * 16 * W * 2);
-      soff_p = soff0 + (it >> 1) * 16 * 256 + (it & 1) * 4 * 256;
+      const int r = 2 * it + rlo;                     // (row0 is a multiple of 16: the swizzle sees r & 15)
+      v = *reinterpret_cast<const V8*>(xb + r * (W * 2) + ((c ^ (r & 15)) << 4));
+      soff_p = soff0 + it * 2 * 256;
     }
   }
   __device__ __forceinline__ void emit() {
@@ -348,7 +357,13 @@ struct SaveRider8 {
     q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v, v, 4, 5), inv, false);
     q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v, v, 6, 7), inv, true);
     const lp_u32x2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
-    __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff_p, 2);    // nt
+#ifndef RID_AUX
+#define RID_AUX 2     // nt
+#endif
+#ifdef RID_KO_STORE
+    if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u)
+#endif
+    __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff_p, RID_AUX);
   }
 };
 
@@ -430,10 +445,10 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF,
     const int kn = (KBX) + 1 < KB ? (KBX) + 1 : (KBX);                  \
     __builtin_amdgcn_sched_barrier(0);                                  \
     MFMA2(0, A.s[R], b0) LOAD_BL(kn, 0, b0)                             \
-    if constexpr (RID::ON) { if ((KBX) <= RID::NCH) rid.emit(); }       \
+    if constexpr (RID::ON) { if ((KBX) >= 2 && (KBX) - 2 < RID::NCH) rid.emit(); } \
     __builtin_amdgcn_sched_barrier(0);                                  \
     MFMA2(1, A.s[R], b1) LOAD_BL(kn, 1, b1)                             \
-    if constexpr (RID::ON) rid.read(KBX);                               \
+    if constexpr (RID::ON) rid.read((KBX) - 1);                         \
     __builtin_amdgcn_sched_barrier(0);                                  \
     if constexpr (NPT > 2) {                                            \
       MFMA2(2, A.s[R], b2) LOAD_BL(kn, 2, b2)                           \
@@ -463,9 +478,9 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF,
       __builtin_amdgcn_sched_barrier(0);
     }
     MFMA2_FIRST(0, A.s[ROT], b0) LOAD_BL(kn, 0, b0)
-    if constexpr (RID::ON) rid.read(0);
     __builtin_amdgcn_sched_barrier(0);
   }
+  if constexpr (RID::ON) rid.begin(lane);
   // a real loop over groups of NS k-blocks (one body per register set); never fully unrolled: ten
   // layers of straight-line k-loops would not fit the instruction cache
   static_assert(NS >= 3 && NS <= 6, "layer_gemm_lp: three to six A sets");
@@ -485,7 +500,11 @@ __device__ __forceinline__ void layer_gemm_lp(f32x16 (&acc)[NT][NPT], AFragN<BF,
   if constexpr (REM >= 3) KBLOCK(kb + 2, (ROT + 3) % NS)
   if constexpr (REM >= 4) KBLOCK(kb + 3, (ROT + 4) % NS)
   if constexpr (REM >= 5) KBLOCK(kb + 4, (ROT + 5) % NS)
-  if constexpr (RID::ON && KB <= RID::NCH) rid.emit();        // the chunk read in the last k-block
+  if constexpr (RID::ON) {        // chunk kb - 1 is read in k-block kb and leaves in k-block kb + 1: what is left
+    if constexpr (KB >= 2 && KB - 2 < RID::NCH) rid.emit();
+#pragma unroll
+    for (int c = KB - 1; c < RID::NCH; ++c) { rid.read(c); rid.emit(); }
+  }
 #undef KBLOCK
 #undef FETCH_A
 #undef LOAD_BL

@@ -30,6 +30,37 @@ for _ in range(10):
     tr.step(rays, tgt, hyp)
 torch.cuda.synchronize()
 lib = _lib.load()
+if "--fwd" in sys.argv:
+    if not hasattr(lib, "scade_debug_fl_trace"):
+        sys.exit("this library was not built with -DFL_TRACE")
+    fb = (ctypes.c_ulonglong * (16 * 4 * 48))()
+    lib.scade_debug_fl_trace.argtypes = [ctypes.c_void_p]
+    assert lib.scade_debug_fl_trace(fb) == 0
+    f = np.array(fb[:], dtype=np.int64).reshape(16, 4, 48).astype(float)
+    def rep(name, x):
+        print(f"   {name:34s} mean {x.mean():8.0f}   min {x.min():8.0f}   max {x.max():8.0f}")
+    print(f"training forward (format code 2), fine launch, 16 workgroups x 4 waves; lifetime {np.mean(f[..., 45] - f[..., 0]):.0f} cycles")
+    rep("entry -> embedding tile (+barrier)", f[..., 1] - f[..., 0])
+    rep("embedding rows saved, A/bias preload", f[..., 2] - f[..., 1])
+    for L in range(8):
+        start = f[..., 35] if L == 6 else f[..., 2 + 4 * L]
+        if L == 6:
+            rep("view pad (loads + LDS writes)", f[..., 35] - f[..., 26])
+        rep(f"layer {L}: k-loop", f[..., 3 + 4 * L] - start)
+        rep(f"layer {L}: barrier", f[..., 4 + 4 * L] - f[..., 3 + 4 * L])
+        rep(f"layer {L}: epilogue + sign words", f[..., 5 + 4 * L] - f[..., 4 + 4 * L])
+        rep(f"layer {L}: tile copy + barrier", f[..., 6 + 4 * L] - f[..., 5 + 4 * L])
+    rep("alpha head", f[..., 36] - f[..., 34])
+    rep("feature: k-loop", f[..., 37] - f[..., 36])
+    rep("feature: barrier", f[..., 38] - f[..., 37])
+    rep("feature: epilogue", f[..., 39] - f[..., 38])
+    rep("feature: tile copy + barrier", f[..., 40] - f[..., 39])
+    rep("views: k-loop", f[..., 41] - f[..., 40])
+    rep("views: barrier", f[..., 42] - f[..., 41])
+    rep("views: epilogue", f[..., 43] - f[..., 42])
+    rep("views: tile copy + barrier", f[..., 44] - f[..., 43])
+    rep("rgb head + outputs", f[..., 45] - f[..., 44])
+    sys.exit(0)
 if not hasattr(lib, "scade_debug_dg_trace"):
     sys.exit("this library was not built with -DDG_TRACE (see the docstring)")
 buf = (ctypes.c_ulonglong * (16 * 4 * 9 * 6))()
