@@ -113,3 +113,21 @@ __device__ __forceinline__ T wave_scan_incl(T v, Op op) {
   }
   return v;
 }
+
+// workgroup barrier that orders LDS only (lgkmcnt(0), never vmcnt(0)): tiles are exchanged through LDS and nothing a
+// workgroup stores to HBM is read back by it, so the stores of a tile copy and the weight fragments fetched ahead
+// across a layer boundary stay in flight over the barrier (__syncthreads() drains both: its release fence is
+// s_waitcnt vmcnt(0))
+__device__ __forceinline__ void lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+#ifdef SYNC_FULL
+#define LDS_SYNC() __syncthreads()
+#else
+#define LDS_SYNC() lds_barrier()
+#endif
+

@@ -107,42 +107,53 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_kernel(MlpDgradArgs2 aa) {
   auto mask_of = [&](int layer) { return load_relu_words<PT>(acts, P, layer, tid, blk); };
 
   // ---- heads: d alpha_pre, dZ of the views layer (rgb head + ReLU mask) ----------
+  // Round 4: a lane owns ONE 16-byte chunk of the 128 views columns for all its rows (its twelve head weights stay
+  // in registers; a wave instruction covers two whole 512-byte rows) and every load of the section is issued before
+  // the first use.  The earlier form - one row per four lanes, a guarded load per chunk - made the compiler close
+  // each guarded block with a wait for its load: ten memory latencies in a chain per tile.  Same arithmetic, same
+  // bits.
   {
-    // (PT == 1: the upper half of the workgroup has no rows)
-    const int row = tid >> 2, sub = tid & 3;
-    const int pt = p0 + row;
-    const bool ok = pt < P && (PT == 2 || row < TM);
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    if (ok) g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
-    if (sub == 0) {
-      float da = 0.f;
-      if (ok) {
-        // softplus(x, beta=10)' = sigmoid(10 x)  (1 beyond the linear threshold 10x > 20)
-        const float bx = acts[acts_alpha_off(P) + pt] * 10.f;
-        da = bx > 20.f ? g[3] : g[3] / (1.f + expf(-bx));
-        dz[dz_dalpha_off(P) + pt] = da;
-      }
-      if (PT == 2 || row < TM) dal[row] = da;
-    }
+    constexpr int HIT = TM / 8;                           // rows per lane: row = 8 it + (tid >> 5)
+    const int chunk = tid & 31, r8 = tid >> 5;
     const float* wr = pk + OFF_WR;
+    const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
+    const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
+    const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
     const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
     float* dzv = dz + acts_slot_off(P, SLOT_VIEWS_H);
+    f32x4 g[HIT], m[HIT];
+    float g3r = 0.f, apr = 0.f;                           // d alpha_pre: lane `tid` owns row `tid`
+    if (tid < TM) {
+      const int pt = min(p0 + tid, P - 1);
+      g3r = a.g_out[(size_t)pt * 4 + 3];
+      apr = acts[acts_alpha_off(P) + pt];
+    }
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int chunk = i * 4 + sub;
-      const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
-      const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
-      const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
-      f32x4 m = {0.f, 0.f, 0.f, 0.f};
-      if (ok) m = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * W + chunk * 4);
+    for (int it = 0; it < HIT; ++it) {                    // (rows past P read row P - 1 and are zeroed by a select)
+      const int pt = min(p0 + it * 8 + r8, P - 1);
+      g[it] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+      m[it] = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * W + chunk * 4);
+    }
+#pragma unroll
+    for (int it = 0; it < HIT; ++it) {
+      const int row = it * 8 + r8, pt = p0 + row;
+      const bool ok = pt < P;
       f32x4 v;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const float d = g[0] * w0[j] + g[1] * w1[j] + g[2] * w2[j];
-        v[j] = m[j] > 0.f ? d : 0.f;
+        const float d = g[it][0] * w0[j] + g[it][1] * w1[j] + g[it][2] * w2[j];
+        v[j] = (m[it][j] > 0.f && ok) ? d : 0.f;
       }
-      if (PT == 2 || row < TM) *reinterpret_cast<f32x4*>(hbuf + h_idx(row, chunk)) = v;
+      *reinterpret_cast<f32x4*>(hbuf + h_idx(row, chunk)) = v;
       if (ok) *reinterpret_cast<f32x4*>(dzv + (size_t)pt * W + chunk * 4) = v;
+    }
+    if (tid < TM) {
+      const int pt = p0 + tid;
+      // softplus(x, beta=10)' = sigmoid(10 x)  (1 beyond the linear threshold 10x > 20)
+      const float bx = apr * 10.f;
+      float da = bx > 20.f ? g3r : g3r / (1.f + expf(-bx));
+      if (pt < P) dz[dz_dalpha_off(P) + pt] = da; else da = 0.f;
+      dal[tid] = da;
     }
   }
   __syncthreads();

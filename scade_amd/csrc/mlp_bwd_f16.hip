@@ -125,14 +125,22 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
   {
+    // (round 4: no guarded loads - the compiler closes a divergent block with a wait for its loads, which chained
+    // ten memory latencies per tile; rows past P read row P - 1 and are zeroed by selects.  Same arithmetic.)
     const int row = tid >> 2, sub = tid & 3;
     const int pt = p0 + row;
     const bool ok = pt < P;
-    f32x4 g = {0.f, 0.f, 0.f, 0.f};
-    if (ok) g = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
+    const size_t ptc = (size_t)min(pt, P - 1);
+    const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
+    f32x4 g = *reinterpret_cast<const f32x4*>(a.g_out + ptc * 4);
+    const float apre = acts[acts_alpha_off(P) + ptc];
+    f32x4 mks[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) mks[i] = *reinterpret_cast<const f32x4*>(hv + ptc * W + (i * 4 + sub) * 4);
+    if (!ok) g = f32x4{0.f, 0.f, 0.f, 0.f};
     float da = 0.f;
     if (ok) {
-      const float bx = acts[acts_alpha_off(P) + pt] * 10.f;
+      const float bx = apre * 10.f;
       da = bx > 20.f ? g[3] : g[3] / (1.f + expf(-bx));
     }
     const float m = fmaxf(fmaxf(fabsf(g[0]), fabsf(g[1])), fmaxf(fabsf(g[2]), fabsf(da)));
@@ -155,7 +163,6 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
       if (lane == 0) wmx[wave] = wm;
     }
     const float* wr = pk + OFF_WR;
-    const float* hv = acts + acts_slot_off(P, SLOT_VIEWS_H);
     float* dzv = dz + acts_slot_off(P, SLOT_VIEWS_H);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
@@ -163,14 +170,13 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
       const f32x4 w0 = *reinterpret_cast<const f32x4*>(wr + chunk * 4);
       const f32x4 w1 = *reinterpret_cast<const f32x4*>(wr + 128 + chunk * 4);
       const f32x4 w2 = *reinterpret_cast<const f32x4*>(wr + 256 + chunk * 4);
-      f32x4 mk = {0.f, 0.f, 0.f, 0.f};
-      if (ok) mk = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * W + chunk * 4);
+      const f32x4 mk = mks[i];
       f32x4 v;
       half4 vh, vl;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const float d = g[0] * w0[j] + g[1] * w1[j] + g[2] * w2[j];
-        v[j] = mk[j] > 0.f ? d : 0.f;
+        v[j] = (mk[j] > 0.f && ok) ? d : 0.f;
         _Float16 h, l;
         split2(v[j] * s, h, l);
         vh[j] = h; vl[j] = l;

@@ -106,8 +106,12 @@ __device__ unsigned long long fl_trace[16 * 4 * 48];
 #define FL_STAMP(I)                                                                                        \
   if (SAVE == 2 && NPT == 4 && gridDim.x == 1536 && blockIdx.x >= 1100 && blockIdx.x < 1116 && lane == 0)  \
     fl_trace[((blockIdx.x - 1100) * 4 + wave) * 48 + (I)] = clock64();
+#define FL_STAMP_RT(I)                                                                                     \
+  if (SAVE == 2 && NPT == 4 && gridDim.x == 1536 && blockIdx.x >= 1100 && blockIdx.x < 1116 && lane == 0)  \
+    fl_trace[((blockIdx.x - 1100) * 4 + wave) * 48 + (I)] = wall_clock64();
 #else
 #define FL_STAMP(I)
+#define FL_STAMP_RT(I)
 #endif
 // SAVE: 0 inference; 1 training, 16-bit rows saved; 2 training, 8-bit (e5m2) rows saved (format code 2)
 template <bool BF, int MODE, int SAVE, int NPT>
@@ -122,6 +126,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   FL_STAMP(0)
+  FL_STAMP_RT(46)
   const int p0 = blockIdx.x * LM;
   const int P = a.P;
   const T* __restrict__ wpk = reinterpret_cast<const T*>(a.packed);
@@ -188,17 +193,29 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0 - one 16-byte chunk per item
     T* eo = actsT + acts_emb_off(P);
     unsigned char* eo8 = a.acts + acts_emb_off(P) * 2;        // format code 2: fp8 e4m3 rows, 64 bytes per point
-    for (int i = tid; i < LM * 8; i += 256) {
-      const int row = i >> 3, ch = i & 7;
-      const int pt = p0 + row;
-      if (pt < P) {
-        V8 v = *reinterpret_cast<const V8*>(e + e_idx(row, ch));   // columns 57..63 of the tile are zero
-        if (ch == 7) {
+    // (a lane keeps its chunk column ch = tid & 7 for all its rows; the view directions of the ch == 7 lanes are
+    // fetched for every lane up front - a load inside the divergent block is waited for at the block's end, which
+    // chained LM / 32 memory latencies)
+    constexpr int EIT = LM * 8 / 256;
+    const int ch = tid & 7;
+    float vd[EIT][3];
 #pragma unroll
-          for (int c = 0; c < 3; ++c)
-            v[4 + c] = (T)(MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c]
-                                     : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c]);
-        }
+    for (int k = 0; k < EIT; ++k) {
+      const int pt = min(p0 + (tid >> 3) + 32 * k, P - 1);
+#pragma unroll
+      for (int c = 0; c < 3; ++c)
+        vd[k][c] = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
+    }
+#pragma unroll
+    for (int k = 0; k < EIT; ++k) {
+      const int row = (tid >> 3) + 32 * k;
+      const int pt = p0 + row;
+      V8 v = *reinterpret_cast<const V8*>(e + e_idx(row, ch));   // columns 57..63 of the tile are zero
+      if (ch == 7) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) v[4 + c] = (T)vd[k][c];
+      }
+      if (pt < P) {
         if (SAVE == 2) {
           lp_u32x2 o;
           o[0] = lp_pack4_fp8((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
@@ -298,6 +315,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   int badf[LM / 64];
   {
     const float* wa = TAIL(OFF_WA);
+    // this lane's 64 alpha weights (its four-column-chunk stride is the same for every row block): loaded once
+    f32x4 waq[16];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      waq[2 * i] = *reinterpret_cast<const f32x4*>(wa + (i * 4 + (tid & 3)) * 8);
+      waq[2 * i + 1] = *reinterpret_cast<const f32x4*>(wa + (i * 4 + (tid & 3)) * 8 + 4);
+    }
 #pragma unroll
     for (int rb = 0; rb < LM / 64; ++rb) {
       const int row = rb * 64 + (tid >> 2), sub = tid & 3;
@@ -318,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
         const int c = i * 4 + sub;
         const V8 v = *reinterpret_cast<const V8*>(x + x_idx(row, c));
 #pragma unroll
-        for (int j = 0; j < 8; ++j) s = fmaf((float)v[j], wa[c * 8 + j], s);
+        for (int j = 0; j < 8; ++j) s = fmaf((float)v[j], waq[2 * i + (j >> 2)][j & 3], s);
       }
       s += __shfl_xor(s, 1, 64);
       s += __shfl_xor(s, 2, 64);
@@ -367,6 +391,16 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   {
     const float* wr = TAIL(OFF_WR);
     const float* br = TAIL(OFF_BR);
+    // this lane's 3 x 32 colour weights: loaded once for all its row blocks (the accumulators' registers are free)
+    f32x4 wq[3][8];
+#pragma unroll
+    for (int o = 0; o < 3; ++o)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        wq[o][2 * i] = *reinterpret_cast<const f32x4*>(wr + o * 128 + (i * 4 + (tid & 3)) * 8);
+        wq[o][2 * i + 1] = *reinterpret_cast<const f32x4*>(wr + o * 128 + (i * 4 + (tid & 3)) * 8 + 4);
+      }
+    const float br0 = br[0], br1 = br[1], br2 = br[2];
 #pragma unroll
     for (int rb = 0; rb < LM / 64; ++rb) {
       const int row = rb * 64 + (tid >> 2), sub = tid & 3;
@@ -378,9 +412,9 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xv = (float)v[j];
-          s0 = fmaf(xv, wr[c * 8 + j], s0);
-          s1 = fmaf(xv, wr[128 + c * 8 + j], s1);
-          s2 = fmaf(xv, wr[256 + c * 8 + j], s2);
+          s0 = fmaf(xv, wq[0][2 * i + (j >> 2)][j & 3], s0);
+          s1 = fmaf(xv, wq[1][2 * i + (j >> 2)][j & 3], s1);
+          s2 = fmaf(xv, wq[2][2 * i + (j >> 2)][j & 3], s2);
         }
       }
       s0 += __shfl_xor(s0, 1, 64); s0 += __shfl_xor(s0, 2, 64);
@@ -390,7 +424,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
         const float al = alpha[rb];
         const float bx = al * 10.f;
         const float sp = bx > 20.f ? al : log1pf(expf(bx)) / 10.f;
-        f32x4 o = {s0 + br[0], s1 + br[1], s2 + br[2], sp};
+        f32x4 o = {s0 + br0, s1 + br1, s2 + br2, sp};
         if (badf[rb]) {       // poisoned inputs (see the alpha head): colour NaN; density already is
           const float qn = __builtin_nanf("");
           o[0] = o[1] = o[2] = qn;
@@ -400,6 +434,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     }
   }
   FL_STAMP(45)
+  FL_STAMP_RT(47)
 #undef TAIL
 }
 

@@ -282,22 +282,9 @@ __device__ __forceinline__ void save_tile_lp_wave8(const typename LP<BF>::T* x, 
   }
 }
 
-// workgroup barrier that orders LDS only (lgkmcnt(0), never vmcnt(0)): tiles are exchanged through LDS and nothing a
-// workgroup stores to HBM is read back by it, so the stores of a tile copy and the weight fragments fetched ahead
-// across a layer boundary stay in flight over the barrier (__syncthreads() drains both: its release fence is
-// s_waitcnt vmcnt(0))
-__device__ __forceinline__ void lp_lds_barrier() {
-  __builtin_amdgcn_sched_barrier(0);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-  asm volatile("" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-}
-#ifdef LP_SYNC_FULL
-#define LP_SYNC() __syncthreads()
-#else
-#define LP_SYNC() lp_lds_barrier()
-#endif
+// (common.h: lds_barrier / LDS_SYNC - a workgroup barrier that orders LDS only)
+__device__ __forceinline__ void lp_lds_barrier() { lds_barrier(); }
+#define LP_SYNC() LDS_SYNC()
 
 // The same copy as a RIDER of the next layer's k-loop (round 4): the tile that was just written stays in LDS as the
 // B operand of the next gemm, so its sixteen chunks per lane leave one per k-block - read in block kb, converted

@@ -26,9 +26,15 @@ rays = synthetic_rays(N, seed=1).to(dev)
 torch.manual_seed(1)
 tgt = torch.rand(N, 3, device=dev)
 hyp = torch.rand(K, N, 1, device=dev) * 4.9 + 0.1
-for _ in range(10):
+import time
+nsteps = int(os.environ.get("TRACE_STEPS", "10"))
+for _ in range(nsteps):
     tr.step(rays, tgt, hyp)
 torch.cuda.synchronize()
+if os.environ.get("TRACE_IDLE"):                       # clocks after an idle gap: one step from a cold start
+    time.sleep(float(os.environ["TRACE_IDLE"]))
+    tr.step(rays, tgt, hyp)
+    torch.cuda.synchronize()
 lib = _lib.load()
 if "--fwd" in sys.argv:
     if not hasattr(lib, "scade_debug_fl_trace"):
@@ -40,6 +46,8 @@ if "--fwd" in sys.argv:
     def rep(name, x):
         print(f"   {name:34s} mean {x.mean():8.0f}   min {x.min():8.0f}   max {x.max():8.0f}")
     print(f"training forward (format code 2), fine launch, 16 workgroups x 4 waves; lifetime {np.mean(f[..., 45] - f[..., 0]):.0f} cycles")
+    rt = (f[..., 47] - f[..., 46]) / 100.0        # s_memrealtime: 100 MHz
+    print(f"   the same lifetime on the constant 100 MHz counter: {rt.mean():.1f} us => core clock {np.mean(f[..., 45] - f[..., 0]) / rt.mean() / 1e3:.2f} GHz")
     rep("entry -> embedding tile (+barrier)", f[..., 1] - f[..., 0])
     rep("embedding rows saved, A/bias preload", f[..., 2] - f[..., 1])
     for L in range(8):
