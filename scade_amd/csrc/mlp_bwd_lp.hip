@@ -236,7 +236,97 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   // three weight loads per chunk, one chunk's loads waiting for the previous chunk's stores).  Now a lane owns ONE
   // 8-column chunk of the 128 columns for all its rows (the 24 head weights stay in registers), a wave instruction
   // covers four whole 256-byte rows, and every load of the section is issued before the first use.
-  {
+#ifdef LP_HEADS_VALU
+  constexpr bool MFMA_HEADS = false;
+#else
+  constexpr bool MFMA_HEADS = BF;
+#endif
+  if constexpr (MFMA_HEADS) {
+    // bf16 formats: dZv[p][c] = mask * sum_k go[p][k] wr[k][c] is a K = 3 GEMM - ONE 32x32x16 MFMA per point tile
+    // with both operands split into bf16 high + low parts in the 16 k-slots (hi*hi + lo*hi + hi*lo: 2^-17 relative,
+    // far inside the bf16 rounding of the result): wave w owns the 32 views columns [32 w, 32 w + 32), operands are
+    // built in registers from the fp32 head weights and the fp32 output gradient (no staging), the epilogue is the
+    // chain's own (mask on the packed pair, v_permlane32_swap, ds_write_b128).  4 MFMAs and ~150 VALU
+    // instructions per lane where the VALU form needed ~600.
+    const int r = lane & 31, hh = lane >> 5;
+    const float* wr = tl + TL_WR;
+    const int ncol = 32 * wave + r;
+    const float wv0 = wr[ncol], wv1 = wr[128 + ncol], wv2 = wr[256 + ncol];
+    f32x4 gq[NPT];
+    // ReLU mask: the forward's sign words of the views layer (same (wave, lane, register) map as this MFMA's output)
+    const u32x4 hw = masks[((size_t)8 * ntiles + blk) * 256 + tid];
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      const size_t pt = (size_t)min(p0 + 32 * p + r, P - 1);       // (rows past P: zeroed below)
+      gq[p] = *reinterpret_cast<const f32x4*>(a.g_out + pt * 4);
+    }
+    float go3r = 0.f, apr = 0.f;                         // d alpha_pre: lane `tid` owns row `tid`
+    if (tid < LM) {
+      const int pt = min(p0 + tid, P - 1);
+      go3r = a.g_out[(size_t)pt * 4 + 3];
+      apr = alpha_pre[pt];
+    }
+    DH_STAMP(2)
+    auto split = [](float x, T& h, T& l) {
+      h = (T)x;
+      const float hf = (float)h;
+      l = (fabsf(hf) <= 3.0e38f) ? (T)(x - hf) : (T)0.f;   // (inf: no inf - inf)
+    };
+    T wh0, wl0, wh1, wl1, wh2, wl2;
+    split(wv0, wh0, wl0); split(wv1, wh1, wl1); split(wv2, wh2, wl2);
+    const T z = (T)0.f;
+    V8 af;
+    if (hh == 0) af = V8{wh0, wh1, wh2, wh0, wh1, wh2, z, z};
+    else af = V8{wl0, wl1, wl2, z, z, z, z, z};
+    f32x16 hacc[NPT];
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < NPT; ++p) {
+      const bool ok = p0 + 32 * p + r < P;
+      T gh0, gl0, gh1, gl1, gh2, gl2;
+      split(ok ? gq[p][0] : 0.f, gh0, gl0); split(ok ? gq[p][1] : 0.f, gh1, gl1); split(ok ? gq[p][2] : 0.f, gh2, gl2);
+      V8 bfr;
+      if (hh == 0) bfr = V8{gh0, gh1, gh2, gl0, gl1, gl2, z, z};
+      else bfr = V8{gh0, gh1, gh2, z, z, z, z, z};
+      hacc[p] = LP<BF>::mfma(af, bfr, zero16);
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int p = 0; p < NPT; ++p) {
+        u32x2 v[2];
+#pragma unroll
+        for (int qq = 0; qq < 2; ++qq) {
+          const int q = 2 * m + qq;
+          v[qq][0] = pack2<BF, false>(hacc[p][4 * q + 0], hacc[p][4 * q + 1]);
+          v[qq][1] = pack2<BF, false>(hacc[p][4 * q + 2], hacc[p][4 * q + 3]);
+          const int d0 = (q * 4 + p) * 2;                  // sign words (mlp_tile_lp.h), n-tile 0 of this wave
+          v[qq][0] = mask_pair(v[qq][0], d0 < 16 ? hw[0] : hw[1], d0 & 15);
+          v[qq][1] = mask_pair(v[qq][1], d0 < 16 ? hw[0] : hw[1], (d0 & 15) + 1);
+        }
+        u32x4 w;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          unsigned lo, hi;
+          lp_swap_halves(v[0][j], v[1][j], lo, hi);
+          w[j] = lo;
+          w[2 + j] = hi;
+        }
+        *reinterpret_cast<u32x4*>(g + x_idx(p * 32 + r, wave * 4 + 2 * m + hh)) = w;
+      }
+    // (format code 2: the 8-bit copy of this tile rides in the views gemm below; plain bf16: S = 1, the rows leave
+    // as they are - a wave saves the 32 columns it wrote)
+    if (!S8) save_tile_lp_wave<BF, 32, NPT>(g, dzT + acts_slot_off(P, SLOT_VIEWS_H), p0, P, nullptr, 32 * wave, lane);
+    if (tid < LM) {
+      const int pt = p0 + tid;
+      const float bx = apr * 10.f;
+      float da = bx > 20.f ? go3r : go3r / (1.f + expf(-bx));
+      if (pt < P) dalpha[pt] = da; else da = 0.f;
+      dal[tid] = da;
+      fac[tid] = S;
+    }
+    DH_STAMP(3)
+  } else {
     constexpr int HIT = LM / 16;                          // rows per lane: row = 16 it + (tid >> 4)
     const int chunk = tid & 15, r16 = tid >> 4;
     const float* wr = tl + TL_WR;
@@ -395,7 +485,13 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   }
 #endif
   DT_STAMP(0, 0)
-  layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), DNS, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
+  if constexpr (S8 && MFMA_HEADS) {   // the 8-bit copy of the views dZ tile (128 columns) rides in this k-loop
+    SaveRider8<NPT, 128> rid0;
+    rid0.init(g, dz8 + acts_slot_off(P, SLOT_VIEWS_H) * 2, p0, P, fac, wave);
+    layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), DNS, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr, rid0);
+  } else {
+    layer_gemm_lp<BF, 2, 0, 8, false, DROT(0), DNS, NPT>(acc, A, WTL(8, 8), WTL(7, 16), 16, g, g, lane, nullptr);
+  }
   DT_STAMP(0, 1)
   LP_SYNC();
   DT_STAMP(0, 2)

@@ -376,7 +376,11 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     FL_STAMP(41)
     LP_SYNC();
     FL_STAMP(42)
-    layer_store_lp<BF, 1, true, false, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
+    layer_store_lp<BF, 1, true, SAVE != 0, 0, NPT>(av, wave, x, lane, bits, cb, nullptr, 0);
+    if (SAVE) {   // sign words of the views layer (index 8): the dgrad's head epilogue masks with them
+      u32x4 mw_ = {bits[0], bits[1], 0u, 0u};
+      reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[((size_t)8 * gridDim.x + blockIdx.x) * 256 + tid] = mw_;
+    }
     FL_STAMP(43)
     // (format code 2 keeps THIS slot 16-bit: the 128-wide views hidden layer is what the dgrad kernel derives the
     // views ReLU mask from - an activation below e5m2's range must not read as "inactive" - and 256 bytes per

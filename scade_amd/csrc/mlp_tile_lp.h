@@ -80,7 +80,7 @@ constexpr long lp_align(long b) { return (b + 255) / 256 * 256; }
 constexpr long lp_tiles(long P) { return (P + LM - 1) / LM; }
 constexpr long lp_acts_alpha_byte(long P) { return lp_align((acts_emb_off(P) + P * 64) * 2); }
 constexpr long lp_acts_mask_byte(long P) { return lp_align(lp_acts_alpha_byte(P) + P * 4); }
-constexpr long lp_acts_bytes(long P) { return lp_acts_mask_byte(P) + 8L * ((P + 63) / 64) * 256 * 16; }   // sized for 64-point workgroups
+constexpr long lp_acts_bytes(long P) { return lp_acts_mask_byte(P) + 9L * ((P + 63) / 64) * 256 * 16; }   // 8 trunk layers + the views layer; sized for 64-point workgroups
 // dz: slots [10][P][256] T, every row multiplied by the launch-wide power of two S | d alpha_pre [P] fp32
 constexpr long lp_dz_dalpha_byte(long P) { return lp_align((long)N_ACT_SLOTS * P * 256 * 2); }
 constexpr long lp_dz_bytes(long P) { return lp_align(lp_dz_dalpha_byte(P) + P * 4); }
@@ -302,10 +302,12 @@ struct NoRider {
 // (512 contiguous bytes) where the per-wave column slices of the burst copy write 64-byte quarters of eight rows.
 // init() keeps wave-uniform state only (SGPRs); begin() derives the lane's part - the gemm calls it behind its
 // peeled first k-block, where the registers of the initial accumulator value (the bias vector) have just died.
-template <int NPT = LPT>
+template <int NPT = LPT, int NCOLS = W>
 struct SaveRider8 {
   static constexpr bool ON = true;
-  static constexpr int NCH = 4 * NPT;                 // chunks per lane = row pairs per wave
+  static constexpr int LPR = NCOLS / 8;               // lanes per row (8 columns = 16 bytes of LDS, 8 of HBM each)
+  static constexpr int RPI = 64 / LPR;                // rows per store instruction: 2 (256 columns) or 4 (128)
+  static constexpr int NCH = 8 * NPT / RPI;           // chunks per lane: the wave's 8 NPT rows
   typedef __bf16 V8 __attribute__((ext_vector_type(8)));
   typedef short s16x2 __attribute__((ext_vector_type(2)));
   const unsigned char* xb;
@@ -315,7 +317,7 @@ struct SaveRider8 {
   float inv;
   V8 v;
   __device__ __forceinline__ void init(const __bf16* x, unsigned char* __restrict__ dst8, int p0, int P, const float* fac, int wave) {
-    row0 = 2 * NCH * wave;
+    row0 = 8 * NPT * wave;
     xb = reinterpret_cast<const unsigned char*>(x) + row0 * W * 2;
     const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8);
     const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
@@ -326,15 +328,15 @@ struct SaveRider8 {
   }
   __device__ __forceinline__ void begin(int lane) {
     asm volatile("" : "+v"(lane));                    // (not hoisted above the caller's first k-block)
-    c = lane & 31;
-    rlo = lane >> 5;
-    voff = lane * 8;
+    c = lane % LPR;
+    rlo = lane / LPR;
+    voff = rlo * 256 + c * 8;                         // (rows are 256 bytes apart in HBM whatever NCOLS)
   }
-  __device__ __forceinline__ void read(int it) {     // it: wave-uniform chunk index; rows row0 + 2 it + {0, 1}
+  __device__ __forceinline__ void read(int it) {     // it: wave-uniform chunk index; rows row0 + RPI it + {0 .. RPI-1}
     if (it < NCH) {
-      const int r = 2 * it + rlo;                     // (row0 is a multiple of 16: the swizzle sees r & 15)
+      const int r = RPI * it + rlo;                   // (row0 is a multiple of 16: the swizzle sees r & 15)
       v = *reinterpret_cast<const V8*>(xb + r * (W * 2) + ((c ^ (r & 15)) << 4));
-      soff_p = soff0 + it * 2 * 256;
+      soff_p = soff0 + it * RPI * 256;
     }
   }
   __device__ __forceinline__ void emit() {
