@@ -231,16 +231,9 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   DH_STAMP(1)
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
-  // Round 4 (the phase trace, tools/probe_dgrad_trace.py, showed this section at 32 k cycles = 23 % of a
-  // workgroup's life: 4-column chunks per lane - 8-byte loads of the saved rows and 4-byte stores 256 bytes apart,
-  // three weight loads per chunk, one chunk's loads waiting for the previous chunk's stores).  Now a lane owns ONE
-  // 8-column chunk of the 128 columns for all its rows (the 24 head weights stay in registers), a wave instruction
-  // covers four whole 256-byte rows, and every load of the section is issued before the first use.
-#ifdef LP_HEADS_VALU
-  constexpr bool MFMA_HEADS = false;
-#else
+  // (Round 4: the phase trace - tools/probe_dgrad_trace.py, profiles/r04_lp_phase_trace.txt - showed this section at
+  // 32 k cycles = 23 % of a workgroup's life; 8 k now.  DESIGN.md section 3.1c.)
   constexpr bool MFMA_HEADS = BF;
-#endif
   if constexpr (MFMA_HEADS) {
     // bf16 formats: dZv[p][c] = mask * sum_k go[p][k] wr[k][c] is a K = 3 GEMM - ONE 32x32x16 MFMA per point tile
     // with both operands split into bf16 high + low parts in the 16 k-slots (hi*hi + lo*hi + hi*lo: 2^-17 relative,
@@ -327,6 +320,11 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
     }
     DH_STAMP(3)
   } else {
+    // fp16 (per-point power-of-two scale s, launch-wide loss scale S) on the VALU: a lane owns ONE 8-column chunk of
+    // the 128 columns for all its rows (the 24 head weights stay in registers, a wave instruction covers four whole
+    // 256-byte rows) and every load is issued before the first use (no `if (ok)` around the loads: the compiler
+    // closes a divergent block with a wait for its loads, which chained eight HBM latencies; rows past P read row
+    // P - 1 and are zeroed by a select).  The mask is derived from the saved 16-bit views activations.
     constexpr int HIT = LM / 16;                          // rows per lane: row = 16 it + (tid >> 4)
     const int chunk = tid & 15, r16 = tid >> 4;
     const float* wr = tl + TL_WR;
@@ -342,22 +340,12 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
     V8 mk[HIT];
     f32x4 go[HIT];
     float ap[HIT];
-    // bf16 formats: d alpha_pre (an exp and a division) once per row - lane `tid` owns row `tid` - instead of in
-    // each of the row's sixteen chunk lanes
-    float go3r = 0.f, apr = 0.f;
-    if (BF && tid < LM) {
-      const int pt = min(p0 + tid, P - 1);
-      go3r = a.g_out[(size_t)pt * 4 + 3];
-      apr = alpha_pre[pt];
-    }
-    // (no `if (ok)` around the loads: the compiler closes every divergent block with a wait for its loads, which
-    // chained eight HBM latencies - 30 k cycles; rows past P read row P - 1 and are zeroed by a select)
 #pragma unroll
     for (int it = 0; it < HIT; ++it) {
       const int pt = min(p0 + it * 16 + r16, P - 1);
-      mk[it] = *reinterpret_cast<const V8*>(hv + (size_t)pt * W + chunk * 8);      // (16-bit in every format)
+      mk[it] = *reinterpret_cast<const V8*>(hv + (size_t)pt * W + chunk * 8);
       go[it] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
-      if (!BF) ap[it] = alpha_pre[pt];
+      ap[it] = alpha_pre[pt];
     }
     DH_STAMP(2)
 #pragma unroll
@@ -369,65 +357,27 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 #pragma unroll
         for (int j = 0; j < 8; ++j) mk[it][j] = (T)0.f;
       }
-      // per-point power-of-two scale: an fp16 matter like S (bf16 carries fp32's exponent range and a power of
-      // two commutes with every rounding of the chain: s = 1 gives the same bits, and the dZ rows then leave
-      // LDS as plain copies - no un-scaling multiply, i.e. no bf16 -> fp32 -> bf16 round trip per element).
-      // CAVEAT: "same bits" holds while every value of the chain stays in bf16's NORMAL range.  A point whose
-      // output gradient is below ~1e-30 produces dZ values under 2^-126: those flush to bf16 subnormals / zero
-      // here, where the per-point scale would have kept them normal.  Such gradients are 22 decades under
-      // Adam's eps (1e-8) and change no update; tests/test_gpu_lp.py pins the behaviour (finite, -> 0).
+      const float bx = ap[it] * 10.f;
+      float da = bx > 20.f ? go[it][3] : go[it][3] / (1.f + expf(-bx));
+      if (!ok) da = 0.f;
+      const float m = fmaxf(fmaxf(fabsf(go[it][0]), fabsf(go[it][1])), fmaxf(fabsf(go[it][2]), fabsf(da)));
+      // per-point power-of-two scale: an fp16 matter like S.  (bf16 carries fp32's exponent range and a power of
+      // two commutes with every rounding of the chain: s = 1 gives the same bits, and the dZ rows then leave LDS as
+      // plain copies.  CAVEAT: "same bits" holds while every value of the chain stays in bf16's NORMAL range - a
+      // point whose output gradient is below ~1e-30 produces dZ values under 2^-126, which flush to bf16
+      // subnormals / zero where a per-point scale would have kept them normal.  Such gradients are 22 decades under
+      // Adam's eps (1e-8) and change no update; tests/test_gpu_lp.py pins the behaviour (finite, -> 0).)
       float s = 1.f;
-      if constexpr (!BF) {                                 // (bf16: d alpha_pre is one row per lane, below)
-        const float bx = ap[it] * 10.f;
-        float da = bx > 20.f ? go[it][3] : go[it][3] / (1.f + expf(-bx));
-        if (!ok) da = 0.f;
-        const float m = fmaxf(fmaxf(fabsf(go[it][0]), fabsf(go[it][1])), fmaxf(fabsf(go[it][2]), fabsf(da)));
-        if (m > 0.f && m < 3.0e38f) {
-          int e;
-          frexpf(m, &e);
-          s = ldexpf(1.f, min(-4 - e, 96));    // denormal gradients: keep the scale finite
-        }
-        if (chunk == 0) {
-          if (ok) dalpha[pt] = da;
-          dal[row] = da * s;
-          fac[row] = S / s;
-        }
+      if (m > 0.f && m < 3.0e38f) {
+        int e;
+        frexpf(m, &e);
+        s = ldexpf(1.f, min(-4 - e, 96));    // denormal gradients: keep the scale finite
       }
-      if constexpr (BF) {
-        // bf16 formats, two columns per instruction: d as three packed fp32 FMAs, rounded to a bf16 pair, the ReLU
-        // mask as the 0 / 1 halves of v_pk_min_u16(h, 1) (the saved views activations are post-ReLU: 0 or positive)
-        // multiplied in as 16-bit integers, and the 8-bit row straight from the bf16 pair under the loss scale -
-        // 4 VALU operations per value where the scalar form took 10
-        const u32x4 mkw = __builtin_bit_cast(u32x4, mk[it]);
-        const lp_f32x2 g0 = {go[it][0], go[it][0]}, g1 = {go[it][1], go[it][1]}, g2 = {go[it][2], go[it][2]};
-        u32x4 vw;
-#pragma unroll
-        for (int jp = 0; jp < 4; ++jp) {
-          const lp_f32x2 a0 = {w0[jp >> 1][2 * (jp & 1)], w0[jp >> 1][2 * (jp & 1) + 1]};
-          const lp_f32x2 a1 = {w1[jp >> 1][2 * (jp & 1)], w1[jp >> 1][2 * (jp & 1) + 1]};
-          const lp_f32x2 a2 = {w2[jp >> 1][2 * (jp & 1)], w2[jp >> 1][2 * (jp & 1) + 1]};
-          const lp_f32x2 d = __builtin_elementwise_fma(g2, a2, __builtin_elementwise_fma(g1, a1, g0 * a0));
-          const unsigned mkd = jp == 0 ? mkw[0] : (jp == 1 ? mkw[1] : (jp == 2 ? mkw[2] : mkw[3]));
-          unsigned w = __builtin_bit_cast(unsigned, __builtin_convertvector(d, lp_bf16x2));
-          asm("v_pk_mul_lo_u16 %0, %1, %2" : "=v"(w) : "v"(w), "v"(sign_pair(mkd)));
-          if (jp == 0) vw[0] = w; else if (jp == 1) vw[1] = w; else if (jp == 2) vw[2] = w; else vw[3] = w;
-        }
-        *reinterpret_cast<u32x4*>(g + x_idx(row, chunk)) = vw;
-        if (S8) {
-          typedef short s16x2 __attribute__((ext_vector_type(2)));
-          const V8 vb = __builtin_bit_cast(V8, vw);
-          const float invS = __builtin_amdgcn_rcpf(S);
-          s16x2 q0 = {0, 0}, q1 = {0, 0};
-          q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(vb, vb, 0, 1), invS, false);
-          q0 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q0, __builtin_shufflevector(vb, vb, 2, 3), invS, true);
-          q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(vb, vb, 4, 5), invS, false);
-          q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(vb, vb, 6, 7), invS, true);
-          const lp_u32x2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
-          if (ok) *reinterpret_cast<lp_u32x2*>(dz8 + acts_slot_off(P, SLOT_VIEWS_H) * 2 + (size_t)pt * W + chunk * 8) = o;
-        } else if (ok) {
-          *reinterpret_cast<u32x4*>(dzv + (size_t)pt * W + chunk * 8) = vw;       // (bf16: S = 1)
-        }
-      } else {
+      if (chunk == 0) {
+        if (ok) dalpha[pt] = da;
+        dal[row] = da * s;
+        fac[row] = S / s;
+      }
       V8 vs, vS;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -439,15 +389,6 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
       }
       *reinterpret_cast<V8*>(g + x_idx(row, chunk)) = vs;
       if (ok) *reinterpret_cast<V8*>(dzv + (size_t)pt * W + chunk * 8) = vS;
-      }
-    }
-    if (BF && tid < LM) {
-      const int pt = p0 + tid;
-      const float bx = apr * 10.f;
-      float da = bx > 20.f ? go3r : go3r / (1.f + expf(-bx));
-      if (pt < P) dalpha[pt] = da; else da = 0.f;
-      dal[tid] = da;
-      fac[tid] = S;
     }
     DH_STAMP(3)
   }
