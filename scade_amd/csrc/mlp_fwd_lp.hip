@@ -293,6 +293,31 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 #pragma unroll
     for (int j = 1; j < 4; ++j) e[row * 16 + 4 * j + c] = (T)0.f;
   }
+  // bf16: the alpha / colour heads run on the MFMA (below); their fp32 weights, split into bf16 high + low parts,
+  // go to a small table behind the view pad: [k-block][rows: high.., low.., one zero row][16 k]
+  T* tab_a = e + LM * 16;                // alpha:  16 k-blocks x 3 rows
+  T* tab_r = tab_a + 16 * 3 * 16;        // colour:  8 k-blocks x 7 rows
+  if constexpr (BF) {
+    auto split = [](float w, T& h, T& l) {
+      h = (T)w;
+      const float hf = (float)h;
+      l = (fabsf(hf) <= 3.0e38f) ? (T)(w - hf) : (T)0.f;    // (inf: no inf - inf)
+    };
+    {
+      T h, l;
+      split(TAIL(OFF_WA)[tid], h, l);
+      T* t = tab_a + (tid >> 4) * 48 + (tid & 15);
+      t[0] = h; t[16] = l; t[32] = (T)0.f;
+    }
+    for (int i = tid; i < 384; i += 256) {
+      const int c = i >> 7, k = i & 127;
+      T h, l;
+      split(TAIL(OFF_WR)[i], h, l);
+      T* t = tab_r + (k >> 4) * 112 + (k & 15);
+      t[c * 16] = h; t[(3 + c) * 16] = l;
+      if (c == 0) t[96] = (T)0.f;
+    }
+  }
   FL_STAMP(35)
 
   PTS_LAYER_L(6, 7, 0)
@@ -313,7 +338,43 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   // parameters need no help: the heads are fp32 arithmetic.
   float alpha[LM / 64];
   int badf[LM / 64];
-  {
+  // bf16: alpha_pre as 16 MFMAs per wave - wave w owns point tile w (row 32 w + (lane & 31)), B fragments are the
+  // gemm's own reads of the activation tile, A fragments come from the table (rows 0 / 1 = high / low parts, every
+  // other row the zero row): alpha = acc row 0 + acc row 1, in the lanes of the wave's lower half.  (The VALU form
+  // below - fp16 - is 64 dependent FMAs per row block and lane.)
+  float alpha_v = 0.f;
+  int bad_v = 0;
+  const bool mine = wave < NPT;          // (64-point workgroups: waves 2, 3 have no point tile)
+  if constexpr (BF) {
+    const int r = lane & 31, hh = lane >> 5;
+    const int row = (mine ? wave : 0) * 32 + r;
+    const size_t ptc = (size_t)min(p0 + row, P - 1);
+    float q0, q1, q2, v0, v1, v2;
+    if (MODE == 1) {
+      const float* q = a.in + ptc * 3;
+      const float* vd = a.viewdirs + (ptc / a.S) * a.vd_stride;
+      q0 = q[0]; q1 = q[1]; q2 = q[2]; v0 = vd[0]; v1 = vd[1]; v2 = vd[2];
+    } else {
+      const float* q = a.in + ptc * 60;
+      q0 = q[0]; q1 = q[1]; q2 = q[2]; v0 = q[57]; v1 = q[58]; v2 = q[59];
+    }
+    if (mine) {
+      const T* ta = tab_a + (r < 2 ? r : 2) * 16 + 8 * hh;
+      f32x16 ha = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 16; ++kb) {
+        const V8 bfr = *reinterpret_cast<const V8*>(x + x_idx(row, 2 * kb + hh));
+        const V8 afr = *reinterpret_cast<const V8*>(ta + kb * 48);
+        ha = LP<BF>::mfma(afr, bfr, ha);
+      }
+      alpha_v = (ha[0] + ha[1]) + TAIL(OFF_BA)[0];
+    }
+    const bool badp = lp_nonfinite(q0) | lp_nonfinite(q1) | lp_nonfinite(q2) | nan_trunk;
+    bad_v = badp | lp_nonfinite(v0) | lp_nonfinite(v1) | lp_nonfinite(v2) | nan_colour;
+    if (badp) alpha_v = __builtin_nanf("");
+    if (SAVE && mine && hh == 0 && p0 + row < P)
+      reinterpret_cast<float*>(a.acts + lp_acts_alpha_byte(P))[p0 + row] = alpha_v;
+  } else {
     const float* wa = TAIL(OFF_WA);
     // this lane's 64 alpha weights (its four-column-chunk stride is the same for every row block): loaded once
     f32x4 waq[16];
@@ -392,7 +453,35 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 #undef WLBASE
 
   // ---- rgb head + softplus ---------------------------------------------------------------
-  {
+  if constexpr (BF) {
+    // 8 MFMAs per wave on the views tile: table rows 0..2 = high parts of the three colour rows, 3..5 = low parts
+    // (as A rows 0..2 and 8..10: both land in the lower half-wave's registers 0..2 and 4..6), row 6 = zeros
+    const int r = lane & 31, hh = lane >> 5;
+    const int row = (mine ? wave : 0) * 32 + r;
+    if (mine) {
+      const int tr = r < 3 ? r : ((r >= 8 && r < 11) ? r - 5 : 6);
+      const T* tb = tab_r + tr * 16 + 8 * hh;
+      f32x16 hr = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kb = 0; kb < 8; ++kb) {
+        const V8 bfr = *reinterpret_cast<const V8*>(x + x_idx(row, 2 * kb + hh));
+        const V8 afr = *reinterpret_cast<const V8*>(tb + kb * 112);
+        hr = LP<BF>::mfma(afr, bfr, hr);
+      }
+      if (hh == 0 && p0 + row < P) {
+        const float* br = TAIL(OFF_BR);
+        const float al = alpha_v;
+        const float bx = al * 10.f;
+        const float sp = bx > 20.f ? al : log1pf(expf(bx)) / 10.f;
+        f32x4 o = {(hr[0] + hr[4]) + br[0], (hr[1] + hr[5]) + br[1], (hr[2] + hr[6]) + br[2], sp};
+        if (bad_v) {          // poisoned inputs (see the alpha head): colour NaN; density already is
+          const float qn = __builtin_nanf("");
+          o[0] = o[1] = o[2] = qn;
+        }
+        *reinterpret_cast<f32x4*>(a.out + (size_t)(p0 + row) * 4) = o;
+      }
+    }
+  } else {
     const float* wr = TAIL(OFF_WR);
     const float* br = TAIL(OFF_BR);
     // this lane's 3 x 32 colour weights: loaded once for all its row blocks (the accumulators' registers are free)
