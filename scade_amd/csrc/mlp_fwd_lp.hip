@@ -132,13 +132,8 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   const T* __restrict__ wpk = reinterpret_cast<const T*>(a.packed);
   const float* __restrict__ tail = reinterpret_cast<const float*>(wpk + PACKED_LP_ELEMS);
 #define TAIL(off) (tail + (int)CE<(off) - OFF_BIAS>::v)
-  // NaN census of the hidden layers' parameters (pack kernel; used by the heads): two wave-uniform flags
-  bool nan_trunk, nan_colour;
-  {
-    const float ft = TAIL(LP_NAN_TRUNK)[lane], fc = TAIL(LP_NAN_COLOUR)[lane];
-    nan_trunk = __builtin_amdgcn_readfirstlane(__any(ft != ft)) != 0;
-    nan_colour = __builtin_amdgcn_readfirstlane(__any(fc != fc)) != 0;
-  }
+  // (the NaN census of the hidden layers' parameters - pack kernel; used by the heads - is read in front of the
+  // alpha head: read here, its wait sat in front of the prologue)
 
   // ---- prologue: embedding tile [128][64] (57 real channels, zero padded) ------------
   {
@@ -169,20 +164,32 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       // fract are exact in fp32, so the hardware v_sin_f32 / v_cos_f32 (argument in revolutions,
       // ~1e-6 absolute) sees an exact argument.  The reference rounds x*pi_f32 first (up to 5e-5 rad
       // off at the top octave); both are far inside the 16-bit rounding of this path.
-      for (int i = tid; i < LM * 3; i += 256) {
-        const int row = i / 3, c = i - row * 3;
-        const int pt = min(p0 + row, P - 1);
-        const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
-        const float xv = (a.in[(size_t)pt * 3 + c] - ctr) * sc;
-        e[e_idx(row, 0) + c] = (T)xv;
-        float t = 0.5f * xv;
+      // (both items of a thread are fetched before the first sine: the loop form waited for each load in turn)
+      constexpr int NIT = (LM * 3 + 255) / 256;
+      float xin[NIT];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) {
-          const float fr = __builtin_amdgcn_fractf(t);
-          const int col0 = 3 + 6 * k + c, col1 = col0 + 3;
-          e[e_idx(row, col0 >> 3) + (col0 & 7)] = (T)__builtin_amdgcn_sinf(fr);
-          e[e_idx(row, col1 >> 3) + (col1 & 7)] = (T)__builtin_amdgcn_cosf(fr);
-          t += t;
+      for (int k = 0; k < NIT; ++k) {
+        const int i = min(tid + 256 * k, LM * 3 - 1);
+        const int row = i / 3, c = i - row * 3;
+        xin[k] = a.in[(size_t)min(p0 + row, P - 1) * 3 + c];
+      }
+#pragma unroll
+      for (int k = 0; k < NIT; ++k) {
+        const int i = tid + 256 * k;
+        if (i < LM * 3) {
+          const int row = i / 3, c = i - row * 3;
+          const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
+          const float xv = (xin[k] - ctr) * sc;
+          e[e_idx(row, 0) + c] = (T)xv;
+          float t = 0.5f * xv;
+#pragma unroll
+          for (int o = 0; o < 9; ++o) {
+            const float fr = __builtin_amdgcn_fractf(t);
+            const int col0 = 3 + 6 * o + c, col1 = col0 + 3;
+            e[e_idx(row, col0 >> 3) + (col0 & 7)] = (T)__builtin_amdgcn_sinf(fr);
+            e[e_idx(row, col1 >> 3) + (col1 & 7)] = (T)__builtin_amdgcn_cosf(fr);
+            t += t;
+          }
         }
       }
     }
@@ -334,8 +341,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   // NaN is a negative int16 to the packed ReLU), so the pack kernel takes a census of the fp32 parameters and
   // leaves it in the tail as 0 / NaN floats (LP_NAN_TRUNK: pts_linears - the reference then returns NaN in
   // all four outputs of every point; LP_NAN_COLOUR: feature_linear / views_linears - NaN colour, finite
-  // density); nan_trunk / nan_colour were read at the top of the kernel, where registers are free.  NaN head
+  // density); nan_trunk / nan_colour are read right below.  NaN head
   // parameters need no help: the heads are fp32 arithmetic.
+  bool nan_trunk, nan_colour;            // NaN census of the hidden layers' parameters: two wave-uniform flags
+  {
+    const float ft = TAIL(LP_NAN_TRUNK)[lane], fc = TAIL(LP_NAN_COLOUR)[lane];
+    nan_trunk = __builtin_amdgcn_readfirstlane(__any(ft != ft)) != 0;
+    nan_colour = __builtin_amdgcn_readfirstlane(__any(fc != fc)) != 0;
+  }
   float alpha[LM / 64];
   int badf[LM / 64];
   // bf16: alpha_pre as 16 MFMAs per wave - wave w owns point tile w (row 32 w + (lane & 31)), B fragments are the
