@@ -135,24 +135,35 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
   } else {
     const float cx = a.bb[0], cy = a.bb[1], cz = a.bb[2], sc = a.bb[3];
-    // item = (point, coord c, slot s): s == 0 -> raw x, s = 1..9 -> freq 2^(s-1)
-    for (int i = tid; i < TM * 30; i += 256) {
-      const int row = i / 30, rem = i - row * 30;
-      const int c = rem / 10, s = rem - c * 10;
+    // one thread per (point, coordinate): ONE load, the raw slot and all nine octaves (round 4: the item loop over
+    // (point, coordinate, slot) re-read x ten times through a chain of eight dependent memory latencies and called
+    // the library's sincosf - ~3x the VALU work of sincos_cw, and VALU instructions are matrix time in this kernel)
+    if (tid < TM * 3) {
+      const int row = tid / 3, c = tid - row * 3;
       const int pt = min(p0 + row, P - 1);
       const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
       const float x = (a.in[(size_t)pt * 3 + c] - ctr) * sc;   // run_scade_scannet.py:52
       float* e = ebuf + row * EMB_STRIDE;
-      if (s == 0) {
-        e[c] = canon_nonfinite(x);
-        e[57 + c] = 0.f;
-      } else {
-        // helpers:165  p_fn(x * np.pi * freq): fl32(x*pi_f32) * 2^k (exact)
-        const float arg = (x * 3.14159274101257324f) * (float)(1 << (s - 1));
-        float sn, cs;
-        sincosf(arg, &sn, &cs);
-        e[3 + 6 * (s - 1) + c] = canon_nan(sn);
-        e[6 + 6 * (s - 1) + c] = canon_nan(cs);
+      e[c] = canon_nonfinite(x);
+      e[57 + c] = 0.f;
+      // helpers:165  p_fn(x * np.pi * freq): fl32(x*pi_f32) * 2^k (exact)
+      const float t = x * 3.14159274101257324f;
+      if (sincos_cw_ok(t * 256.f)) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+          float sn, cs;
+          sincos_cw(t * (float)(1 << k), sn, cs);
+          e[3 + 6 * k + c] = sn;
+          e[6 + 6 * k + c] = cs;
+        }
+      } else {                             // far outside the scene box, or poisoned: the library (one copy of it)
+#pragma unroll 1
+        for (int k = 0; k < 9; ++k) {
+          float sn, cs;
+          sincosf(t * (float)(1 << k), &sn, &cs);
+          e[3 + 6 * k + c] = canon_nan(sn);
+          e[6 + 6 * k + c] = canon_nan(cs);
+        }
       }
     }
   }

@@ -117,6 +117,40 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
       const int o = e_idx(row, c >> 3) + (c & 7);
       eh[o] = (_Float16)0.f; el[o] = (_Float16)0.f;
     }
+    if (MODE == 1) {
+      // one thread per (point, coordinate): one load, the raw slot and all nine octaves (as mlp_fwd.hip, round 4)
+      if (tid < HM * 3) {
+        const int row = tid / 3, c = tid - row * 3;
+        const int pt = min(p0 + row, P - 1);
+        const float ctr = c == 0 ? cx : (c == 1 ? cy : cz);
+        const float x = (a.in[(size_t)pt * 3 + c] - ctr) * sc;
+        auto put = [&](int col, float v) {
+          _Float16 h, l;
+          split2(v, h, l);
+          const int o = e_idx(row, col >> 3) + (col & 7);
+          eh[o] = h; el[o] = l;
+        };
+        put(c, x);
+        const float t = x * 3.14159274101257324f;
+        if (sincos_cw_ok(t * 256.f)) {
+#pragma unroll
+          for (int k = 0; k < 9; ++k) {
+            float sn, cs;
+            sincos_cw(t * (float)(1 << k), sn, cs);
+            put(3 + 6 * k + c, sn);
+            put(6 + 6 * k + c, cs);
+          }
+        } else {
+#pragma unroll 1
+          for (int k = 0; k < 9; ++k) {
+            float sn, cs;
+            sincosf(t * (float)(1 << k), &sn, &cs);
+            put(3 + 6 * k + c, sn);
+            put(6 + 6 * k + c, cs);
+          }
+        }
+      }
+    } else
     for (int i = tid; i < HM * 30; i += 256) {
       const int row = i / 30, rem = i - row * 30;
       const int c = rem / 10, s = rem - c * 10;
