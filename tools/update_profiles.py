@@ -88,9 +88,9 @@ notes = {
     "mlp_fwd_lp_kernel_f16": "same kernel, fp16 operands",
     "mlp_fwd_lp_kernel_bf16_train": "bf16 training forward: 16-bit activation rows; round 3: conflict-free lane map of the tile copies",
     "mlp_dgrad_lp_kernel_bf16": "16-bit dZ rows, both networks in one launch; round 3: epilogue halves traded with v_permlane32_swap + ds_write_b128 (was 30.1 % conflict cycles)",
-    "mlp_fwd_lp_kernel_bf16_s8_train": "round 3, format code 2: the bf16 training forward saving 8-bit e5m2 rows",
-    "mlp_dgrad_lp_kernel_bf16_s8": "format code 2: 8-bit e5m2 dZ rows under the launch-wide loss scale",
-    "mlp_wgrad_lp_kernel_bf16_s8": "format code 2: e5m2 rows widened to fp16 (one v_perm_b32 per two values) while staging into LDS; balanced persistent launch",
+    "mlp_fwd_lp_kernel_bf16_s8_train": "format code 2: the bf16 training forward saving 8-bit e5m2 rows (round 4: as whole-row riders of the next k-loop), fp8 embedding rows, sign words for the views layer too, heads on the MFMA",
+    "mlp_dgrad_lp_kernel_bf16_s8": "format code 2: 8-bit e5m2 dZ rows under the launch-wide loss scale (round 4: riders; heads as one MFMA per point tile, masked by sign words - the 16-bit views rows are no longer read: -200 MB)",
+    "mlp_wgrad_lp_kernel_bf16_s8": "format code 2 (round 4): e5m2 rows by LDS-DMA into a ring, ds_read_b64_tr_b8 fragments, MX-scaled bf8 MFMA at twice the 16-bit rate; balanced persistent launch; 1.53 GB at the memory system's rate",
     "wgrad2_reduce_pair_kernel": "sums the per-chunk partials of both networks",
     "wgrad_lp_reduce_pair_kernel": "sums the per-chunk partials of both networks (16-bit path)",
     "wgrad_lp_reduce_kernel": "round 3: sums, per parameter, the partial rows of the job that owns it (balanced launch: one row per segment)",
