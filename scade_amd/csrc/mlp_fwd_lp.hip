@@ -89,16 +89,6 @@ __device__ __forceinline__ void layer_store_lp(const f32x16 (&acc)[NT][NPT], int
 
 __device__ __forceinline__ bool lp_nonfinite(float v) { return !(fabsf(v) <= 3.4028234664e38f); }   // NaN or +-inf
 
-#ifdef FWD_KO_SAVE      // (knock-out experiments, variant builds only)
-constexpr bool KO_SAVE = true;
-#else
-constexpr bool KO_SAVE = false;
-#endif
-#ifdef FWD_KO_SIGN
-constexpr bool KO_SIGN = true;
-#else
-constexpr bool KO_SIGN = false;
-#endif
 // -DFL_TRACE (variant build; tools/probe_dgrad_trace.py --fwd): core-clock stamps of sixteen consecutive workgroups of a
 // 1536-tile launch's third round at the phase boundaries of the format-code-2 training forward
 #ifdef FL_TRACE
@@ -262,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
     LP_SYNC();                                                                            \
     FL_STAMP(4 + 4 * (L))                                                                 \
     layer_store_lp<BF, 2, true, SAVE != 0, 2, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(LNEXT)), nt0); \
-    if (SAVE && !KO_SIGN) {                                                                     \
+    if (SAVE) {                                                                                \
       u32x4 mw_ = {bits[0], bits[1], bits[2], bits[3]};                                         \
       reinterpret_cast<u32x4*>(a.acts + lp_acts_mask_byte(P))[                                  \
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
