@@ -170,11 +170,6 @@ __device__ __forceinline__ void dgrad_store_lp(const f32x16 (&acc)[2][NPT], int 
     }
 }
 
-#ifdef DGRAD_KO_SAVE    // (knock-out experiment, variant builds only)
-constexpr bool DG_KO = true;
-#else
-constexpr bool DG_KO = false;
-#endif
 constexpr int dgrad_lp_lds_bytes(int NPT) { return 32 * NPT * W * 2 + 2 * 32 * NPT * 4; }
 
 // -DDG_TRACE (variant build; tools/probe_dgrad_trace.py): core-clock stamps of sixteen consecutive workgroups of the

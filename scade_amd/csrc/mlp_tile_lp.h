@@ -273,9 +273,6 @@ __device__ __forceinline__ void save_tile_lp_wave8(const typename LP<BF>::T* x, 
       q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 4, 5), inv, false);
       q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v[j], v[j], 6, 7), inv, true);
       const lp_u32x2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
-#ifdef SAVE8_KO_STORE   // (knock-out experiment: the conversions stay live through a never-true store)
-      if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u)
-#endif
       __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff + (it & 1) * 4 * 256, soff + (it >> 1) * 16 * 256, 2);    // nt
     }
     __builtin_amdgcn_sched_barrier(0);                // keep the batches apart
@@ -346,13 +343,9 @@ struct SaveRider8 {
     q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v, v, 4, 5), inv, false);
     q1 = __builtin_amdgcn_cvt_scalef32_pk_bf8_bf16(q1, __builtin_shufflevector(v, v, 6, 7), inv, true);
     const lp_u32x2 o = {__builtin_bit_cast(unsigned, q0), __builtin_bit_cast(unsigned, q1)};
-#ifndef RID_AUX
-#define RID_AUX 2     // nt
-#endif
-#ifdef RID_KO_STORE
-    if (o[0] == 0x12345678u && o[1] == 0x9abcdef0u)
-#endif
-    __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff_p, RID_AUX);
+    // nt: with a cached store the dgrad chain measured +10 % and the weight gradient, whose ring then finds the
+    // rows' lines dirty in L2, +27 %
+    __builtin_amdgcn_raw_buffer_store_b64(o, rs, voff, soff_p, 2);
   }
 };
 
