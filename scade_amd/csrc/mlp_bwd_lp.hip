@@ -433,13 +433,17 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   DT_STAMP(0, 2)
   dgrad_store_lp<BF, false, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);
   DT_STAMP(0, 3)
-  if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  constexpr bool RID16 = BF && !S8;      // plain bf16: the 16-bit copies ride too (SaveRider16; S = 1, no factor)
+  if (!S8 && !RID16) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, SLOT_FEAT), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   LP_SYNC();
 
   // format code 2: the 8-bit copy of the tile just written leaves as a rider of the NEXT gemm's k-loop
   // (SaveRider8, mlp_tile_lp.h); only the last tile of the chain is saved as a burst
-  typename std::conditional<S8 && BF, SaveRider8<NPT>, NoRider>::type rid;
-#define RID_INIT(SLOT) if constexpr (S8 && BF) rid.init(g, dz8 + acts_slot_off(P, SLOT) * 2, p0, P, fac, wave);
+  typename std::conditional<S8 && BF, SaveRider8<NPT>,
+                            typename std::conditional<RID16, SaveRider16<NPT>, NoRider>::type>::type rid;
+#define RID_INIT(SLOT)                                                                        \
+  if constexpr (S8 && BF) rid.init(g, dz8 + acts_slot_off(P, SLOT) * 2, p0, P, fac, wave);    \
+  if constexpr (RID16) rid.init(g, dzT + acts_slot_off(P, SLOT), p0, P, wave);
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   load_mask(7);
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   DT_STAMP(1, 2)
   dgrad_store_lp<BF, true, true, NPT>(acc, kt0, g, mb, tl + TL_WA, dal, lane);
   DT_STAMP(1, 3)
-  if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
+  if (!S8 && !RID16) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, 7), p0, P, BF ? nullptr : fac, 64 * wave, lane);
   LP_SYNC();
 
 #define DGRAD_LAYER_L(L)                                                                            \
@@ -466,7 +470,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
   dgrad_store_lp<BF, true, false, NPT>(acc, kt0, g, mb, nullptr, dal, lane);                             \
   DT_STAMP(9 - (L), 3)                                                                              \
   if (S8 && (L) == 1) save_tile_lp_wave8<BF, 64, NPT>(g, dz8 + acts_slot_off(P, 0) * 2, p0, P, fac, 64 * wave, lane);      \
-  else if (!S8) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
+  else if (!S8 && (!RID16 || (L) == 1)) save_tile_lp_wave<BF, 64, NPT>(g, dzT + acts_slot_off(P, (L)-1), p0, P, BF ? nullptr : fac, 64 * wave, lane);    \
   LP_SYNC();
 
   DGRAD_LAYER_L(7)

@@ -237,11 +237,15 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
 
   // rotation of the A register sets on entry of layer L = (k-blocks of all earlier layers) % 3
 #define FROT(L) ((int)CE<fwd_rot(L, NS)>::v)
-  typename std::conditional<SAVE == 2 && BF, SaveRider8<NPT>, NoRider>::type rid;
+  // (the 16-bit rows of plain bf16 training ride the same way: SaveRider16)
+  typename std::conditional<SAVE == 2 && BF, SaveRider8<NPT>,
+                            typename std::conditional<SAVE == 1 && BF, SaveRider16<NPT>, NoRider>::type>::type rid;
+  constexpr bool RID16 = SAVE == 1 && BF;
 #define PTS_LAYER_L(L, LNEXT, KBP)                                                              \
   {                                                                                             \
-    if constexpr (SAVE == 2 && (L) > 0) {   /* the 8-bit copy of layer L-1's tile rides in this k-loop (SaveRider8) */ \
-      rid.init(x, a.acts + acts_slot_off(P, (L) > 0 ? (L)-1 : 0) * 2, p0, P, nullptr, wave);   \
+    if constexpr ((SAVE == 2 || RID16) && (L) > 0) {   /* the copy of layer L-1's tile rides in this k-loop */ \
+      if constexpr (RID16) rid.init(x, actsT + acts_slot_off(P, (L) > 0 ? (L)-1 : 0), p0, P, wave);   \
+      else rid.init(x, a.acts + acts_slot_off(P, (L) > 0 ? (L)-1 : 0) * 2, p0, P, nullptr, wave);   \
       layer_gemm_lp<BF, 2, KBP, kbh16(L), false, FROT(L), NS, NPT>(acc, A, WLBASE(L), WLBASE(LNEXT), \
                                                           (int)CE<kb16(LNEXT)>::v, e, x, lane, cb, rid); \
     } else {                                                                                    \
@@ -258,7 +262,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
           ((size_t)(L)*gridDim.x + blockIdx.x) * 256 + tid] = mw_;                              \
     }                                                                                           \
     FL_STAMP(5 + 4 * (L))                                                                       \
-    if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
+    if (SAVE == 1 && !RID16) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, L), p0, P, nullptr, 64 * wave, lane); \
     LP_SYNC();                                                                            \
     FL_STAMP(6 + 4 * (L))                                                                 \
   }
@@ -422,13 +426,14 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   // ---- feature_linear ------------------------------------------------------------------
   FL_STAMP(36)
   if constexpr (SAVE == 2) rid.init(x, a.acts + acts_slot_off(P, 7) * 2, p0, P, nullptr, wave);
+  if constexpr (RID16) rid.init(x, actsT + acts_slot_off(P, 7), p0, P, wave);
   layer_gemm_lp<BF, 2, 0, 16, false, FROT(L_FEAT), NS, NPT>(acc, A, WLBASE(L_FEAT), WLBASE(L_VIEWS), 0, e, x, lane, cb, rid);
   FL_STAMP(37)
   LP_SYNC();
   FL_STAMP(38)
   layer_store_lp<BF, 2, false, false, 1, NPT>(acc, nt0, x, lane, bits, cb, TAIL(off_b(L_VIEWS)), wave);
   FL_STAMP(39)
-  if (SAVE == 1) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, 64 * wave, lane);
+  if (SAVE == 1 && !RID16) save_tile_lp_wave<BF, 64, NPT>(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, nullptr, 64 * wave, lane);
   LP_SYNC();
   FL_STAMP(40)
 
@@ -436,6 +441,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
   {
     f32x16 av[1][LPT];
     if constexpr (SAVE == 2) rid.init(x, a.acts + acts_slot_off(P, SLOT_FEAT) * 2, p0, P, nullptr, wave);
+    if constexpr (RID16) rid.init(x, actsT + acts_slot_off(P, SLOT_FEAT), p0, P, wave);
     layer_gemm_lp<BF, 1, 1, 16, true, FROT(L_VIEWS), NS, NPT>(av, A, WLBASE(L_VIEWS), WLBASE(L_VIEWS), 0, e, x, lane, cb, rid);
     FL_STAMP(41)
     LP_SYNC();

@@ -349,6 +349,43 @@ struct SaveRider8 {
   }
 };
 
+// the same rider for 16-bit saved rows (plain bf16 training: a copy, 512-byte rows): a store instruction writes two
+// complete rows = 1 KiB
+template <int NPT = LPT>
+struct SaveRider16 {
+  static constexpr bool ON = true;
+  static constexpr int NCH = 4 * NPT;                 // chunks per lane: the wave's 8 NPT rows, two per instruction
+  typedef unsigned u4 __attribute__((ext_vector_type(4)));
+  const unsigned char* xb;
+  int row0;
+  __amdgpu_buffer_rsrc_t rs;
+  int voff, soff0, soff_p, c, rlo;
+  u4 v;
+  __device__ __forceinline__ void init(const __bf16* x, __bf16* __restrict__ dst, int p0, int P, int wave) {
+    row0 = 8 * NPT * wave;
+    xb = reinterpret_cast<const unsigned char*>(x) + row0 * W * 2;
+    const unsigned long long pd = reinterpret_cast<unsigned long long>(dst);
+    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+    rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
+                                           __builtin_amdgcn_readfirstlane((unsigned)P * 512u), 0x00020000);
+    soff0 = __builtin_amdgcn_readfirstlane((p0 + row0) * 512);
+  }
+  __device__ __forceinline__ void begin(int lane) {
+    asm volatile("" : "+v"(lane));
+    c = lane & 31;
+    rlo = lane >> 5;
+    voff = lane * 16;
+  }
+  __device__ __forceinline__ void read(int it) {
+    if (it < NCH) {
+      const int r = 2 * it + rlo;
+      v = *reinterpret_cast<const u4*>(xb + r * (W * 2) + ((c ^ (r & 15)) << 4));
+      soff_p = soff0 + it * 2 * 512;
+    }
+  }
+  __device__ __forceinline__ void emit() { __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff_p, 2); }
+};
+
 // ReLU sign bits of one layer: 4 x 32-bit words per lane.  The 64 packed dwords a lane produces
 // per layer are numbered d = ((t*4 + q)*4 + p)*2 + j (n-tile t, row group q, point tile p, value
 // pair j); word d >> 4 holds, at bit (d & 15), the sign of the dword's LOW half and at bit
