@@ -1532,59 +1532,49 @@ struct ReduceLpArgs {
   unsigned char nseg[2][MAX_WGRAD_JOBS];
   int uniform[2];      // > 0: every job of the network has this many rows (the small-launch grid): no lookup
 };
-// Sum of n partial rows of one f32x4 column, in the order of the round-3 kernel (row c < 4 floor(n / 4) goes to
-// accumulator c mod 4, the remainder rows to accumulator 0, result (s0 + s1) + (s2 + s3): the same bits) - but with
-// SIXTEEN rows in flight per round trip instead of four: the kernel is a chain of dependent HBM latencies (18-19
-// rows per fine job = 6 trips before, 2 now), not a bandwidth problem (57 MB at 2.5 TB/s).  One call site: 86
-// registers = five waves per SIMD, the whole grid (4.5 per SIMD) resident in one round.
-__device__ __forceinline__ f32x4 lp_reduce_rows(const f32x4* __restrict__ p, int n) {
-  constexpr size_t ST = N_PARAM_FLOATS / 4;
-  constexpr int U = 16;
-  const int m4 = n & ~3;
-  f32x4 s[4];
-#pragma unroll
-  for (int k = 0; k < 4; ++k) s[k] = f32x4{0.f, 0.f, 0.f, 0.f};
-  for (int c0 = 0; c0 < n; c0 += U) {
-    f32x4 v[U];
-#pragma unroll
-    for (int q = 0; q < U; ++q)
-      if (c0 + q < n) v[q] = p[(size_t)(c0 + q) * ST];
-#pragma unroll
-    for (int q = 0; q < U; ++q) {
-      const int c = c0 + q;
-      if (c < m4) s[q & 3] += v[q];
-      else if (c < n) s[0] += v[q];
-    }
-  }
-  return (s[0] + s[1]) + (s[2] + s[3]);
-}
-
-__global__ static __launch_bounds__(256) void wgrad_lp_reduce_kernel(ReduceLpArgs r) {
+__global__ static void wgrad_lp_reduce_kernel(ReduceLpArgs r) {
   const bool second = blockIdx.x >= WGRAD_REDUCE_BLOCKS;
   const int i = (blockIdx.x - (second ? WGRAD_REDUCE_BLOCKS : 0)) * 256 + threadIdx.x;
   if (i >= N_PARAM_FLOATS / 4) return;
   const float* part = second ? r.partial[1] : r.partial[0];
   const unsigned char* nseg = second ? r.nseg[1] : r.nseg[0];
   const int uni = second ? r.uniform[1] : r.uniform[0];
-  int n = uni;
-  bool whole = true;                               // one job owns all four elements
-  int job[4] = {0, 0, 0, 0};
-  if (uni <= 0) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) job[q] = lp_param_job(4 * i + q);
-    whole = job[0] == job[3];                      // (jobs own contiguous runs within a tensor row: ends equal = all equal)
-    n = nseg[job[0]];
+  if (uni > 0) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+    constexpr size_t ST = N_PARAM_FLOATS / 4;
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int c = 0;
+    for (; c + 4 <= uni; c += 4) {
+      s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+      s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+    }
+    for (; c < uni; ++c) s0 += p[(size_t)c * ST];
+    reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = (s0 + s1) + (s2 + s3);
+    return;
   }
+  int job[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) job[q] = lp_param_job(4 * i + q);
   f32x4 res;
-  if (whole) {
-    res = lp_reduce_rows(reinterpret_cast<const f32x4*>(part) + i, n);
+  if (job[0] == job[3]) {                          // (jobs own contiguous runs within a tensor row: ends equal = all equal)
+    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
+    constexpr size_t ST = N_PARAM_FLOATS / 4;
+    const int n = nseg[job[0]];
+    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+    int c = 0;
+    for (; c + 4 <= n; c += 4) {
+      s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+      s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+    }
+    for (; c < n; ++c) s0 += p[(size_t)c * ST];
+    res = (s0 + s1) + (s2 + s3);
   } else {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const float* p = part + 4 * i + q;
-      const int nq = nseg[job[q]];
+      const int n = nseg[job[q]];
       float t = 0.f;
-      for (int c = 0; c < nq; ++c) t += p[(size_t)c * N_PARAM_FLOATS];
+      for (int c = 0; c < n; ++c) t += p[(size_t)c * N_PARAM_FLOATS];
       res[q] = t;
     }
   }

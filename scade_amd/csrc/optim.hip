@@ -73,31 +73,14 @@ __global__ void adam_step2_kernel(Adam2Args a) {
   float lr = s.lr, beta1 = s.beta1, beta2 = s.beta2, eps = s.eps, bc1 = s.bc1, bc2_sqrt = s.bc2_sqrt, gs = s.grad_scale;
   if (s.st) { beta1 = s.st[4]; beta2 = s.st[5]; eps = s.st[6]; gs = s.st[7]; lr = s.st[8]; bc1 = s.st[9]; bc2_sqrt = s.st[10]; }
   const float step_size = lr / bc1;
-  auto update = [&](float g, float& m, float& v, float& p) {
-    const float gi = g * gs;
-    m = m * beta1 + gi * (1.0f - beta1);
-    v = v * beta2 + (gi * gi) * (1.0f - beta2);
-    const float denom = sqrtf(v) / bc2_sqrt + eps;
-    p = p - step_size * (m / denom);
-  };
-  // 16-byte accesses where the four arrays allow it (the networks' segment of the bucket: 1.18 M floats), the same
-  // arithmetic per element; the remainder (and the two-float scale / shift segment) element by element
-  const bool vec = ((reinterpret_cast<unsigned long long>(s.p) | reinterpret_cast<unsigned long long>(s.g) |
-                     reinterpret_cast<unsigned long long>(s.m) | reinterpret_cast<unsigned long long>(s.v)) & 15ull) == 0;
-  const long n4 = vec ? s.n / 4 : 0;
-  for (long i = b * 256 + threadIdx.x; i < n4; i += nb * 256) {
-    const f32x4 g = reinterpret_cast<const f32x4*>(s.g)[i];
-    f32x4 m = reinterpret_cast<f32x4*>(s.m)[i], v = reinterpret_cast<f32x4*>(s.v)[i], p = reinterpret_cast<f32x4*>(s.p)[i];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) update(g[j], m[j], v[j], p[j]);
-    reinterpret_cast<f32x4*>(s.m)[i] = m;
-    reinterpret_cast<f32x4*>(s.v)[i] = v;
-    reinterpret_cast<f32x4*>(s.p)[i] = p;
-  }
-  for (long i = 4 * n4 + b * 256 + threadIdx.x; i < s.n; i += nb * 256) {
-    float m = s.m[i], v = s.v[i], p = s.p[i];
-    update(s.g[i], m, v, p);
-    s.m[i] = m; s.v[i] = v; s.p[i] = p;
+  for (long i = b * 256 + threadIdx.x; i < s.n; i += nb * 256) {
+    const float gi = s.g[i] * gs;
+    const float mi = s.m[i] * beta1 + gi * (1.0f - beta1);
+    const float vi = s.v[i] * beta2 + (gi * gi) * (1.0f - beta2);
+    s.m[i] = mi;
+    s.v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    s.p[i] = s.p[i] - step_size * (mi / denom);
   }
 }
 __device__ __forceinline__ void adam_tick(float* st) {
@@ -178,8 +161,7 @@ extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, cons
   return scade_check_launch("scade_stage_inputs");
 }
 
-// (one 16-byte group per thread up to 2048 workgroups: adam_step2_kernel)
-static int adam_blocks(long n) { const long g = (n + 3) / 4; return (int)((g + 255) / 256 < 2048 ? (g + 255) / 256 : 2048); }
+static int adam_blocks(long n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }
 
 // Both optimizers of a train step in ONE launch.  Arrays of two entries; n[1] = 0 skips the second segment
 // (scale / shift frozen, run_scade_scannet.py:996).  state[i] != NULL: that segment's scalars live on the device
