@@ -249,8 +249,9 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
     # (with a process group the first steps also pay RCCL's one-time work - channel setup, the first
     # launch of its kernels beside ours - which has been seen to leak past five warm-up steps)
     # secondary region: steady state, not the contract's W / K (those govern the headline only) - at least
-    # 10 warm-up and 40 timed steps, so that allocator start-up and the clock ramp are not in the figure
-    nwarm, nsteps = max(10, args.warmup) + (10 if dist.is_initialized() else 0), max(40, args.steps)
+    # 30 warm-up and 100 timed steps (0.1 s of a 16-bit step), so that allocator start-up and the clock ramp are not
+    # in the figure and one host hiccup is 1 % of it, not 2.5 %
+    nwarm, nsteps = max(30, args.warmup) + (10 if dist.is_initialized() else 0), max(100, args.steps)
     for _ in range(nwarm):
         one()
     # the figure is the whole timed span between two barriers (as before); device events at the boundaries of five
