@@ -833,6 +833,31 @@ def test_one_launch_pack_of_both_networks_writes_the_same_blobs(dev, fmt):
     assert torch.equal((fine._packed if fmt == "f32" else fine._packed_lp).view(torch.uint8), ref.view(torch.uint8))
 
 
+def test_pack_step_checks_parameters_again_when_their_storage_changes(dev):
+    """ops.mlp_pack_step validates the 24 parameter tensors once per SET OF POINTERS (round 4: the checks were 60 us
+    of every eager step); a parameter whose storage is replaced - here by one of another dtype, then by a
+    non-contiguous view - has a new pointer and must be looked at again, not packed blindly."""
+    from scade_amd import ops
+    from scade_amd.train import make_scade_nets
+    coarse, fine = make_scade_nets(dev, seed=5)
+    ops.mlp_pack_step([coarse, fine], "f32")
+    ops.mlp_pack_step([coarse, fine], "f32")            # cached pointers, nothing stale
+    good = fine.rgb_linear.bias.data
+    fine.rgb_linear.bias.data = good.double()
+    with pytest.raises(TypeError):
+        ops.mlp_pack_step([coarse, fine], "f32")
+    fine.rgb_linear.bias.data = good
+    w = fine.feature_linear.weight.data
+    fine.feature_linear.weight.data = w.t().contiguous().t()        # same values, column-major strides
+    with pytest.raises(ValueError):
+        ops.mlp_pack_step([coarse, fine], "f32")
+    fine.feature_linear.weight.data = w
+    ops.mlp_pack_step([coarse, fine], "f32")
+    ref = ops.mlp_pack(fine.ordered_params())
+    torch.cuda.synchronize()
+    assert torch.equal(fine._packed, ref)
+
+
 @pytest.mark.parametrize("variant", ["plain", "wild_mask_thr", "warm_start", "dev_index"])
 def test_unit_gradient_loss_form_equals_the_two_entry_form(dev, variant):
     """Trainer.step runs the three-term loss forward AND backward as one launch pair (ops.TrainLossUnitFn,
