@@ -63,7 +63,7 @@ class MlpPointsFn(torch.autograd.Function):
             out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts)
         else:
             out = ops.mlp_fwd_points(net.packed(), pts, viewdirs, bb, acts)
-        ctx.net, ctx.mode = net, 1
+        ctx.net, ctx.mode, ctx.n_params = net, 1, len(params)
         ctx.save_for_backward(pts, viewdirs, bb, acts if acts is not None else pts.new_empty(0))
         return out
 
@@ -72,4 +72,11 @@ class MlpPointsFn(torch.autograd.Function):
         from .mlp_bwd import mlp_backward
         pts, viewdirs, bb, acts = ctx.saved_tensors
         grads = mlp_backward(ctx.net, acts, g_out)
+        if ctx.n_params != len(grads):
+            # the forward saw a gradient sink and passed one stand-in parameter (NeRF.forward_points): the sink has
+            # taken the gradient and there is nothing to return - unless the sink was detached in between
+            if any(g is not None for g in grads):
+                raise RuntimeError("scade_amd: the gradient sink of this network was detached between the forward and "
+                                   "the backward of a step")
+            return (None,) * (5 + ctx.n_params)
         return (None, None, None, None, None) + tuple(grads)
