@@ -964,3 +964,32 @@ def test_default_trainer_step_gradient_bucket_vs_golden(dev, precision):
     assert_close(bucket[o:o + 1], g["train/grad_scale"].reshape(1), rtol=5e-3, atol=1e-9, what="d scale")
     assert_close(bucket[o + 1:o + 2], g["train/grad_shift"].reshape(1), rtol=5e-3, atol=1e-9, what="d shift")
     assert o + 2 == bucket.numel()
+
+
+def test_gradient_sink_detached_between_forward_and_backward_raises(dev):
+    """With a gradient sink attached (FlatParams.attach_grad_sinks) the MLP's autograd node takes ONE stand-in parameter
+    (round 4: the sink receives the gradient, autograd nothing).  If the sink is taken away between the forward and the
+    backward of a step the gradients would have nowhere to go: that must be an error, not a silent drop - and without a
+    sink the node takes all 24 parameters and returns their gradients as before."""
+    from scade_amd.train import Trainer, make_scade_nets
+    from scade_amd.synthetic import synthetic_rays
+    coarse, fine = make_scade_nets(dev, seed=3)
+    tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1)
+    rays = synthetic_rays(32, seed=4).to(dev)
+    torch.manual_seed(4)
+    tgt, hyp = torch.rand(32, 3, device=dev), torch.rand(20, 32, 1, device=dev) * 4.9 + 0.1
+    tr.begin()
+    loss, _ = tr.forward_loss(rays, tgt, hyp)
+    fine._grad_sink = None
+    with pytest.raises(RuntimeError, match="gradient sink"):
+        tr.backward(loss)
+    # no sinks at all: plain autograd semantics, every parameter receives its own gradient tensor
+    c2, f2 = make_scade_nets(dev, seed=3)
+    import scade_amd as S
+    e, _ = S.get_embedder(9, 0)
+    ed, _ = S.get_embedder(0, 0)
+    q = S.make_network_query_fn(e, ed, torch.zeros(3, device=dev), torch.tensor(0.2, device=dev))
+    out = S.render_rays(rays, True, c2, q, 64, N_importance=128, network_fine=f2, perturb=0.)
+    (S.img2mse(out["rgb_map"], tgt) + S.img2mse(out["rgb0"], tgt)).backward()
+    for net in (c2, f2):
+        assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in net.parameters())
