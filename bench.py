@@ -290,9 +290,11 @@ def train_region(args, dev, world, rank, barrier, precision="f32", rays_per_gpu=
            "ms_per_step": elapsed / nsteps * 1e3, "ms_per_step_blocks": {"median": sorted(blk)[nblk // 2], "min": min(blk), "max": max(blk), "blocks": nblk},
            "steps_timed": nsteps, "rays_per_gpu": n, "global_rays": n * world,
            "scaling": scaling, "hypotheses": args.hyp, "graphed": graphed,
-           "collective": (f"RCCL all-reduce(sum, fp32) of ONE bucket of {tr.bucket.numel} floats per step over "
-                          f"{world} ranks, mode={allreduce}" if world > 1 else "none (1 GPU)"),
-           "rccl_ranks": world if world > 1 else 0,
+           "collective": (f"{dist.get_backend()} all-reduce(sum, fp32) of ONE bucket of {tr.bucket.numel} floats per "
+                          f"step over {world} rank(s), mode={allreduce}"
+                          + (" (one-rank group: the collective is issued, nothing crosses a link)" if world == 1 else "")
+                          if (world > 1 or tr.force_allreduce) else "none (1 GPU, no process group)"),
+           "rccl_ranks": world if (world > 1 or tr.force_allreduce) else 0,
            "whole_step_tflops_per_gpu": tfl,
            "whole_step_frac_of_peak": tfl / peak, "peak": f"{peak:.1f} TFLOP/s ({peak_name})"}
     if not graphed:
@@ -406,7 +408,7 @@ def interleaved_ab(fns, steps, reps, warmup):
     return out
 
 
-def graph_region(args, dev, n_rays, precision):
+def graph_region(args, dev, n_rays, precision, n_hyp=None):
     """Secondary measurement (single process): the same train step at ``n_rays`` rays, eager vs captured in one
     HIP graph (scade_amd/graphs.py), as an INTERLEAVED A/B (interleaved_ab: 7 alternating blocks of >= 40 steps per
     mode after a common warm-up; median and spread reported).  128 rays = the per-GPU shard of a strongly-scaled
@@ -418,27 +420,123 @@ def graph_region(args, dev, n_rays, precision):
     from scade_amd.graphs import GraphedTrainer
     from scade_amd.synthetic import synthetic_rays
     from scade_amd.train import Trainer, make_scade_nets
+    n_hyp = n_hyp or args.hyp
     rays = synthetic_rays(n_rays, seed=4000).to(dev)
     g = torch.Generator(device="cpu").manual_seed(4001)
     tgt = torch.rand(n_rays, 3, generator=g).to(dev)
-    hyp = (torch.rand(args.hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
+    hyp = (torch.rand(n_hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
     fns, last = {}, {}
     for mode in ("eager", "graph"):
         coarse, fine = make_scade_nets(dev, seed=0)
         tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
         if mode == "graph":
-            gt = GraphedTrainer(tr, n_rays, args.hyp)
+            gt = GraphedTrainer(tr, n_rays, n_hyp)
             fns[mode] = lambda gt=gt: last.__setitem__("graph", gt.step(rays, tgt, hyp))
         else:
             fns[mode] = lambda tr=tr: last.__setitem__("eager", tr.step(rays, tgt, hyp)[0])
     res = interleaved_ab(fns, steps=max(40, args.steps), reps=7, warmup=max(20, args.warmup))
     assert all(bool(torch.isfinite(v)) for v in last.values())
-    out = {"rays": n_rays, "precision": precision, "harness": "interleaved A/B, 7 alternating blocks per mode, median"}
+    out = {"rays": n_rays, "precision": precision, "hypotheses": n_hyp,
+           "harness": "interleaved A/B, 7 alternating blocks per mode, median"}
     for mode, r in res.items():
         out[f"ms_per_step_{mode}"] = r["median_ms"]
         out[f"spread_{mode}_ms"] = [r["min_ms"], r["max_ms"]]
     out["graph_over_eager"] = res["graph"]["median_ms"] / res["eager"]["median_ms"]
     return out
+
+
+def synthetic_scene(dev, n_hyp, Hh=468, Ww=624, n_train=18):
+    """A ScanNet-sized scene held in memory, in the tuple the scene loaders return (scene.load_scene_scannet):
+    468 x 624 pinhole views (fx = fy = 578), ``n_train`` training views + 1 test view
+    on a short baseline, smooth colour ramps, a tilted depth plane, K hypotheses = the depth + noise clipped to
+    [near, far] (data/load_scene.py:319-348).  The hypothesis stack (n_train x K x H x W floats: 420 MB at K = 20) is
+    generated on the device."""
+    import numpy as np
+    yy, xx = np.meshgrid(np.linspace(0, 1, Hh), np.linspace(0, 1, Ww), indexing="ij")
+    imgs = np.stack([np.stack([xx, yy, 0.5 + 0.3 * np.sin(3 * xx + i)], -1) for i in range(n_train + 1)]).astype(np.float32)
+    dep = (1.0 + 1.5 * xx + 0.5 * yy).astype(np.float32)
+    depths = np.repeat(dep[None, :, :, None], n_train + 1, 0)
+    valid = np.ones((n_train + 1, Hh, Ww), bool)
+    poses = np.repeat(np.eye(4, dtype=np.float32)[None], n_train + 1, 0)
+    poses[:, 0, 3] = np.linspace(0, 0.5, n_train + 1)
+    intr = np.repeat(np.array([[578.0, 578.0, 312.0, 234.0]], np.float32), n_train + 1, 0)
+    g = torch.Generator(device=dev).manual_seed(11)
+    hyps = (torch.as_tensor(dep, device=dev)[None, None, :, :, None]
+            + 0.2 * torch.randn(n_train, n_hyp, Hh, Ww, 1, device=dev, generator=g)).clamp_(0.1, 5.0)
+    i_split = [np.arange(n_train), np.arange(0), np.arange(n_train, n_train + 1), np.arange(0)]
+    return (imgs, depths, valid, poses, Hh, Ww, intr, 0.1, 5.0, i_split, None, None, hyps)
+
+
+def driver_loop_region(args, dev, scene_data, precision, n_rays, iters=300, warm=60):
+    """The training LOOP a user runs (scade_amd.driver.train_scene = the call sequence of the reference's train_nerf,
+    run_scade_scannet.py:942-997: image pick, pixel pick, batch gather, render_hyp, three-term loss, backward, both
+    optimizer steps), on the resident synthetic scene: ms per ITERATION all in, host clock, steady state (the first
+    ``warm`` iterations - graph capture, allocator, clock ramp - are left out; the final test render and the
+    checkpoint / image writes are outside the loop's clock as they are outside the reference's per-iteration work)."""
+    import shutil
+    import tempfile
+    from scade_amd import driver
+    out = tempfile.mkdtemp(prefix="scade_bench_loop_")
+    try:
+        res = driver.train_scene(scene_data, out, f"{precision}_{n_rays}", "synthetic", num_iterations=warm + iters,
+                                 N_rand=n_rays, i_weights=10 ** 9, i_print=10 ** 9, precision=precision, no_reload=True,
+                                 loop_warmup=warm, log=lambda *_: None, test_chunk=16384)
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    assert res["graphed"] and res["trace"] and all(v == v for _, v in res["trace"])
+    return {"ms_per_iteration": res["ms_per_iteration"], "rays": n_rays, "precision": precision,
+            "iterations_timed": res["iterations_timed"], "graphed": res["graphed"],
+            "rays_per_s": n_rays / (res["ms_per_iteration"] * 1e-3),
+            "final_loss": res["trace"][-1][1], "test_psnr_after_loop": res["test"].get("psnr"),
+            "host_calls_per_iteration": "np.random.choice (view) + scade_gather_batch + hipGraphLaunch"}
+
+
+def dropin_region(args, dev, n_rays, steps=60, warm=15):
+    """The path INTEGRATION.md section 2 gives a reference maintainer - nothing of this package above the public
+    operators: run_scade_scannet.py:951-997 as written there (target_h = hyp * scale + shift, render_rays(perturb=1),
+    img2mse + 0.007 compute_space_carving_loss + img2mse, loss.backward(), torch.optim.Adam over the 48 parameter
+    tensors, a second torch.optim.Adam over the depth scales / shifts), exact fp32, eager."""
+    import scade_amd as S
+    from scade_amd.synthetic import synthetic_rays
+    from scade_amd.train import make_scade_nets
+    coarse, fine = make_scade_nets(dev, seed=0)
+    e, _ = S.get_embedder(9, 0)
+    ed, _ = S.get_embedder(0, 0)
+    query = S.make_network_query_fn(e, ed, torch.zeros(3, device=dev), torch.tensor(0.2, device=dev))
+    optimizer = torch.optim.Adam(list(coarse.parameters()) + list(fine.parameters()), lr=5e-4, betas=(0.9, 0.999))
+    scales = torch.ones(1, 1, device=dev, requires_grad=True)
+    shifts = torch.zeros(1, 1, device=dev, requires_grad=True)
+    optimizer_ss = torch.optim.Adam([scales, shifts], lr=1e-7)
+    rays = synthetic_rays(n_rays, seed=6000).to(dev)
+    g = torch.Generator(device="cpu").manual_seed(6001)
+    tgt = torch.rand(n_rays, 3, generator=g).to(dev)
+    hyp = (torch.rand(args.hyp, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
+
+    def one():
+        target_h = hyp * scales[0] + shifts[0]                                              # :954
+        ret = S.render_rays(rays, True, coarse, query, N_COARSE, N_importance=N_FINE, network_fine=fine,
+                            perturb=1., raw_noise_std=0.)                                   # :963
+        optimizer.zero_grad()
+        optimizer_ss.zero_grad()
+        loss = S.img2mse(ret["rgb_map"], tgt)                                               # :968
+        loss = loss + 0.007 * S.compute_space_carving_loss(ret["pred_hyp"], target_h, is_joint=False, norm_p=2,
+                                                           threshold=0.0)                   # :973-979
+        loss = loss + S.img2mse(ret["rgb0"], tgt)                                           # :981-983
+        loss.backward()                                                                     # :985
+        optimizer.step()                                                                    # :993
+        optimizer_ss.step()                                                                 # :997
+        return loss
+    for _ in range(warm):
+        one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    assert bool(torch.isfinite(loss))
+    return {"ms_per_step": ms, "rays": n_rays, "precision": "f32", "rays_per_s": n_rays / (ms * 1e-3),
+            "path": "public operators + loss.backward() + torch.optim.Adam x 2 (INTEGRATION.md section 2), eager"}
 
 
 def main():
@@ -495,7 +593,8 @@ def main():
     # one-time setup, not part of the measurement: first-launch kernel attributes, the caching
     # allocator's pools, and the chip's clock ramp (the first ~10 steps of a cold process run 7 %
     # slower); the W warm-up steps and the K timed steps of the contract follow
-    for _ in range(12):
+    SETUP_STEPS = 12
+    for _ in range(SETUP_STEPS):
         step()
     for _ in range(args.warmup):
         step()
@@ -544,6 +643,9 @@ def main():
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
+        "setup_steps": SETUP_STEPS,
+        "setup_steps_note": "untimed one-time steps run BEFORE the declared warm-up (first-launch kernel attributes, "
+                            "allocator pools, clock ramp of a cold process)",
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True,
         "scaling": "weak",
@@ -706,10 +808,38 @@ def main():
                         rays_per_gpu=args.rays // world, graphed=True, scaling="strong")
             if world == 1 and not args.no_graph:
                 guarded("train_step_graph", lambda: [graph_region(args, dev, 128, "f32"),
+                                                     graph_region(args, dev, 128, "f16x3"),
                                                      graph_region(args, dev, 128, "bf16"),
                                                      graph_region(args, dev, args.rays, "bf16"),
                                                      graph_region(args, dev, 128, "bf16-s8"),
-                                                     graph_region(args, dev, args.rays, "bf16-s8")])
+                                                     graph_region(args, dev, args.rays, "bf16-s8"),
+                                                     # BASELINE.json configs[4]'s per-GPU shard: 4096 rays / 8, K = 40
+                                                     graph_region(args, dev, 512, "bf16-s8", n_hyp=40)])
+
+                def ceilings():
+                    """ms(1024-ray step) / ms(128-ray graphed shard): what 8 GPUs could give a strongly-scaled
+                    1024-ray batch (configs[3]) before one microsecond of RCCL."""
+                    full = {"f32": out.get("train_step"), "f16x3": out.get("train_step_f16x3"),
+                            "bf16": out.get("train_step_bf16"), "bf16-s8": out.get("train_step_bf16_s8")}
+                    res = {}
+                    for row in out["train_step_graph"]:
+                        f = full.get(row["precision"])
+                        if row["rays"] == 128 and isinstance(f, dict) and "ms_per_step" in f and args.rays == 1024:
+                            res[row["precision"]] = f["ms_per_step"] / row["ms_per_step_graph"]
+                    return res
+                guarded("strong_scaling_ceiling_8gpu", ceilings)
+        if world == 1 and not args.no_graph:
+            # the loop a user runs (driver.train_scene, graph-captured step + fused batch gather) and the drop-in
+            # operator path, beside the bare Trainer.step figures above
+            def loops():
+                rows = []
+                data = synthetic_scene(dev, args.hyp)
+                for prec, n in (("f32", args.rays), ("f32", 128)) + \
+                        ((() if args.no_fast else (("bf16-s8", args.rays), ("bf16-s8", 128)))):
+                    rows.append(driver_loop_region(args, dev, data, prec, n))
+                return rows
+            guarded("driver_loop", loops)
+            guarded("train_step_dropin", dropin_region, args, dev, args.rays)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         state["region"] = "cpu_baseline"
         out["cpu_baseline"] = cpu_baseline(pc, pf, 1024, args.hyp)

@@ -327,6 +327,19 @@ int scade_gen_rays(const int* coords, int N, int H, int W, const float* intrinsi
                    int K, int corner_px, int edge_px, float* rays, float* rays_o, float* rays_d,
                    float* target_s, float* target_h, float* mask, void* stream);
 
+/* The training loop's per-iteration batch assembly (run_scade_scannet.py:946 image pick, :786 pixel pick,
+ * get_ray_batch_from_one_image_hypothesis_idx :772-827, ray rows :200-219) as the ONE launch in front of a
+ * graph-captured train step.  pix[N] int64: flat pixel indices row * W + col, every one in [0, H*W) (the caller's
+ * contract - e.g. a slice of a device-resident permutation of the pixels); intrinsic / c2w / image [H,W,3] /
+ * hyps [K,H,W] are those of the step's training view.  Outputs as scade_gen_rays (same arithmetic, same bits):
+ * rays [N,11], target_s [N,3], target_h [K,N], mask [N]; any may be NULL.  scalar_dst != NULL: one 8-byte store
+ * (the view's index, :951-954); tick_states != NULL: up to two device-resident optimizer states advanced by one
+ * step, exactly as scade_stage_inputs does (pass ticked = 1 to scade_adam_step2 then). */
+int scade_gather_batch(const long long* pix, int N, int H, int W, const float* intrinsic, const float* c2w,
+                       int c2w_stride, float near, float far, const float* image, const float* hyps, int K,
+                       int corner_px, int edge_px, float* rays, float* target_s, float* target_h, float* mask,
+                       long long* scalar_dst, long long scalar, float* const* tick_states, void* stream);
+
 /* ---- optimizer step (torch.optim.Adam defaults, run_scade_scannet.py:469, :888, :993-997) -- */
 /* One launch over a flat buffer holding every trainable tensor; grads are multiplied by
  * grad_scale first (1/world_size after a sum all-reduce).  step counts from 1. */

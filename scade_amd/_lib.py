@@ -81,6 +81,8 @@ SIGNATURES = {
                                     _I, _I, _I, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "scade_gen_rays": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P,
                                 _P, _P, _P, _P]),
+    "scade_gather_batch": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P, _P,
+                                   _P, ctypes.c_longlong, _P, _P]),
     "scade_adam_step": (c_int, [_P, _P, _P, _P, c_long, c_float, c_float, c_float, c_float, _I, c_float, _P]),
     "scade_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, _P]),
     "scade_adam_step2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),

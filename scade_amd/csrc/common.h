@@ -34,6 +34,30 @@ static inline void scade_attr_done(unsigned long long& mask) { mask |= 1ull << s
 int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, int P, float* partial,
                        float* grad_flat, hipStream_t s);
 
+// ---- device-resident optimizer scalars (optim.hip: float[16] per FusedAdam) -------------------------------
+// One tick = the start of a step: t += 1, the staircase learning rate on the reference's loop index
+// (train_utils/hyperparameter_update.py:8-13, run_scade_scannet.py:988-991) and Adam's bias corrections.
+// Shared by the kernels that open a graph-captured step (scade_stage_inputs, scade_gather_batch).
+namespace scade {
+__device__ __forceinline__ void adam_tick(float* st) {
+  st[13] = st[0];                      // steps taken BEFORE this one: the step's index for in-kernel draws
+  const float t = st[0] + 1.0f;
+  st[0] = t;
+  const double it = (double)t + (double)st[11];
+  const double k = st[3] > 0.f ? floor(it / (double)st[3]) : 0.0;
+  st[8] = (float)((double)st[1] * pow((double)st[2], k));
+  st[9] = (float)(1.0 - pow((double)st[4], (double)t));
+  st[10] = (float)sqrt(1.0 - pow((double)st[5], (double)t));
+}
+}  // namespace scade
+
+// rows a tile copy's buffer descriptor spans: from the tile's first row p0 to the end of the slot at row P, at most
+// 4096 (no tile is larger; 4096 rows x 1 KiB fits the descriptor's 32-bit range with room to spare)
+__device__ __forceinline__ unsigned tile_rows_left(int p0, int P) {
+  const int n = P - p0;
+  return (unsigned)(n < 0 ? 0 : (n > 4096 ? 4096 : n));
+}
+
 // ---- wave-level primitives -------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
@@ -125,11 +149,7 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("" ::: "memory");
   __builtin_amdgcn_sched_barrier(0);
 }
-#ifdef SYNC_FULL
-#define LDS_SYNC() __syncthreads()
-#else
 #define LDS_SYNC() lds_barrier()
-#endif
 
 // sin and cos of an fp32 argument in ~35 VALU operations (the library's sincosf is ~3x that and branches): three-term
 // Cody-Waite reduction by pi/2 (fused multiply-adds: the products are exact, |a| < 3e4) and the minimax polynomials

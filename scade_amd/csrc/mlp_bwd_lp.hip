@@ -392,10 +392,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_lp_kernel(MlpDgradLpArgs2 aa
 
   f32x16 acc[2][LPT];
   unsigned mb[4] = {0u, 0u, 0u, 0u};
-#ifndef LP_DNS
-#define LP_DNS 4
-#endif
-  constexpr int DNS = LP_DNS;          // A register sets: weights fetched three k-blocks ahead (round 4: the dgrad has the registers)
+  constexpr int DNS = 4;               // A register sets: weights fetched three k-blocks ahead (round 4: the dgrad has the registers)
   AFragN<BF, DNS> A;
   const int kt0 = wave * 2;
   auto load_mask = [&](int layer) {
@@ -555,11 +552,8 @@ constexpr int WL_PITCH = 288;                      // elements per LDS row: 256 
 constexpr int WL_TILE = WL_PT * WL_PITCH;          // elements per operand tile
 constexpr int WL_STAGE = 2 * WL_TILE;              // dZ tile + input tile
 constexpr int WL_LDS_BYTES = 3 * WL_STAGE * 2;         // triple buffered: 110592
-#ifndef W8_D_VALUE
-#define W8_D_VALUE 3
-#endif
 constexpr int W8_S = 64;                               // format code 2 (wgrad_lp8_dma_job): points per ring slot,
-constexpr int W8_D = W8_D_VALUE;                       // ring slots,
+constexpr int W8_D = 3;                                 // ring slots,
 constexpr int W8_SLOT = 2 * W8_S * 256 + 256;          // bytes per slot: dZ [64][256] | input [64][256] | d alpha [64] fp32
 constexpr int WGRAD_LP_LDS_BYTES = W8_D * W8_SLOT > WL_LDS_BYTES ? W8_D * W8_SLOT : WL_LDS_BYTES;
 
@@ -752,205 +746,8 @@ __device__ __forceinline__ void wgrad_lp_job(const WgradLpNet& a, const WgradLpJ
   }
 }
 
-// ---- format code 2: the same job on 8-bit (e5m2) dZ / activation rows (mlp_tile_lp.h).  Only the staging
-// differs: a thread owns 16 columns of ONE row of the 32-point stage (one 16-byte load = 16 values per operand) and
-// widens them on the way into the same LDS tiles.  An e5m2 number IS the top byte of an fp16 number, so the
-// widening is one v_perm_b32 per two values (byte b -> halfword b << 8, exact) and the contraction runs on the fp16
-// MFMA (same rate as bf16; every operand value is exactly representable either way) - as bf16 the widening was
-// v_cvt_pk_f32_bf8 + v_cvt_pk_bf16_f32 per pair, four times the VALU work of the commit phase.  The embedding rows
-// (KW = 64 jobs' input) are saved as bf16 and converted to fp16 here (|gamma(x)| <= 1, |viewdir| <= 1: in range).
-struct WStage8 {
-  lp_u32x4 a, b;       // 16 e5m2 values of the dZ row / the input row
-  __bf16 __attribute__((ext_vector_type(8))) e;   // KW = 64: 8 embedding columns (bf16 rows)
-  float d;             // d alpha_pre of the row (WF_ALPHA job)
-};
-// four e5m2 bytes of w -> two dwords of packed fp16 (v_perm_b32 selectors: 0x0c = constant zero byte)
-__device__ __forceinline__ void widen4_bf8_f16(unsigned w, unsigned& lo, unsigned& hi) {
-  lo = __builtin_amdgcn_perm(0u, w, 0x010c000cu);      // [0, b0, 0, b1]
-  hi = __builtin_amdgcn_perm(0u, w, 0x030c020cu);      // [0, b2, 0, b3]
-}
-
-template <int KW>
-__device__ __forceinline__ void wgrad_lp8_job(const WgradLpNet& a, const WgradLpJob& jb, _Float16* lds,
-                                              int c0, int c1, float invS, float* __restrict__ out) {
-  constexpr bool BF = false;                    // fp16 tiles and MFMAs (see above)
-  typedef _Float16 T;
-  typedef typename LP<BF>::V8 V8;
-  typedef __bf16 __attribute__((ext_vector_type(8))) BV8;
-  constexpr int NKT = KW == 256 ? 4 : 1;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int r = lane & 31, hh = lane >> 5;
-  const int n0 = (wave >> 1) * 64;
-  const int k0 = (wave & 1) * (KW / 2);
-  const bool active = n0 < jb.n_rows;
-  const int P = a.P;
-  const unsigned char* __restrict__ dzm = a.dz + jb.dz_off * 2;       // 8-bit rows: first half of the slot region
-  const unsigned char* __restrict__ inm8 = a.acts + jb.in_off * 2;
-  const __bf16* __restrict__ inm16 = reinterpret_cast<const __bf16*>(a.acts) + jb.in_off;   // embedding rows
-  const float* __restrict__ dalp = reinterpret_cast<const float*>(a.dz + lp_dz_dalpha_byte(P));
-  const int cc = tid & 15, rr = tid >> 4;      // 16-column chunk cc of row rr of the stage
-  const V8 zero8 = __builtin_bit_cast(V8, s16x8{0, 0, 0, 0, 0, 0, 0, 0});
-
-  f32x16 acc[2][NKT];
-#pragma unroll
-  for (int t = 0; t < 2; ++t)
-#pragma unroll
-    for (int u = 0; u < NKT; ++u)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
-  float bias_acc[16], alpha_acc[16], dal_acc = 0.f;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) { bias_acc[j] = 0.f; alpha_acc[j] = 0.f; }
-
-  const bool want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
-  auto issue = [&](WStage8& s, int pt0) {       // unconditional loads (see wgrad_lp_job)
-    const int pa = min(pt0 + rr, P - 1);
-    s.a = __builtin_nontemporal_load(reinterpret_cast<const lp_u32x4*>(dzm + (size_t)pa * 256 + 16 * cc));
-    if (KW == 256) {
-      s.b = __builtin_nontemporal_load(reinterpret_cast<const lp_u32x4*>(inm8 + (size_t)pa * 256 + 16 * cc));
-      s.d = dalp[want_alpha ? pa : 0];
-    } else {
-      const int pe = min(pt0 + ((tid >> 3) & 31), P - 1);
-      s.e = *reinterpret_cast<const BV8*>(inm16 + (size_t)pe * 64 + 8 * (tid & 7));
-    }
-  };
-  auto widen = [&](const lp_u32x4& w, V8& lo, V8& hi) {
-    unsigned q[8];
-    widen4_bf8_f16(w[0], q[0], q[1]);
-    widen4_bf8_f16(w[1], q[2], q[3]);
-    widen4_bf8_f16(w[2], q[4], q[5]);
-    widen4_bf8_f16(w[3], q[6], q[7]);
-    lo = __builtin_bit_cast(V8, lp_u32x4{q[0], q[1], q[2], q[3]});
-    hi = __builtin_bit_cast(V8, lp_u32x4{q[4], q[5], q[6], q[7]});
-  };
-  auto commit = [&](const WStage8& s, int pt0, int buf) {
-    T* st = lds + buf * WL_STAGE;
-    // whole stages (all but a segment's last) skip the row-validity selects: a wave-uniform branch
-    const bool full = pt0 + WL_PT <= c1;
-    const bool va = full || pt0 + rr < c1;
-    V8 a0 = zero8, a1 = zero8, b0 = zero8, b1 = zero8;
-    if (full) widen(s.a, a0, a1);
-    else if (va) widen(s.a, a0, a1);
-    // a lane's two 16-byte halves lie 16 bytes apart, the lanes of a row 32 bytes apart: written in program order
-    // the eight lanes of a ds_write_b128 group would cover 256 bytes with 16-byte holes and hit every bank group
-    // twice (measured: 29.7 % conflict cycles).  Lanes 4..7 of each group of eight write their HIGH half first:
-    // the group then covers 8 distinct 16-byte bank groups in both instructions.
-    const bool hi_first = (cc & 4) != 0;
-    T* pa_ = st + rr * WL_PITCH + 16 * cc;
-    *reinterpret_cast<V8*>(pa_ + (hi_first ? 8 : 0)) = hi_first ? a1 : a0;
-    *reinterpret_cast<V8*>(pa_ + (hi_first ? 0 : 8)) = hi_first ? a0 : a1;
-    if (KW == 256) {
-      if (full) widen(s.b, b0, b1);
-      else if (va) widen(s.b, b0, b1);
-      T* pb_ = st + WL_TILE + rr * WL_PITCH + 16 * cc;
-      *reinterpret_cast<V8*>(pb_ + (hi_first ? 8 : 0)) = hi_first ? b1 : b0;
-      *reinterpret_cast<V8*>(pb_ + (hi_first ? 0 : 8)) = hi_first ? b0 : b1;
-    } else if (tid < 256) {
-      V8 e = zero8;
-      if (pt0 + (tid >> 3) < c1) {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) e[j] = (T)(float)s.e[j];
-      }
-      *reinterpret_cast<V8*>(st + WL_TILE + (tid >> 3) * WL_PITCH + 8 * (tid & 7)) = e;
-    }
-    if (jb.flags & WF_BIAS) {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { bias_acc[j] += (float)a0[j]; bias_acc[8 + j] += (float)a1[j]; }
-    }
-    if (want_alpha) {
-      const float d = va ? s.d : 0.f;
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        alpha_acc[j] = fmaf(d, (float)b0[j], alpha_acc[j]);
-        alpha_acc[8 + j] = fmaf(d, (float)b1[j], alpha_acc[8 + j]);
-      }
-      if (cc == 0) dal_acc += d;
-    }
-  };
-  auto compute = [&](int buf) {
-    if (!active) return;
-    const T* st = lds + buf * WL_STAGE;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      const V8 a0 = tr_frag<BF>(st, 16 * kk, n0, lane);
-      const V8 a1 = tr_frag<BF>(st, 16 * kk, n0 + 32, lane);
-#pragma unroll
-      for (int u = 0; u < NKT; ++u) {
-        const V8 b = tr_frag<BF>(st + WL_TILE, 16 * kk, k0 + 32 * u, lane);
-        acc[0][u] = LP<BF>::mfma(a0, b, acc[0][u]);
-        acc[1][u] = LP<BF>::mfma(a1, b, acc[1][u]);
-      }
-    }
-  };
-
-  WStage8 r0, r1, r2;
-  issue(r0, c0);
-  issue(r1, c0 + WL_PT);
-  issue(r2, c0 + 2 * WL_PT);
-  commit(r0, c0, 0);
-  issue(r0, c0 + 3 * WL_PT);
-  __syncthreads();
-#define WL_STEP(RN, BUF, BUFN, K)                                   \
-  if (pt0 + ((K) + 1) * WL_PT < c1) commit(RN, pt0 + ((K) + 1) * WL_PT, BUFN); \
-  issue(RN, pt0 + ((K) + 4) * WL_PT);                               \
-  compute(BUF);                                                     \
-  __syncthreads();                                                  \
-  if (pt0 + ((K) + 1) * WL_PT >= c1) break;
-  for (int pt0 = c0;; pt0 += 3 * WL_PT) {
-    WL_STEP(r1, 0, 1, 0)
-    WL_STEP(r2, 1, 2, 1)
-    WL_STEP(r0, 2, 0, 2)
-  }
-#undef WL_STEP
-
-  if (active) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int u = 0; u < NKT; ++u) {
-        const int k = k0 + 32 * u + r;
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          const int n = n0 + 32 * t + (i & 3) + 8 * (i >> 2) + 4 * hh;
-          if (n < jb.n_rows && k >= jb.kfirst && k < jb.kvalid)
-            out[jb.w_off + (size_t)n * jb.ld + jb.kcol0 + (k - jb.kfirst)] = acc[t][u][i] * invS;
-        }
-      }
-  }
-  // riders: the 32 rows of a column are combined through LDS
-  float* red = reinterpret_cast<float*>(lds);      // [32][256] (+ 32)
-  if (jb.flags & WF_BIAS) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) red[rr * 256 + 16 * cc + j] = bias_acc[j];
-    __syncthreads();
-    if (tid < jb.n_rows) {
-      float s = 0.f;
-      for (int g = 0; g < 32; ++g) s += red[g * 256 + tid];
-      out[jb.b_off + tid] = s * invS;
-    }
-    __syncthreads();
-  }
-  if (KW == 256 && (jb.flags & WF_ALPHA)) {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) red[rr * 256 + 16 * cc + j] = alpha_acc[j];
-    if (cc == 0) red[32 * 256 + rr] = dal_acc;
-    __syncthreads();
-    if (tid < 256) {
-      float s = 0.f;
-      for (int g = 0; g < 32; ++g) s += red[g * 256 + tid];
-      out[jb.aux_off + tid] = s;
-    }
-    if (tid == 0) {
-      float s = 0.f;
-      for (int g = 0; g < 32; ++g) s += red[32 * 256 + g];
-      out[jb.aux_off + 256] = s;
-    }
-  }
-}
-
-// ---- format code 2, round 4: the 256-wide jobs contract the e5m2 rows AS THEY LIE IN HBM, on the fp8-family MFMA.
-// The commit design above passes every byte through registers (load -> v_perm widening to fp16 -> ds_write ->
+// ---- format code 2 (8-bit e5m2 dZ / activation rows, mlp_tile_lp.h): the 256-wide jobs contract the rows AS THEY LIE
+// IN HBM, on the fp8-family MFMA.  The round-3 design (deleted in round 5; git history) passed every byte through registers (load -> v_perm widening to fp16 -> ds_write ->
 // transposing 16-bit read -> fp16 MFMA) and runs commit (830 cycles, VALU) | MFMA (950) | barrier (500) in series per
 // 32-point stage.  Here:
 //  * the rows go HBM -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds), 1 KiB = four 256-byte rows per wave
@@ -1433,9 +1230,6 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
     const int c0 = grid_mode ? gc * pl.chunk : s0 * WL_PT;
     int c1 = grid_mode ? min(a.P, c0 + pl.chunk)
                        : min(a.P, max(s1, s0) * WL_PT);       // an empty segment (c1 == c0) still writes its zero row
-#ifdef W8_KO_OTHER      // (experiment: only the ring jobs stream, the others write their zero rows)
-    if (S8 && ((jb.flags & WF_RGB) || jb.kw != 256)) c1 = c0;
-#endif
     float* out = a.partial + (size_t)(grid_mode ? gc : w - pl.first_wg[e]) * N_PARAM_FLOATS;
     const float invS = (BF && !S8) ? 1.0f : 1.0f / lp_loss_scale(lp_read_gmax(a.gmax));
     if (!first) __syncthreads();                        // the previous segment's riders still read the LDS
@@ -1443,20 +1237,11 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_lp_kernel(WgradLpArgs aa) {
     if (jb.flags & WF_RGB) {
       wgrad_rgb_lp_job<BF, false>(a, jb, reinterpret_cast<float*>(ldsw16), c0, c1, out);   // (its input slot is 16-bit in every format)
     } else if (S8) {
-#ifdef LP8_COMMIT_PATH      // (A/B variant builds only: the round-3 register-staged job)
-      if (jb.kw == 256) {
-        wgrad_lp8_job<256>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
-      } else
-#endif
       if (jb.kw == 256) {
         if (jb.flags & WF_ALPHA) wgrad_lp8_dma_job<true>(a, jb, reinterpret_cast<unsigned char*>(ldsw16), c0, c1, invS, out);
         else wgrad_lp8_dma_job<false>(a, jb, reinterpret_cast<unsigned char*>(ldsw16), c0, c1, invS, out);
       } else {
-#ifdef LP8_COMMIT_EMB       // (A/B variant builds only; needs 16-bit embedding rows: the forward of this build saves fp8)
-        wgrad_lp8_job<64>(a, jb, reinterpret_cast<_Float16*>(ldsw16), c0, c1, invS, out);
-#else
         wgrad_lp8_dma_emb_job(a, jb, reinterpret_cast<unsigned char*>(ldsw16), c0, c1, invS, out);
-#endif
       }
     } else if (jb.kw == 256) {
       wgrad_lp_job<BF, 256>(a, jb, reinterpret_cast<T*>(ldsw16), c0, c1, invS, out);

@@ -113,9 +113,6 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   const int p0 = blockIdx.x * TM;
   const int P = a.P;
   const float* __restrict__ pk = a.packed;
-#ifdef MLP_PRIO
-  __builtin_amdgcn_s_setprio(MLP_PRIO);
-#endif
 
   FS_STAMP(0)
   // ---------------- prologue: embedding tile [64][60] (+ zeroed tail pad) ----

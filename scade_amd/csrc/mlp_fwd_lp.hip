@@ -215,6 +215,13 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_lp_kernel(MlpLpArgs a) {
       if (pt < P) {
         if (SAVE == 2) {
           lp_u32x2 o;
+          if (ch == 0) {
+            // columns 0..2 are the raw normalised coordinate (x - centre) * scale: unbounded for a point outside the
+            // scene box, where every other column is a sine / cosine / unit-vector component.  e4m3 ends at +-448:
+            // kept finite here (the weight gradient of such a point sees the clamped coordinate)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) v[c] = (T)__builtin_fminf(__builtin_fmaxf((float)v[c], -448.0f), 448.0f);
+          }
           o[0] = lp_pack4_fp8((float)v[0], (float)v[1], (float)v[2], (float)v[3]);
           o[1] = lp_pack4_fp8((float)v[4], (float)v[5], (float)v[6], (float)v[7]);
           __builtin_nontemporal_store(o, reinterpret_cast<lp_u32x2*>(eo8 + (size_t)pt * 64 + 8 * ch));

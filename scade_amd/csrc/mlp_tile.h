@@ -43,9 +43,6 @@ __device__ __forceinline__ void layer_gemm_b(f32x16 (&acc)[NT][PT], f32x4 (&an)[
                                              const f32x4 (&binit)[NT][4]) {
   constexpr int KB = KBP + KBH;
   const int r = lane & 31, hh = lane >> 5;
-#ifdef MLP_PRIO
-  __builtin_amdgcn_s_setprio(0);       // the k-loop yields to the CU's other workgroup's epilogue / copy / prologue
-#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -101,10 +98,6 @@ __device__ __forceinline__ void layer_gemm_b(f32x16 (&acc)[NT][PT], f32x4 (&an)[
     __builtin_amdgcn_sched_barrier(0);
     mfma_block(a, b);
   }
-#ifdef MLP_PRIO
-  __builtin_amdgcn_sched_barrier(0);
-  __builtin_amdgcn_s_setprio(MLP_PRIO);
-#endif
 }
 template <int NT, int KBP, int KBH, int PRE_STRIDE, int PT = 2>
 __device__ __forceinline__ void layer_gemm(f32x16 (&acc)[NT][PT], f32x4 (&an)[2], const f32x4* __restrict__ wp,
@@ -157,12 +150,15 @@ __device__ __forceinline__ void save_tile_wave(const float* hbuf, float* __restr
   const unsigned char* base[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) base[b] = hb + (RPI * b + lr) * (W * 4) + ((c ^ (RPI * b + lr)) << 4);
-  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst);
+  // the descriptor starts at the TILE's first row and ends at row P (at most 4096 rows on): nothing in it depends on
+  // P * pitch fitting 32 bits (a slot of 4 M points is 4 GiB)
+  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)p0 * 1024ull;
   const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0, __builtin_amdgcn_readfirstlane((unsigned)P * 1024u), 0x00020000);
+      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
+      __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 1024u), 0x00020000);
   const int voff = lr * 1024 + c * 16;
-  const int soff = __builtin_amdgcn_readfirstlane(p0 * 1024);
+  constexpr int soff = 0;
   typedef unsigned u32x4_ __attribute__((ext_vector_type(4)));
 #pragma unroll
   for (int it0 = 0; it0 < ITERS; it0 += BATCH) {

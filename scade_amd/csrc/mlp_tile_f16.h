@@ -235,12 +235,13 @@ __device__ __forceinline__ void save_tile_h_wave(const _Float16* xh, const _Floa
   int off[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) off[b] = (RPI * b + lr) * W + ((c ^ (RPI * b + lr)) << 3);      // x_idx(row, c) in halves
-  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst);
+  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)p0 * 1024ull;   // (mlp_tile.h)
   const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0, __builtin_amdgcn_readfirstlane((unsigned)P * 1024u), 0x00020000);
+      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
+      __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 1024u), 0x00020000);
   const int voff = lr * 1024 + c * 32;
-  const int soff = __builtin_amdgcn_readfirstlane(p0 * 1024);
+  constexpr int soff = 0;
 #pragma unroll
   for (int it0 = 0; it0 < ITERS; it0 += 2) {
     u32x4 vh[2], vl[2];

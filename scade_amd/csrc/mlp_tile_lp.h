@@ -249,12 +249,13 @@ __device__ __forceinline__ void save_tile_lp_wave8(const typename LP<BF>::T* x, 
   const unsigned char* xb = reinterpret_cast<const unsigned char*>(x);
   const unsigned char* a0 = xb + 2 * (rl * W + ((c ^ rl) << 3));            // it even
   const unsigned char* a1 = xb + 2 * ((rl + 4) * W + ((c ^ rl ^ 4) << 3));  // it odd (row & 15 = rl | 4)
-  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8);
+  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8) + (unsigned long long)p0 * 256ull;   // (mlp_tile.h)
   const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0, __builtin_amdgcn_readfirstlane((unsigned)P * 256u), 0x00020000);
+      reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
+      __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 256u), 0x00020000);
   const int voff = rl * 256 + 8 * c;
-  const int soff = __builtin_amdgcn_readfirstlane(p0 * 256);
+  constexpr int soff = 0;
   const float inv = fac ? __builtin_amdgcn_rcpf(fac[0]) : 1.0f;
 #pragma unroll
   for (int it0 = 0; it0 < ITERS; it0 += 4) {          // batches of four chunks in flight (all sixteen would spill)
@@ -316,11 +317,11 @@ struct SaveRider8 {
   __device__ __forceinline__ void init(const __bf16* x, unsigned char* __restrict__ dst8, int p0, int P, const float* fac, int wave) {
     row0 = 8 * NPT * wave;
     xb = reinterpret_cast<const unsigned char*>(x) + row0 * W * 2;
-    const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8);
+    const unsigned long long pd = reinterpret_cast<unsigned long long>(dst8) + (unsigned long long)p0 * 256ull;   // (mlp_tile.h)
     const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
     rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
-                                           __builtin_amdgcn_readfirstlane((unsigned)P * 256u), 0x00020000);
-    soff0 = __builtin_amdgcn_readfirstlane((p0 + row0) * 256);
+                                           __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 256u), 0x00020000);
+    soff0 = __builtin_amdgcn_readfirstlane(row0 * 256);
     inv = fac ? __builtin_amdgcn_rcpf(fac[0]) : 1.0f;
   }
   __device__ __forceinline__ void begin(int lane) {
@@ -364,11 +365,11 @@ struct SaveRider16 {
   __device__ __forceinline__ void init(const __bf16* x, __bf16* __restrict__ dst, int p0, int P, int wave) {
     row0 = 8 * NPT * wave;
     xb = reinterpret_cast<const unsigned char*>(x) + row0 * W * 2;
-    const unsigned long long pd = reinterpret_cast<unsigned long long>(dst);
+    const unsigned long long pd = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)p0 * 512ull;   // (mlp_tile.h)
     const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
     rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
-                                           __builtin_amdgcn_readfirstlane((unsigned)P * 512u), 0x00020000);
-    soff0 = __builtin_amdgcn_readfirstlane((p0 + row0) * 512);
+                                           __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 512u), 0x00020000);
+    soff0 = __builtin_amdgcn_readfirstlane(row0 * 512);
   }
   __device__ __forceinline__ void begin(int lane) {
     asm volatile("" : "+v"(lane));

@@ -413,12 +413,6 @@ __global__ static void wgrad2_reduce_pair_kernel(Reduce2Args r) {
 // 2 x CUs slots with chunks near `target_pts` points.
 static constexpr int W2_TARGET_PTS = 2400;   // ring depth 2..6 and chunks of 1,600..3,600 points measure within 1 %
 int pick_chunks_v2(int P) {
-#ifndef W2_PER_CHUNK
-#define W2_PER_CHUNK 17.0
-#endif
-#ifndef W2_PER_CHUNK1
-#define W2_PER_CHUNK1 20.0
-#endif
   const double slots = 2.0 * device_cus();
   const int target = W2_TARGET_PTS;
   long k = (long)((double)P * 18.5 / (slots * target) + 0.5);
@@ -427,7 +421,7 @@ int pick_chunks_v2(int P) {
   // resident beside the heavy ones instead of queueing behind them (per chunk 20: 1.002 ms per graphed 128-ray
   // step against 1.006 with 18.5 and 1.085 with 17); several rounds: the 17 heavy workgroups of a chunk alone fill
   // the slots and the light ones slip into the gaps (1024 rays: 6.92 ms against 7.00 with 18.5, 7.07 with 20)
-  const double per_chunk = k == 1 ? W2_PER_CHUNK1 : W2_PER_CHUNK;
+  const double per_chunk = k == 1 ? 20.0 : 17.0;
   long n = (long)(slots * k / per_chunk);
   const long nmax = P / 256 > 1 ? P / 256 : 1;
   if (n > nmax) n = nmax;

@@ -83,16 +83,6 @@ __global__ void adam_step2_kernel(Adam2Args a) {
     s.p[i] = s.p[i] - step_size * (mi / denom);
   }
 }
-__device__ __forceinline__ void adam_tick(float* st) {
-  st[13] = st[0];                      // steps taken BEFORE this one: the step's index for in-kernel draws
-  const float t = st[0] + 1.0f;
-  st[0] = t;
-  const double it = (double)t + (double)st[11];
-  const double k = st[3] > 0.f ? floor(it / (double)st[3]) : 0.0;
-  st[8] = (float)((double)st[1] * pow((double)st[2], k));
-  st[9] = (float)(1.0 - pow((double)st[4], (double)t));
-  st[10] = (float)sqrt(1.0 - pow((double)st[5], (double)t));
-}
 __global__ void adam_tick2_kernel(float* st0, float* st1) {
   if (threadIdx.x == 0 && st0) adam_tick(st0);
   if (threadIdx.x == 64 && st1) adam_tick(st1);

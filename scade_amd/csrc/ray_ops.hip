@@ -1635,49 +1635,102 @@ struct GenRaysArgs {
   int N, H, W, K, c2w_stride, corner_px, edge_px;
 };
 
-__global__ void gen_rays_kernel(GenRaysArgs a) {
-  const float fx = a.intrinsic[0], fy = a.intrinsic[1], cx = a.intrinsic[2], cy = a.intrinsic[3];
+struct CamRT {
+  float fx, fy, cx, cy;
   float R[3][3], T[3];
+};
+__device__ __forceinline__ CamRT load_cam(const float* intrinsic, const float* c2w, int c2w_stride) {
+  CamRT c;
+  c.fx = intrinsic[0]; c.fy = intrinsic[1]; c.cx = intrinsic[2]; c.cy = intrinsic[3];
 #pragma unroll
   for (int r = 0; r < 3; ++r) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) R[r][c] = a.c2w[r * a.c2w_stride + c];
-    T[r] = a.c2w[r * a.c2w_stride + 3];
+    for (int k = 0; k < 3; ++k) c.R[r][k] = c2w[r * c2w_stride + k];
+    c.T[r] = c2w[r * c2w_stride + 3];
   }
+  return c;
+}
+// everything of pixel (row j, col i) that is per ray: direction, the [o d near far viewdir] row, the target
+// colour and the corner / edge mask, written at batch position n
+__device__ __forceinline__ void gen_ray_item(const GenRaysArgs& a, const CamRT& c, int n, int j, int i) {
+  // helpers:296  dirs = [((i+.5)-cx)/fx, (H-(j+.5)-cy)/fy, -1]
+  const float d0 = (((float)i + 0.5f) - c.cx) / c.fx;
+  const float d1 = ((float)a.H - ((float)j + 0.5f) - c.cy) / c.fy;
+  const float d2 = -1.0f;
+  float d[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) d[r] = (d0 * c.R[r][0] + d1 * c.R[r][1]) + d2 * c.R[r][2];   // helpers:298
+  if (a.rays_o) { a.rays_o[3 * n] = c.T[0]; a.rays_o[3 * n + 1] = c.T[1]; a.rays_o[3 * n + 2] = c.T[2]; }
+  if (a.rays_d) { a.rays_d[3 * n] = d[0]; a.rays_d[3 * n + 1] = d[1]; a.rays_d[3 * n + 2] = d[2]; }
+  if (a.rays) {
+    float* o = a.rays + (size_t)n * 11;
+    const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);     // :128 viewdirs / norm
+    o[0] = c.T[0]; o[1] = c.T[1]; o[2] = c.T[2];
+    o[3] = d[0]; o[4] = d[1]; o[5] = d[2];
+    o[6] = a.near; o[7] = a.far;
+    o[8] = d[0] / nrm; o[9] = d[1] / nrm; o[10] = d[2] / nrm;
+  }
+  const size_t pix = (size_t)j * a.W + i;
+  if (a.image && a.target_s) {
+    a.target_s[3 * n] = a.image[pix * 3]; a.target_s[3 * n + 1] = a.image[pix * 3 + 1];
+    a.target_s[3 * n + 2] = a.image[pix * 3 + 2];
+  }
+  if (a.mask) {
+    float m = 1.f;
+    const int cp = a.corner_px, e = a.edge_px;
+    if (cp > 0 && (j < cp || j >= a.H - cp) && (i < cp || i >= a.W - cp)) m = 0.f;     // :810-817
+    if (e > 0 && (j < e || j >= a.H - e || i < e || i >= a.W - e)) m = 0.f;            // wild :818-830
+    a.mask[n] = m;
+  }
+}
+
+__global__ void gen_rays_kernel(GenRaysArgs a) {
+  const CamRT c = load_cam(a.intrinsic, a.c2w, a.c2w_stride);
   for (int n = blockIdx.x * 256 + threadIdx.x; n < a.N; n += gridDim.x * 256) {
     int j, i;
     if (a.coords) { j = a.coords[2 * n]; i = a.coords[2 * n + 1]; }
     else { j = n / a.W; i = n - j * a.W; }
-    // helpers:296  dirs = [((i+.5)-cx)/fx, (H-(j+.5)-cy)/fy, -1]
-    const float d0 = (((float)i + 0.5f) - cx) / fx;
-    const float d1 = ((float)a.H - ((float)j + 0.5f) - cy) / fy;
-    const float d2 = -1.0f;
-    float d[3];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) d[r] = (d0 * R[r][0] + d1 * R[r][1]) + d2 * R[r][2];   // helpers:298
-    if (a.rays_o) { a.rays_o[3 * n] = T[0]; a.rays_o[3 * n + 1] = T[1]; a.rays_o[3 * n + 2] = T[2]; }
-    if (a.rays_d) { a.rays_d[3 * n] = d[0]; a.rays_d[3 * n + 1] = d[1]; a.rays_d[3 * n + 2] = d[2]; }
-    if (a.rays) {
-      float* o = a.rays + (size_t)n * 11;
-      const float nrm = sqrtf((d[0] * d[0] + d[1] * d[1]) + d[2] * d[2]);     // :128 viewdirs / norm
-      o[0] = T[0]; o[1] = T[1]; o[2] = T[2];
-      o[3] = d[0]; o[4] = d[1]; o[5] = d[2];
-      o[6] = a.near; o[7] = a.far;
-      o[8] = d[0] / nrm; o[9] = d[1] / nrm; o[10] = d[2] / nrm;
-    }
-    const size_t pix = (size_t)j * a.W + i;
-    if (a.image && a.target_s) {
-      a.target_s[3 * n] = a.image[pix * 3]; a.target_s[3 * n + 1] = a.image[pix * 3 + 1];
-      a.target_s[3 * n + 2] = a.image[pix * 3 + 2];
-    }
-    if (a.hyps && a.target_h)
+    gen_ray_item(a, c, n, j, i);
+    if (a.hyps && a.target_h) {
+      const size_t pix = (size_t)j * a.W + i;
       for (int k = 0; k < a.K; ++k) a.target_h[(size_t)k * a.N + n] = a.hyps[(size_t)k * a.H * a.W + pix];
-    if (a.mask) {
-      float m = 1.f;
-      const int c = a.corner_px, e = a.edge_px;
-      if (c > 0 && (j < c || j >= a.H - c) && (i < c || i >= a.W - c)) m = 0.f;     // :810-817
-      if (e > 0 && (j < e || j >= a.H - e || i < e || i >= a.W - e)) m = 0.f;       // wild :818-830
-      a.mask[n] = m;
+    }
+  }
+}
+
+// The per-iteration batch assembly of the training loop (run_scade_scannet.py:946 image pick, :786 pixel pick,
+// :784-821 gathers, :200-219 ray rows) as the ONE launch in front of a graph-captured train step: the N pixels are
+// flat indices pix[n] = row * W + col (a slice of a device-resident permutation of the H*W pixels), the camera and
+// the image / hypothesis planes are those of the step's training view; outputs go straight into the captured step's
+// static input buffers.  The same launch stores the view's index where the captured step reads it (:951-954: which
+// row of the depth scales / shifts) and advances the device-resident optimizer scalars (adam_tick), which is what
+// scade_stage_inputs does for a batch assembled elsewhere.  One work item per ray row and one per (hypothesis, ray):
+// the K gathers of a ray are independent loads, not a serial loop behind the row.
+struct GatherBatchArgs {
+  GenRaysArgs g;
+  const long long* pix;
+  long long* scalar_dst;
+  long long scalar;
+  float* tick[2];
+};
+__global__ void gather_batch_kernel(GatherBatchArgs b) {
+  const GenRaysArgs& a = b.g;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && b.scalar_dst) *b.scalar_dst = b.scalar;
+  if (blockIdx.x == 0 && threadIdx.x == 64 && b.tick[0]) adam_tick(b.tick[0]);
+  if (blockIdx.x == 0 && threadIdx.x == 128 && b.tick[1]) adam_tick(b.tick[1]);
+  const long items = (long)a.N * (1 + (a.hyps && a.target_h ? a.K : 0));
+  const size_t plane = (size_t)a.H * a.W;
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < items; t += (long)gridDim.x * 256) {
+    if (t < a.N) {
+      const int n = (int)t;
+      const long long p = b.pix[n];
+      const int j = (int)(p / a.W), i = (int)(p - (long long)j * a.W);
+      const CamRT c = load_cam(a.intrinsic, a.c2w, a.c2w_stride);
+      gen_ray_item(a, c, n, j, i);
+    } else {
+      const long q = t - a.N;
+      const int k = (int)(q / a.N), n = (int)(q - (long)k * a.N);
+      a.target_h[(size_t)k * a.N + n] = a.hyps[(size_t)k * plane + (size_t)b.pix[n]];
     }
   }
 }
@@ -1696,4 +1749,28 @@ extern "C" int scade_gen_rays(const int* coords, int N, int H, int W, const floa
   const int grid = (N + 255) / 256 < 2048 ? (N + 255) / 256 : 2048;
   hipLaunchKernelGGL(scade::gen_rays_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_gen_rays");
+}
+
+extern "C" int scade_gather_batch(const long long* pix, int N, int H, int W, const float* intrinsic,
+                                  const float* c2w, int c2w_stride, float near, float far, const float* image,
+                                  const float* hyps, int K, int corner_px, int edge_px, float* rays,
+                                  float* target_s, float* target_h, float* mask, long long* scalar_dst,
+                                  long long scalar, float* const* tick_states, void* stream) {
+  SCADE_REQUIRE(N >= 0 && H > 0 && W > 0 && K >= 0, -2, "scade_gather_batch: bad sizes");
+  SCADE_REQUIRE(N == 0 || (pix && intrinsic && c2w && c2w_stride >= 4), -1, "scade_gather_batch: pix / intrinsic / c2w missing");
+  SCADE_REQUIRE(!hyps == !target_h || K == 0, -1, "scade_gather_batch: hyps and target_h go together");
+  scade::GatherBatchArgs b{};
+  b.g = scade::GenRaysArgs{nullptr, intrinsic, c2w, image, hyps, rays, nullptr, nullptr, target_s, target_h,
+                           mask, near, far, N, H, W, K, c2w_stride, corner_px, edge_px};
+  b.pix = pix;
+  b.scalar_dst = scalar_dst;
+  b.scalar = scalar;
+  if (tick_states) { b.tick[0] = tick_states[0]; b.tick[1] = tick_states[1]; }
+  if (N == 0 && !scalar_dst && !b.tick[0] && !b.tick[1]) return 0;
+  const long items = (long)N * (1 + (hyps && target_h ? K : 0));
+  long grid = (items + 255) / 256;
+  if (grid < 1) grid = 1;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(scade::gather_batch_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, b);
+  return scade_check_launch("scade_gather_batch");
 }

@@ -12,9 +12,11 @@ loop and the image writer - so that a scene directory goes in and checkpoints, t
 
 Per iteration i (counted from 1 like the reference, :899-900): pick a training image (numpy stream seeded
 like :831), pick N_rand pixels without replacement (:786), gather ray rows / colours / K hypotheses / corner
-mask for THOSE pixels only (``get_ray_batch``: the reference generates all H*W rays first), one
-``Trainer.step`` (hypotheses * scale + shift, render, three-term loss, backward, gradient all-reduce, both
-Adam updates, staircase learning rate, scale/shift freeze).  With a process group every rank takes its
+mask for THOSE pixels only (the reference generates all H*W rays first), one train step (hypotheses * scale +
+shift, render, three-term loss, backward, gradient all-reduce, both Adam updates, staircase learning rate,
+scale/shift freeze).  By default the iteration is TWO host calls: one batch-gather launch that writes into the
+static inputs of the graph-captured step (``scade_gather_batch``) and one ``graph.replay()``
+(``GraphedTrainer.step_staged``); ``graph=False`` keeps the eager ``get_ray_batch`` + ``Trainer.step`` pair.  With a process group every rank takes its
 contiguous share of the SAME N_rand pixels, so the global batch is the reference's batch.
 """
 from __future__ import annotations
@@ -29,8 +31,9 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import parallel, scene
+from . import ops, parallel, scene
 from . import run_nerf_helpers as H
+from .graphs import GraphedTrainer
 from .train import Trainer, make_scade_nets
 
 
@@ -51,7 +54,8 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
                 wild: bool = False, scale_init: float = 1.0, shift_init: float = 0.0, scales_init=None,
                 shifts_init=None, seed: int = 0, precision: str = "f32", eval_precision: Optional[str] = None,
                 test_chunk: int = 1024 * 16, no_reload: bool = False, log=print, pixel_sampler: str = "device",
-                i_img: int = 0, n_val_images: int = 8, **trainer_kw):
+                i_img: int = 0, n_val_images: int = 8, graph: Optional[bool] = None, loop_warmup: int = 0,
+                **trainer_kw):
     """``data`` = the tuple of scene.load_scene_scannet / load_scene_processed.  Returns a dict with the
     trainer, the loss trace and (rank 0) the test metrics.  ``trainer_kw`` goes to ``Trainer`` (lrate,
     scaleshift_lr, space_carving_weight, is_joint, warm_start_nerf, freeze_ss, allreduce, ...).
@@ -62,7 +66,15 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
     ``np.random.choice(H*W, N_rand, replace=False)`` (:786) - 4 ms of host time per step at 468 x 624, which
     is more than a whole bf16 train step.  ``i_img`` > 0: every i_img iterations the first ``n_val_images``
     validation views (the test views when the scene has no validation split, :854-857) are rendered and their
-    mean metrics logged and kept in the result (:1036-1045)."""
+    mean metrics logged and kept in the result (:1036-1045).
+    ``graph``: the iteration as ONE batch-gather launch + ONE HIP-graph replay (``GraphedTrainer.step_staged``): the
+    launch gathers the N_rand pixels' ray rows / colours / K hypotheses / mask of the picked view from the resident
+    training set straight into the captured step's static buffers, stores the view's index and advances the
+    optimizers' device scalars.  ``None`` = on, except where the step cannot be captured (a process group whose
+    backend is not RCCL; the joint loss over ranks, whose shared draw is a host-side broadcast).  ``False`` = the
+    eager ``Trainer.step`` on a batch from ``get_ray_batch`` (same pixels, same draws, same arithmetic: a test holds
+    the two loops' parameters equal).  ``loop_warmup``: iterations left out of ``ms_per_iteration`` (graph capture,
+    allocator warm-up, clock ramp) - the figure is then the steady-state rate."""
     imgs, depths, valid, poses, Hh, Ww, intr, near, far, i_split, gt_d, gt_v, hyps = data[:13]
     if len(data) >= 15 and scales_init is None:
         scales_init, shifts_init = data[13], data[14]
@@ -76,10 +88,14 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
         depths, valid = np.array(depths, copy=True), np.array(valid, copy=True)   # the caller's arrays stay as loaded
         for ix in (i_test, i_val):
             depths[ix], valid[ix] = gt_d[ix], gt_v[ix]
-    to = lambda a, dt=torch.float32: torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
+    def to(a, dt=torch.float32):
+        """-> device tensor (numpy arrays from the loaders, or tensors a caller already holds on the device)"""
+        if torch.is_tensor(a):
+            return a.to(device=dev, dtype=dt)
+        return torch.as_tensor(np.asarray(a), dtype=dt, device=dev)
     # the whole training set is resident (288 GB of HBM: a ScanNet scene is a few hundred MB)
-    t_img, t_pose, t_intr = to(imgs[i_train]), to(poses[i_train]), to(intr[i_train])
-    t_hyp = to(hyps)                                                        # [N_train, K, H, W, 1]
+    t_img, t_pose, t_intr = to(imgs[i_train]).contiguous(), to(poses[i_train]).contiguous(), to(intr[i_train]).contiguous()
+    t_hyp = to(hyps).contiguous()                                           # [N_train, K, H, W, 1]
     n_train = t_img.shape[0]
 
     np.random.seed(seed)                                                    # :831-833
@@ -113,28 +129,46 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
         ix = i_eval[:n_val_images]
         val = (to(imgs[ix]), to(depths[ix]), to(valid[ix], torch.bool), to(poses[ix]), to(intr[ix]))
     val_trace = []
-    trace, t0, t_aux = [], time.time(), 0.0     # t_aux: validation renders + checkpoint writes, not loop time
+    a, b = parallel.shard_range(N_rand, rank, world)                        # this rank's share of every batch
+    if graph is None:
+        graph = not (world > 1 and (dist.get_backend() != "nccl" or trainer_kw.get("is_joint", False)))
+    gt = gather = None
+    if graph:
+        masked = bool(mask_corners or mask_edges)
+        gt = GraphedTrainer(tr, b - a, t_hyp.shape[1], n_total=N_rand, with_mask=masked)
+        gather = ops.ResidentBatchGather(Hh, Ww, t_img, t_hyp, t_pose, t_intr, near, far, gt.rays, gt.tgt, gt.hyp,
+                                         gt.mask, corner_px=20 if mask_corners else 0, edge_px=10 if mask_edges else 0,
+                                         scalar_dst=gt.img_i, tick_states=(tr.opt.state, tr.opt_ss.state))
+    trace, t0, t_aux, i0 = [], time.time(), 0.0, start     # t_aux: validation renders + checkpoint writes, not loop time
     for i in range(start + 1, num_iterations + 1):
+        if loop_warmup > 0 and i == start + 1 + loop_warmup:
+            torch.cuda.synchronize()
+            t0, t_aux, i0 = time.time(), 0.0, i - 1
         img_i = int(np.random.choice(n_train))                             # :946 (same stream on every rank)
-        a, b = parallel.shard_range(N_rand, rank, world)
         if pixel_sampler == "numpy":
             sel = np.random.choice(Hh * Ww, size=[N_rand], replace=False)  # :786 / helpers:279-283
-            coords = all_coords[torch.from_numpy(sel[a:b])].to(dev)
+            pix, off = torch.from_numpy(sel[a:b]).to(dev), 0
         else:
             if perm is None or cursor + N_rand > Hh * Ww:
                 perm, cursor = torch.randperm(Hh * Ww, generator=g_pix, device=dev), 0
-            coords = all_coords_dev[perm[cursor + a:cursor + b]]
+            pix, off = perm, cursor + a
             cursor += N_rand
-        rays, target_s, target_h, mask = H.get_ray_batch(
-            Hh, Ww, t_intr[img_i], t_pose[img_i], coords, near, far, image=t_img[img_i], hypotheses=t_hyp[img_i],
-            mask_corners=mask_corners, mask_edges=mask_edges)
-        loss, aux = tr.step(rays, target_s, target_h, img_i=img_i, mask=mask, n_total=N_rand)
+        if graph:
+            gather(pix, off, img_i, tick_second=tr.scaleshift_active())
+            loss = gt.step_staged()
+        else:
+            coords = all_coords_dev[pix[off:off + b - a]]
+            rays, target_s, target_h, mask = H.get_ray_batch(
+                Hh, Ww, t_intr[img_i], t_pose[img_i], coords, near, far, image=t_img[img_i], hypotheses=t_hyp[img_i],
+                mask_corners=mask_corners, mask_edges=mask_edges)
+            loss, aux = tr.step(rays, target_s, target_h, img_i=img_i, mask=mask, n_total=N_rand)
         if i % i_print == 0 or i == num_iterations:
             lv = float(loss)
             trace.append((i, lv))
             if rank == 0:
-                log(f"[TRAIN] iter {i}  loss (this rank's term) {lv:.6f}  psnr {float(H.mse2psnr(aux['img_loss'])):.2f}"
-                    f"  {(time.time() - t0 - t_aux) / max(1, i - start) * 1e3:.2f} ms/it")
+                img_loss = gt.terms[0] if graph else aux["img_loss"]
+                log(f"[TRAIN] iter {i}  loss (this rank's term) {lv:.6f}  psnr {float(H.mse2psnr(img_loss)):.2f}"
+                    f"  {(time.time() - t0 - t_aux) / max(1, i - i0) * 1e3:.2f} ms/it")
         if val is not None and i % i_img == 0:                              # :1036-1045
             torch.cuda.synchronize()
             ta = time.time()
@@ -155,7 +189,7 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
             t_aux += time.time() - ta
 
     torch.cuda.synchronize()
-    loop_ms = (time.time() - t0 - t_aux) * 1e3 / max(1, num_iterations - start)
+    loop_ms = (time.time() - t0 - t_aux) * 1e3 / max(1, num_iterations - i0)
 
     # ---- test at the last iteration (:1071-1086): every test image, metrics, images on disk -------------
     kw = render_kwargs_test(tr, near, far, eval_precision)
@@ -164,7 +198,8 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
                                            to(poses[i_test]), Hh, Ww, to(intr[i_test]), kw,
                                            chunk=test_chunk, shard_group=group)
     out = {"trainer": tr, "trace": trace, "test": res["mean"], "iterations": num_iterations,
-           "ms_per_iteration": loop_ms, "val": val_trace}
+           "ms_per_iteration": loop_ms, "val": val_trace, "graphed": bool(graph),
+           "iterations_timed": num_iterations - i0}
     if rank == 0:
         args = SimpleNamespace(ckpt_dir=out_dir, expname=expname, scene_id=scene_id)
         scene.write_images_with_metrics(res["images"], res["mean_metrics"], far, args)
@@ -234,9 +269,10 @@ def main(argv=None):
     p.add_argument("--freeze_ss", type=int, default=400000)
     p.add_argument("--is_joint", action="store_true")
     p.add_argument("--mask_corners", action="store_true")
-    p.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16", "f16"])
+    p.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16", "bf16-s8", "f16"])
     p.add_argument("--eval_precision", default=None, choices=[None, "f32", "f16x3", "bf16", "f16"])
     p.add_argument("--no_reload", action="store_true")
+    p.add_argument("--no_graph", action="store_true", help="eager Trainer.step per iteration instead of the HIP-graph replay")
     a = p.parse_args(argv)
     local = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local)
@@ -254,7 +290,7 @@ def main(argv=None):
                 eval_precision=a.eval_precision, no_reload=a.no_reload, i_img=a.i_img, lrate=a.lrate,
                 scaleshift_lr=a.scaleshift_lr if a.scaleshift_lr is not None else (1e-5 if wild else 1e-7),
                 space_carving_weight=a.space_carving_weight, warm_start_nerf=a.warm_start_nerf,
-                freeze_ss=a.freeze_ss, is_joint=a.is_joint)
+                freeze_ss=a.freeze_ss, is_joint=a.is_joint, graph=False if a.no_graph else None)
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -1,8 +1,9 @@
 """Whole train step (zero_grad, render, 3-term loss, backward, Adam) captured in ONE HIP graph.
 
-The eager step costs ~1.7 ms of host time (about sixty launches plus the autograd engine), which
-is the limit once the device work is short: a 128-ray shard of a strongly-scaled batch, or the
-bf16 path at 1024 rays.  Captured, the step is one ``graph.replay()``.
+The eager step costs ~0.7-0.8 ms of host time (about thirty launches plus the autograd engine; 1.7 ms before
+round 3's launch fusion), which is the limit once the device work is short: a 128-ray shard of a strongly-scaled
+batch, or the 16-bit paths at 1024 rays.  Captured, the step is one ``graph.replay()``; the training loop
+(driver.train_scene) assembles each batch straight into the static buffers with one launch (``step_staged``).
 
 The Trainer's two-stream backward is captured as a fork/join inside the graph, and so is the RCCL
 all-reduce of the gradient bucket when the rays are sharded over ranks (every rank captures and
@@ -70,7 +71,9 @@ class GraphedTrainer:
         self._step_dev = tr.opt.state[13:14]
         self.graph = None
         self.loss = None
+        self.terms = None
         self._captured = None     # (scale/shift update in the graph?, carving term in the graph?)
+        self._key = None          # Philox key baked into the captured launches (None: draws are injected)
 
     def _body(self):
         tr = self.tr
@@ -79,7 +82,10 @@ class GraphedTrainer:
         if self.draws is not None:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
         else:
-            key = (tr.draw_key() + self._resume_offset * 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
+            # the Philox key is a kernel ARGUMENT of the captured launches: recorded, and step() re-captures when
+            # Trainer.reseed_draws() / a new torch seed changed it (eager and graphed steps stay on one stream)
+            self._key = tr.draw_key()
+            key = (self._key + self._resume_offset * 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
             kw = dict(draws=ops.Draws(key, 0, self._step_dev))
         loss, aux = tr.forward_loss(self.rays, self.tgt, self.hyp, img_i=self.img_i, mask=self.mask,
                                     n_total=self.n_total, **kw)
@@ -90,6 +96,8 @@ class GraphedTrainer:
         tr.bucket.end_backward()
         tr.reduce_grads()
         adam_step_pair(tr.opt, tr.opt_ss if tr.scaleshift_active() else None, dev=True, ticked=True)
+        # the three loss terms of the step (:968-983) as static tensors too: the loop's log line reads them
+        self.terms = (aux["img_loss"], aux["carve"], aux["img_loss0"])
         return aux["loss_report"]
 
     def _state(self):
@@ -139,10 +147,25 @@ class GraphedTrainer:
         if self.draws is not None:
             pairs += [(t_rand, self.draws[0]), (u_coarse, self.draws[1]), (cached_u, self.draws[2])]
         # ... and the optimizers' device-resident step scalars advance in the same launch (no tick launch in the graph)
-        ops.stage_inputs(pairs, scalar, tick=[tr.opt.state, tr.opt_ss.state if tr.scaleshift_active() else None])
+        ops.stage_inputs(pairs, scalar, tick=self.tick_states())
+        return self.step_staged()
+
+    def tick_states(self):
+        """The device-resident optimizer scalars the launch in FRONT of a replay advances (``ops.stage_inputs`` /
+        ``ops.gather_batch`` ``tick=``): the networks' Adam and, until the freeze point (:996), the scale / shift one."""
+        tr = self.tr
+        return [tr.opt.state, tr.opt_ss.state if tr.scaleshift_active() else None]
+
+    def step_staged(self):
+        """The step on what the static buffers hold NOW: the caller has written ``rays`` / ``tgt`` / ``hyp`` /
+        ``img_i`` (/ ``mask`` / ``draws``) itself and advanced ``tick_states()`` in that launch - the training
+        loop's fused batch gather (``ops.ResidentBatchGather``) does.  One ``graph.replay()``."""
+        tr = self.tr
         with_ss = tr.scaleshift_active()
-        if self.graph is None or (with_ss, tr.carving_active()) != self._captured:
-            self._capture()      # first step, or the warm-start (:973) / scale-shift freeze point (:996) was crossed
+        if self.graph is None or (with_ss, tr.carving_active()) != self._captured or \
+                (self._key is not None and self._key != tr.draw_key()):
+            self._capture()      # first step, the warm-start (:973) / scale-shift freeze point (:996) was crossed, or
+            #                      the draws were re-seeded (the key is baked into the captured launches)
         self.graph.replay()
         tr.it += 1
         tr.opt.steps += 1

@@ -11,7 +11,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib
-from ._lib import call, check, check_current_device, ptr, stream
+from ._lib import call, check, check_current_device, last_error, load, ptr, stream
 
 Tensor = torch.Tensor
 
@@ -160,9 +160,11 @@ def mlp_pack_step(nets, fmt: str) -> None:
         ptrs = tuple(k[0] for k in key[1:])
         if net.__dict__.get("_pack_checked") != ptrs:
             for p in ps:
-                if not check(p, "mlp_pack_step").is_contiguous():
-                    raise ValueError("mlp_pack_step: parameters must be contiguous")
+                check(p, "mlp_pack_step")
             net.__dict__["_pack_checked"] = ptrs
+        # the layout is NOT implied by the pointer (``w.data = w.data.t()`` keeps it): checked every time (~2 us)
+        if not all(p.is_contiguous() for p in ps):
+            raise ValueError("mlp_pack_step: parameters must be contiguous")
         if code == 0:
             bf = torch.empty(int(lib.scade_mlp_packed_floats()), device=dev, dtype=torch.float32) if need_f else None
             bt = torch.empty(int(lib.scade_mlp_packed_t_floats()), device=dev, dtype=torch.float32) if need_t else None
@@ -746,6 +748,122 @@ def gen_rays(H: int, W: int, intrinsic: Tensor, c2w: Tensor, coords: Optional[Te
          ptr(out["rays_o"]), ptr(out["rays_d"]), ptr(out["target_s"]), ptr(out["target_h"]),
          ptr(out["mask"]), stream())
     return out
+
+
+def gather_batch(pix: Tensor, H: int, W: int, intrinsic: Tensor, c2w: Tensor, near: float, far: float,
+                 image: Optional[Tensor], hyps: Optional[Tensor], rays: Tensor, target_s: Optional[Tensor],
+                 target_h: Optional[Tensor], mask: Optional[Tensor] = None, corner_px: int = 0, edge_px: int = 0,
+                 scalar=None, tick=None) -> None:
+    """scade_gather_batch: the batch of ONE training iteration (run_scade_scannet.py:772-827, :200-219) gathered
+    straight INTO the given buffers - the static inputs of a graph-captured step - in one launch that also stores
+    ``scalar = (int64 device tensor, value)`` (the view's index) and advances the ``tick`` optimizer states, like
+    ``stage_inputs``.  ``pix`` [N] int64 flat pixel indices (row * W + col) on the device; ``intrinsic`` [4],
+    ``c2w`` [>= 3, 4], ``image`` [H, W, 3], ``hyps`` [K, H, W(, 1)] of the step's view.  Nothing is allocated."""
+    if pix.dtype != torch.int64 or not pix.is_cuda or not pix.is_contiguous():
+        raise ValueError("gather_batch: pix must be a contiguous int64 device tensor")
+    N = pix.numel()
+    check(intrinsic, "gather_batch: intrinsic")
+    check(c2w, "gather_batch: c2w")
+    if intrinsic.numel() < 4 or not intrinsic.is_contiguous():
+        raise ValueError("gather_batch: intrinsic = contiguous [fx, fy, cx, cy]")
+    if c2w.dim() != 2 or c2w.shape[0] < 3 or c2w.shape[1] < 4 or c2w.stride(1) != 1:
+        raise ValueError("gather_batch: c2w must be [>= 3, >= 4] with unit column stride")
+    K = 0
+    outs = [(rays, (N, 11), "rays"), (target_s, (N, 3), "target_s"), (mask, (N,), "mask")]
+    if image is not None:
+        check(image, "gather_batch: image")
+        if tuple(image.shape) != (H, W, 3) or not image.is_contiguous():
+            raise ValueError("gather_batch: image must be contiguous [H, W, 3]")
+    if (hyps is None) != (target_h is None):
+        raise ValueError("gather_batch: hyps and target_h go together")
+    if hyps is not None:
+        check(hyps, "gather_batch: hyps")
+        K = hyps.shape[0]
+        if hyps.numel() != K * H * W or not hyps.is_contiguous():
+            raise ValueError("gather_batch: hyps must be contiguous [K, H, W] or [K, H, W, 1]")
+        if target_h.numel() != K * N:
+            raise ValueError("gather_batch: target_h must hold [K, N] floats")
+        outs.append((target_h, None, "target_h"))
+    for t, shape, what in outs:
+        if t is None:
+            continue
+        check(t, "gather_batch: " + what)
+        if not t.is_contiguous() or (shape is not None and tuple(t.shape) != shape):
+            raise ValueError(f"gather_batch: {what} must be contiguous {shape}")
+    sd, sv = (None, 0)
+    if scalar is not None:
+        if scalar[0].dtype != torch.int64 or not scalar[0].is_cuda:
+            raise ValueError("gather_batch: the scalar destination must be an int64 device tensor")
+        sd, sv = scalar[0].data_ptr(), int(scalar[1])
+    ticks = None
+    if tick is not None and any(t is not None for t in tick):
+        for t in tick:
+            if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() >= 16 and t.is_contiguous()):
+                raise ValueError("gather_batch: tick entries are the float32[16] device states of FusedAdam")
+        t2 = (list(tick) + [None])[:2]
+        ticks = ctypes.cast((ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in t2]), ctypes.c_void_p)
+    call("scade_gather_batch", ptr(pix), N, int(H), int(W), ptr(intrinsic), ptr(c2w), c2w.stride(0), float(near),
+         float(far), ptr(image), ptr(hyps), K, int(corner_px), int(edge_px), ptr(rays), ptr(target_s), ptr(target_h),
+         ptr(mask), sd, sv, ticks, stream())
+
+
+class ResidentBatchGather:
+    """``gather_batch`` for a training set that is RESIDENT on the device, prepared once: ``images`` [V, H, W, 3],
+    ``hyps`` [V, K, H, W(, 1)], ``poses`` [V, >= 3, 4], ``intrinsics`` [V, 4] (V training views) and the output
+    buffers of a captured step are validated here; ``__call__(pix, offset, view)`` is then pointer arithmetic and
+    ONE library call (the loop's host cost per iteration: ~10 us).  ``pix`` int64 device tensor, the batch =
+    ``pix[offset : offset + N]``.  ``scalar_dst`` receives ``view``; ``tick_states`` = (state, state | None): the
+    FusedAdam device states the launch advances (``tick_second=False`` at call time leaves the second alone: the
+    scale / shift optimizer after its freeze point)."""
+
+    def __init__(self, H, W, images, hyps, poses, intrinsics, near, far, rays, target_s, target_h, mask=None,
+                 corner_px=0, edge_px=0, scalar_dst=None, tick_states=None):
+        V = images.shape[0]
+        for t, what in ((images, "images"), (hyps, "hyps"), (poses, "poses"), (intrinsics, "intrinsics")):
+            check(t, "ResidentBatchGather: " + what)
+            if not t.is_contiguous() or t.shape[0] != V:
+                raise ValueError(f"ResidentBatchGather: {what} must be contiguous with one entry per view")
+        if tuple(images.shape[1:]) != (H, W, 3) or hyps.numel() != V * hyps.shape[1] * H * W:
+            raise ValueError("ResidentBatchGather: images [V,H,W,3] / hyps [V,K,H,W] expected")
+        if poses.dim() != 3 or poses.shape[1] < 3 or poses.shape[2] != 4 or intrinsics.shape[1:] != (4,):
+            raise ValueError("ResidentBatchGather: poses [V, >= 3, 4] / intrinsics [V, 4] expected")
+        self.N, self.K, self.V = rays.shape[0], hyps.shape[1], V
+        # one validated call against view 0 (shapes of the outputs, dtypes, devices); nothing is launched for N = 0 ...
+        gather_batch(torch.zeros(self.N, dtype=torch.int64, device=rays.device), H, W, intrinsics[0], poses[0], near,
+                     far, images[0], hyps[0], rays, target_s, target_h, mask, corner_px, edge_px)
+        if scalar_dst is not None and (scalar_dst.dtype != torch.int64 or not scalar_dst.is_cuda):
+            raise ValueError("ResidentBatchGather: the scalar destination must be an int64 device tensor")
+        self._keep = (images, hyps, poses, intrinsics, rays, target_s, target_h, mask, scalar_dst, tick_states)
+        self._img = (images.data_ptr(), H * W * 3 * 4)
+        self._hyp = (hyps.data_ptr(), self.K * H * W * 4)
+        self._pose = (poses.data_ptr(), poses.shape[1] * 4 * 4)
+        self._intr = (intrinsics.data_ptr(), 16)
+        self._fixed_a = (self.N, int(H), int(W))
+        self._fixed_b = (4, float(near), float(far))
+        self._fixed_c = (self.K, int(corner_px), int(edge_px), ptr(rays), ptr(target_s), ptr(target_h), ptr(mask),
+                         None if scalar_dst is None else scalar_dst.data_ptr())
+        self._ticks = {True: None, False: None}
+        if tick_states is not None and any(t is not None for t in tick_states):
+            t2 = (list(tick_states) + [None])[:2]
+            for t in t2:
+                if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() >= 16 and t.is_contiguous()):
+                    raise ValueError("ResidentBatchGather: tick_states are the float32[16] device states of FusedAdam")
+            p2 = [None if t is None else t.data_ptr() for t in t2]
+            self._tick_arrs = ((ctypes.c_void_p * 2)(*p2), (ctypes.c_void_p * 2)(p2[0], None))
+            self._ticks = {True: ctypes.cast(self._tick_arrs[0], ctypes.c_void_p),
+                           False: ctypes.cast(self._tick_arrs[1], ctypes.c_void_p)}
+        self._fn = getattr(load(), "scade_gather_batch")
+
+    def __call__(self, pix: Tensor, offset: int, view: int, tick_second: bool = True) -> None:
+        if not 0 <= view < self.V:
+            raise IndexError(f"ResidentBatchGather: view {view} outside [0, {self.V})")
+        if pix.dtype != torch.int64 or offset < 0 or offset + self.N > pix.numel():
+            raise ValueError("ResidentBatchGather: pix[offset : offset + N] must lie inside an int64 tensor")
+        rc = self._fn(pix.data_ptr() + 8 * offset, *self._fixed_a, self._intr[0] + view * self._intr[1],
+                      self._pose[0] + view * self._pose[1], *self._fixed_b, self._img[0] + view * self._img[1],
+                      self._hyp[0] + view * self._hyp[1], *self._fixed_c, view, self._ticks[bool(tick_second)], stream())
+        if rc != 0:
+            raise RuntimeError(f"scade_gather_batch failed (code {rc}): {last_error()}")
 
 
 # ---------------------------------------------------------------------------

@@ -71,71 +71,70 @@ def load_scene_processed(basedir, cimle_dir, num_hypothesis=20, train_json="tran
     return _load_scene(basedir, cimle_dir, num_hypothesis, train_json, init_scales, scales_dir, gt_init, True)
 
 
-def _load_scene(basedir, cimle_dir, num_hypothesis, train_json, init_scales, scales_dir, gt_init, processed):
-    splits = ['train', 'val', 'test', 'video']
-    all_imgs, all_depths, all_valid, all_poses, all_intr = [], [], [], [], []
-    counts, filenames = [0], []
-    near = far = depth_scaling_factor = None
-    Hh = Ww = None
-    for s in splits:
-        if not os.path.exists(os.path.join(basedir, f'transforms_{s}.json')):
-            counts.append(counts[-1])
-            continue
-        jf = os.path.join(basedir, train_json if s == "train" else f'transforms_{s}.json')
-        with open(jf) as fp:
-            meta = json.load(fp)
-        if 'train' in s:
-            near, far = float(meta['near']), float(meta['far'])
-            depth_scaling_factor = float(meta['depth_scaling_factor'])
-        imgs, depths, valids, poses, intr = [], [], [], [], []
-        for frame in meta['frames']:
-            if len(frame['file_path']) != 0 or len(frame['depth_file_path']) != 0:
-                depth_file = frame['depth_file_path']
-                if processed:
-                    depth_file = depth_file.split(".")[0] + ".png"
-                img, depth = read_files(basedir, frame['file_path'], depth_file)
-                if depth.ndim == 2:
-                    depth = np.expand_dims(depth, -1)
-                valids.append(depth[:, :, 0] > 0.5)
-                depths.append((depth / depth_scaling_factor).astype(np.float32))
-                filenames.append(frame['file_path'])
-                imgs.append(img)
-                Hh, Ww = img.shape[:2]
-            poses.append(np.array(frame['transform_matrix']))
-            intr.append(np.array((frame['fx'], frame['fy'], frame['cx'], frame['cy'])))
-        counts.append(counts[-1] + len(poses))
-        if imgs:
-            all_imgs.append(np.array(imgs)); all_depths.append(np.array(depths)); all_valid.append(np.array(valids))
-        all_poses.append(np.array(poses).astype(np.float32))
-        all_intr.append(np.array(intr).astype(np.float32))
-    i_split = [np.arange(counts[i], counts[i + 1]) for i in range(len(splits))]
-    imgs = np.concatenate(all_imgs, 0)
-    depths = np.concatenate(all_depths, 0)
-    valid_depths = np.concatenate(all_valid, 0)
-    poses = np.concatenate(all_poses, 0)
-    intrinsics = np.concatenate(all_intr, 0)
-    gt_depths, gt_valid_depths = (None, None) if processed else \
-        load_ground_truth_depth(basedir, filenames, (Hh, Ww), depth_scaling_factor)
+SPLITS = ("train", "val", "test", "video")
 
+
+def _frame_table(basedir, train_json, processed):
+    """The scene's ``transforms_<split>.json`` files flattened into ONE table with a row per frame, in split order:
+    split id, pose, intrinsics, and the two file names ('' for a frame that has none - the video poses).  The header
+    values near / far / depth_scaling_factor are the training file's (data/load_scene.py:261-294)."""
+    rows, header = [], {}
+    for sid, split in enumerate(SPLITS):
+        if not os.path.exists(os.path.join(basedir, f"transforms_{split}.json")):
+            continue
+        with open(os.path.join(basedir, train_json if split == "train" else f"transforms_{split}.json")) as fp:
+            meta = json.load(fp)
+        if split == "train":
+            header = {k: float(meta[k]) for k in ("near", "far", "depth_scaling_factor")}
+        for fr in meta["frames"]:
+            rgb, dep = fr["file_path"], fr["depth_file_path"]
+            if processed and (rgb or dep):
+                dep = dep.split(".")[0] + ".png"                       # :423: always the .png beside the json's name
+            rows.append((sid, fr["transform_matrix"], (fr["fx"], fr["fy"], fr["cx"], fr["cy"]), rgb, dep))
+    return rows, header
+
+
+def _load_scene(basedir, cimle_dir, num_hypothesis, train_json, init_scales, scales_dir, gt_init, processed):
+    """Both loaders: the frame table first, then every array of the reference's return tuple assembled in one pass
+    each - poses / intrinsics by one ``np.asarray`` over the table's columns, the split index lists from the split-id
+    column, images / depth maps read frame by frame into arrays allocated once at their final size."""
+    rows, header = _frame_table(basedir, train_json, processed)
+    near, far, dsf = header["near"], header["far"], header["depth_scaling_factor"]
+    sid = np.asarray([r[0] for r in rows], dtype=np.int64)
+    poses = np.asarray([r[1] for r in rows], dtype=np.float32)
+    intrinsics = np.asarray([r[2] for r in rows], dtype=np.float32)
+    i_split = [np.flatnonzero(sid == k) for k in range(len(SPLITS))]
+    # frames that name files (every split but the video poses), in table order = the order of the image arrays
+    with_files = [r for r in rows if r[3] or r[4]]
+    filenames = [r[3] for r in with_files]
+    imgs = depths = valid_depths = None
+    for n, r in enumerate(with_files):
+        img, depth = read_files(basedir, r[3], r[4])
+        depth = depth[..., None] if depth.ndim == 2 else depth
+        if imgs is None:
+            imgs = np.empty((len(with_files),) + img.shape, np.float32)
+            depths = np.empty((len(with_files),) + depth.shape, np.float32)
+            valid_depths = np.empty((len(with_files),) + depth.shape[:2], bool)
+        imgs[n], depths[n], valid_depths[n] = img, depth / dsf, depth[:, :, 0] > 0.5
+    Hh, Ww = imgs.shape[1:3]
+    gt_depths, gt_valid_depths = (None, None) if processed else load_ground_truth_depth(basedir, filenames, (Hh, Ww), dsf)
+
+    # K depth hypotheses per training view: train/leres_cimle/<cimle_dir>/<image id>_<j>.npy, clipped to [near, far]
+    # (data/load_scene.py:319-348) -> [N_train, K, H, W, 1]
+    stems = [filenames[idx].split("/")[-1].split(".")[0] for idx in i_split[0]]
     leres_dir = os.path.join(basedir, "train", "leres_cimle", cimle_dir)
-    hyps = []
-    for idx in i_split[0]:
-        img_id = filenames[idx].split("/")[-1].split(".")[0]
-        cur = [np.expand_dims(np.load(os.path.join(leres_dir, f"{img_id}_{j}.npy")).astype(np.float32), -1)
-               for j in range(num_hypothesis)]
-        hyps.append(np.array(cur))
-    all_depth_hypothesis = np.clip(np.array(hyps), near, far)          # [N_train, K, H, W, 1]
-    ret = [imgs, depths, valid_depths, poses, Hh, Ww, intrinsics, near, far, i_split, gt_depths,
-           gt_valid_depths, all_depth_hypothesis]
+    hyp = np.empty((len(stems), num_hypothesis, Hh, Ww, 1), np.float32)
+    for v, stem in enumerate(stems):
+        for j in range(num_hypothesis):
+            hyp[v, j, :, :, 0] = np.load(os.path.join(leres_dir, f"{stem}_{j}.npy"))
+    np.clip(hyp, near, far, out=hyp)
+    ret = (imgs, depths, valid_depths, poses, Hh, Ww, intrinsics, near, far, i_split, gt_depths, gt_valid_depths, hyp)
     if init_scales:
         sdir = os.path.join(basedir, "train", "scale_shift_inits", scales_dir)
-        sc, sh = [], []
-        for idx in i_split[0]:
-            img_id = filenames[idx].split("/")[-1].split(".")[0]
-            ss = np.load(os.path.join(sdir, img_id + ("_gtinit.npy" if gt_init else "_sfminit.npy"))).astype(np.float32)
-            sc.append(ss[0]); sh.append(ss[1])
-        ret += [np.array(sc), np.array(sh)]
-    return tuple(ret)
+        ss = np.asarray([np.load(os.path.join(sdir, stem + ("_gtinit.npy" if gt_init else "_sfminit.npy")))
+                         for stem in stems], dtype=np.float32)
+        ret += (ss[:, 0], ss[:, 1])
+    return ret
 
 
 def scene_bbox(Hh, Ww, intrinsics, poses, i_train, far, device):

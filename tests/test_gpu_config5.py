@@ -18,12 +18,15 @@ def _psnr(a, b):
     return float(-10 * torch.log10(torch.mean((a.double().cpu() - b.double().cpu()) ** 2) + 1e-30))
 
 
-def test_config5_render_4096_rays_bf16(dev):
+@pytest.mark.parametrize("prec", ["bf16", "f16x3"])
+def test_config5_render_4096_rays(dev, prec):
+    """The 4096-ray test render on the 16-bit MFMA path (config 5's) and on the split-precision path, which holds
+    the exact path's bar (PSNR against the fp32 reference > 80 dB where bf16 is held to 30 - 35 dB)."""
     rays = O.synthetic_rays(N5, seed=55)
     pc, pf = O.nerf_init(56), O.nerf_init(57)
     bbc, bbs = torch.zeros(3), torch.tensor(0.2)
     coarse, fine, query = build(dev, pc, pf, bbc, bbs)
-    coarse.inference_precision = fine.inference_precision = "bf16"
+    coarse.inference_precision = fine.inference_precision = prec
     kw = dict(N_importance=128, network_fine=fine, perturb=0., retraw=True)
     with torch.no_grad():
         ret = S.render_rays(rays.to(dev), True, coarse, query, 64, **kw)
@@ -49,14 +52,22 @@ def test_config5_render_4096_rays_bf16(dev):
         assert torch.equal(torch.nan_to_num(part[k]), torch.nan_to_num(ret[k][:256])), k
     # ---- against the exact reference on the slice: bf16 operand rounding, PSNR-class agreement
     assert torch.equal(part["z_vals0"].cpu(), want["z_vals0"])
-    assert _psnr(part["rgb0"], want["rgb0"]) > 35 and _psnr(part["rgb_map"], want["rgb_map"]) > 30
-    assert rel_l2(part["depth0"], want["depth0"]) < 2e-2 and rel_l2(part["depth_map"], want["depth_map"]) < 5e-2
+    if prec == "f16x3":
+        assert _psnr(part["rgb0"], want["rgb0"]) > 100 and _psnr(part["rgb_map"], want["rgb_map"]) > 80
+        assert rel_l2(part["depth0"], want["depth0"]) < 1e-5 and rel_l2(part["depth_map"], want["depth_map"]) < 1e-3
+    else:
+        assert _psnr(part["rgb0"], want["rgb0"]) > 35 and _psnr(part["rgb_map"], want["rgb_map"]) > 30
+        assert rel_l2(part["depth0"], want["depth0"]) < 2e-2 and rel_l2(part["depth_map"], want["depth_map"]) < 5e-2
 
 
-def test_config5_train_step_4096_rays_k40_bf16(dev):
+@pytest.mark.parametrize("N5,prec", [(4096, "bf16"), (4096, "bf16-s8"), (512, "bf16-s8"), (4096, "f16x3")])
+def test_config5_train_step_k40(dev, N5, prec):
     """One Trainer.step at the config-5 shape (wild variant: mask on all three loss terms) against the
     exact fp32 loss of the oracle on a 256-ray slice with the same draws; gradients finite; a second
-    step lowers the loss on the same batch."""
+    step lowers the loss on the same batch.  4096 rays = the whole batch on one GPU (786,432 fine-network points:
+    the 8-bit weight gradient's balanced persistent plan at its full size); 512 rays = its per-GPU shard on 8 GPUs
+    (run_scade_wild.py --N_rand 4096 --num_hypothesis 40).  "bf16-s8" = the format the step is benchmarked in
+    (bf16 arithmetic, e5m2 / e4m3 saved rows); "f16x3" = the fast path that keeps the exact bar."""
     from scade_amd.train import Trainer
     from test_gpu_ops import make_net
     g = torch.Generator().manual_seed(58)
@@ -68,7 +79,7 @@ def test_config5_train_step_4096_rays_k40_bf16(dev):
                  cached_u=torch.rand(N5, 128, generator=g))
     pc, pf = O.nerf_init(60), O.nerf_init(61)
     bbc, bbs = torch.zeros(3), torch.tensor(0.2)
-    tr = Trainer(make_net(pc, dev), make_net(pf, dev), bbc, bbs, n_images=1, precision="bf16", mask_mode="wild",
+    tr = Trainer(make_net(pc, dev), make_net(pf, dev), bbc, bbs, n_images=1, precision=prec, mask_mode="wild",
                  scaleshift_lr=1e-5)
     dd = {k: v.to(dev) for k, v in draws.items()}
     loss, aux = tr.step(rays.to(dev), tgt.to(dev), hyp.to(dev), mask=mask.to(dev), **dd)
@@ -89,10 +100,11 @@ def test_config5_train_step_4096_rays_k40_bf16(dev):
            "img0": S.img2mse_masked(r["rgb0"].detach(), tgt[sl].to(dev), m.to(dev)),
            "carve": S.compute_space_carving_loss(r["pred_hyp"].detach().contiguous(), hyp[:, sl].to(dev).contiguous(),
                                                  mask=m.to(dev))}
+    tol = 1e-3 if prec == "f16x3" else 2e-2
     for k in want:
-        assert abs(float(got[k]) - float(want[k])) <= 2e-2 * abs(float(want[k])), (k, float(got[k]), float(want[k]))
+        assert abs(float(got[k]) - float(want[k])) <= tol * abs(float(want[k])), (k, float(got[k]), float(want[k]))
     psnr_gap = abs(float(S.mse2psnr(got["img"])) - float(O.mse2psnr(want["img"])))
-    assert psnr_gap < 0.05, f"PSNR(bf16) vs PSNR(reference fp32) on the slice: {psnr_gap:.4f} dB"
+    assert psnr_gap < 0.05, f"PSNR({prec}) vs PSNR(reference fp32) on the slice: {psnr_gap:.4f} dB"
     # the same batch again: Adam moved the parameters downhill
     loss2, _ = tr.step(rays.to(dev), tgt.to(dev), hyp.to(dev), mask=mask.to(dev), **dd)
     assert float(loss2) < float(loss)

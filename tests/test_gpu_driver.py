@@ -82,3 +82,114 @@ def test_driver_trains_checkpoints_resumes_and_writes_test_images(dev, tmp_path)
     # the reference's host-side pixel stream (np.random.choice without replacement) is available too
     res3 = driver.train_scene(data, str(tmp_path / "ckpt_np"), "t", "tiny", num_iterations=20, pixel_sampler="numpy", **kw)
     assert np.isfinite(res3["trace"][-1][1])
+
+
+def _memory_scene(Hh=40, Ww=56, n_train=4, K=6, seed=3):
+    """A scene tuple held in memory (what scene.load_scene_scannet returns), smooth images + noisy hypotheses."""
+    rng = np.random.RandomState(seed)
+    yy, xx = np.meshgrid(np.linspace(0, 1, Hh), np.linspace(0, 1, Ww), indexing="ij")
+    n = n_train + 1
+    imgs = np.stack([np.stack([xx, yy, 0.5 + 0.3 * np.sin(3 * xx + i)], -1) for i in range(n)]).astype(np.float32)
+    dep = (1.0 + 1.5 * xx + 0.5 * yy).astype(np.float32)
+    depths = np.repeat(dep[None, :, :, None], n, 0)
+    valid = np.ones((n, Hh, Ww), bool)
+    poses = np.repeat(np.eye(4, dtype=np.float32)[None], n, 0)
+    poses[:, 0, 3] = np.linspace(0, 0.3, n)
+    poses[:, :3, :3] += 0.01 * rng.randn(n, 3, 3).astype(np.float32)
+    intr = np.repeat(np.array([[48.0, 47.0, Ww / 2, Hh / 2]], np.float32), n, 0)
+    hyps = np.clip(dep[None, None, :, :, None] + 0.2 * rng.randn(n_train, K, Hh, Ww, 1).astype(np.float32), 0.1, 5.0)
+    i_split = [np.arange(n_train), np.arange(0), np.arange(n_train, n), np.arange(0)]
+    return (imgs, depths, valid, poses, Hh, Ww, intr, 0.1, 5.0, i_split, None, None, hyps)
+
+
+@pytest.mark.parametrize("masked", [False, True])
+def test_gather_batch_writes_what_get_ray_batch_returns(dev, masked):
+    """scade_gather_batch (the launch in front of a captured step) against scade_gen_rays on the same pixels: same
+    bits in every buffer, the view index stored, both optimizer states advanced by exactly one tick."""
+    from scade_amd import ops
+    from scade_amd import run_nerf_helpers as H
+    data = _memory_scene()
+    imgs, poses, Hh, Ww, intr, hyps = data[0], data[3], data[4], data[5], data[6], data[12]
+    V, K, N = hyps.shape[0], hyps.shape[1], 96
+    t_img = torch.as_tensor(imgs[:V], device=dev).contiguous()
+    t_hyp = torch.as_tensor(hyps, device=dev).contiguous()
+    t_pose = torch.as_tensor(poses[:V], device=dev).contiguous()
+    t_intr = torch.as_tensor(intr[:V], device=dev).contiguous()
+    perm = torch.randperm(Hh * Ww, device=dev, generator=torch.Generator(device=dev).manual_seed(5))
+    rays, tgt, th = torch.zeros(N, 11, device=dev), torch.zeros(N, 3, device=dev), torch.zeros(K, N, 1, device=dev)
+    mask = torch.full((N,), -1.0, device=dev) if masked else None
+    idx = torch.full((1,), -7, device=dev, dtype=torch.long)
+    st = [torch.zeros(16, device=dev), torch.zeros(16, device=dev)]
+    for s_, lr in zip(st, (5e-4, 1e-7)):
+        s_[1], s_[2], s_[3], s_[4], s_[5], s_[6], s_[7] = lr, 0.1, 400000.0, 0.9, 0.999, 1e-8, 1.0
+    g = ops.ResidentBatchGather(Hh, Ww, t_img, t_hyp, t_pose, t_intr, 0.1, 5.0, rays, tgt, th, mask,
+                                corner_px=6 if masked else 0, edge_px=2 if masked else 0, scalar_dst=idx, tick_states=st)
+    off, view = 37, 2
+    g(perm, off, view)
+    pix = perm[off:off + N]
+    coords = torch.stack([pix // Ww, pix % Ww], -1)
+    # get_ray_batch's masks are the reference's fixed widths (20 / 10 px); the raw operator takes any
+    want = ops.gen_rays(Hh, Ww, t_intr[view], t_pose[view], coords=coords.to(torch.int32), near=0.1, far=5.0,
+                        image=t_img[view], hyps=t_hyp[view].reshape(K, Hh, Ww), corner_px=6 if masked else 0,
+                        edge_px=2 if masked else 0, want_rows=True, want_mask=masked)
+    assert torch.equal(rays, want["rays"]) and torch.equal(tgt, want["target_s"])
+    assert torch.equal(th[..., 0], want["target_h"])
+    if masked:
+        assert torch.equal(mask, want["mask"]) and 0 < float(mask.sum()) < N
+    assert int(idx) == view
+    for s_ in st:
+        assert float(s_[0]) == 1.0 and float(s_[13]) == 0.0 and abs(float(s_[9]) - 0.1) < 1e-6
+    g(perm, off, view, tick_second=False)                   # the scale / shift optimizer past its freeze point
+    assert float(st[0][0]) == 2.0 and float(st[1][0]) == 1.0
+    with pytest.raises(IndexError):
+        g(perm, off, V)
+    with pytest.raises(ValueError):
+        g(perm, Hh * Ww - N + 1, 0)
+    # the validated one-shot form writes the same bits
+    r2, t2, h2 = torch.zeros_like(rays), torch.zeros_like(tgt), torch.zeros_like(th)
+    ops.gather_batch(pix.contiguous(), Hh, Ww, t_intr[view], t_pose[view], 0.1, 5.0, t_img[view], t_hyp[view], r2, t2, h2)
+    assert torch.equal(r2, rays) and torch.equal(t2, tgt) and torch.equal(h2, th)
+    with pytest.raises(ValueError):
+        ops.gather_batch(pix.to(torch.int32), Hh, Ww, t_intr[view], t_pose[view], 0.1, 5.0, t_img[view], t_hyp[view], r2, t2, h2)
+
+
+@pytest.mark.parametrize("precision,masked", [("f32", False), ("f32", True), ("bf16-s8", False)])
+def test_graphed_driver_loop_equals_the_eager_loop(dev, tmp_path, precision, masked):
+    """driver.train_scene with the iteration as gather launch + graph replay against the eager get_ray_batch +
+    Trainer.step loop: same views, pixels, draws and arithmetic -> the parameters, the scale / shift rows and the
+    logged losses after 20 iterations agree to 1e-6 (run_scade_scannet.py:942-997)."""
+    from scade_amd import driver
+    data = _memory_scene()
+    res = {}
+    for mode in (True, False):
+        torch.manual_seed(0)
+        res[mode] = driver.train_scene(data, str(tmp_path / f"ck{int(mode)}"), "t", "mem", num_iterations=20, N_rand=128,
+                                       i_weights=10 ** 9, i_print=5, scaleshift_lr=1e-4, test_chunk=1024, precision=precision,
+                                       mask_corners=masked, log=lambda *_: None, graph=mode, no_reload=True)
+    assert res[True]["graphed"] and not res[False]["graphed"]
+    a, b = res[True]["trainer"], res[False]["trainer"]
+    assert a.it == b.it == 20
+    pa, pb = a.bucket.data, b.bucket.data
+    tol = 1e-6 if precision == "f32" else 1e-5
+    assert float((pa - pb).abs().max()) <= tol * max(1.0, float(pb.abs().max())), float((pa - pb).abs().max())
+    assert not torch.equal(a.depth_scales, torch.ones_like(a.depth_scales)), "scale rows were stepped on"
+    for (ia, la), (ib, lb) in zip(res[True]["trace"], res[False]["trace"]):
+        assert ia == ib and abs(la - lb) <= 1e-5 * abs(lb) + 1e-7, (ia, la, lb)
+    assert abs(res[True]["test"]["psnr"] - res[False]["test"]["psnr"]) < 1e-3
+
+
+def test_graphed_driver_crosses_the_freeze_point_and_resumes(dev, tmp_path):
+    """The captured loop re-captures where the reference's loop changes shape: scale / shift frozen from iteration
+    freeze_ss on (:996) - their rows stop moving, the networks keep training - and a resumed run continues the
+    staircase / draw streams at the checkpoint's step."""
+    from scade_amd import driver
+    data = _memory_scene()
+    kw = dict(N_rand=64, i_weights=8, i_print=4, scaleshift_lr=1e-3, test_chunk=1024, log=lambda *_: None, freeze_ss=6)
+    r = driver.train_scene(data, str(tmp_path / "ck"), "t", "mem", num_iterations=8, no_reload=True, **kw)
+    tr = r["trainer"]
+    assert r["graphed"] and tr.it == 8 and tr.opt.steps == 8 and tr.opt_ss.steps == 5, (tr.opt.steps, tr.opt_ss.steps)
+    ss8 = tr.depth_scales.detach().clone()
+    os.rename(os.path.join(str(tmp_path / "ck"), "t", "000008.tar"), os.path.join(str(tmp_path / "ck"), "t", "008000.tar"))
+    r2 = driver.train_scene(data, str(tmp_path / "ck"), "t", "mem", num_iterations=12, **kw)
+    assert r2["trainer"].it == 12 and torch.equal(r2["trainer"].depth_scales, ss8), "frozen rows restored and left alone"
+    assert np.isfinite(r2["trace"][-1][1])

@@ -544,3 +544,128 @@ def test_bf16_with_8bit_saved_rows(dev, P):
     # sum, so the zero-mean e5m2 rounding of the operands hardly averages out; uniform batches average far more)
     assert torch.isfinite(g8).all()
     assert rel_l2(g8, g16) < 0.09, rel_l2(g8, g16)
+
+
+def test_bf16_s8_weight_gradient_at_config5_size(dev):
+    """The 8-bit weight gradient at the FULL size of BASELINE config 5's fine launch (4096 rays x 192 samples =
+    786,432 points): the balanced persistent plan cuts every job into segments per workgroup there, and a segment
+    boundary that dropped or doubled a stage of 64 points would pass every small-P test.  One ring job (a hidden
+    layer: pts_linears.3) and the embedding job (pts_linears.0, bf8 x fp8 operands) against the fp64 contraction of
+    the kernel's OWN 8-bit rows, as test_bf16_with_8bit_saved_rows does at small P; every tensor finite."""
+    import math
+    from scade_amd import ops, _lib
+    from scade_amd._lib import call, ptr, stream
+    P = 4096 * 192
+    params = O.nerf_init(5)
+    net = make_net(params, dev)
+    g = torch.Generator(device=dev).manual_seed(21)
+    x = torch.cat([torch.rand(P, 3, device=dev, generator=g) * 2 - 1, torch.randn(P, 3, device=dev, generator=g)], -1)
+    x = torch.cat([S.get_embedder(9, 0)[0](x[:, :3]), torch.nn.functional.normalize(x[:, 3:], dim=-1)], -1).contiguous()
+    G = torch.randn(P, 4, device=dev, generator=g) * 1e-4
+    lib = _lib.load()
+    acts = ops.mlp_acts_lp_alloc(P, dev)
+    ops.mlp_fwd_lp(net.packed_lp(True), 2, x, None, None, acts)
+    ws = torch.zeros(int(lib.scade_mlp_bwd_lp_workspace_bytes(P)), device=dev, dtype=torch.uint8)
+    grad = torch.empty(ops.N_PARAM_FLOATS, device=dev)
+    call("scade_mlp_bwd_lp", None, ptr(net.packed_t_lp(True)), 2, ptr(acts), ptr(G), P, ptr(ws), ptr(grad), stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(grad).all()
+    slot8 = lambda t, s: t[s * P * 512:s * P * 512 + P * 256].view(torch.float8_e5m2).view(P, 256)
+    S_ = 2.0 ** min(6 - math.frexp(float(G.abs().max()))[1], 96)
+    off, flat = 0, {}
+    for name in ops.PARAM_ORDER:
+        n = math.prod(ops.PARAM_SHAPES[name])
+        flat[name] = grad[off:off + n].view(ops.PARAM_SHAPES[name])
+        off += n
+
+    def contract(dz8, in8):
+        """dz^T in in fp64, in slices of 65,536 points (a [P, 256] fp64 copy of both operands is 3 GB)"""
+        acc = torch.zeros(dz8.shape[1], in8.shape[1], device=dev, dtype=torch.float64)
+        col = torch.zeros(dz8.shape[1], device=dev, dtype=torch.float64)
+        for a in range(0, P, 65536):
+            d = dz8[a:a + 65536].double()
+            acc += d.t() @ in8[a:a + 65536].double()
+            col += d.sum(0)
+        return acc / S_, col / S_
+    ref_w, ref_b = contract(slot8(ws, 3), slot8(acts, 2))
+    assert rel_l2(flat["pts_linears.3.weight"], ref_w) < 2e-3, rel_l2(flat["pts_linears.3.weight"], ref_w)
+    assert rel_l2(flat["pts_linears.3.bias"], ref_b) < 2e-3
+    e0 = 10 * P * 512
+    emb8 = acts[e0:e0 + P * 64].view(torch.float8_e4m3fn).view(P, 64)
+    ref_e, ref_b0 = contract(slot8(ws, 0), emb8)
+    assert rel_l2(flat["pts_linears.0.weight"], ref_e[:, :57]) < 2e-3, rel_l2(flat["pts_linears.0.weight"], ref_e[:, :57])
+    assert rel_l2(flat["pts_linears.0.bias"], ref_b0) < 2e-3
+
+
+@pytest.mark.parametrize("P", [1, 65, 200, 3001])
+@pytest.mark.parametrize("fmt", ["f32", "bf16", "bf16-s8"])
+def test_ragged_tiles_stay_inside_their_slots(dev, fmt, P):
+    """Canary bytes around everything the training kernels write: the tile copies of the forward and the
+    dgrad chain are buffer stores whose ragged last tile is cut by the descriptor's range check (rows >= P are dropped,
+    no branch), and an 8-bit row uses the first half of its 16-bit slot - an overrun into the unused half, or past the
+    end of the buffer, would go unnoticed by every parity test.  Saved-row buffer and backward workspace are allocated
+    with a 64 KiB tail and pre-filled with 0xA5; after forward + backward the tail is intact, and in format code 2 so
+    is the unused half of every slot (activations, dZ) and of the embedding rows."""
+    from scade_amd import ops, _lib
+    from scade_amd._lib import call, ptr, stream
+    lib = _lib.load()
+    params = O.nerf_init(5)
+    net = make_net(params, dev)
+    x, G = lp_inputs(P, seed=31)
+    x, G = x.to(dev).contiguous(), G.to(dev).contiguous()
+    PAD = 65536
+    if fmt == "f32":
+        na, nw = int(lib.scade_mlp_acts_floats(P)) * 4, int(lib.scade_mlp_bwd_workspace_floats(P)) * 4
+    else:
+        na, nw = int(lib.scade_mlp_acts_lp_bytes(P)), int(lib.scade_mlp_bwd_lp_workspace_bytes(P))
+    acts = torch.full((na + PAD,), 0xA5, device=dev, dtype=torch.uint8)
+    ws = torch.full((nw + PAD,), 0xA5, device=dev, dtype=torch.uint8)
+    grad = torch.empty(ops.N_PARAM_FLOATS, device=dev)
+    out = torch.empty(P, 4, device=dev)
+    if fmt == "f32":
+        call("scade_mlp_fwd", ptr(net.packed()), 0, ptr(x), None, 0, None, P, 1, ptr(out), ptr(acts), stream())
+        call("scade_mlp_bwd", ptr(net.packed()), ptr(net.packed_t()), ptr(acts), ptr(G), P, ptr(ws), ptr(grad), stream())
+    else:
+        code = 2 if fmt == "bf16-s8" else 1
+        out = ops.mlp_fwd_lp(net.packed_lp(True), code, x, None, None, acts[:na])
+        call("scade_mlp_bwd_lp", None, ptr(net.packed_t_lp(True)), code, ptr(acts), ptr(G), P, ptr(ws), ptr(grad), stream())
+    torch.cuda.synchronize()
+    assert torch.isfinite(out).all() and torch.isfinite(grad).all()
+    assert bool((acts[na:] == 0xA5).all()), "saved rows: bytes past the end of the buffer were written"
+    assert bool((ws[nw:] == 0xA5).all()), "backward workspace: bytes past the end of the buffer were written"
+    assert not bool((acts[:min(na, P * 256)] == 0xA5).all()), "(the forward did write its rows)"
+    if fmt == "bf16-s8":
+        for s_ in range(10):
+            for name, buf in (("activation", acts), ("dZ", ws)):
+                unused = buf[s_ * P * 512 + P * 256:(s_ + 1) * P * 512]
+                assert bool((unused == 0xA5).all()), f"{name} slot {s_}: the unused half of an 8-bit slot was written"
+        e0 = 10 * P * 512
+        assert bool((acts[e0 + P * 64:e0 + P * 128] == 0xA5).all()), "embedding rows: 64 fp8 bytes per point, no more"
+
+
+def test_bf16_s8_points_outside_the_scene_box_keep_finite_fp8_rows(dev):
+    """Format code 2 saves the embedding rows as fp8 e4m3 (|sin|, |cos|, |viewdir| <= 1) - but columns 0..2 are the raw
+    normalised coordinate, which is unbounded for a point outside the bounding box.  e4m3 ends at 448: the
+    saved coordinate is clamped there, stays finite, and so does every weight gradient; in-box points are untouched."""
+    from scade_amd import ops, _lib
+    from scade_amd._lib import call, ptr, stream
+    P = 300
+    net = make_net(O.nerf_init(5), dev)
+    x, G = lp_inputs(P, seed=41)
+    x[5, 0], x[9, 1], x[200, 2] = 1.0e4, -2.0e3, 449.0
+    x, G = x.to(dev).contiguous(), G.to(dev).contiguous()
+    acts = ops.mlp_acts_lp_alloc(P, dev)
+    out = ops.mlp_fwd_lp(net.packed_lp(True), 2, x, None, None, acts)
+    ws = torch.zeros(int(_lib.load().scade_mlp_bwd_lp_workspace_bytes(P)), device=dev, dtype=torch.uint8)
+    grad = torch.empty(ops.N_PARAM_FLOATS, device=dev)
+    call("scade_mlp_bwd_lp", None, ptr(net.packed_t_lp(True)), 2, ptr(acts), ptr(G), P, ptr(ws), ptr(grad), stream())
+    torch.cuda.synchronize()
+    e0 = 10 * P * 512
+    emb8 = acts[e0:e0 + P * 64].view(torch.float8_e4m3fn).view(P, 64).float()
+    assert torch.isfinite(emb8).all()
+    assert float(emb8[5, 0]) == 448.0 and float(emb8[9, 1]) == -448.0 and float(emb8[200, 2]) == 448.0
+    inbox = torch.ones(P, dtype=torch.bool, device=dev)
+    inbox[[5, 9, 200]] = False
+    want = x[:, :3].to(torch.bfloat16).to(torch.float8_e4m3fn).float()
+    assert torch.equal(emb8[inbox][:, :3], want[inbox])
+    assert torch.isfinite(grad).all() and torch.isfinite(out[inbox]).all()
