@@ -476,11 +476,14 @@ def driver_loop_region(args, dev, scene_data, precision, n_rays, iters=300, warm
     import shutil
     import tempfile
     from scade_amd import driver
+    import contextlib
     out = tempfile.mkdtemp(prefix="scade_bench_loop_")
     try:
-        res = driver.train_scene(scene_data, out, f"{precision}_{n_rays}", "synthetic", num_iterations=warm + iters,
-                                 N_rand=n_rays, i_weights=10 ** 9, i_print=10 ** 9, precision=precision, no_reload=True,
-                                 loop_warmup=warm, log=lambda *_: None, test_chunk=16384)
+        # (the image writer prints its metrics: stdout belongs to the JSON line)
+        with contextlib.redirect_stdout(sys.stderr):
+            res = driver.train_scene(scene_data, out, f"{precision}_{n_rays}", "synthetic", num_iterations=warm + iters,
+                                     N_rand=n_rays, i_weights=10 ** 9, i_print=10 ** 9, precision=precision,
+                                     no_reload=True, loop_warmup=warm, log=lambda *_: None, test_chunk=16384)
     finally:
         shutil.rmtree(out, ignore_errors=True)
     assert res["graphed"] and res["trace"] and all(v == v for _, v in res["trace"])

@@ -637,7 +637,11 @@ def test_ragged_tiles_stay_inside_their_slots(dev, fmt, P):
     if fmt == "bf16-s8":
         for s_ in range(10):
             for name, buf in (("activation", acts), ("dZ", ws)):
-                unused = buf[s_ * P * 512 + P * 256:(s_ + 1) * P * 512]
+                if s_ == 8 and name == "activation":
+                    # the 128-wide views hidden layer stays 16-bit (512-byte row pitch, 128 columns = 256 bytes used)
+                    unused = buf[s_ * P * 512:(s_ + 1) * P * 512].view(P, 512)[:, 256:]
+                else:
+                    unused = buf[s_ * P * 512 + P * 256:(s_ + 1) * P * 512]
                 assert bool((unused == 0xA5).all()), f"{name} slot {s_}: the unused half of an 8-bit slot was written"
         e0 = 10 * P * 512
         assert bool((acts[e0 + P * 64:e0 + P * 128] == 0xA5).all()), "embedding rows: 64 fp8 bytes per point, no more"
