@@ -16,6 +16,7 @@
 // cumsum/cumprod kernels do.
 #include "common.h"
 #include "train_loss_dev.h"
+#include "mlp_layout.h"
 
 namespace scade {
 
@@ -759,26 +760,50 @@ __global__ void ray_tail_bwd_kernel(TailBwdArgs a) {
 }
 
 // The fine tail, the three-term train loss (forward AND backward, unit gradient) and the backward of both tails
-// of a TRAIN step in ONE launch: one wave per ray runs ray_tail_body's forward, the per-ray loss functions of
-// train_loss_dev.h on the colour it still holds in registers and the depth hypotheses it just wrote to LDS,
-// the sampler's backward, the fine compositing backward on the forward state still in registers (nothing is
-// recomputed) and - c0.raw given - the coarse ray's compositing backward.  Same device functions and operation
-// order as scade_ray_tail -> scade_train_loss_fb -> scade_ray_tail_bwd (+ scade_composite_bwd for the coarse
-// ray) => the same bits; four launches of ~10 us become one (a 128-ray graph step is 0.31 ms).
+// of a TRAIN step in ONE launch: ray_tail_body's forward, the per-ray loss functions of train_loss_dev.h on the
+// colour still in registers and the depth hypotheses just written to LDS, the sampler's backward, the fine
+// compositing backward on the forward state still in registers (nothing is recomputed) and - c0.raw given - the
+// coarse ray's compositing backward.  Same device functions and operation order as scade_ray_tail ->
+// scade_train_loss_fb -> scade_ray_tail_bwd (+ scade_composite_bwd for the coarse ray) => the same bits; four
+// launches of ~10 us became one in round 3.
+// Round 5: ONE RAY PER WORKGROUP OF FOUR WAVES (WAVES = 4; launches that fit the chip's wave slots).  As one wave
+// per ray the kernel was a single dependent chain of ~4,500 VALU instructions at 13 clocks each
+// (profiles/r04_per_ray_pmc.txt: a lone wave per SIMD, 3 % of the time in s_waitcnt) - 24-30 us whatever the batch
+// size.  A ray's work is not one chain: the coarse ray's compositing (forward recomputed + backward) depends on
+// nothing of the fine ray, the loss VALUE (min over K per sample, summed) and the scale / shift gradient (the
+// scatter into the winning hypotheses) are read by nobody in this kernel, the spread of the samples (z_std) only
+// leaves, and d loss / d hypothesis is per sample.  So:
+//   wave 0 (the critical chain): fine compositing -> cdf -> inverse cdf | barrier | d loss / d hypotheses ->
+//           sampler backward -> fine compositing backward
+//   wave 1: coarse compositing forward + backward (its colour gradient needs rgb0 and the target only)
+//           | barrier | the loss value of the ray (tl_fwd_ray)
+//   wave 2: | barrier | scale / shift gradient of the ray (tl_bwd_ray<TL_SS>: the argmin again, the scatter)
+//   wave 3: | barrier | z_std
+// Every output is produced by the same device function with the same operands in the same order as before (the
+// parts of tl_bwd_ray are template switches around unchanged code), so the bits do not move; four waves per SIMD
+// (1024 rays on 256 CUs) interleave where one left the issue slots empty: 24.4 -> 15.3 us at 128 rays, 25.6 -> 18.6
+// at 1024, 29.6 -> 19.7 at 512 rays / K = 40 (rocprofv3, same box, tools/probe_tail_train.py).  (Halving wave 0's
+// d loss / d hypotheses with wave 1 behind a second barrier measured SLOWER, 16.3 / 19.1 / 21.7 us: the wait costs more
+// than 64 argmins.)  The form costs one more argmin pass per ray and parks three waves at a barrier, so launches
+// beyond four waves per SIMD (2048 rays: 32.6 us, no gain; 4096 rays: 62 us against 50) keep WAVES = 1: four rays
+// per workgroup, one wave each, the sequential form.
 struct TailTrainArgs {
   TailArgs t;              // fine tail, merge-less form (z_out = pts = null)
   TrainLossArgs l;         // rgb / pred / g_rgb / g_pred unused (registers, LDS); g_rgb0 optional
   float* g_raw;            // [N,S,4] fine
   CompositeArgs c0;        // coarse ray: raw, z, rays_d, noise, g_raw (S0 <= 64), or raw = null
 };
-template <int NC>
-__global__ void ray_tail_train_kernel(TailTrainArgs a) {
+template <int NC, int WAVES>
+__device__ __forceinline__ void ray_tail_train_body(TailTrainArgs a) {
+  static_assert(WAVES == 1 || WAVES == 4, "one wave per ray (4 rays per workgroup) or four");
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int wv = threadIdx.x >> 6, lane = lane_id();
-  const int ray = blockIdx.x * RAYS_PER_WG + wv;
-  if (ray >= a.t.c.N) return;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = lane_id();
+  const int ray = WAVES == 4 ? (int)blockIdx.x : (int)blockIdx.x * RAYS_PER_WG + wv;
+  if (WAVES == 1 && ray >= a.t.c.N) return;
+  const int role = WAVES == 4 ? wv : 0;
   const int S = a.t.c.S, M = S - 1, Si = a.t.Si;
-  float* w = smem + (size_t)wv * (7 * S + 2 * Si);   // w[S] | cat[S+Si] | cdf[S] | bins[S] | pdf[S] | dcdf[S] | gwi[S] | gs[Si]
+  // w[S] | cat[S+Si] | cdf[S] | bins[S] | pdf[S] | dcdf[S] | gwi[S] | gs[Si] | colour[4]
+  float* w = smem + (WAVES == 4 ? 0 : (size_t)wv * (7 * S + 2 * Si + 4));
   float* cat = w + S;
   float* cdf = cat + S + Si;
   float* bins = cdf + S;
@@ -786,77 +811,128 @@ __global__ void ray_tail_train_kernel(TailTrainArgs a) {
   float* dcdf = pdf + S;
   float* gwi = dcdf + S;
   float* gs = gwi + S;
+  float* colour = gs + Si;
+  float* part = a.l.partial + 4 * (size_t)a.l.N;
 
-  // ---- forward (ray_tail_body<NC, 0>) ----
-  SampleState st[NC];
-  double sr, sg, sb, sd, sa;
-  composite_ray<NC>(a.t.c, ray, lane, st, sr, sg, sb, sd, sa);
+  if (role == 0) {
+    // ---- forward (ray_tail_body<NC, 0>) ----
+    SampleState st[NC];
+    double sr, sg, sb, sd, sa;
+    composite_ray<NC>(a.t.c, ray, lane, st, sr, sg, sb, sd, sa);
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const int i = c * 64 + lane;
-    if (i < S) {
-      a.t.c.weights[(size_t)ray * S + i] = st[c].w;
-      w[i] = st[c].w;
-      cat[i] = st[c].z;
+    for (int c = 0; c < NC; ++c) {
+      const int i = c * 64 + lane;
+      if (i < S) {
+        a.t.c.weights[(size_t)ray * S + i] = st[c].w;
+        w[i] = st[c].w;
+        cat[i] = st[c].z;
+      }
     }
-  }
-  if (lane == 0) {
-    const float depth = (float)sd, acc = (float)sa;
-    a.t.c.rgb_map[ray * 3 + 0] = (float)sr;
-    a.t.c.rgb_map[ray * 3 + 1] = (float)sg;
-    a.t.c.rgb_map[ray * 3 + 2] = (float)sb;
-    a.t.c.depth_map[ray] = depth;
-    a.t.c.acc_map[ray] = acc;
-    const float q = depth / acc;                                      // :559
-    a.t.c.disp_map[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
-  }
-  __builtin_amdgcn_wave_barrier();
-  const float total = build_cdf_rows(cat, 1, w + 1, nullptr, M, lane, cdf, bins, pdf);   // z_mid, weights[1:-1]
-  const float* ur = a.t.u + (size_t)ray * a.t.u_stride;
-  double s1 = 0.0;
-  for (int s = lane; s < Si; s += 64) {
-    int ind;
-    const float smp = inverse_cdf(cdf, bins, M, ur[s], ind);
-    if (a.t.samples) a.t.samples[(size_t)ray * Si + s] = smp;
-    cat[S + s] = smp;
-    s1 += (double)smp;
-  }
-  if (a.t.z_std) {                                 // torch.std(unbiased=False), :744
-    const double mean = wave_sum_d(s1) / (double)Si;
-    double s2 = 0.0;
+    if (lane == 0) {
+      const float depth = (float)sd, acc = (float)sa;
+      a.t.c.rgb_map[ray * 3 + 0] = colour[0] = (float)sr;
+      a.t.c.rgb_map[ray * 3 + 1] = colour[1] = (float)sg;
+      a.t.c.rgb_map[ray * 3 + 2] = colour[2] = (float)sb;
+      a.t.c.depth_map[ray] = depth;
+      a.t.c.acc_map[ray] = acc;
+      const float q = depth / acc;                                      // :559
+      a.t.c.disp_map[ray] = 1.0f / ((q != q) ? q : fmaxf(1e-10f, q));
+    }
+    __builtin_amdgcn_wave_barrier();
+    const float total = build_cdf_rows(cat, 1, w + 1, nullptr, M, lane, cdf, bins, pdf);   // z_mid, weights[1:-1]
+    const float* ur = a.t.u + (size_t)ray * a.t.u_stride;
     for (int s = lane; s < Si; s += 64) {
-      const double dlt = (double)cat[S + s] - mean;
-      s2 += dlt * dlt;
+      int ind;
+      const float smp = inverse_cdf(cdf, bins, M, ur[s], ind);
+      if (a.t.samples) a.t.samples[(size_t)ray * Si + s] = smp;
+      cat[S + s] = smp;
     }
-    s2 = wave_sum_d(s2);
-    if (lane == 0) a.t.z_std[ray] = (float)sqrt(s2 / (double)Si);
-  }
-  __builtin_amdgcn_wave_barrier();
+    if (WAVES == 4) __syncthreads();               // the hypotheses and the colour are published
+    else __builtin_amdgcn_wave_barrier();
 
-  // ---- loss, forward and backward (train_loss_fb_kernel) ----
-  TlRayIo io;
-  io.pred_row = cat + S; io.g_pred_row = gs; io.have_rgb = true;
-  io.r = (float)sr; io.g = (float)sg; io.b = (float)sb;
-  tl_fwd_ray(a.l, ray, lane, io);
-  const float gx = tl_bwd_ray(a.l, ray, lane, 1.0f, a.l.partial + 4 * (size_t)a.l.N, io);
-  const float g_r = tl_bcast(gx, 0), g_g = tl_bcast(gx, 1), g_b = tl_bcast(gx, 2);
-  const float g0_r = tl_bcast(gx, 3), g0_g = tl_bcast(gx, 4), g0_b = tl_bcast(gx, 5);
-  __builtin_amdgcn_wave_barrier();
+    TlRayIo io;
+    io.pred_row = cat + S; io.g_pred_row = gs; io.have_rgb = true;
+    io.r = (float)sr; io.g = (float)sg; io.b = (float)sb;
+    float gx;
+    if (WAVES == 4) {
+      // ---- d loss / d hypotheses, d loss / d colour (train_loss_fb_kernel's backward, unit gradient) ----
+      io.store_gx = false;
+      gx = tl_bwd_ray<TL_GX | TL_GP>(a.l, ray, lane, 1.0f, part, io);
+      __builtin_amdgcn_wave_barrier();
+    } else {
+      // ---- z_std, the loss forward and backward, whole (the sequential form) ----
+      if (a.t.z_std) {                             // torch.std(unbiased=False), :744
+        double s1 = 0.0;
+        for (int s = lane; s < Si; s += 64) s1 += (double)cat[S + s];
+        const double mean = wave_sum_d(s1) / (double)Si;
+        double s2 = 0.0;
+        for (int s = lane; s < Si; s += 64) {
+          const double dlt = (double)cat[S + s] - mean;
+          s2 += dlt * dlt;
+        }
+        s2 = wave_sum_d(s2);
+        if (lane == 0) a.t.z_std[ray] = (float)sqrt(s2 / (double)Si);
+      }
+      tl_fwd_ray(a.l, ray, lane, io);
+      gx = tl_bwd_ray(a.l, ray, lane, 1.0f, part, io);
+      __builtin_amdgcn_wave_barrier();
+    }
+    const float g_r = tl_bcast(gx, 0), g_g = tl_bcast(gx, 1), g_b = tl_bcast(gx, 2);
 
-  // ---- backward of the fine tail (ray_tail_bwd_kernel; the forward state is still here) ----
-  sample_pdf_bwd_rows(cdf, bins, pdf, dcdf, total, ur, gs, M, Si, lane, gwi);
-  __builtin_amdgcn_wave_barrier();
-  CompositeArgs cb = a.t.c;
-  cb.g_rgb = nullptr; cb.g_disp = nullptr; cb.g_acc = nullptr; cb.g_w = nullptr; cb.g_depth = nullptr;
-  cb.g_raw = a.g_raw;
-  composite_bwd_ray<NC>(cb, ray, lane, st, sd, sa, gwi, true, g_r, g_g, g_b);
-
-  // ---- backward of the coarse ray's compositing (composite_bwd_kernel<1>) ----
-  if (a.c0.raw) {
-    SampleState s0[1];
-    double r0, g0, b0, d0, a0;
-    composite_ray<1>(a.c0, ray, lane, s0, r0, g0, b0, d0, a0);
-    composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b);
+    // ---- backward of the fine tail (ray_tail_bwd_kernel; the forward state is still here) ----
+    sample_pdf_bwd_rows(cdf, bins, pdf, dcdf, total, ur, gs, M, Si, lane, gwi);
+    __builtin_amdgcn_wave_barrier();
+    CompositeArgs cb = a.t.c;
+    cb.g_rgb = nullptr; cb.g_disp = nullptr; cb.g_acc = nullptr; cb.g_w = nullptr; cb.g_depth = nullptr;
+    cb.g_raw = a.g_raw;
+    composite_bwd_ray<NC>(cb, ray, lane, st, sd, sa, gwi, true, g_r, g_g, g_b);
+    if (WAVES == 1 && a.c0.raw) {
+      // ---- backward of the coarse ray's compositing (composite_bwd_kernel<1>) ----
+      const float g0_r = tl_bcast(gx, 3), g0_g = tl_bcast(gx, 4), g0_b = tl_bcast(gx, 5);
+      SampleState s0[1];
+      double r0, g0, b0, d0, a0;
+      composite_ray<1>(a.c0, ray, lane, s0, r0, g0, b0, d0, a0);
+      composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b);
+    }
+  } else if (role == 1) {
+    // ---- backward of the coarse ray's compositing (composite_bwd_kernel<1>); its colour gradient is the loss's
+    //      d / d rgb0 = 2 (rgb0 - target) mask / (3 N): no part of the fine ray enters ----
+    TlRayIo io;
+    io.have_rgb = true;                            // (lanes 0..2 idle: the fine colour belongs to wave 0)
+    const float gx = tl_bwd_ray<TL_GX>(a.l, ray, lane, 1.0f, part, io);
+    if (a.c0.raw) {
+      const float g0_r = tl_bcast(gx, 3), g0_g = tl_bcast(gx, 4), g0_b = tl_bcast(gx, 5);
+      SampleState s0[1];
+      double r0, g0, b0, d0, a0;
+      composite_ray<1>(a.c0, ray, lane, s0, r0, g0, b0, d0, a0);
+      composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b);
+    }
+    __syncthreads();
+    // ---- the ray's loss terms (train_loss_fb_kernel's forward) ----
+    TlRayIo io2;
+    io2.pred_row = cat + S; io2.have_rgb = true;
+    io2.r = colour[0]; io2.g = colour[1]; io2.b = colour[2];
+    tl_fwd_ray(a.l, ray, lane, io2);
+  } else if (role == 2) {
+    __syncthreads();
+    // ---- the ray's scale / shift gradient ----
+    TlRayIo io;
+    io.pred_row = cat + S;
+    tl_bwd_ray<TL_SS>(a.l, ray, lane, 1.0f, part, io);
+  } else {
+    __syncthreads();
+    if (a.t.z_std) {                               // torch.std(unbiased=False), :744
+      double s1 = 0.0;
+      for (int s = lane; s < Si; s += 64) s1 += (double)cat[S + s];
+      const double mean = wave_sum_d(s1) / (double)Si;
+      double s2 = 0.0;
+      for (int s = lane; s < Si; s += 64) {
+        const double dlt = (double)cat[S + s] - mean;
+        s2 += dlt * dlt;
+      }
+      s2 = wave_sum_d(s2);
+      if (lane == 0) a.t.z_std[ray] = (float)sqrt(s2 / (double)Si);
+    }
   }
 }
 
@@ -1366,6 +1442,12 @@ extern "C" int scade_ray_tail_bwd(const float* raw, const float* z_vals, const f
 // ray, raw0 != NULL) in ONE launch + the loss's reduce: see ray_tail_train_kernel.  The loss differentiates the
 // total with a UNIT gradient (scade_train_loss_fb's contract); gradients w.r.t. the five compositing outputs
 // other than the colour are zero by construction of the train loss.
+namespace scade {
+template <int NC>
+__global__ __launch_bounds__(256) void ray_tail_train_split(TailTrainArgs a) { ray_tail_train_body<NC, 4>(a); }
+template <int NC>
+__global__ __launch_bounds__(256) void ray_tail_train_seq(TailTrainArgs a) { ray_tail_train_body<NC, 1>(a); }
+}  // namespace scade
 extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const float* rays, int ray_stride,
                                     const float* noise, int N, int S, const float* u, int u_stride, int Si,
                                     float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
@@ -1403,9 +1485,14 @@ extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const
     a.c0.raw = raw0; a.c0.z = z0; a.c0.rays_d = rays + 3; a.c0.noise = noise0; a.c0.d_stride = ray_stride;
     a.c0.g_raw = g_raw0; a.c0.N = N; a.c0.S = S0;
   }
-  const size_t lds = (size_t)RAYS_PER_WG * (7 * S + 2 * Si) * sizeof(float);
   hipStream_t s = (hipStream_t)stream;
-  DISPATCH_NC(ray_tail_train_kernel, S, dim3(grid_rays(N)), dim3(256), lds, s, a);
+  // four waves per ray up to four waves per SIMD (4 SIMDs per CU), else one
+  const size_t row = (size_t)(7 * S + 2 * Si + 4) * sizeof(float);
+  if ((long)N * 4 <= 16L * device_cus()) {
+    DISPATCH_NC(ray_tail_train_split, S, dim3(N), dim3(256), row, s, a);
+  } else {
+    DISPATCH_NC(ray_tail_train_seq, S, dim3(grid_rays(N)), dim3(256), RAYS_PER_WG * row, s, a);
+  }
   if (int e = scade_check_launch("scade_ray_tail_train")) return e;
   return scade_launch_train_loss_fb_reduce(a.l, n_ss, s);
 }

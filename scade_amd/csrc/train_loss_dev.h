@@ -59,7 +59,13 @@ struct TlRayIo {
   float* g_pred_row = nullptr;       // [P] receives d loss / d pred of this ray
   bool have_rgb = false;             // fine colour given below (wave-uniform)
   float r = 0.f, g = 0.f, b = 0.f;
+  bool store_gx = true;              // write g_rgb / g_rgb0 (when given); false: the colour gradient is only returned
 };
+// the parts of tl_bwd_ray (all = the whole backward of the ray; the fused tail kernel gives the parts to different
+// waves of the ray's workgroup - every output is computed by the same operations in the same order either way)
+constexpr int TL_GX = 1;             // d / d colour (lanes 0..5)
+constexpr int TL_GP = 2;             // d / d pred: the g_pred rows
+constexpr int TL_SS = 4;             // d / d scale, shift: the scatter into the winning hypotheses + the ray's partial
 
 __device__ __forceinline__ void tl_fwd_ray(const TrainLossArgs& a, int ray, int lane, const TlRayIo& io = TlRayIo()) {
   const float* pred_row = io.pred_row ? io.pred_row : a.pred + (size_t)ray * a.P;
@@ -115,6 +121,7 @@ __device__ __forceinline__ void tl_fwd_ray(const TrainLossArgs& a, int ray, int 
 // ``g_in``: the gradient arriving at the total; ``part``: where the ray's scale / shift partial goes
 // returns, in lanes 0..2 / 3..5, the gradient w.r.t. the fine / coarse colour channel (also stored to g_rgb /
 // g_rgb0 when those are given)
+template <int PARTS = TL_GX | TL_GP | TL_SS>
 __device__ __forceinline__ float tl_bwd_ray(const TrainLossArgs& a, int ray, int lane, float g_in, float* part,
                                             const TlRayIo& io = TlRayIo()) {
   const float* pred_row = io.pred_row ? io.pred_row : a.pred + (size_t)ray * a.P;
@@ -124,7 +131,7 @@ __device__ __forceinline__ float tl_bwd_ray(const TrainLossArgs& a, int ray, int
   const float m = hm ? a.mask[ray] : 1.f;
   float g = g_in;
   if (a.out_scale != 1.0f) g = g * a.out_scale;
-  if (lane < 6) {                                  // d mse / d x = 2 (x - y) mask / (3 N)
+  if ((PARTS & TL_GX) && lane < 6) {               // d mse / d x = 2 (x - y) mask / (3 N)
     const int c = lane % 3;
     const float x = (lane < 3 && io.have_rgb) ? (c == 0 ? io.r : c == 1 ? io.g : io.b)
                                               : (lane < 3 ? a.rgb : a.rgb0)[ray * 3 + c];
@@ -132,9 +139,10 @@ __device__ __forceinline__ float tl_bwd_ray(const TrainLossArgs& a, int ray, int
     float gx = (x - a.target[ray * 3 + c]) * scale;
     if (hm && a.mse_masked) gx = gx * m;
     float* gdst = lane < 3 ? a.g_rgb : a.g_rgb0;
-    if (gdst) gdst[ray * 3 + c] = gx;
+    if (gdst && io.store_gx) gdst[ray * 3 + c] = gx;
     gx_ret = gx;
   }
+  if (!(PARTS & (TL_GP | TL_SS))) return gx_ret;
   float gsc = 0.f, gsh = 0.f;
   if (a.carve_on) {
     const int im = tl_image(a);
@@ -142,6 +150,7 @@ __device__ __forceinline__ float tl_bwd_ray(const TrainLossArgs& a, int ray, int
     const float gl = g * a.carve_weight;
     const float scale = gl / ((float)a.N * (float)a.P);
     for (int k0 = 0; k0 < a.K; k0 += 64) {
+      if (!(PARTS & TL_SS) && k0 > 0) break;        // the g_pred rows are complete after the first pass
       const int kl = k0 + lane;
       const float hraw = kl < a.K ? a.hyp[(size_t)kl * a.N + ray] : 0.f;
       float hreg = hraw * sc;
@@ -167,30 +176,34 @@ __device__ __forceinline__ float tl_bwd_ray(const TrainLossArgs& a, int ray, int
           const bool dead = a.threshold > 0.f && dd < a.threshold;
           const float sgn = dead ? 0.f : (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f));
           gp = sgn * m * scale;
-          if (k0 == 0) {
+          if ((PARTS & TL_GP) && k0 == 0) {
             if (g_pred_row) g_pred_row[s] = gp;
             if (io.g_pred_row) io.g_pred_row[s] = gp;
           }
         } else {
           kbest = -1;
         }
-        for (int l = 0; l < 64; ++l) {              // scatter -gp into the winning hypothesis
-          const int kb = __builtin_amdgcn_readlane(kbest, l);
-          const float gg = tl_bcast(gp, l);
-          if (kl == kb) ghk -= gg;
+        if (PARTS & TL_SS) {
+          for (int l = 0; l < 64; ++l) {            // scatter -gp into the winning hypothesis
+            const int kb = __builtin_amdgcn_readlane(kbest, l);
+            const float gg = tl_bcast(gp, l);
+            if (kl == kb) ghk -= gg;
+          }
         }
       }
-      // d target_h / d scale = hyp_raw, d / d shift = 1
-      gsc += (float)tl_wave_sum_d((double)(ghk * hraw));
-      gsh += (float)tl_wave_sum_d((double)ghk);
+      if (PARTS & TL_SS) {
+        // d target_h / d scale = hyp_raw, d / d shift = 1
+        gsc += (float)tl_wave_sum_d((double)(ghk * hraw));
+        gsh += (float)tl_wave_sum_d((double)ghk);
+      }
     }
-  } else {
+  } else if (PARTS & TL_GP) {
     for (int s = lane; s < a.P; s += 64) {
       if (g_pred_row) g_pred_row[s] = 0.f;
       if (io.g_pred_row) io.g_pred_row[s] = 0.f;
     }
   }
-  if (lane == 0) {
+  if ((PARTS & TL_SS) && lane == 0) {
     f32x4 o = {gsc, gsh, 0.f, 0.f};
     reinterpret_cast<f32x4*>(part)[ray] = o;
   }
