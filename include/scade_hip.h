@@ -96,7 +96,11 @@ int scade_mlp_bwd2(const float* const* packed, const float* const* packed_t, con
  * carried as two fp16 numbers x ~= h + l*2^-11 and every product as three f16 MFMAs into two fp32
  * accumulators (~2^-21 relative error per product; requires |activations|,|weights| < 65504).
  * packed_f16 = scade_mlp_pack_f16(params), scade_mlp_packed_f16_bytes() bytes.  Same modes,
- * arguments, output and (optional) training workspace as scade_mlp_fwd. */
+ * arguments, output and (optional) training workspace as scade_mlp_fwd.  mode + 2 (with acts): the saved rows are
+ * written in the 24-bit form scade_mlp_bwd_f16(wgrad_f16 = 1) reads - every fp32 value rounded to its upper 24 bits
+ * (16 significant bits), bits 31..16 in a u16 plane [P][256] at the start of the row slot, bits 15..8 in a u8 plane
+ * [P][256] P * 512 bytes on: 768 of the slot's 1024 bytes per point (the weight gradient streams these rows at the
+ * memory system's rate).  Without + 2: fp32 rows, for scade_mlp_bwd_f16(wgrad_f16 = 0) / scade_mlp_bwd. */
 long scade_mlp_packed_f16_bytes(void);
 int scade_mlp_pack_f16(const float* const* params, void* packed_f16, void* stream);
 int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in, const float* viewdirs,
@@ -152,7 +156,8 @@ int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* cons
 /* Split-precision variant of scade_mlp_bwd (opt-in training mode): the dgrad chain runs on
  * f16 MFMAs with a per-point power-of-two gradient scale (exactly removed on store); the weight
  * gradient runs on the exact fp32 kernel (wgrad_f16 = 0) or on f16 MFMAs with one power-of-two
- * scale per launch (wgrad_f16 = 1).  packed = the fp32 forward pack (head weights);
+ * scale per launch (wgrad_f16 = 1: acts must hold the 24-bit rows of scade_mlp_fwd_f16(mode + 2), and the dZ rows
+ * of the workspace are written and read in the same form).  packed = the fp32 forward pack (head weights);
  * packed_t_f16 = scade_mlp_pack_t_f16(params); other arguments as scade_mlp_bwd. */
 long scade_mlp_packed_t_f16_bytes(void);
 int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f16, void* stream);

@@ -105,6 +105,9 @@ __device__ __forceinline__ void dgrad_store_h(const f32x16 (&acc0)[2][2], const 
     }
 }
 
+// R24: the dZ rows leave as 24-bit rows (mlp_tile_f16.h) and the saved views-layer rows (the ReLU mask of the heads)
+// are read as such - the split-precision weight gradient follows; false: fp32 rows for the exact weight gradient
+template <bool R24>
 __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* gh = ldsh;
@@ -136,7 +139,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
     const float apre = acts[acts_alpha_off(P) + ptc];
     f32x4 mks[8];
 #pragma unroll
-    for (int i = 0; i < 8; ++i) mks[i] = *reinterpret_cast<const f32x4*>(hv + ptc * W + (i * 4 + sub) * 4);
+    for (int i = 0; i < 8; ++i)
+      mks[i] = R24 ? r24_load4(hv, P, ptc, (i * 4 + sub) * 4) : *reinterpret_cast<const f32x4*>(hv + ptc * W + (i * 4 + sub) * 4);
     if (!ok) g = f32x4{0.f, 0.f, 0.f, 0.f};
     float da = 0.f;
     if (ok) {
@@ -154,6 +158,8 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
       if (ok) dz[dz_dalpha_off(P) + pt] = da;
       dal[row] = da * s;
       inv_s[row] = 1.f / s;
+      // 24-bit rows stay in the per-point scaled domain: the weight gradient needs 1 / s_p (mlp_tile_f16.h)
+      if (R24 && ok) reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(dz) + rows24_invs_byte(P))[pt] = 1.f / s;
     }
     {   // launch-wide max for the weight-gradient kernel's dZ scale: one atomic per WORKGROUP (after the
         // barrier below; 12,000 per-wave atomics on one address were a serial tail of the launch)
@@ -184,7 +190,10 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
       const int o = x_idx(row, chunk >> 1) + (chunk & 1) * 4;
       *reinterpret_cast<half4*>(gh + o) = vh;
       *reinterpret_cast<half4*>(gl + o) = vl;
-      if (ok) *reinterpret_cast<f32x4*>(dzv + (size_t)pt * W + chunk * 4) = v;
+      if (ok) {
+        if (R24) r24_store4(dzv, P, (size_t)pt, chunk * 4, vh, vl);
+        else *reinterpret_cast<f32x4*>(dzv + (size_t)pt * W + chunk * 4) = v;
+      }
     }
   }
   __syncthreads();
@@ -207,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   layer_gemm_h<2, 0, 8, false>(acc0, acc1, an, WT16(8, 8), WT16(7, 16), 16, gh, gl, gh, gl, lane);
   __syncthreads();
   dgrad_store_h<false, false>(acc0, acc1, kt0, gh, gl, 0ull, nullptr, dal, lane);
-  save_tile_h_wave<64>(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, inv_s, lane);
+  save_tile_h_wave<64, R24>(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, inv_s, lane);
   __syncthreads();
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
@@ -215,7 +224,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16(7, 16), WT16(6, 16), 16, gh, gl, gh, gl, lane);
   __syncthreads();
   dgrad_store_h<true, true>(acc0, acc1, kt0, gh, gl, mbits, pk + OFF_WA, dal, lane);
-  save_tile_h_wave<64>(gh, gl, dz + acts_slot_off(P, 7), p0, P, 64 * wave, inv_s, lane);
+  save_tile_h_wave<64, R24>(gh, gl, dz + acts_slot_off(P, 7), p0, P, 64 * wave, inv_s, lane);
   __syncthreads();
 
 #define DGRAD_LAYER_H(L)                                                                         \
@@ -224,7 +233,7 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
                                 gh, gl, gh, gl, lane);                                           \
   __syncthreads();                                                                               \
   dgrad_store_h<true, false>(acc0, acc1, kt0, gh, gl, mbits, nullptr, dal, lane);                \
-  save_tile_h_wave<64>(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, inv_s, lane);     \
+  save_tile_h_wave<64, R24>(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, inv_s, lane);     \
   __syncthreads();
 
   DGRAD_LAYER_H(7)
@@ -265,9 +274,14 @@ constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4 + 16;   // + the fo
 // per-point scalars (d alpha, view direction) ride the ring as 4-byte LDS-DMA pieces.
 // ---------------------------------------------------------------------------
 constexpr int HW_PT = 16;                                 // points per ring slot = one k16 block
-constexpr int HW_D = 4;                                   // ring slots
-constexpr int HW_SLOT = HW_PT * 512 + 64;                 // floats: dZ [16][256] | input [16][KW] | d alpha [16] | view dirs [16][3]
-constexpr int WGRAD_F16_LDS_BYTES = HW_D * HW_SLOT * 4;   // 132,096
+constexpr int HW_D = 5;                                   // ring slots
+// bytes of a slot: dZ h [16][256] fp16 | dZ l8 [16][256] e5m2 | input h | input l8 (KW = 64: the fp32 embedding
+// rows [16][64] instead) | d alpha [16] fp32 | view dirs [16][3] fp32 | 1 / s_p [16] fp32
+constexpr int HW_DZ_HI = 0, HW_DZ_MID = HW_PT * 512, HW_IN_HI = HW_PT * 768, HW_IN_MID = HW_PT * 1280;
+constexpr int HW_SCAL = HW_PT * 1536;                     // d alpha [16] | view dirs [16][3] | 1 / s_p [16]
+constexpr int HW_SLOT = HW_SCAL + 320;                    // 24,896
+constexpr int WGRAD_F16_RED_BYTES = (2 * 256 * 5 + 2) * 4;              // the riders' reduction scratch
+constexpr int WGRAD_F16_LDS_BYTES = HW_D * HW_SLOT > WGRAD_F16_RED_BYTES ? HW_D * HW_SLOT : WGRAD_F16_RED_BYTES;   // 124,480
 
 struct WgradF16Args {
   WgradArgs w;
@@ -292,14 +306,20 @@ __device__ __forceinline__ void hw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// value of column c of a 24-bit row in LDS (h plane row, l8 plane row): h + l * 2^-11
+__device__ __forceinline__ float hw_col24(const unsigned char* h_row, const unsigned char* l_row, int c) {
+  return r24_value(*reinterpret_cast<const unsigned short*>(h_row + 2 * c), l_row[c]);
+}
+
 template <int KW>
-__device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob& jb, float* lds,
+__device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob& jb, float* lds_f,
                                               int c0, int c1, float S, float* __restrict__ out) {
   constexpr int NKT = KW == 256 ? 4 : 1;
   constexpr int D = HW_D, PT = HW_PT;
-  constexpr int NI = (KW == 256 ? 4 : 3) + 2;     // LDS-DMA instructions per wave and stage
+  constexpr int NI = (KW == 256 ? 4 : 3) + 3;     // LDS-DMA instructions per wave and stage
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, hh = lane >> 5;
@@ -308,9 +328,19 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   const bool active = n0 < jb.n_rows;
   const int P = a.P;
   const int npts = c1 - c0;
-  const hw_rsrc_t ra = hw_make_rsrc(a.dz + jb.dz_off + (size_t)c0 * 256, (unsigned)npts * 1024u);
-  const hw_rsrc_t rb = hw_make_rsrc(a.acts + jb.in_off + (size_t)c0 * KW, (unsigned)npts * (KW * 4u));
+  // 24-bit rows (mlp_tile_f16.h): the h plane of a slot at its float offset, the l8 plane P * 512 bytes on; the dZ
+  // rows are in the dgrad chain's per-point scaled domain, 1 / s_p per point in dZ slot 0's unused quarter
+  const unsigned char* dzb = reinterpret_cast<const unsigned char*>(a.dz + jb.dz_off);
+  const unsigned char* inb = reinterpret_cast<const unsigned char*>(a.acts + jb.in_off);
+  const hw_rsrc_t rah = hw_make_rsrc(reinterpret_cast<const float*>(dzb + (size_t)c0 * 512), (unsigned)npts * 512u);
+  const hw_rsrc_t ram = hw_make_rsrc(reinterpret_cast<const float*>(dzb + rows24_l8_byte(P) + (size_t)c0 * 256), (unsigned)npts * 256u);
+  const hw_rsrc_t rbh = KW == 256 ? hw_make_rsrc(reinterpret_cast<const float*>(inb + (size_t)c0 * 512), (unsigned)npts * 512u)
+                                  : hw_make_rsrc(a.acts + jb.in_off + (size_t)c0 * 64, (unsigned)npts * 256u);   // fp32 embedding rows
+  const hw_rsrc_t rbm = hw_make_rsrc(reinterpret_cast<const float*>(inb + rows24_l8_byte(P) + (size_t)c0 * 256),
+                                     KW == 256 ? (unsigned)npts * 256u : 0u);
   const hw_rsrc_t rd = hw_make_rsrc(a.dz + dz_dalpha_off(P) + c0, (unsigned)npts * 4u);
+  const hw_rsrc_t rs = hw_make_rsrc(reinterpret_cast<const float*>(reinterpret_cast<const unsigned char*>(a.dz) + rows24_invs_byte(P)) + c0,
+                                    (unsigned)npts * 4u);
   const hw_rsrc_t rv = hw_make_rsrc(a.acts + acts_emb_off(P) + (size_t)c0 * 64, (unsigned)npts * 256u);
 
   f32x16 acc[2][NKT];
@@ -321,114 +351,148 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
-  // ---- LDS-DMA of stage st into slot sl: wave w moves point rows 2w, 2w+1 of both tiles (1-KiB rows: one
-  // instruction each; the 256-byte embedding rows: one instruction, lanes 0-31) and the rider scalars of
-  // those two points.  The same count in every stage, also past the chunk end (zeros, no traffic), so the
-  // vmcnt below is a compile-time constant.
+  // ---- LDS-DMA of stage st into slot sl: wave w moves point rows 2w, 2w+1 of both tiles - their two hi rows are
+  // 1 KiB (one instruction), their two mid rows 512 bytes (one instruction, lanes 0-31), the two 256-byte
+  // embedding rows likewise - and the rider scalars of those two points.  The same count in every stage, also
+  // past the chunk end (zeros, no traffic), so the vmcnt below is a compile-time constant.
   auto issue = [&](int st, int sl) {
-    float* slot = lds + sl * HW_SLOT;
+    unsigned char* slot = lds + sl * HW_SLOT;
     const int grow = st * PT + 2 * wave;
-#pragma unroll
-    for (int q = 0; q < 2; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ra, (lds_ptr_t)(slot + (2 * wave + q) * 256), 16, lane * 16, (grow + q) * 1024, 0, 2);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr_t)(slot + HW_DZ_HI + 2 * wave * 512), 16, lane * 16, grow * 512, 0, 2);
+    if (lane < 32)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + 2 * wave * 256), 16, lane * 16, grow * 256, 0, 2);
     if (KW == 256) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + PT * 256 + (2 * wave + q) * 256), 16, lane * 16,
-                                                 (grow + q) * 1024, 0, 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 2 * wave * 512), 16, lane * 16, grow * 512, 0, 2);
+      if (lane < 32)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbm, (lds_ptr_t)(slot + HW_IN_MID + 2 * wave * 256), 16, lane * 16, grow * 256, 0, 2);
     } else {
       if (lane < 32)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rb, (lds_ptr_t)(slot + PT * 256 + 2 * wave * 64), 16, lane * 16, grow * 256, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 2 * wave * 256), 16, lane * 16, grow * 256, 0, 2);
     }
     if (lane < 2)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(slot + PT * 512 + 2 * wave), 4, lane * 4, grow * 4, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(slot + HW_SCAL + 4 * 2 * wave), 4, lane * 4, grow * 4, 0, 0);
+    if (lane < 2)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(slot + HW_SCAL + 256 + 4 * 2 * wave), 4, lane * 4, grow * 4, 0, 0);
     if (lane < 6)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(slot + PT * 512 + 16 + 6 * wave), 4,
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(slot + HW_SCAL + 64 + 4 * 6 * wave), 4,
                                                (lane / 3) * 256 + (60 + lane % 3) * 4, grow * 256, 0, 0);
   };
 
-  // ---- riders on the exact fp32 values of the published slot: thread = (column tid & 255, point half
-  // tid >> 8).  The column reads are issued unconditionally with the fragment reads and summed behind the
-  // MFMAs; the two rare riders (one job each) take one wave-uniform branch per stage, not one per point.
+  // ---- riders on the values of the published slot: thread = (column tid & 255, point half tid >> 8).  The column
+  // reads are issued unconditionally with the fragment reads and summed behind the MFMAs; the two rare riders
+  // (one job each) take one wave-uniform branch per stage, not one per point.
   float bias_acc = 0.f, alpha_acc = 0.f, dal_acc = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
   const int col = tid & 255, ph = __builtin_amdgcn_readfirstlane(tid >> 8);
   const bool want_view = (jb.flags & WF_VIEWCOLS) != 0, want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
   float rcol[PT / 2];
   auto riders_read = [&](int sl) {
-    const float* slot = lds + sl * HW_SLOT;
+    const unsigned char* slot = lds + sl * HW_SLOT;
+    const float* isv = reinterpret_cast<const float*>(slot + HW_SCAL + 256);
 #pragma unroll
-    for (int q = 0; q < PT / 2; ++q) rcol[q] = slot[(ph * (PT / 2) + q) * 256 + col];
+    for (int q = 0; q < PT / 2; ++q) {
+      const int p = ph * (PT / 2) + q;
+      rcol[q] = hw_col24(slot + HW_DZ_HI + p * 512, slot + HW_DZ_MID + p * 256, col) * isv[p];   // the true dZ value
+    }
   };
   auto riders_add = [&](int sl) {
-    const float* slot = lds + sl * HW_SLOT;
+    const unsigned char* slot = lds + sl * HW_SLOT;
 #pragma unroll
     for (int q = 0; q < PT / 2; ++q) bias_acc += rcol[q];
     if (want_view) {
-      const float* vw = slot + PT * 512 + 16 + 3 * ph * (PT / 2);
+      const float* vw = reinterpret_cast<const float*>(slot + HW_SCAL + 64) + 3 * ph * (PT / 2);
 #pragma unroll
       for (int q = 0; q < PT / 2; ++q) {
         vc0 = fmaf(rcol[q], vw[3 * q + 0], vc0); vc1 = fmaf(rcol[q], vw[3 * q + 1], vc1); vc2 = fmaf(rcol[q], vw[3 * q + 2], vc2);
       }
     }
     if (want_alpha) {
-      const float* da = slot + PT * 512 + ph * (PT / 2);
+      const float* da = reinterpret_cast<const float*>(slot + HW_SCAL) + ph * (PT / 2);
 #pragma unroll
       for (int q = 0; q < PT / 2; ++q) {
-        alpha_acc = fmaf(da[q], slot[PT * 256 + (ph * (PT / 2) + q) * 256 + col], alpha_acc);
+        const int p = ph * (PT / 2) + q;
+        alpha_acc = fmaf(da[q], hw_col24(slot + HW_IN_HI + p * 512, slot + HW_IN_MID + p * 256, col), alpha_acc);
         dal_acc += da[q];
       }
     }
   };
 
-  // ---- fragments: lane (r, hh) reads its 8 points p = 8 hh + j; features 2r + t of dZ, NKT r + u of the input
-  // two values -> packed fp16 planes: h = rne16(x), l = rne16(x - h).  Three VALU ops per pair: v_cvt_pk_f16_f32,
-  // then v_fma_mixlo/hi_f16 (h * -1 + x in fp32 - exact - rounded to fp16 into the low / high half), which read
-  // the fp16 h in place; hipcc's own selection converts h back, subtracts and converts again (and SLP-packs the
-  // arithmetic into v_pk_* at the price of a register move per operand): 320 VALU ops per wave and stage, 4x
-  // the MFMA time of the stage.
+  // ---- fragments: lane (r, hh) reads its 8 points p = 8 hh + j; features 2r + t of dZ, NKT r + u of the input: per
+  // point one h dword + one l8 halfword (two values), or an h pair + an l8 dword (four).  An MFMA operand is the
+  // pair (point 2 j2, point 2 j2 + 1) of ONE column: one v_perm_b32 per pair and plane picks the column's half / byte
+  // out of the two points' words (the byte lands in the upper half of its fp16: widened on the way); the l pairs take
+  // their 2^-11 and - dZ - the points' S / s_p (powers of two, packed fp16 multiplies).  No conversion-class VALU
+  // work at all; the fp32 embedding rows of the KW = 64 jobs keep the split (v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16).
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
   auto split_pair = [](float x0, float x1, unsigned& h, unsigned& l) {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
     asm("v_fma_mixhi_f16 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(l) : "v"(h), "v"(x1));
   };
+  auto pk_mul = [](unsigned a, half2v k) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(half2v, a) * k); };
+  const half2v k_l = {(_Float16)LINV, (_Float16)LINV};
   auto compute = [&](int sl) {
     if (!active) return;
-    const float* slot = lds + sl * HW_SLOT;
-    f32x2 av[8];
-    f32x4 bv[8];
+    const unsigned char* slot = lds + sl * HW_SLOT;
+    // (S / s_p) of the lane's point pairs, and the same times 2^-11 for the l plane
+    half2v kp[4], kl[4];
+    {
+      const f32x4* isv = reinterpret_cast<const f32x4*>(slot + HW_SCAL + 256) + 2 * hh;
+      const f32x4 i0 = isv[0], i1 = isv[1];
+      kp[0] = half2v{(_Float16)(i0[0] * S), (_Float16)(i0[1] * S)};
+      kp[1] = half2v{(_Float16)(i0[2] * S), (_Float16)(i0[3] * S)};
+      kp[2] = half2v{(_Float16)(i1[0] * S), (_Float16)(i1[1] * S)};
+      kp[3] = half2v{(_Float16)(i1[2] * S), (_Float16)(i1[3] * S)};
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) kl[j2] = kp[j2] * k_l;
+    }
+    unsigned ah[8], am[8];
+    u32x2 bh[8];
+    unsigned bm[8];
+    float be[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int p = 8 * hh + j;
-      av[j] = *reinterpret_cast<const f32x2*>(slot + p * 256 + n0 + 2 * r);
-      if (NKT == 4) bv[j] = *reinterpret_cast<const f32x4*>(slot + PT * 256 + p * 256 + k0 + 4 * r);
-      else bv[j][0] = slot[PT * 256 + p * 64 + k0 + r];
+      ah[j] = *reinterpret_cast<const unsigned*>(slot + HW_DZ_HI + p * 512 + (n0 + 2 * r) * 2);
+      am[j] = *reinterpret_cast<const unsigned short*>(slot + HW_DZ_MID + p * 256 + n0 + 2 * r);
+      if (NKT == 4) {
+        bh[j] = *reinterpret_cast<const u32x2*>(slot + HW_IN_HI + p * 512 + (k0 + 4 * r) * 2);
+        bm[j] = *reinterpret_cast<const unsigned*>(slot + HW_IN_MID + p * 256 + k0 + 4 * r);
+      } else {
+        be[j] = reinterpret_cast<const float*>(slot + HW_IN_HI)[p * 64 + k0 + r];
+      }
     }
     u32x4 ahp[2], alp[2], bhp[NKT], blp[NKT];
 #pragma unroll
     for (int j2 = 0; j2 < 4; ++j2) {
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      const int e = 2 * j2, o = 2 * j2 + 1;
+      ahp[0][j2] = pk_mul(__builtin_amdgcn_perm(ah[o], ah[e], 0x05040100u), kp[j2]);
+      ahp[1][j2] = pk_mul(__builtin_amdgcn_perm(ah[o], ah[e], 0x07060302u), kp[j2]);
+      alp[0][j2] = pk_mul(__builtin_amdgcn_perm(am[o], am[e], 0x040c000cu), kl[j2]);
+      alp[1][j2] = pk_mul(__builtin_amdgcn_perm(am[o], am[e], 0x050c010cu), kl[j2]);
+      if (NKT == 4) {
+        bhp[0][j2] = __builtin_amdgcn_perm(bh[o][0], bh[e][0], 0x05040100u);
+        bhp[NKT > 1 ? 1 : 0][j2] = __builtin_amdgcn_perm(bh[o][0], bh[e][0], 0x07060302u);
+        bhp[NKT > 2 ? 2 : 0][j2] = __builtin_amdgcn_perm(bh[o][1], bh[e][1], 0x05040100u);
+        bhp[NKT > 3 ? 3 : 0][j2] = __builtin_amdgcn_perm(bh[o][1], bh[e][1], 0x07060302u);
+        blp[0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x040c000cu), k_l);
+        blp[NKT > 1 ? 1 : 0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x050c010cu), k_l);
+        blp[NKT > 2 ? 2 : 0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x060c020cu), k_l);
+        blp[NKT > 3 ? 3 : 0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x070c030cu), k_l);
+      } else {
         unsigned h, l;
-        split_pair(av[2 * j2][t] * S, av[2 * j2 + 1][t] * S, h, l);
-        ahp[t][j2] = h; alp[t][j2] = l;
-      }
-#pragma unroll
-      for (int u = 0; u < NKT; ++u) {
-        unsigned h, l;
-        split_pair(bv[2 * j2][u], bv[2 * j2 + 1][u], h, l);
-        bhp[u][j2] = h; blp[u][j2] = l;
+        split_pair(be[e], be[o], h, l);
+        bhp[0][j2] = h; blp[0][j2] = l;
       }
     }
 #pragma unroll
     for (int u = 0; u < NKT; ++u)
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const half8 ah = __builtin_bit_cast(half8, ahp[t]), al = __builtin_bit_cast(half8, alp[t]);
-        const half8 bh = __builtin_bit_cast(half8, bhp[u]), bl = __builtin_bit_cast(half8, blp[u]);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t][u], 0, 0, 0);
+        const half8 ah8 = __builtin_bit_cast(half8, ahp[t]), al8 = __builtin_bit_cast(half8, alp[t]);
+        const half8 bh8 = __builtin_bit_cast(half8, bhp[u]), bl8 = __builtin_bit_cast(half8, blp[u]);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah8, bh8, acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah8, bl8, acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, bh8, acc[t][u], 0, 0, 0);
       }
   };
 
@@ -476,7 +540,7 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
       }
   }
   // riders: the two point halves of a column are combined through LDS
-  float* red = lds;      // [2][256][5] | [2]
+  float* red = lds_f;    // [2][256][5] | [2]
   red[(ph * 256 + col) * 5 + 0] = bias_acc;
   red[(ph * 256 + col) * 5 + 1] = alpha_acc;
   red[(ph * 256 + col) * 5 + 2] = vc0;
@@ -513,7 +577,7 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) 
     S = ldexpf(1.f, min(8 - e, 96));
   }
   if (jb.flags & WF_RGB) {
-    wgrad_rgb_job(a, jb, ldsw, c0, c1, out);
+    wgrad_rgb_job<true>(a, jb, ldsw, c0, c1, out);
   } else if (jb.kw == 256) {
     wgrad_f16_job<256>(a, jb, ldsw, c0, c1, S, out);
   } else {
@@ -548,8 +612,11 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   hipStream_t s = (hipStream_t)stream;
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   if (scade_attr_needed(attr_set)) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_f16_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_f16_kernel<false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, DGRAD_F16_LDS_BYTES);
+    SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_f16_kernel<true>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, DGRAD_F16_LDS_BYTES);
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(attr_set);
   }
@@ -564,7 +631,9 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(64), 0, s, gmax);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(zero)")) return e;
   MlpDgradF16Args d{packed, reinterpret_cast<const _Float16*>(packed_t_f16), acts, g_out, dz, gmax, P};
-  hipLaunchKernelGGL(mlp_dgrad_f16_kernel, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
+  // wgrad_f16: the whole backward works on 24-bit saved rows (the forward was run with mode + 2); else on fp32 rows
+  if (wgrad_f16) hipLaunchKernelGGL(mlp_dgrad_f16_kernel<true>, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
+  else hipLaunchKernelGGL(mlp_dgrad_f16_kernel<false>, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(dgrad)")) return e;
   if (!wgrad_f16) return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
   static unsigned long long wattr = 0;   // one bit per device ordinal

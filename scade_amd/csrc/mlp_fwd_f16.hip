@@ -90,7 +90,7 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
   return bits;
 }
 
-template <int MODE, bool SAVE>
+template <int MODE, int SAVE>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* xh = ldsh;
@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     const unsigned long long bits_ =                                                             \
         layer_store_h<2, true, 2>(acc0, acc1, nt0, xh, xl, lane, cb, TAIL(off_b(LNEXT)), nt0);   \
     if (SAVE) store_relu_words<2>(a.acts, P, L, tid, bits_);                                     \
-    if (SAVE) save_tile_h_wave<64>(xh, xl, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, nullptr, lane); \
+    if (SAVE) save_tile_h_wave<64, SAVE == 2>(xh, xl, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, nullptr, lane); \
     __syncthreads();                                                                             \
   }
 
@@ -275,7 +275,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
   layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WHBASE(L_FEAT), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane, cb);
   __syncthreads();
   layer_store_h<2, false, 1>(acc0, acc1, nt0, xh, xl, lane, cb, TAIL(off_b(L_VIEWS)), wave);
-  if (SAVE) save_tile_h_wave<64>(xh, xl, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, nullptr, lane);
+  if (SAVE) save_tile_h_wave<64, SAVE == 2>(xh, xl, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, nullptr, lane);
   __syncthreads();
 
   // ---- views layer: [view pad | feature] -> 128, ReLU --------------------------------
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_f16_kernel(MlpF16Args a) {
     layer_gemm_h<1, 1, 16, true>(av0, av1, an, WHBASE(L_VIEWS), WHBASE(L_VIEWS), 0, eh, el, xh, xl, lane, cb);
     __syncthreads();
     layer_store_h<1, true, 0>(av0, av1, wave, xh, xl, lane, cb, nullptr, 0);
-    if (SAVE) save_tile_h_wave<32>(xh, xl, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, nullptr, lane);
+    if (SAVE) save_tile_h_wave<32, SAVE == 2>(xh, xl, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, nullptr, lane);
     __syncthreads();
   }
 #undef WHBASE
@@ -394,7 +394,7 @@ extern "C" int scade_mlp_pack_f16(const float* const* params, void* packed, void
   return scade_check_launch("scade_mlp_pack_f16");
 }
 
-template <int MODE, bool SAVE>
+template <int MODE, int SAVE>
 static int launch_f16(const MlpF16Args& a, hipStream_t s) {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   auto kern = mlp_fwd_f16_kernel<MODE, SAVE>;
@@ -413,13 +413,16 @@ extern "C" int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* 
                                  float* out, float* acts, void* stream) {
   if (P == 0) return 0;
   SCADE_REQUIRE(packed_f16 && in && out, -1, "scade_mlp_fwd_f16: null pointer");
-  SCADE_REQUIRE(mode == 0 || mode == 1, -2, "scade_mlp_fwd_f16: mode must be 0 or 1");
+  SCADE_REQUIRE(mode >= 0 && mode <= 3, -2, "scade_mlp_fwd_f16: mode must be 0 or 1 (+ 2: 24-bit saved rows)");
+  const bool rows24 = (mode & 2) != 0;
+  mode &= 1;
+  SCADE_REQUIRE(!rows24 || acts, -2, "scade_mlp_fwd_f16: mode + 2 (24-bit saved rows) needs the training workspace");
   if (mode == 1) {
     SCADE_REQUIRE(viewdirs && bb && vd_stride >= 3, -1, "scade_mlp_fwd_f16: mode 1 needs viewdirs and bb");
     SCADE_REQUIRE(S > 0 && P % S == 0, -2, "scade_mlp_fwd_f16: P must be a multiple of S");
   }
   MlpF16Args a{packed_f16, in, viewdirs, bb, out, acts, P, S, vd_stride};
   hipStream_t s = (hipStream_t)stream;
-  if (mode == 0) return acts ? launch_f16<0, true>(a, s) : launch_f16<0, false>(a, s);
-  return acts ? launch_f16<1, true>(a, s) : launch_f16<1, false>(a, s);
+  if (mode == 0) return !acts ? launch_f16<0, 0>(a, s) : rows24 ? launch_f16<0, 2>(a, s) : launch_f16<0, 1>(a, s);
+  return !acts ? launch_f16<1, 0>(a, s) : rows24 ? launch_f16<1, 2>(a, s) : launch_f16<1, 1>(a, s);
 }

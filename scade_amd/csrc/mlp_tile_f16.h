@@ -217,15 +217,70 @@ __device__ __forceinline__ void save_tile_h(const _Float16* xh, const _Float16* 
   }
 }
 
+// ---- 24-bit saved rows ("f16x3" training, round 5) ----------------------------------------------------------
+// The rows a training forward / dgrad chain saves for the weight gradient were fp32 (1 KiB per point and layer):
+// the step's weight gradient reads 4.2 GB of them per fine launch AT THE MEMORY SYSTEM'S RATE, so the
+// lever is bytes.  A row now leaves AS THE KERNELS HOLD IT IN LDS - the two fp16 planes x ~= h + l * 2^-11 - with the
+// low plane rounded (RNE) to 8 bits: an e5m2 number IS the upper byte of an fp16 number, so
+//   h   [P][256] fp16 at byte 0       of the row's old slot (the MFMA operand of the weight gradient as it lies)
+//   l8  [P][256] e5m2 at byte P * 512 of the slot           (l to 3 significant bits: x to 14, relative error
+//                                                            <= 2^-14, zero-mean)
+// 768 of the slot's 1024 bytes per point.  The weight gradient then needs NO split on the VALU (the 88
+// conversion-class operations per wave and stage that were its compute side): a byte widens to fp16 by one
+// v_perm_b32 per pair, which also does the point-pair transposition of the fragment.  dZ rows stay in the dgrad
+// chain's PER-POINT scaled domain (gh, gl as they lie; fp16 has no range for the true 1e-8 .. 1e-3 gradients) and
+// 1 / s_p is kept per point (rows24_invs_byte: in the unused quarter of dZ slot 0); the weight gradient multiplies
+// the pair of a fragment by (S / s_p) as packed fp16 - a power of two.  "f16x3-dgrad" (exact weight gradient) keeps
+// fp32 rows.  A first form of this round - fp32 rounded to its upper 24 bits, reassembled by v_perm_b32 in front of
+// the unchanged split - cut the forward and dgrad by 7 % each and made the weight gradient 27 % SLOWER (the split's
+// conversions + 48 perms + twice the LDS reads: compute-bound): measured, replaced by this form.
+constexpr long rows24_l8_byte(long P) { return P * 512; }
+constexpr long rows24_invs_byte(long P) { return P * 768; }     // [P] fp32 inside dZ slot 0's unused quarter
+typedef _Float16 half2v __attribute__((ext_vector_type(2)));
+// the e5m2 bytes of four packed halves (two dwords of the l plane), RNE
+__device__ __forceinline__ unsigned l8_of4(unsigned l01, unsigned l23) {
+  typedef short s16x2 __attribute__((ext_vector_type(2)));
+  s16x2 q = {0, 0};
+  q = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(q, __builtin_bit_cast(half2v, l01), 1.0f, false);
+  q = __builtin_amdgcn_cvt_scalef32_pk_bf8_f16(q, __builtin_bit_cast(half2v, l23), 1.0f, true);
+  return __builtin_bit_cast(unsigned, q);
+}
+// x = h + l * 2^-11 from an fp16 h (low 16 bits of hbits) and an e5m2 byte (low 8 bits of lbyte)
+__device__ __forceinline__ float r24_value(unsigned hbits, unsigned lbyte) {
+  float x;
+  const unsigned l16 = lbyte << 8;
+  const float inv = LINV;
+  asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,1]" : "=v"(x) : "v"(l16), "s"(inv), "v"(hbits));
+  return x;
+}
+// four values of a row from global memory: columns [c4, c4 + 4) of point pt
+__device__ __forceinline__ f32x4 r24_load4(const float* slot, long P, size_t pt, int c4) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const unsigned char* b = reinterpret_cast<const unsigned char*>(slot);
+  const u32x2 h = *reinterpret_cast<const u32x2*>(b + pt * 512 + c4 * 2);
+  const unsigned m = *reinterpret_cast<const unsigned*>(b + rows24_l8_byte(P) + pt * 256 + c4);
+  return f32x4{r24_value(h[0] & 0xffffu, m & 0xffu), r24_value(h[0] >> 16, (m >> 8) & 0xffu),
+               r24_value(h[1] & 0xffffu, (m >> 16) & 0xffu), r24_value(h[1] >> 16, m >> 24)};
+}
+// four values given as their planes (vh, vl: the pair the kernels write to LDS) -> the row
+__device__ __forceinline__ void r24_store4(float* slot, long P, size_t pt, int c4, const half4& vh, const half4& vl) {
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  unsigned char* b = reinterpret_cast<unsigned char*>(slot);
+  const u32x2 h = __builtin_bit_cast(u32x2, vh), l = __builtin_bit_cast(u32x2, vl);
+  *reinterpret_cast<u32x2*>(b + pt * 512 + c4 * 2) = h;
+  *reinterpret_cast<unsigned*>(b + rows24_l8_byte(P) + pt * 256 + c4) = l8_of4(l[0], l[1]);
+}
+
 // the same copy for the NCW columns (from column c0) ONE WAVE has just written (see save_tile_wave in mlp_tile.h), in
 // its round-4 form: the lane's chunks are two LDS base addresses + immediates (rows 16 apart share their swizzle),
 // the stores are buffer stores with a fixed lane offset, the row part in the scalar offset and the ragged last tile
 // left to the descriptor's range check - no address arithmetic, no exec-mask branch per chunk; two chunks in flight
-template <int NCW>
+template <int NCW, bool R24 = false>
 __device__ __forceinline__ void save_tile_h_wave(const _Float16* xh, const _Float16* xl, float* __restrict__ dst,
                                                  int p0, int P, int c0, const float* row_scale, int lane) {
   static_assert(NCW == 64 || NCW == 32, "a wave owns 64 columns (32 in the views layer)");
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   constexpr int CPR = NCW >> 3;                         // 8-half chunks per row of this wave's columns: 8 or 4
   constexpr int RPI = 64 / CPR;                         // rows per wave instruction: 8 or 16
   constexpr int NB = 16 / RPI;                          // swizzle classes: 2 or 1
@@ -235,12 +290,21 @@ __device__ __forceinline__ void save_tile_h_wave(const _Float16* xh, const _Floa
   int off[NB];
 #pragma unroll
   for (int b = 0; b < NB; ++b) off[b] = (RPI * b + lr) * W + ((c ^ (RPI * b + lr)) << 3);      // x_idx(row, c) in halves
-  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)p0 * 1024ull;   // (mlp_tile.h)
+  constexpr unsigned PITCH = R24 ? 512u : 1024u;        // bytes per row of the (first) plane
+  const unsigned long long pd = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)p0 * PITCH;   // (mlp_tile.h)
   const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
       reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
-      __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 1024u), 0x00020000);
-  const int voff = lr * 1024 + c * 32;
+      __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * PITCH), 0x00020000);
+  // 24-bit rows: the l8 plane behind the h plane of the slot (rows24_l8_byte)
+  const unsigned long long pm = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)rows24_l8_byte(P) +
+                                (unsigned long long)p0 * 256ull;
+  const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)pm), mhi = __builtin_amdgcn_readfirstlane((unsigned)(pm >> 32));
+  const __amdgpu_buffer_rsrc_t rm = __builtin_amdgcn_make_buffer_rsrc(
+      reinterpret_cast<void*>(((unsigned long long)mhi << 32) | mlo), 0,
+      __builtin_amdgcn_readfirstlane(R24 ? tile_rows_left(p0, P) * 256u : 0u), 0x00020000);
+  const int voff = R24 ? lr * 512 + c * 16 : lr * 1024 + c * 32;
+  const int voffm = lr * 256 + c * 8;
   constexpr int soff = 0;
 #pragma unroll
   for (int it0 = 0; it0 < ITERS; it0 += 2) {
@@ -251,18 +315,25 @@ __device__ __forceinline__ void save_tile_h_wave(const _Float16* xh, const _Floa
       const int it = it0 + j, o = off[it % NB] + (it / NB) * 16 * W;
       vh[j] = *reinterpret_cast<const u32x4*>(xh + o);
       vl[j] = *reinterpret_cast<const u32x4*>(xl + o);
-      sc[j] = row_scale ? row_scale[it * RPI + lr] : 1.0f;
+      sc[j] = (!R24 && row_scale) ? row_scale[it * RPI + lr] : 1.0f;
     }
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
       const int it = it0 + j;
-      float x[8];
+      if (R24) {
+        // the planes as they lie (the dgrad chain's rows stay in its per-point scaled domain: row_scale is not applied)
+        const u32x2 om = {l8_of4(vl[j][0], vl[j][1]), l8_of4(vl[j][2], vl[j][3])};
+        __builtin_amdgcn_raw_buffer_store_b128(vh[j], rs, voff, soff + it * RPI * 512, 2);      // streamed once: nt
+        __builtin_amdgcn_raw_buffer_store_b64(om, rm, voffm, soff + it * RPI * 256, 2);
+      } else {
+        float x[8];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) join2(vh[j][k], vl[j][k], x[2 * k], x[2 * k + 1]);
-      const u32x4 o0 = {__float_as_uint(x[0] * sc[j]), __float_as_uint(x[1] * sc[j]), __float_as_uint(x[2] * sc[j]), __float_as_uint(x[3] * sc[j])};
-      const u32x4 o1 = {__float_as_uint(x[4] * sc[j]), __float_as_uint(x[5] * sc[j]), __float_as_uint(x[6] * sc[j]), __float_as_uint(x[7] * sc[j])};
-      __builtin_amdgcn_raw_buffer_store_b128(o0, rs, voff, soff + it * RPI * 1024, 2);          // streamed once: nt
-      __builtin_amdgcn_raw_buffer_store_b128(o1, rs, voff + 16, soff + it * RPI * 1024, 2);
+        for (int k = 0; k < 4; ++k) join2(vh[j][k], vl[j][k], x[2 * k], x[2 * k + 1]);
+        const u32x4 o0 = {__float_as_uint(x[0] * sc[j]), __float_as_uint(x[1] * sc[j]), __float_as_uint(x[2] * sc[j]), __float_as_uint(x[3] * sc[j])};
+        const u32x4 o1 = {__float_as_uint(x[4] * sc[j]), __float_as_uint(x[5] * sc[j]), __float_as_uint(x[6] * sc[j]), __float_as_uint(x[7] * sc[j])};
+        __builtin_amdgcn_raw_buffer_store_b128(o0, rs, voff, soff + it * RPI * 1024, 2);          // streamed once: nt
+        __builtin_amdgcn_raw_buffer_store_b128(o1, rs, voff + 16, soff + it * RPI * 1024, 2);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
   }

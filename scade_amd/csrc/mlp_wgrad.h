@@ -114,11 +114,14 @@ inline int build_wgrad_jobs(WgradArgs& w, const float* acts, const float* dz, co
 // A thread owns 4 columns (one 16-byte load per point) of every 16th point, four points in
 // flight: this job is pure load latency and, as the LAST job of the table, its workgroups
 // would otherwise set the end of the whole launch.
+// R24: the views rows are 24-bit rows (mlp_tile_f16.h: h plane fp16 [P][256], l8 plane e5m2 [P][256] behind it)
+template <bool R24 = false>
 __device__ __forceinline__ void wgrad_rgb_job(const WgradArgs& a, const WgradJob& jb, float* lds,
                                               int c0, int c1, float* __restrict__ out) {
   const int tid = threadIdx.x;
   const int k4 = tid & 31, pl = tid >> 5;       // 32 column groups x 16 point lanes
   const float* __restrict__ hv = a.acts + jb.in_off + 4 * k4;
+  const unsigned char* __restrict__ hvb = reinterpret_cast<const unsigned char*>(a.acts + jb.in_off);
   const int P = a.P;
   float s[3][4], b[3] = {0.f, 0.f, 0.f};
 #pragma unroll
@@ -130,7 +133,21 @@ __device__ __forceinline__ void wgrad_rgb_job(const WgradArgs& a, const WgradJob
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int pt = min(pt0 + 16 * q, P - 1);
-      h[q] = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * 256);
+      if (R24) {
+        typedef unsigned u32x2_ __attribute__((ext_vector_type(2)));
+        const u32x2_ hh_ = *reinterpret_cast<const u32x2_*>(hvb + (size_t)pt * 512 + 8 * k4);
+        const unsigned mm_ = *reinterpret_cast<const unsigned*>(hvb + (size_t)P * 512 + (size_t)pt * 256 + 4 * k4);
+        auto val = [](unsigned h16, unsigned l8) {          // h + l * 2^-11 (l8: the upper byte of the fp16 l)
+          return (float)__builtin_bit_cast(_Float16, (unsigned short)h16) +
+                 (float)__builtin_bit_cast(_Float16, (unsigned short)(l8 << 8)) * (1.0f / 2048.0f);
+        };
+        h[q][0] = val(hh_[0] & 0xffffu, mm_ & 0xffu);
+        h[q][1] = val(hh_[0] >> 16, (mm_ >> 8) & 0xffu);
+        h[q][2] = val(hh_[1] & 0xffffu, (mm_ >> 16) & 0xffu);
+        h[q][3] = val(hh_[1] >> 16, mm_ >> 24);
+      } else {
+        h[q] = *reinterpret_cast<const f32x4*>(hv + (size_t)pt * 256);
+      }
       g[q] = *reinterpret_cast<const f32x4*>(a.g_out + (size_t)pt * 4);
     }
 #pragma unroll

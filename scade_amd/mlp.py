@@ -30,7 +30,7 @@ class MlpEmbeddedFn(torch.autograd.Function):
             code, bf16 = ops.LP_FORMATS[net.train_precision]
             out = ops.mlp_fwd_lp(net.packed_lp(bf16), code, x, None, None, acts)
         elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
-            out = ops.mlp_fwd_f16(net.packed_f16(), x, None, None, acts)
+            out = ops.mlp_fwd_f16(net.packed_f16(), x, None, None, acts, rows24=net.train_precision == "f16x3")
         else:
             out = ops.mlp_fwd_embedded(net.packed(), x, acts)
         ctx.net, ctx.mode = net, 0
@@ -60,7 +60,7 @@ class MlpPointsFn(torch.autograd.Function):
             code, bf16 = ops.LP_FORMATS[net.train_precision]
             out = ops.mlp_fwd_lp(net.packed_lp(bf16), code, pts, viewdirs, bb, acts)
         elif train and net.train_precision in ("f16x3", "f16x3-dgrad"):
-            out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts)
+            out = ops.mlp_fwd_f16(net.packed_f16(), pts, viewdirs, bb, acts, rows24=net.train_precision == "f16x3")
         else:
             out = ops.mlp_fwd_points(net.packed(), pts, viewdirs, bb, acts)
         ctx.net, ctx.mode, ctx.n_params = net, 1, len(params)

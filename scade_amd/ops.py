@@ -234,7 +234,9 @@ def mlp_pack_t_f16(params: Sequence[Tensor]) -> Tensor:
 
 def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tensor,
                 wgrad_f16: bool = True, out: Optional[Tensor] = None) -> Tensor:
-    """Split-precision dgrad + exact wgrad -> flat gradient [589700] in PARAM_ORDER."""
+    """Split-precision dgrad + weight gradient -> flat gradient [589700] in PARAM_ORDER.  ``wgrad_f16``: the
+    split-precision weight gradient on 24-bit saved rows (the forward must have run with ``rows24=True``); False: the
+    exact fp32 weight gradient on fp32 rows."""
     g = _c(check(g_out, "mlp_bwd_f16: g_out")).reshape(-1, 4)
     P = g.shape[0]
     ws = torch.empty(int(_lib.load().scade_mlp_bwd_workspace_floats(P)), device=g.device, dtype=torch.float32)
@@ -248,23 +250,28 @@ def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tenso
 
 
 def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb: Optional[Tensor],
-                acts: Optional[Tensor] = None) -> Tensor:
-    """Split-precision forward: inp [P,60] (viewdirs None) or pts [N,S,3] + viewdirs [N,3] + bb [4]."""
+                acts: Optional[Tensor] = None, rows24: bool = False) -> Tensor:
+    """Split-precision forward: inp [P,60] (viewdirs None) or pts [N,S,3] + viewdirs [N,3] + bb [4].  ``rows24``
+    (with ``acts``): the saved rows in the 24-bit form the split-precision weight gradient reads (mode + 2) - what
+    ``mlp_bwd_f16(wgrad_f16=True)`` expects; False: fp32 rows (``wgrad_f16=False``, the exact weight gradient)."""
     check(inp, "mlp_fwd_f16: input")
     inp = _c(inp)
+    if rows24 and acts is None:
+        raise ValueError("mlp_fwd_f16: rows24 needs the training workspace")
+    fmt = 2 if rows24 else 0
     if viewdirs is None:
         if inp.dim() != 2 or inp.shape[1] != 60:
             raise ValueError("mlp_fwd_f16: x must be [P,60]")
         P = inp.shape[0]
         out = torch.empty(P, 4, device=inp.device, dtype=torch.float32)
-        call("scade_mlp_fwd_f16", ptr(packed_f16), 0, ptr(inp), None, 0, None, P, 1, ptr(out), ptr(acts), stream())
+        call("scade_mlp_fwd_f16", ptr(packed_f16), 0 + fmt, ptr(inp), None, 0, None, P, 1, ptr(out), ptr(acts), stream())
         return out
     N, S = inp.shape[0], inp.shape[1]
     viewdirs, vstride = _rows(viewdirs, "mlp_fwd_f16: viewdirs")
     bb = _c(check(bb, "mlp_fwd_f16: bb"))
     out = torch.empty(N, S, 4, device=inp.device, dtype=torch.float32)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
-    call("scade_mlp_fwd_f16", ptr(packed_f16), 1, ptr(inp), ptr(viewdirs), vstride, ptr(bb), N * S, S,
+    call("scade_mlp_fwd_f16", ptr(packed_f16), 1 + fmt, ptr(inp), ptr(viewdirs), vstride, ptr(bb), N * S, S,
          ptr(out), ptr(acts), stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_fwd_f16_kernel", t0, float(N * S) * MLP_FLOP_PER_POINT)

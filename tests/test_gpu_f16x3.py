@@ -116,6 +116,20 @@ def sub(g):
     return f if f.numel() <= 4096 else f[::97]
 
 
+def rows24_to_fp32(acts, P):
+    """The f16x3 forward's saved rows (round 5: fp16 h plane [P,256] + e5m2 l plane [P,256] inside each row slot,
+    x = h + l * 2^-11; include/scade_hip.h, scade_mlp_fwd_f16 mode + 2) as the fp32 rows the exact backward reads:
+    the ten row slots unpacked, everything behind them (embedding rows, alpha_pre, ReLU sign words) as it is."""
+    out = acts.clone()
+    raw = acts.view(torch.uint8)
+    for s in range(10):
+        b = raw[s * P * 1024:(s + 1) * P * 1024]
+        h = b[:P * 512].view(torch.float16).view(P, 256).float()
+        l = b[P * 512:P * 768].view(torch.float8_e5m2).view(P, 256).float()
+        out[s * P * 256:(s + 1) * P * 256] = (h + l / 2048.0).reshape(-1)
+    return out
+
+
 def test_f16x3_training_gradients_golden(dev):
     """train_precision='f16x3': forward + dgrad on f16 MFMAs (per-point gradient scale), exact
     wgrad -- same gradient bar as the exact backward (tests/test_gpu_train.py)."""
@@ -186,7 +200,7 @@ def test_f16x3_train_step_golden(dev):
     assert_close(loss, g["train/loss"], rtol=1e-4, atol=1e-7, what="loss")
     for P, net in ((32 * 64, coarse), (32 * 192, fine)):
         acts, g_out, flat = cap[P]
-        exact = ops.mlp_bwd(net.packed(), net.packed_t(), acts, g_out)
+        exact = ops.mlp_bwd(net.packed(), net.packed_t(), rows24_to_fp32(acts, P), g_out)
         assert rel_l2(flat, exact) < 2e-5, (P, rel_l2(flat, exact))
         got = torch.cat([p.grad.reshape(-1) for p in net.ordered_params()])
         assert torch.equal(got, flat)
