@@ -274,13 +274,13 @@ constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4 + 16;   // + the fo
 // per-point scalars (d alpha, view direction) ride the ring as 4-byte LDS-DMA pieces.
 // ---------------------------------------------------------------------------
 constexpr int HW_PT = 16;                                 // points per ring slot = one k16 block
-constexpr int HW_D = 5;                                   // ring slots
+constexpr int HW_D = 5;                                   // ring slots (4 and 6 measure the same)
 // bytes of a slot: dZ h [16][256] fp16 | dZ l8 [16][256] e5m2 | input h | input l8 (KW = 64: the fp32 embedding
 // rows [16][64] instead) | d alpha [16] fp32 | view dirs [16][3] fp32 | 1 / s_p [16] fp32
 constexpr int HW_DZ_HI = 0, HW_DZ_MID = HW_PT * 512, HW_IN_HI = HW_PT * 768, HW_IN_MID = HW_PT * 1280;
 constexpr int HW_SCAL = HW_PT * 1536;                     // d alpha [16] | view dirs [16][3] | 1 / s_p [16]
 constexpr int HW_SLOT = HW_SCAL + 320;                    // 24,896
-constexpr int WGRAD_F16_RED_BYTES = (2 * 256 * 5 + 2) * 4;              // the riders' reduction scratch
+constexpr int WGRAD_F16_RED_BYTES = (2 * 256 * 4 + 2) * 4;             // the riders' reduction scratch
 constexpr int WGRAD_F16_LDS_BYTES = HW_D * HW_SLOT > WGRAD_F16_RED_BYTES ? HW_D * HW_SLOT : WGRAD_F16_RED_BYTES;   // 124,480
 
 struct WgradF16Args {
@@ -316,7 +316,7 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
                                               int c0, int c1, float S, float* __restrict__ out) {
   constexpr int NKT = KW == 256 ? 4 : 1;
   constexpr int D = HW_D, PT = HW_PT;
-  constexpr int NI = (KW == 256 ? 4 : 3) + 3;     // LDS-DMA instructions per wave and stage
+  constexpr int NI = (KW == 256 ? 3 : 2) + 3;     // LDS-DMA instructions per wave and stage
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f);
@@ -359,15 +359,20 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
     unsigned char* slot = lds + sl * HW_SLOT;
     const int grow = st * PT + 2 * wave;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr_t)(slot + HW_DZ_HI + 2 * wave * 512), 16, lane * 16, grow * 512, 0, 2);
-    if (lane < 32)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + 2 * wave * 256), 16, lane * 16, grow * 256, 0, 2);
+    // the l8 rows four at a time (1 KiB per instruction): waves 0-3 the dZ tile's, waves 4-7 the input tile's
+    const int w4 = wave & 3, grow4 = st * PT + 4 * w4;
     if (KW == 256) {
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 2 * wave * 512), 16, lane * 16, grow * 512, 0, 2);
-      if (lane < 32)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbm, (lds_ptr_t)(slot + HW_IN_MID + 2 * wave * 256), 16, lane * 16, grow * 256, 0, 2);
+      if (wave < 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbm, (lds_ptr_t)(slot + HW_IN_MID + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
     } else {
-      if (lane < 32)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 2 * wave * 256), 16, lane * 16, grow * 256, 0, 2);
+      // (the fp32 embedding rows are 256 bytes too: waves 4-7 take them four at a time)
+      if (wave < 4)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
+      else
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
     }
     if (lane < 2)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(slot + HW_SCAL + 4 * 2 * wave), 4, lane * 4, grow * 4, 0, 0);
@@ -378,31 +383,30 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
                                                (lane / 3) * 256 + (60 + lane % 3) * 4, grow * 256, 0, 0);
   };
 
-  // ---- riders on the values of the published slot: thread = (column tid & 255, point half tid >> 8).  The column
-  // reads are issued unconditionally with the fragment reads and summed behind the MFMAs; the two rare riders
-  // (one job each) take one wave-uniform branch per stage, not one per point.
-  float bias_acc = 0.f, alpha_acc = 0.f, dal_acc = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
+  // ---- riders.  Bias: db[n] = sum over points of dZ[p][n] is a dot product of the dZ fragment the lane has just built
+  // (eight points of feature 2r + t, already scaled by S / s_p) with ones: v_dot2_f32_f16, fp32 accumulate, in
+  // compute() on the waves of the first k half - no LDS read, no conversion.  (As a separate pass over the published
+  // slot - per column and point two LDS reads, a widening and three conversion-class operations, 512 threads x 8
+  // values per stage - the riders were 18 % of the kernel: knock-out 693 -> 568 us; four columns x two points per
+  // thread with v_fma_mix_f32 on the planes: 674.)
+  // View columns / alpha head (one job each): thread = (column tid & 255, point half tid >> 8) on reassembled values,
+  // behind one wave-uniform branch per stage.
+  float bacc[2] = {0.f, 0.f};
+  float alpha_acc = 0.f, dal_acc = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
   const int col = tid & 255, ph = __builtin_amdgcn_readfirstlane(tid >> 8);
   const bool want_view = (jb.flags & WF_VIEWCOLS) != 0, want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
-  float rcol[PT / 2];
-  auto riders_read = [&](int sl) {
+  const bool bias_wave = (wave & 1) == 0;
+  auto riders_add = [&](int sl) {
+    if (!(want_view || want_alpha)) return;
     const unsigned char* slot = lds + sl * HW_SLOT;
     const float* isv = reinterpret_cast<const float*>(slot + HW_SCAL + 256);
-#pragma unroll
-    for (int q = 0; q < PT / 2; ++q) {
-      const int p = ph * (PT / 2) + q;
-      rcol[q] = hw_col24(slot + HW_DZ_HI + p * 512, slot + HW_DZ_MID + p * 256, col) * isv[p];   // the true dZ value
-    }
-  };
-  auto riders_add = [&](int sl) {
-    const unsigned char* slot = lds + sl * HW_SLOT;
-#pragma unroll
-    for (int q = 0; q < PT / 2; ++q) bias_acc += rcol[q];
     if (want_view) {
       const float* vw = reinterpret_cast<const float*>(slot + HW_SCAL + 64) + 3 * ph * (PT / 2);
 #pragma unroll
       for (int q = 0; q < PT / 2; ++q) {
-        vc0 = fmaf(rcol[q], vw[3 * q + 0], vc0); vc1 = fmaf(rcol[q], vw[3 * q + 1], vc1); vc2 = fmaf(rcol[q], vw[3 * q + 2], vc2);
+        const int p = ph * (PT / 2) + q;
+        const float x = hw_col24(slot + HW_DZ_HI + p * 512, slot + HW_DZ_MID + p * 256, col) * isv[p];   // the true dZ value
+        vc0 = fmaf(x, vw[3 * q + 0], vc0); vc1 = fmaf(x, vw[3 * q + 1], vc1); vc2 = fmaf(x, vw[3 * q + 2], vc2);
       }
     }
     if (want_alpha) {
@@ -438,10 +442,13 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
     {
       const f32x4* isv = reinterpret_cast<const f32x4*>(slot + HW_SCAL + 256) + 2 * hh;
       const f32x4 i0 = isv[0], i1 = isv[1];
-      kp[0] = half2v{(_Float16)(i0[0] * S), (_Float16)(i0[1] * S)};
-      kp[1] = half2v{(_Float16)(i0[2] * S), (_Float16)(i0[3] * S)};
-      kp[2] = half2v{(_Float16)(i1[0] * S), (_Float16)(i1[1] * S)};
-      kp[3] = half2v{(_Float16)(i1[2] * S), (_Float16)(i1[3] * S)};
+      // (a point without gradient has s_p = 1 and rows of zeros: S alone overflows fp16, and inf x 0 is NaN -
+      // any finite factor serves such a row; a point at the launch maximum has S / s_p = 2^12)
+      auto kf = [&](float is) { return (_Float16)fminf(is * S, 32768.0f); };
+      kp[0] = half2v{kf(i0[0]), kf(i0[1])};
+      kp[1] = half2v{kf(i0[2]), kf(i0[3])};
+      kp[2] = half2v{kf(i1[0]), kf(i1[1])};
+      kp[3] = half2v{kf(i1[2]), kf(i1[3])};
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) kl[j2] = kp[j2] * k_l;
     }
@@ -484,6 +491,22 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
         bhp[0][j2] = h; blp[0][j2] = l;
       }
     }
+    if (bias_wave) {
+      auto dot_ones = [](unsigned w, float c) {
+        const half2v ones = {(_Float16)1.0f, (_Float16)1.0f};
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, w), ones, c, false);
+      };
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int j2 = 0; j2 < 4; ++j2) {
+          // (through scalars: hipcc lowers __builtin_bit_cast of a vector-element subscript as element 0 in unrolled
+          // loops - DESIGN.md toolchain notes)
+          const unsigned wh = ahp[t][j2], wl = alp[t][j2];
+          bacc[t] = dot_ones(wh, bacc[t]);
+          bacc[t] = dot_ones(wl, bacc[t]);
+        }
+    }
 #pragma unroll
     for (int u = 0; u < NKT; ++u)
 #pragma unroll
@@ -505,7 +528,6 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NI) : "memory");
     hw_barrier();                                 // ... and so have everybody's; the slot of stage st-1 is read out
     issue(st + D - 1, sl == 0 ? D - 1 : sl - 1);
-    riders_read(sl);
     compute(sl);
     riders_add(sl);
     sl = sl + 1 == D ? 0 : sl + 1;
@@ -539,26 +561,33 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
         }
       }
   }
-  // riders: the two point halves of a column are combined through LDS
-  float* red = lds_f;    // [2][256][5] | [2]
-  red[(ph * 256 + col) * 5 + 0] = bias_acc;
-  red[(ph * 256 + col) * 5 + 1] = alpha_acc;
-  red[(ph * 256 + col) * 5 + 2] = vc0;
-  red[(ph * 256 + col) * 5 + 3] = vc1;
-  red[(ph * 256 + col) * 5 + 4] = vc2;
-  if (col == 0) red[2 * 256 * 5 + ph] = dal_acc;
-  __syncthreads();
-  if (tid < 256) {
-    const float* r0 = red + (size_t)tid * 5, *r1 = red + (size_t)(256 + tid) * 5;
-    if ((jb.flags & WF_BIAS) && tid < jb.n_rows) out[jb.b_off + tid] = r0[0] + r1[0];
-    if (KW == 256 && (jb.flags & WF_ALPHA)) out[jb.aux_off + tid] = r0[1] + r1[1];
-    if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
-      out[jb.w_off + (size_t)tid * jb.ld + 256] = r0[2] + r1[2];
-      out[jb.w_off + (size_t)tid * jb.ld + 257] = r0[3] + r1[3];
-      out[jb.w_off + (size_t)tid * jb.ld + 258] = r0[4] + r1[4];
+  // bias: the two point halves (lanes r and r + 32) of a feature meet by a lane exchange; dZ scale removed
+  if (active && bias_wave && (jb.flags & WF_BIAS)) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const float b = bacc[t] + __shfl_xor(bacc[t], 32, 64);
+      const int n = n0 + 2 * r + t;
+      if (hh == 0 && n < jb.n_rows) out[jb.b_off + n] = b * invS;
     }
   }
-  if (KW == 256 && (jb.flags & WF_ALPHA) && tid == 0) out[jb.aux_off + 256] = red[2 * 256 * 5] + red[2 * 256 * 5 + 1];
+  // riders: the two point halves of a column are combined through LDS
+  float* red = lds_f;    // [2][256][4] alpha | view cols, [2] d alpha
+  red[(ph * 256 + col) * 4 + 0] = alpha_acc;
+  red[(ph * 256 + col) * 4 + 1] = vc0;
+  red[(ph * 256 + col) * 4 + 2] = vc1;
+  red[(ph * 256 + col) * 4 + 3] = vc2;
+  if (col == 0) red[2 * 256 * 4 + ph] = dal_acc;
+  __syncthreads();
+  if (tid < 256) {
+    const float* r0 = red + (size_t)tid * 4, *r1 = red + (size_t)(256 + tid) * 4;
+    if (KW == 256 && (jb.flags & WF_ALPHA)) out[jb.aux_off + tid] = r0[0] + r1[0];
+    if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
+      out[jb.w_off + (size_t)tid * jb.ld + 256] = r0[1] + r1[1];
+      out[jb.w_off + (size_t)tid * jb.ld + 257] = r0[2] + r1[2];
+      out[jb.w_off + (size_t)tid * jb.ld + 258] = r0[3] + r1[3];
+    }
+  }
+  if (KW == 256 && (jb.flags & WF_ALPHA) && tid == 0) out[jb.aux_off + 256] = red[2 * 256 * 4] + red[2 * 256 * 4 + 1];
 }
 
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) {
