@@ -762,6 +762,7 @@ def main():
     if not args.no_train:
         guarded("train_step", train_region, *tr_args)
         if use_dist:
+            guarded("train_step_staged", train_region, *tr_args, allreduce="staged")
             guarded("train_step_overlap", train_region, *tr_args, allreduce="overlap")
     if use_dist and not args.no_image:
         # ONE 468 x 624 test image with its rays split over the ranks, maps all-gathered
@@ -797,6 +798,7 @@ def main():
             # the same with the saved rows (activations, dZ) as 8-bit e5m2: half the HBM bytes of that step
             guarded("train_step_bf16_s8", train_region, *tr_args, precision="bf16-s8")
             if use_dist:
+                guarded("train_step_bf16_s8_staged", train_region, *tr_args, precision="bf16-s8", allreduce="staged")
                 guarded("train_step_bf16_overlap", train_region, *tr_args, precision="bf16", allreduce="overlap")
     if not args.no_train:
         if strong:
@@ -806,6 +808,9 @@ def main():
         if not args.no_fast:
             if use_dist:
                 guarded("train_step_bf16_graph", train_region, *tr_args, precision="bf16", graphed=True)
+                guarded("train_step_bf16_s8_graph", train_region, *tr_args, precision="bf16-s8", graphed=True)
+                guarded("train_step_bf16_s8_staged_graph", train_region, *tr_args, precision="bf16-s8", graphed=True,
+                        allreduce="staged")
             if strong:
                 guarded("train_step_bf16_strong_graph", train_region, *tr_args, precision="bf16",
                         rays_per_gpu=args.rays // world, graphed=True, scaling="strong")

@@ -91,6 +91,14 @@ long scade_mlp_bwd2_workspace_floats(int P, int P_other);
 int scade_mlp_bwd2(const float* const* packed, const float* const* packed_t, const float* const* acts,
                    const float* const* g_out, const int* P, float* const* workspace, float* const* grad_flat,
                    void* stream);
+/* The same backward in phases - phases is a mask: bit 0 = the joint dgrad chain of both networks, bit 1 / bit 2 =
+ * weight gradient + reduce of network 0 / 1 (both = ONE joint weight-gradient launch: scade_mlp_bwd2 = all three).
+ * A ray-sharded step (replaces nn.DataParallel, run_scade_scannet.py:438,455) calls 1, then 2, starts the all-reduce of
+ * network 0's gradient behind it, and calls 4: the exchange runs under network 1's weight gradient.  Same bits per
+ * network as the joint launch. */
+int scade_mlp_bwd2_phases(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                          const float* const* g_out, const int* P, float* const* workspace, float* const* grad_flat,
+                          int phases, void* stream);
 
 /* Split-precision INFERENCE variant of scade_mlp_fwd (opt-in): every fp32 value is
  * carried as two fp16 numbers x ~= h + l*2^-11 and every product as three f16 MFMAs into two fp32
@@ -152,6 +160,10 @@ long scade_mlp_bwd_lp2_workspace_bytes(int P, int P_other);
 int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,
                       const float* const* g_out, const int* P, void* const* workspace,
                       float* const* grad_flat, void* stream);
+/* scade_mlp_bwd_lp2 in phases (see scade_mlp_bwd2_phases; bit 0 also takes the loss-scale maxima). */
+int scade_mlp_bwd_lp2_phases(const void* const* packed_t_lp, int bf16, const void* const* acts,
+                             const float* const* g_out, const int* P, void* const* workspace,
+                             float* const* grad_flat, int phases, void* stream);
 
 /* Split-precision variant of scade_mlp_bwd (opt-in training mode): the dgrad chain runs on
  * f16 MFMAs with a per-point power-of-two gradient scale (exactly removed on store); the weight

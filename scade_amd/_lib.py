@@ -35,6 +35,7 @@ SIGNATURES = {
     "scade_mlp_bwd": (c_int, [_P, _P, _P, _P, _I, _P, _P, _P]),
     "scade_mlp_bwd2_workspace_floats": (c_long, [_I, _I]),
     "scade_mlp_bwd2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    "scade_mlp_bwd2_phases": (c_int, [_P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "scade_mlp_packed_f16_bytes": (c_long, []),
     "scade_mlp_pack_f16": (c_int, [_P, _P, _P]),
     "scade_mlp_fwd_f16": (c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
@@ -49,6 +50,7 @@ SIGNATURES = {
     "scade_mlp_lp_point_tiles": (c_int, [_I]),
     "scade_mlp_bwd_lp2_workspace_bytes": (c_long, [_I, _I]),
     "scade_mlp_bwd_lp2": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P]),
+    "scade_mlp_bwd_lp2_phases": (c_int, [_P, _I, _P, _P, _P, _P, _P, _I, _P]),
     "scade_mlp_packed_t_f16_bytes": (c_long, []),
     "scade_mlp_pack_t_f16": (c_int, [_P, _P, _P]),
     "scade_mlp_bwd_f16": (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),

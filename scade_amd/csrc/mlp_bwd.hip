@@ -286,24 +286,38 @@ extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const f
 // weight-gradient launch and ONE reduce: same arithmetic per network as two scade_mlp_bwd calls (bitwise - a
 // workgroup's work does not depend on its neighbours), but the joint grid fills whole rounds of two workgroups
 // per CU, which matters for the 128-ray shards of a strongly scaled batch, and three launches go.
-extern "C" int scade_mlp_bwd2(const float* const* packed, const float* const* packed_t, const float* const* acts,
-                              const float* const* g_out, const int* P, float* const* workspace,
-                              float* const* grad_flat, void* stream) {
+extern "C" int scade_mlp_bwd2_phases(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                                     const float* const* g_out, const int* P, float* const* workspace,
+                                     float* const* grad_flat, int phases, void* stream) {
   SCADE_REQUIRE(packed && packed_t && acts && g_out && P && workspace && grad_flat, -1, "scade_mlp_bwd2: null pointer");
+  SCADE_REQUIRE(phases > 0 && phases <= 7, -2, "scade_mlp_bwd2: phases is a mask of bits 0..2");
   for (int i = 0; i < 2; ++i) {
     SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd2: P[%d] must be positive", i);
     SCADE_REQUIRE(packed[i] && packed_t[i] && acts[i] && g_out[i] && workspace[i] && grad_flat[i], -1,
                   "scade_mlp_bwd2: null pointer in entry %d", i);
   }
   hipStream_t s = (hipStream_t)stream;
-  // the ReLU words are indexed by 32-point tile, not by workgroup, so the point tiling of this launch is free:
-  // it is chosen for the JOINT grid (64-point workgroups as soon as both networks together give every CU two)
-  const int pt = pick_point_tiles((long)P[0] + P[1]);
-  const int t0 = (P[0] + tile_pts(pt) - 1) / tile_pts(pt), t1 = (P[1] + tile_pts(pt) - 1) / tile_pts(pt);
-  MlpDgradArgs2 d{{{packed[0], packed_t[0], acts[0], g_out[0], workspace[0], P[0]},
-                   {packed[1], packed_t[1], acts[1], g_out[1], workspace[1], P[1]}}, t0};
-  if (int e = pt == 1 ? launch_dgrad<1>(d, t0 + t1, s) : launch_dgrad<2>(d, t0 + t1, s)) return e;
+  if (phases & 1) {
+    // the ReLU words are indexed by 32-point tile, not by workgroup, so the point tiling of this launch is free:
+    // it is chosen for the JOINT grid (64-point workgroups as soon as both networks together give every CU two)
+    const int pt = pick_point_tiles((long)P[0] + P[1]);
+    const int t0 = (P[0] + tile_pts(pt) - 1) / tile_pts(pt), t1 = (P[1] + tile_pts(pt) - 1) / tile_pts(pt);
+    MlpDgradArgs2 d{{{packed[0], packed_t[0], acts[0], g_out[0], workspace[0], P[0]},
+                     {packed[1], packed_t[1], acts[1], g_out[1], workspace[1], P[1]}}, t0};
+    if (int e = pt == 1 ? launch_dgrad<1>(d, t0 + t1, s) : launch_dgrad<2>(d, t0 + t1, s)) return e;
+  }
   float* partial[2] = {workspace[0] + dz_floats(P[0]), workspace[1] + dz_floats(P[1])};
   const float* dz[2] = {workspace[0], workspace[1]};
-  return scade_launch_wgrad2(acts, dz, g_out, P, partial, grad_flat, s);
+  if ((phases & 6) == 6) return scade_launch_wgrad2(acts, dz, g_out, P, partial, grad_flat, s);
+  // one network's weight gradient on its own (scade_mlp_bwd2_workspace_floats covers the separate launch too)
+  for (int i = 0; i < 2; ++i)
+    if (phases & (2 << i))
+      if (int e = scade_launch_wgrad(acts[i], dz[i], g_out[i], P[i], partial[i], grad_flat[i], s)) return e;
+  return 0;
+}
+
+extern "C" int scade_mlp_bwd2(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                              const float* const* g_out, const int* P, float* const* workspace,
+                              float* const* grad_flat, void* stream) {
+  return scade_mlp_bwd2_phases(packed, packed_t, acts, g_out, P, workspace, grad_flat, 7, stream);
 }

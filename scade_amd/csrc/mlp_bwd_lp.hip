@@ -1631,9 +1631,13 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
 }
 
 // two networks: ONE dgrad launch, ONE weight-gradient launch, ONE reduce (scade_mlp_bwd_lp2)
+// phases: bit 0 = loss-scale maxima + the joint dgrad chain of both networks, bit 1 / bit 2 = weight gradient + reduce
+// of network 0 / 1.  Bits 1 and 2 together = ONE balanced weight-gradient launch over both networks; one of them = that
+// network's own balanced launch (a sharded step starts the gradient exchange of the first network behind its reduce
+// and lets it run under the second network's weight gradient).
 template <bool BF, bool S8>
 static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, const float* const* g_out,
-                          const int* P, void* const* wsv, float* const* grad_flat, hipStream_t s) {
+                          const int* P, void* const* wsv, float* const* grad_flat, int phases, hipStream_t s) {
   if (int e = lp_bwd_set_attr<BF, S8>()) return e;
   const int npt = lp_pick_point_tiles(P[0]);
   SCADE_REQUIRE(lp_pick_point_tiles(P[1]) == npt, -3,
@@ -1653,25 +1657,45 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
     d.n[i] = MlpDgradLpArgs{nullptr, packed_t[i], ac, g_out[i], ws, gmax, P[i]};
     w.net[i] = WgradLpNet{ac, ws, g_out[i], partial[i], gmax, P[i]};
   }
-  if (!BF || S8) {                          // both networks' maxima in one launch
-    if (int e = lp_launch_gmax(g_out, P, gmaxs, s)) return e;
+  if (phases & 1) {
+    if (!BF || S8) {                        // both networks' maxima in one launch
+      if (int e = lp_launch_gmax(g_out, P, gmaxs, s)) return e;
+    }
+    d.tiles0 = (P[0] + 32 * npt - 1) / (32 * npt);
+    d.tiles1 = (P[1] + 32 * npt - 1) / (32 * npt);
+    if (npt == 2)
+      hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2, S8>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(2), s, d);
+    else
+      hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4, S8>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(4), s, d);
+    if (int e = scade_check_launch("scade_mlp_bwd_lp2(dgrad)")) return e;
   }
-  d.tiles0 = (P[0] + 32 * npt - 1) / (32 * npt);
-  d.tiles1 = (P[1] + 32 * npt - 1) / (32 * npt);
-  if (npt == 2)
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 2, S8>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(2), s, d);
-  else
-    hipLaunchKernelGGL((mlp_dgrad_lp_kernel<BF, 4, S8>), dim3(d.tiles0 + d.tiles1), dim3(256), dgrad_lp_lds_bytes(4), s, d);
-  if (int e = scade_check_launch("scade_mlp_bwd_lp2(dgrad)")) return e;
-  ReduceLpArgs r{};
-  if (int e = lp_build_plan(w, P, S8, r.nseg)) return e;
-  r.uniform[0] = w.plan.chunk > 0 ? w.plan.gx0 : 0;
-  r.uniform[1] = w.plan.chunk > 0 ? w.plan.gx1 : 0;
-  hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(w.plan.nwg), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
-  if (int e = scade_check_launch("scade_mlp_bwd_lp2(wgrad)")) return e;
-  for (int i = 0; i < 2; ++i) { r.partial[i] = partial[i]; r.grad[i] = grad_flat[i]; }
-  hipLaunchKernelGGL(wgrad_lp_reduce_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
-  return scade_check_launch("scade_mlp_bwd_lp2(reduce)");
+  if ((phases & 6) == 6) {
+    ReduceLpArgs r{};
+    if (int e = lp_build_plan(w, P, S8, r.nseg)) return e;
+    r.uniform[0] = w.plan.chunk > 0 ? w.plan.gx0 : 0;
+    r.uniform[1] = w.plan.chunk > 0 ? w.plan.gx1 : 0;
+    hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(w.plan.nwg), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
+    if (int e = scade_check_launch("scade_mlp_bwd_lp2(wgrad)")) return e;
+    for (int i = 0; i < 2; ++i) { r.partial[i] = partial[i]; r.grad[i] = grad_flat[i]; }
+    hipLaunchKernelGGL(wgrad_lp_reduce_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
+    return scade_check_launch("scade_mlp_bwd_lp2(reduce)");
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!(phases & (2 << i))) continue;
+    WgradLpArgs w1{};
+    build_wgrad_lp_jobs(w1);
+    w1.net[0] = w.net[i];
+    ReduceLpArgs r{};
+    const int Ps[2] = {P[i], 0};
+    if (int e = lp_build_plan(w1, Ps, S8, r.nseg)) return e;
+    r.uniform[0] = w1.plan.chunk > 0 ? w1.plan.gx0 : 0;
+    hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(w1.plan.nwg), dim3(512), WGRAD_LP_LDS_BYTES, s, w1);
+    if (int e = scade_check_launch("scade_mlp_bwd_lp2(wgrad, one network)")) return e;
+    r.partial[0] = partial[i]; r.grad[0] = grad_flat[i];
+    hipLaunchKernelGGL(wgrad_lp_reduce_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
+    if (int e = scade_check_launch("scade_mlp_bwd_lp2(reduce, one network)")) return e;
+  }
+  return 0;
 }
 
 // The launch plan of the 16-bit weight gradient for networks of P[0] and P[1] (0 = absent) points, as the kernel
@@ -1709,10 +1733,11 @@ extern "C" long scade_mlp_bwd_lp2_workspace_bytes(int P, int P_other) {
   return scade_mlp_bwd_lp_workspace_bytes(P);
 }
 
-extern "C" int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,
-                                 const float* const* g_out, const int* P, void* const* workspace,
-                                 float* const* grad_flat, void* stream) {
+extern "C" int scade_mlp_bwd_lp2_phases(const void* const* packed_t_lp, int bf16, const void* const* acts,
+                                        const float* const* g_out, const int* P, void* const* workspace,
+                                        float* const* grad_flat, int phases, void* stream) {
   SCADE_REQUIRE(packed_t_lp && acts && g_out && P && workspace && grad_flat, -1, "scade_mlp_bwd_lp2: null pointer");
+  SCADE_REQUIRE(phases > 0 && phases <= 7, -2, "scade_mlp_bwd_lp2: phases is a mask of bits 0..2");
   for (int i = 0; i < 2; ++i) {
     SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd_lp2: P[%d] must be positive", i);
     SCADE_REQUIRE(packed_t_lp[i] && acts[i] && g_out[i] && workspace[i] && grad_flat[i], -1,
@@ -1720,9 +1745,15 @@ extern "C" int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const
   }
   hipStream_t s = (hipStream_t)stream;
   SCADE_REQUIRE(bf16 >= 0 && bf16 <= 2, -2, "scade_mlp_bwd_lp2: format 0 (fp16), 1 (bf16) or 2 (bf16, 8-bit saved rows)");
-  if (bf16 == 2) return launch_bwd_lp2<true, true>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s);
-  return bf16 ? launch_bwd_lp2<true, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s)
-              : launch_bwd_lp2<false, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, s);
+  if (bf16 == 2) return launch_bwd_lp2<true, true>(packed_t_lp, acts, g_out, P, workspace, grad_flat, phases, s);
+  return bf16 ? launch_bwd_lp2<true, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, phases, s)
+              : launch_bwd_lp2<false, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, phases, s);
+}
+
+extern "C" int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,
+                                 const float* const* g_out, const int* P, void* const* workspace,
+                                 float* const* grad_flat, void* stream) {
+  return scade_mlp_bwd_lp2_phases(packed_t_lp, bf16, acts, g_out, P, workspace, grad_flat, 7, stream);
 }
 
 extern "C" int scade_mlp_bwd_lp(const float* packed, const void* packed_t_lp, int bf16, const void* acts,

@@ -21,8 +21,12 @@ class DeferredBackward:
     nothing downstream waits for them); everything is launched on the stream current at exit."""
     active = None
 
-    def __init__(self):
+    def __init__(self, after_net=None):
+        """``after_net(net)``: called when the gradient of the FIRST network of a joint launch (the one with fewer
+        points: the coarse NeRF) is complete on the stream and the second one's weight gradient has not been launched
+        yet - where a sharded step starts that network's share of the gradient exchange (Trainer(allreduce="staged"))."""
         self.items = []
+        self.after_net = after_net
 
     def __enter__(self):
         if DeferredBackward.active is not None:
@@ -34,7 +38,7 @@ class DeferredBackward:
         DeferredBackward.active = None
         items, self.items = self.items, []
         if et is None:
-            flush_deferred(items)
+            flush_deferred(items, self.after_net)
         return False
 
 
@@ -43,22 +47,33 @@ def _pair_key(net):
     return p if (p == "f32" or p in ops.LP_FORMATS) else None
 
 
-def flush_deferred(items):
+def flush_deferred(items, after_net=None):
     if len(items) == 2 and _pair_key(items[0][0]) is not None and _pair_key(items[0][0]) == _pair_key(items[1][0]) \
             and items[0][0] is not items[1][0]:
+        if after_net is not None:
+            items = sorted(items, key=lambda it: it[2].numel())          # the shorter backward first
         (n0, a0, g0), (n1, a1, g1) = items
         prec = n0.train_precision
         sinks = [n0._grad_sink, n1._grad_sink]
+        hook = None if after_net is None else (lambda: after_net(n0))
         if prec == "f32":
-            ops.mlp_bwd2([n0.packed(), n1.packed()], [n0.packed_t(), n1.packed_t()], [a0, a1], [g0, g1], sinks)
+            ops.mlp_bwd2([n0.packed(), n1.packed()], [n0.packed_t(), n1.packed_t()], [a0, a1], [g0, g1], sinks,
+                         after_first=hook)
+            if after_net is not None:
+                after_net(n1)
             return
         code, bf16 = ops.LP_FORMATS[prec]
         P0, P1 = g0.numel() // 4, g1.numel() // 4
         if ops.lp_point_tiles(P0) == ops.lp_point_tiles(P1):
-            ops.mlp_bwd_lp2([n0.packed_t_lp(bf16), n1.packed_t_lp(bf16)], code, [a0, a1], [g0, g1], sinks)
+            ops.mlp_bwd_lp2([n0.packed_t_lp(bf16), n1.packed_t_lp(bf16)], code, [a0, a1], [g0, g1], sinks,
+                            after_first=hook)
+            if after_net is not None:
+                after_net(n1)
             return
     for net, acts, g in items:
         _backward_now(net, acts, g, net._grad_sink)
+        if after_net is not None:
+            after_net(net)
 
 
 def _backward_now(net, acts, g_out, out):

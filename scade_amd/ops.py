@@ -319,10 +319,12 @@ def _host_ptrs(ts):
     return ctypes.cast((ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
 
 
-def mlp_bwd2(packed, packed_t, acts, g_out, outs) -> None:
+def mlp_bwd2(packed, packed_t, acts, g_out, outs, after_first=None) -> None:
     """Exact backward of TWO network calls (coarse + fine NeRF of a train step) as one dgrad launch, one
     weight-gradient launch and one reduce (scade_mlp_bwd2).  Every argument: a pair; ``outs`` = the two flat
-    gradient buffers [589700], OVERWRITTEN."""
+    gradient buffers [589700], OVERWRITTEN.  ``after_first``: a callable run when the FIRST entry's gradient is
+    complete on the stream (scade_mlp_bwd2_phases: joint dgrad, entry 0's weight gradient + reduce, callback, entry
+    1's) - a sharded step starts entry 0's gradient exchange there, under entry 1's weight gradient."""
     g = [_c(check(t, "mlp_bwd2: g_out")).reshape(-1, 4) for t in g_out]
     P = [t.shape[0] for t in g]
     lib = _lib.load()
@@ -331,13 +333,19 @@ def mlp_bwd2(packed, packed_t, acts, g_out, outs) -> None:
     grads = [_grad_out(o, g[0].device) for o in outs]
     Pa = (ctypes.c_int * 2)(*P)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
-    call("scade_mlp_bwd2", _host_ptrs(packed), _host_ptrs(packed_t), _host_ptrs(acts), _host_ptrs(g),
-         ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads), stream())
+    args = (_host_ptrs(packed), _host_ptrs(packed_t), _host_ptrs(acts), _host_ptrs(g),
+            ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads))
+    if after_first is None:
+        call("scade_mlp_bwd2", *args, stream())
+    else:
+        call("scade_mlp_bwd2_phases", *args, 3, stream())
+        after_first()
+        call("scade_mlp_bwd2_phases", *args, 4, stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
 
 
-def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs) -> None:
+def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs, after_first=None) -> None:
     """16-bit backward of two network calls in one launch each (scade_mlp_bwd_lp2); see mlp_bwd2."""
     g = [_c(check(t, "mlp_bwd_lp2: g_out")).reshape(-1, 4) for t in g_out]
     P = [t.shape[0] for t in g]
@@ -347,8 +355,14 @@ def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs) -> None:
     grads = [_grad_out(o, g[0].device) for o in outs]
     Pa = (ctypes.c_int * 2)(*P)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
-    call("scade_mlp_bwd_lp2", _host_ptrs(packed_t_lp), int(bf16), _host_ptrs(acts), _host_ptrs(g),
-         ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads), stream())
+    args = (_host_ptrs(packed_t_lp), int(bf16), _host_ptrs(acts), _host_ptrs(g),
+            ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads))
+    if after_first is None:
+        call("scade_mlp_bwd_lp2", *args, stream())
+    else:
+        call("scade_mlp_bwd_lp2_phases", *args, 3, stream())
+        after_first()
+        call("scade_mlp_bwd_lp2_phases", *args, 4, stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
 

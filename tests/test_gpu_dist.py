@@ -47,6 +47,11 @@ CASES = [  # name, Trainer kwargs, uses mask
     ("wild_mask", dict(allreduce="single", mask_mode="wild"), True),
     ("joint", dict(allreduce="single", is_joint=True), False),
     ("bf16_overlap", dict(allreduce="overlap", precision="bf16"), False),
+    # round 5: the exchange in two pieces WITHOUT leaving the joint backward - the coarse network's piece starts
+    # behind its own weight gradient + reduce and runs under the fine network's weight gradient
+    ("staged", dict(allreduce="staged"), False),
+    ("staged_wild_mask", dict(allreduce="staged", mask_mode="wild"), True),
+    ("bf16s8_staged", dict(allreduce="staged", precision="bf16-s8"), False),
 ]
 
 
@@ -130,7 +135,7 @@ def _worker(rank, world, port, out_dir, backend):
         from scade_amd.graphs import GraphedTrainer
         from scade_amd.train import Trainer, make_scade_nets
         rays, tgt, hyp, mask, draws, u_joint = _problem()
-        for name, kw in (("graph", {}), ("graph_joint", dict(is_joint=True))):
+        for name, kw in (("graph", {}), ("graph_joint", dict(is_joint=True)), ("graph_staged", dict(allreduce="staged"))):
             res = []
             for graphed in (False, True):
                 coarse, fine = make_scade_nets(dev, seed=5)
@@ -174,17 +179,20 @@ def test_sharded_trainer_two_ranks_matches_single_process(dev, tmp_path):
         g1, p1, l1 = outs[1][name]
         assert torch.equal(g0, g1) and torch.equal(p0, p1), f"{name}: ranks diverged"
         g, p, l = _run_case(dev, kw, use_mask, 0, N_RAYS, None)          # the whole batch, one process
-        tol = 2e-2 if kw.get("precision") == "bf16" else 2e-5           # 16-bit: tile composition changes roundings
+        tol = 2e-2 if kw.get("precision") in ("bf16", "bf16-s8") else 2e-5   # 16-bit: tile composition changes roundings
         n_net = g.numel() - 6
         assert rel_l2(g0[:n_net], g[:n_net]) < tol, f"{name}: network gradients {rel_l2(g0[:n_net], g[:n_net]):.2e}"
         assert rel_l2(g0[n_net:], g[n_net:]) < max(tol, 1e-4), f"{name}: scale/shift gradients"
         assert float(g[n_net + 1].abs()) > 0 and float(g[n_net].abs()) == 0, "step 1 touches image 1 only"
         assert abs(l0 + l1 - l) < max(tol, 1e-5) * abs(l), f"{name}: rank loss terms {l0}+{l1} vs {l}"
-        if kw.get("precision") != "bf16":
+        if kw.get("precision") not in ("bf16", "bf16-s8"):
             # two Adam steps from identical states: the first update is lr * sign(g), so every gradient
             # element that is summation-order noise around zero moves its weight by +-lr in either run
             # (2 lr = 1e-3 against weights of ~0.1); the gradient comparison above is the sharp test
             assert rel_l2(p0, p) < 1e-3, f"{name}: parameters after two steps {rel_l2(p0, p):.2e}"
+    # the staged exchange is the single-bucket exchange in another launch order
+    assert rel_l2(outs[0]["staged"][0], outs[0]["single"][0]) < 2e-5 and rel_l2(outs[0]["staged"][1], outs[0]["single"][1]) < 1e-3
+    assert rel_l2(outs[0]["staged_wild_mask"][0], outs[0]["wild_mask"][0]) < 2e-5
     # sharded test render: every rank holds the whole image, bit-identical to the one-process render
     want = _render_image(dev, shard=False)
     for r in range(world):
@@ -205,7 +213,7 @@ def test_sharded_trainer_two_ranks_matches_single_process(dev, tmp_path):
     assert rel_l2(d0["params"], one["trainer"].bucket.data.cpu()) < 2e-2, "driver: sharded vs one process after 20 Adam steps"
     assert abs(d0["test"]["psnr"] - one["test"]["psnr"]) < 1.0
     if backend == "nccl":
-        for name in ("graph", "graph_joint"):
+        for name in ("graph", "graph_joint", "graph_staged"):
             eager, graphed = outs[0][name]
             assert rel_l2(graphed, eager) < 1e-5, f"{name}: graphed sharded step diverges from eager"
             assert torch.equal(outs[0][name][1], outs[1][name][1])

@@ -85,7 +85,36 @@ def _worker(rank, world, port, out_dir, n_rays, pieces):
     loss = _loss(pc, pf, scale, shift, r, t, h, t_rand[a:b], u[a:b]) * share
     loss.backward()
     assert tensors[0].grad.data_ptr() == flat.grad.data_ptr()       # accumulated in place
-    if pieces:
+    if pieces == "staged":
+        # Trainer(allreduce="staged"): the host logic of the two-piece exchange that keeps the joint backward - the
+        # backward's hook sends a network's piece when its gradient is complete (_send_net_grads: the last network's
+        # piece takes the scale / shift rows along), reduce_grads sends what the hook has not and waits for all
+        import types
+        from scade_amd.train import Trainer
+        n_c = sum(v.numel() for v in pc.values())
+        net_c, net_f = object(), object()
+        flat._sinks = [(net_c, 0), (net_f, n_c)]
+        stub = types.SimpleNamespace(bucket=flat, n_net=2 * n_c, force_allreduce=False, allreduce="staged", sharded=True,
+                                     coarse_stream=None, _staged_works=[], _staged_done=[])
+        Trainer._send_net_grads(stub, net_c)
+        assert stub._staged_done == [(0, n_c)] and len(stub._staged_works) == 1
+        Trainer._send_net_grads(stub, net_f)
+        assert stub._staged_done[1] == (n_c, flat.numel - n_c), "the fine piece takes the scale / shift rows along"
+        Trainer.reduce_grads(stub)
+        assert stub._staged_works == [] and stub._staged_done == []
+    elif pieces == "staged_late":
+        # the same mode when the backward was NOT a joint one (no hook fired for the fine network): reduce_grads
+        # sends the complement of what went out
+        import types
+        from scade_amd.train import Trainer
+        n_c = sum(v.numel() for v in pc.values())
+        net_c = object()
+        flat._sinks = [(net_c, 0)]
+        stub = types.SimpleNamespace(bucket=flat, n_net=2 * n_c, force_allreduce=False, allreduce="staged", sharded=True,
+                                     coarse_stream=None, _staged_works=[], _staged_done=[])
+        Trainer._send_net_grads(stub, net_c)
+        Trainer.reduce_grads(stub)
+    elif pieces:
         n_c = sum(v.numel() for v in pc.values())
         works = flat.allreduce_grads_async([(0, n_c, None), (n_c, flat.numel - n_c, None)])
         assert len(works) == 2
@@ -109,7 +138,7 @@ def _worker(rank, world, port, out_dir, n_rays, pieces):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rays,pieces", [(16, False), (17, False), (17, True)])
+@pytest.mark.parametrize("n_rays,pieces", [(16, False), (17, False), (17, True), (17, "staged"), (16, "staged_late")])
 def test_sharded_gradients_match_single_process(tmp_path, n_rays, pieces):
     """8 + 8 and 9 + 8 rays: the summed share-weighted gradients are the single-process ones."""
     world = 2
