@@ -21,13 +21,16 @@ hyps = np.clip(dep[None, None, :, :, None] + 0.2 * rng.randn(NT, K, Hh, Ww, 1).a
 i_split = [np.arange(NT), np.arange(0), np.arange(NT, NT + 1), np.arange(0)]
 data = (imgs, depths, valid, poses, Hh, Ww, intr, 0.1, 5.0, i_split, None, None, hyps)
 iters = int(os.environ.get("ITERS", "300"))
-for prec in sys.argv[1:] or ["f32", "bf16"]:
-    for sampler in ("device", "numpy"):
-        t0 = time.time()
-        res = driver.train_scene(data, "/tmp/probe_driver_ckpt", f"{prec}_{sampler}", "synthetic", num_iterations=iters,
-                                 i_weights=10 ** 9, i_print=iters, precision=prec, no_reload=True, pixel_sampler=sampler,
-                                 log=lambda *_: None)
-        torch.cuda.synchronize()
-        print(f"{prec:5s} pixel_sampler={sampler:6s}: {res['ms_per_iteration']:.2f} ms / iteration over {iters} iterations "
-              f"(whole call incl. set-up and the test image {time.time() - t0:.2f} s), final loss {res['trace'][-1][1]:.5f}, "
-              f"test psnr {res['test']['psnr']:.2f}")
+for prec in sys.argv[1:] or ["f32", "bf16-s8"]:
+    for n_rand in (1024, 128):
+        for sampler, graph in (("device", True), ("device", False), ("numpy", True)):
+            t0 = time.time()
+            res = driver.train_scene(data, "/tmp/probe_driver_ckpt", f"{prec}_{sampler}_{int(graph)}_{n_rand}", "synthetic",
+                                     num_iterations=iters + 60, N_rand=n_rand, i_weights=10 ** 9, i_print=iters + 60,
+                                     precision=prec, no_reload=True, pixel_sampler=sampler, graph=graph, loop_warmup=60,
+                                     log=lambda *_: None)
+            torch.cuda.synchronize()
+            print(f"{prec:7s} {n_rand:4d} rays pixel_sampler={sampler:6s} {'graph replay' if graph else 'eager step  '}: "
+                  f"{res['ms_per_iteration']:.3f} ms / iteration over {res['iterations_timed']} iterations (whole call incl. "
+                  f"set-up and the test image {time.time() - t0:.2f} s), final loss {res['trace'][-1][1]:.5f}, "
+                  f"test psnr {res['test']['psnr']:.2f}")
