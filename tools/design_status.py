@@ -7,7 +7,7 @@ committed evidence, so that its counts and figures cannot go stale (VERDICT r3 #
     profiles/<tag>_gputests.txt               tail of `python -m pytest tests -m gpu -q` on the MI355X
     (CPU test count: `python -m pytest tests -m "not gpu" --collect-only -q` run here)
 
-Usage: python tools/design_status.py r04"""
+Usage: python tools/design_status.py r05"""
 import json
 import os
 import re
@@ -15,7 +15,7 @@ import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
 P = lambda n: os.path.join(ROOT, "profiles", f"{tag}_{n}")
 d = json.loads(open(P("bench_line.json")).read().strip().splitlines()[-1])
 big = json.loads(open(P("bench_line_4096rays_k40.json")).read().strip().splitlines()[-1]) if os.path.exists(P("bench_line_4096rays_k40.json")) else None
@@ -70,9 +70,22 @@ if isinstance(g, list):
         cells.append(f"{e['rays']} rays {e['precision']}: eager {e['ms_per_step_eager']:.3f} / graph **{e['ms_per_step_graph']:.3f}** ms" +
                      (f" [{sp[0]:.3f}–{sp[1]:.3f}]" if sp else ""))
     rows.append(("train step eager vs one HIP graph (interleaved A/B, medians of 7 blocks)", "; ".join(cells), "`train_step_graph`"))
+dl = d.get("driver_loop")
+if isinstance(dl, list):
+    cells = [f"{e['rays']} rays {e['precision']}: **{e['ms_per_iteration']:.3f}** ms / iteration" for e in dl if isinstance(e, dict) and "ms_per_iteration" in e]
+    rows.append(("the training LOOP (`driver.train_scene`: view pick, pixel pick, fused batch gather into the captured step's inputs, "
+                 "graph replay; 468 × 624, 18 views, K = 20; steady state, host clock)", "; ".join(cells), "`driver_loop`"))
+di = d.get("train_step_dropin")
+if isinstance(di, dict) and "ms_per_step" in di:
+    rows.append(("the drop-in operator path of INTEGRATION.md §2 (public operators + `loss.backward()` + `torch.optim.Adam` × 2, exact, eager)",
+                 f"{di['ms_per_step']:.3f} ms / step at {di['rays']} rays", "`train_step_dropin`"))
+ce = d.get("strong_scaling_ceiling_8gpu")
+if isinstance(ce, dict) and ce:
+    rows.append(("strong-scaling ceiling of a 1024-ray batch on 8 GPUs before any RCCL time = ms(1024-ray step) / ms(128-ray graphed shard)",
+                 "; ".join(f"{k} {v:.2f}×" for k, v in ce.items()), "`strong_scaling_ceiling_8gpu`"))
 if big:
     cells = [f"render {big['ms_per_step']:.3f} ms ({big['value'] / 1e3:.0f} k rays/s)"]
-    for key in ("train_step", "train_step_bf16", "train_step_bf16_s8"):
+    for key in ("train_step", "train_step_f16x3", "train_step_bf16", "train_step_bf16_s8"):
         r = big.get(key)
         if isinstance(r, dict) and "ms_per_step" in r:
             cells.append(f"{key} {r['ms_per_step']:.3f} ms ({r['whole_step_frac_of_peak']:.3f})")

@@ -19,8 +19,10 @@ KEYS = [  # (regex on the kernel name, key in the json); "_small" = the half-siz
     (r"ray_tail_kernel<1, 4>", "ray_tail_coarse"), (r"ray_tail_kernel0<3>", "ray_tail_fine"),
     (r"ray_tail_bwd_kernel<3>", "ray_tail_bwd_fine"), (r"train_loss_fwd_kernel", "train_loss_fwd"),
     (r"train_loss_bwd_kernel", "train_loss_bwd"), (r"ray_tail_train_kernel<3>", "ray_tail_train"),
+    # (round 5: one ray per workgroup of four waves up to four waves per SIMD, else the one-wave-per-ray form)
+    (r"ray_tail_train_split<3>", "ray_tail_train"), (r"ray_tail_train_seq<3>", "ray_tail_train_seq"),
     (r"train_loss_fb_reduce_kernel", "train_loss_fb_reduce"),
-    (r"mlp_fwd_f16_kernel<1, false>", "mlp_fwd_f16_kernel"), (r"mlp_fwd_f16_kernel<1, true>", "mlp_fwd_f16_kernel_train"),
+    (r"mlp_fwd_f16_kernel<1, (false|0)>", "mlp_fwd_f16_kernel"), (r"mlp_fwd_f16_kernel<1, (true|1|2)>", "mlp_fwd_f16_kernel_train"),
     (r"mlp_dgrad_f16_kernel", "mlp_dgrad_f16_kernel"), (r"mlp_wgrad_f16_kernel", "mlp_wgrad_f16_kernel"),
     # (round 3: the SAVE template argument of the 16-bit forward is an int - 0 inference, 1 16-bit rows, 2 8-bit rows;
     # dgrad / wgrad carry an S8 flag; the backward kernels of a train step cover both networks in one launch)

@@ -80,9 +80,9 @@ notes = {
                          "round 3: ONE launch covers both networks of a step; the mean includes the 128-ray launches",
     "wgrad_reduce4_kernel": "sums the per-chunk partials",
     "mlp_fwd_f16_kernel": "opt-in f16x3 render kernel (3 f16 MFMAs per fp32-class product)",
-    "mlp_fwd_f16_kernel_train": "f16x3 training forward, bound by the fp32 activation rows it writes",
-    "mlp_dgrad_f16_kernel": "",
-    "mlp_wgrad_f16_kernel": "HBM-bound (~3 TB/s)",
+    "mlp_fwd_f16_kernel_train": "f16x3 training forward; round 5: the saved rows leave as the fp16 h plane + an e5m2 l plane (768 of 1024 bytes per point and layer)",
+    "mlp_dgrad_f16_kernel": "round 5: dZ rows as h + l8 planes in the per-point scaled domain, 1 / s_p per point beside them",
+    "mlp_wgrad_f16_kernel": "round 5: contracts the h + l8 rows as they lie (v_perm_b32 pairs, no fp16 split); compute-bound now: memory-only knock-out 0.58 of the kernel",
     "mlp_fwd_lp_kernel_bf16": "opt-in bf16 render kernel (config 5); round 2: the epilogue trades chunk halves between lane r and "
                               "r + 32 (v_permlane32_swap) and stores conflict-free ds_write_b128 (was 26.4 % conflict cycles)",
     "mlp_fwd_lp_kernel_f16": "same kernel, fp16 operands",
@@ -106,7 +106,7 @@ notes = {
     "ray_tail_bwd_fine": "round 2: backward of the fine tail in one launch (sampler backward + compositing backward)",
     "train_loss_fwd": "round 2: the three-term train loss as one kernel (+ a one-wave reduce)",
     "train_loss_bwd": "its backward (+ a one-wave scale/shift reduce)",
-    "ray_tail_train": "round 3: fine tail + three-term loss (forward and backward) + the backward of both tails, one wave per ray, ONE launch (was four)",
+    "ray_tail_train": "round 3: fine tail + three-term loss (forward and backward) + the backward of both tails in ONE launch; round 5: one ray per workgroup of FOUR waves (critical chain | coarse ray + loss value | scale / shift scatter | z_std)",
     "train_loss_fb_reduce": "the loss's one-workgroup reduce (loss terms, depth scale / shift gradient rows)",
 }
 rows = []
