@@ -280,7 +280,7 @@ constexpr int HW_D = 5;                                   // ring slots (4 and 6
 constexpr int HW_DZ_HI = 0, HW_DZ_MID = HW_PT * 512, HW_IN_HI = HW_PT * 768, HW_IN_MID = HW_PT * 1280;
 constexpr int HW_SCAL = HW_PT * 1536;                     // d alpha [16] | view dirs [16][3] | 1 / s_p [16]
 constexpr int HW_SLOT = HW_SCAL + 320;                    // 24,896
-constexpr int WGRAD_F16_RED_BYTES = (2 * 256 * 4 + 2) * 4;             // the riders' reduction scratch
+constexpr int WGRAD_F16_RED_BYTES = (2 * 256 * 4 + 8 + 4 * 256 + 4) * 4;   // the riders' reduction scratch
 constexpr int WGRAD_F16_LDS_BYTES = HW_D * HW_SLOT > WGRAD_F16_RED_BYTES ? HW_D * HW_SLOT : WGRAD_F16_RED_BYTES;   // 124,480
 
 struct WgradF16Args {
@@ -311,7 +311,10 @@ __device__ __forceinline__ float hw_col24(const unsigned char* h_row, const unsi
   return r24_value(*reinterpret_cast<const unsigned short*>(h_row + 2 * c), l_row[c]);
 }
 
-template <int KW>
+// RID: the job's rider as a COMPILE-TIME choice (0 none, WF_ALPHA the alpha head, WF_VIEWCOLS the view columns): as
+// run-time branches inside the stage loop the two rare riders cost EVERY 256-wide job its schedule (+6 ... +9 % on the
+// launch mix with the alpha head's dot products behind a wave-uniform flag)
+template <int KW, int RID = 0>
 __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob& jb, float* lds_f,
                                               int c0, int c1, float S, float* __restrict__ out) {
   constexpr int NKT = KW == 256 ? 4 : 1;
@@ -392,12 +395,12 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   // View columns / alpha head (one job each): thread = (column tid & 255, point half tid >> 8) on reassembled values,
   // behind one wave-uniform branch per stage.
   float bacc[2] = {0.f, 0.f};
-  float alpha_acc = 0.f, dal_acc = 0.f, vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
+  float vc0 = 0.f, vc1 = 0.f, vc2 = 0.f;
   const int col = tid & 255, ph = __builtin_amdgcn_readfirstlane(tid >> 8);
-  const bool want_view = (jb.flags & WF_VIEWCOLS) != 0, want_alpha = KW == 256 && (jb.flags & WF_ALPHA);
+  constexpr bool want_view = RID == WF_VIEWCOLS, want_alpha = KW == 256 && RID == WF_ALPHA;
   const bool bias_wave = (wave & 1) == 0;
   auto riders_add = [&](int sl) {
-    if (!(want_view || want_alpha)) return;
+    if (!want_view) return;
     const unsigned char* slot = lds + sl * HW_SLOT;
     const float* isv = reinterpret_cast<const float*>(slot + HW_SCAL + 256);
     if (want_view) {
@@ -409,16 +412,11 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
         vc0 = fmaf(x, vw[3 * q + 0], vc0); vc1 = fmaf(x, vw[3 * q + 1], vc1); vc2 = fmaf(x, vw[3 * q + 2], vc2);
       }
     }
-    if (want_alpha) {
-      const float* da = reinterpret_cast<const float*>(slot + HW_SCAL) + ph * (PT / 2);
-#pragma unroll
-      for (int q = 0; q < PT / 2; ++q) {
-        const int p = ph * (PT / 2) + q;
-        alpha_acc = fmaf(da[q], hw_col24(slot + HW_IN_HI + p * 512, slot + HW_IN_MID + p * 256, col), alpha_acc);
-        dal_acc += da[q];
-      }
-    }
   };
+  // alpha head (the feature job): d w_alpha[k] = sum_p d alpha[p] In[p][k] is a dot product of the INPUT fragments the
+  // lane has just built with the points' d alpha (x S, split h + l' like every other operand): v_dot2_f32_f16 on the two
+  // waves of the first feature block, which cover the 256 input columns between them
+  float aacc[4] = {0.f, 0.f, 0.f, 0.f}, dal_acc = 0.f;
 
   // ---- fragments: lane (r, hh) reads its 8 points p = 8 hh + j; features 2r + t of dZ, NKT r + u of the input: per
   // point one h dword + one l8 halfword (two values), or an h pair + an l8 dword (four).  An MFMA operand is the
@@ -507,6 +505,33 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
           bacc[t] = dot_ones(wl, bacc[t]);
         }
     }
+    if (NKT == 4 && want_alpha) {
+      // (spread over ALL waves - wave pair q = wave >> 1 takes point pair j2 = q of every lane's eight points: on the
+      // two waves of the first feature block alone the 48 dot products per stage made those two the last at every
+      // barrier, +6 % on the whole launch mix)
+      const float* dav = reinterpret_cast<const float*>(slot + HW_SCAL) + 8 * hh;
+      auto dot2 = [](unsigned a, unsigned b, float c) {
+        return __builtin_amdgcn_fdot2(__builtin_bit_cast(half2v, a), __builtin_bit_cast(half2v, b), c, false);
+      };
+      const int j2 = wave >> 1;                       // wave-uniform
+      const float d0 = dav[2 * j2], d1 = dav[2 * j2 + 1];
+      if (r == 0 && (wave & 1) == 0) dal_acc += d0 + d1;   // (lanes 0 and 32 of the even waves: every point once)
+      unsigned dh, dl;
+      split_pair(d0 * S, d1 * S, dh, dl);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        // (bhp / blp are indexed by a wave-uniform j2: selects, not a dynamic register index)
+        unsigned bhw = bhp[NKT > u ? u : 0][0], blw = blp[NKT > u ? u : 0][0];
+#pragma unroll
+        for (int jj = 1; jj < 4; ++jj) {
+          bhw = j2 == jj ? bhp[NKT > u ? u : 0][jj] : bhw;
+          blw = j2 == jj ? blp[NKT > u ? u : 0][jj] : blw;
+        }
+        aacc[u] = dot2(bhw, dh, aacc[u]);
+        aacc[u] = dot2(bhw, dl, aacc[u]);
+        aacc[u] = dot2(blw, dh, aacc[u]);
+      }
+    }
 #pragma unroll
     for (int u = 0; u < NKT; ++u)
 #pragma unroll
@@ -572,22 +597,33 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   }
   // riders: the two point halves of a column are combined through LDS
   float* red = lds_f;    // [2][256][4] alpha | view cols, [2] d alpha
-  red[(ph * 256 + col) * 4 + 0] = alpha_acc;
+  red[(ph * 256 + col) * 4 + 0] = 0.f;
+  float* reda = red + 2 * 256 * 4 + 8;            // alpha head: [4 wave pairs][256 columns] | [4] d alpha sums
+  if (NKT == 4 && want_alpha) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float v = aacc[u] + __shfl_xor(aacc[u], 32, 64);
+      if (hh == 0) reda[(wave >> 1) * 256 + k0 + 4 * r + u] = v;
+    }
+    const float dsum = dal_acc + __shfl_xor(dal_acc, 32, 64);
+    if ((wave & 1) == 0 && lane == 0) reda[4 * 256 + (wave >> 1)] = dsum;
+  }
   red[(ph * 256 + col) * 4 + 1] = vc0;
   red[(ph * 256 + col) * 4 + 2] = vc1;
   red[(ph * 256 + col) * 4 + 3] = vc2;
-  if (col == 0) red[2 * 256 * 4 + ph] = dal_acc;
   __syncthreads();
   if (tid < 256) {
     const float* r0 = red + (size_t)tid * 4, *r1 = red + (size_t)(256 + tid) * 4;
-    if (KW == 256 && (jb.flags & WF_ALPHA)) out[jb.aux_off + tid] = r0[0] + r1[0];
+    if (NKT == 4 && want_alpha) {
+      out[jb.aux_off + tid] = ((reda[tid] + reda[256 + tid]) + (reda[512 + tid] + reda[768 + tid])) * invS;
+      if (tid == 0) out[jb.aux_off + 256] = (reda[1024] + reda[1025]) + (reda[1026] + reda[1027]);   // d b_alpha (unscaled fp32)
+    }
     if ((jb.flags & WF_VIEWCOLS) && tid < 128) {
       out[jb.w_off + (size_t)tid * jb.ld + 256] = r0[1] + r1[1];
       out[jb.w_off + (size_t)tid * jb.ld + 257] = r0[2] + r1[2];
       out[jb.w_off + (size_t)tid * jb.ld + 258] = r0[3] + r1[3];
     }
   }
-  if (KW == 256 && (jb.flags & WF_ALPHA) && tid == 0) out[jb.aux_off + 256] = red[2 * 256 * 4] + red[2 * 256 * 4 + 1];
 }
 
 __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) {
@@ -608,7 +644,9 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) 
   if (jb.flags & WF_RGB) {
     wgrad_rgb_job<true>(a, jb, ldsw, c0, c1, out);
   } else if (jb.kw == 256) {
-    wgrad_f16_job<256>(a, jb, ldsw, c0, c1, S, out);
+    if (jb.flags & WF_ALPHA) wgrad_f16_job<256, WF_ALPHA>(a, jb, ldsw, c0, c1, S, out);
+    else if (jb.flags & WF_VIEWCOLS) wgrad_f16_job<256, WF_VIEWCOLS>(a, jb, ldsw, c0, c1, S, out);
+    else wgrad_f16_job<256>(a, jb, ldsw, c0, c1, S, out);
   } else {
     wgrad_f16_job<64>(a, jb, ldsw, c0, c1, S, out);
   }
