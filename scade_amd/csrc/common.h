@@ -51,6 +51,16 @@ __device__ __forceinline__ void adam_tick(float* st) {
 }
 }  // namespace scade
 
+// Store-data hazard (found in round 5; tools/check_store_hazard.py scans every build for it).  A store of more than
+// 64 bits reads its data registers in the issue slots BEHIND it; gfx940-class parts need two wait states before a VALU
+// write of those registers.  LLVM's hazard recognizer covers flat / global stores and buffer stores without an SGPR
+// soffset (GCNHazardRecognizer::createsVALUHazard) - a `buffer_store_dwordx4 ..., sN offen` followed at once by a VALU
+// write of its first data register reached memory with the NEW value in lanes 12..15 of each 16 on this part.
+// STORE_DATA_HOLD(v) behind the store keeps v's registers untouched over two wait states; STORE_DATA_PIN(w) behind
+// the HOLD extends that to the data of the stores issued just before it.
+#define STORE_DATA_HOLD(v) asm volatile("s_nop 1" : "+v"(v))
+#define STORE_DATA_PIN(v) asm volatile("" : "+v"(v))
+
 // rows a tile copy's buffer descriptor spans: from the tile's first row p0 to the end of the slot at row P, at most
 // 4096 (no tile is larger; 4096 rows x 1 KiB fits the descriptor's 32-bit range with room to spare)
 __device__ __forceinline__ unsigned tile_rows_left(int p0, int P) {

@@ -212,28 +212,43 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
   an.t1h = WT16(8, 8)[(8 * 2 + 0) * 64 + lane];
   an.t1l = WT16(8, 8)[(8 * 2 + 1) * 64 + lane];
 
+  // R24: the 24-bit copy of a layer's dZ tile rides in the NEXT gemm's k-loop (SaveRiderH, mlp_tile_f16.h); the last
+  // tile (slot 0) and the fp32-row mode keep the burst copy
+  SaveRiderH rid;
   // ---- views layer: d feature = Wv[:, :256]^T dZv  (reduction over 128 = 8 k16-blocks) ----
   layer_gemm_h<2, 0, 8, false>(acc0, acc1, an, WT16(8, 8), WT16(7, 16), 16, gh, gl, gh, gl, lane);
   __syncthreads();
   dgrad_store_h<false, false>(acc0, acc1, kt0, gh, gl, 0ull, nullptr, dal, lane);
-  save_tile_h_wave<64, R24>(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, inv_s, lane);
+  if (!R24) save_tile_h_wave<64, false>(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, inv_s, lane);
   __syncthreads();
 
   // ---- feature layer: d h7 = Wf^T d feature + w_alpha * d alpha_pre, mask h7 ---------------
   unsigned long long mbits = mask_of(7);
-  layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16(7, 16), WT16(6, 16), 16, gh, gl, gh, gl, lane);
+  if constexpr (R24) {
+    rid.init(gh, gl, dz + acts_slot_off(P, SLOT_FEAT), p0, P, wave);
+    layer_gemm_h<2, 0, 16, false, SaveRiderH>(acc0, acc1, an, WT16(7, 16), WT16(6, 16), 16, gh, gl, gh, gl, lane, nullptr, rid);
+  } else {
+    layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16(7, 16), WT16(6, 16), 16, gh, gl, gh, gl, lane);
+  }
   __syncthreads();
   dgrad_store_h<true, true>(acc0, acc1, kt0, gh, gl, mbits, pk + OFF_WA, dal, lane);
-  save_tile_h_wave<64, R24>(gh, gl, dz + acts_slot_off(P, 7), p0, P, 64 * wave, inv_s, lane);
+  if (!R24) save_tile_h_wave<64, false>(gh, gl, dz + acts_slot_off(P, 7), p0, P, 64 * wave, inv_s, lane);
   __syncthreads();
 
 #define DGRAD_LAYER_H(L)                                                                         \
   mbits = mask_of((L)-1);                                                                        \
-  layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16((L)-1, 16), WT16((L) > 1 ? (L)-2 : 0, 16), 16, \
-                                gh, gl, gh, gl, lane);                                           \
+  if constexpr (R24) {                                                                           \
+    rid.init(gh, gl, dz + acts_slot_off(P, L), p0, P, wave);                                     \
+    layer_gemm_h<2, 0, 16, false, SaveRiderH>(acc0, acc1, an, WT16((L)-1, 16), WT16((L) > 1 ? (L)-2 : 0, 16), 16, \
+                                              gh, gl, gh, gl, lane, nullptr, rid);               \
+  } else {                                                                                       \
+    layer_gemm_h<2, 0, 16, false>(acc0, acc1, an, WT16((L)-1, 16), WT16((L) > 1 ? (L)-2 : 0, 16), 16, \
+                                  gh, gl, gh, gl, lane);                                         \
+  }                                                                                              \
   __syncthreads();                                                                               \
   dgrad_store_h<true, false>(acc0, acc1, kt0, gh, gl, mbits, nullptr, dal, lane);                \
-  save_tile_h_wave<64, R24>(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, inv_s, lane);     \
+  if (!R24 || (L) == 1)                                                                          \
+    save_tile_h_wave<64, R24>(gh, gl, dz + acts_slot_off(P, (L)-1), p0, P, 64 * wave, inv_s, lane); \
   __syncthreads();
 
   DGRAD_LAYER_H(7)

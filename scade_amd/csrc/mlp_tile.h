@@ -173,6 +173,9 @@ __device__ __forceinline__ void save_tile_wave(const float* hbuf, float* __restr
       const int it = it0 + j;
       __builtin_amdgcn_raw_buffer_store_b128(v[j], rs, voff, soff + it * RPI * 1024, 2);     // streamed once: nt
     }
+    STORE_DATA_HOLD(v[BATCH - 1]);                      // (common.h: the next batch's LDS address landed in v[BATCH - 1][0])
+#pragma unroll
+    for (int j = 0; j + 1 < BATCH; ++j) STORE_DATA_PIN(v[j]);
     __builtin_amdgcn_sched_barrier(0);
   }
 }

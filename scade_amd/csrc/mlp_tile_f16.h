@@ -67,13 +67,24 @@ __device__ __forceinline__ int e_idx(int row, int c) { return row * 64 + ((c ^ (
 // array-reference form of this loop on gfx950 (address temporaries land in a live operand).
 struct AFrag { half8 t0h, t0l, t1h, t1l; };
 
-template <int NT, int KBP, int KBH, bool PRE_VIEW>
+// A rider of the k-loop (round 5, after the 16-bit kernels' SaveRider8): the tile the PREVIOUS layer wrote stays in LDS
+// as this gemm's B operand, so its copy to HBM leaves one chunk per pair of k-blocks - read in one, stored in the
+// next - instead of as a burst between the epilogue and the next layer's first weight fetches.
+struct NoRiderH {
+  static constexpr bool ON = false;
+  static constexpr int NCH = 0;
+  __device__ __forceinline__ void begin(int) {}
+  __device__ __forceinline__ void read(int) {}
+  __device__ __forceinline__ void emit(int) {}
+};
+
+template <int NT, int KBP, int KBH, bool PRE_VIEW, class RID = NoRiderH>
 __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc1)[NT][2], AFrag& an,
                                              const half8* __restrict__ wp,
                                              const half8* __restrict__ wp_next, int kb_next,
                                              const _Float16* eh, const _Float16* el,
                                              const _Float16* xh, const _Float16* xl, int lane,
-                                             const f32x16* cinit = nullptr) {
+                                             const f32x16* cinit, RID& rid) {
   // acc0 + acc1/2048 = cinit + W x.  The first k-block is peeled so that the initial value (the
   // lane's bias vector, or nothing) rides in as the C operand of acc0's first MFMA and acc1
   // starts from the inline constant 0: no zero-fill, no bias add in the epilogue.
@@ -146,6 +157,10 @@ __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc
     __builtin_amdgcn_sched_barrier(0);
     LOAD_B(1, 0, b0h, b0l)
   }
+  if (RID::ON) {                   // behind the peeled block: the registers of the initial value have just died
+    rid.begin(lane);
+    rid.read(0);
+  }
 #undef MFMA6_FIRST
 #define KBLOCK_H(KBX)                                                   \
   {                                                                     \
@@ -173,16 +188,37 @@ __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc
   }
   // a real loop over PAIRS of k-blocks (the A registers alternate by renaming inside the pair);
   // never fully unrolled: ten layers of straight-line k-loops would not fit the instruction cache
-  int kb = 1;
+  int kb = 1, ri = 0;
 #pragma unroll 1
   for (; kb + 1 < KB; kb += 2) {
     KBLOCK_H(kb)
+    if (RID::ON) {
+      rid.emit(ri);
+      rid.read(ri + 1);
+      ++ri;
+    }
     KBLOCK_H(kb + 1)
   }
   if ((KB - 1) & 1) KBLOCK_H(kb)
+  if (RID::ON) {
+    for (; ri < RID::NCH; ++ri) {     // (KB = 16: the eighth chunk)
+      rid.emit(ri);
+      rid.read(ri + 1);
+    }
+  }
 #undef KBLOCK_H
 #undef LOAD_B
 #undef MFMA6
+}
+template <int NT, int KBP, int KBH, bool PRE_VIEW>
+__device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc1)[NT][2], AFrag& an,
+                                             const half8* __restrict__ wp,
+                                             const half8* __restrict__ wp_next, int kb_next,
+                                             const _Float16* eh, const _Float16* el,
+                                             const _Float16* xh, const _Float16* xl, int lane,
+                                             const f32x16* cinit = nullptr) {
+  NoRiderH none;
+  layer_gemm_h<NT, KBP, KBH, PRE_VIEW, NoRiderH>(acc0, acc1, an, wp, wp_next, kb_next, eh, el, xh, xl, lane, cinit, none);
 }
 
 // x = h + l * 2^-11 for the two halves of a packed pair, one v_fma_mix_f32 each (it reads the fp16 operands in
@@ -271,6 +307,58 @@ __device__ __forceinline__ void r24_store4(float* slot, long P, size_t pt, int c
   *reinterpret_cast<unsigned*>(b + rows24_l8_byte(P) + pt * 256 + c4) = l8_of4(l[0], l[1]);
 }
 
+// The 24-bit row copy of a [64][256] tile as a rider (layer_gemm_h): wave w takes the whole rows [16 w, 16 w + 16)
+// - behind the barrier that precedes the k-loop a wave may read any column - so that one store instruction writes two
+// complete h rows (1 KiB) and one two complete l8 rows (512 bytes); eight chunks per lane, one per pair of k-blocks.
+struct SaveRiderH {
+  static constexpr bool ON = true;
+  static constexpr int NCH = 8;
+  typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+  const _Float16* xh;
+  const _Float16* xl;
+  __amdgpu_buffer_rsrc_t rs, rm;
+  int row0, voff, voffm, c, rlo;
+  u32x4 vh, vl;
+  __device__ __forceinline__ void init(const _Float16* xh_, const _Float16* xl_, float* __restrict__ dst, int p0, int P, int wave) {
+    xh = xh_; xl = xl_;
+    row0 = 16 * wave;
+    const unsigned long long pd = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)p0 * 512ull;
+    const unsigned dlo = __builtin_amdgcn_readfirstlane((unsigned)pd), dhi = __builtin_amdgcn_readfirstlane((unsigned)(pd >> 32));
+    rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)dhi << 32) | dlo), 0,
+                                           __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 512u), 0x00020000);
+    const unsigned long long pm = reinterpret_cast<unsigned long long>(dst) + (unsigned long long)rows24_l8_byte(P) +
+                                  (unsigned long long)p0 * 256ull;
+    const unsigned mlo = __builtin_amdgcn_readfirstlane((unsigned)pm), mhi = __builtin_amdgcn_readfirstlane((unsigned)(pm >> 32));
+    rm = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)mhi << 32) | mlo), 0,
+                                           __builtin_amdgcn_readfirstlane(tile_rows_left(p0, P) * 256u), 0x00020000);
+  }
+  __device__ __forceinline__ void begin(int lane) {
+    asm volatile("" : "+v"(lane));                      // (not hoisted above the caller's first k-block)
+    c = lane & 31;
+    rlo = lane >> 5;
+    voff = rlo * 512 + c * 16;
+    voffm = rlo * 256 + c * 8;
+  }
+  __device__ __forceinline__ void read(int it) {       // it: wave-uniform
+    if (it < NCH) {
+      const int r = row0 + 2 * it + rlo;
+      const int o = x_idx(r, c);
+      vh = *reinterpret_cast<const u32x4*>(xh + o);
+      vl = *reinterpret_cast<const u32x4*>(xl + o);
+    }
+  }
+  __device__ __forceinline__ void emit(int it) {
+    if (it < NCH) {
+      const u32x2 om = {l8_of4(vl[0], vl[1]), l8_of4(vl[2], vl[3])};
+      const int r = __builtin_amdgcn_readfirstlane(row0 + 2 * it);
+      __builtin_amdgcn_raw_buffer_store_b128(vh, rs, voff, r * 512, 2);          // streamed once: nt
+      __builtin_amdgcn_raw_buffer_store_b64(om, rm, voffm, r * 256, 2);
+      STORE_DATA_HOLD(vh);             // common.h: read(it + 1)'s row index landed in vh[0] one slot behind the store
+    }
+  }
+};
+
 // the same copy for the NCW columns (from column c0) ONE WAVE has just written (see save_tile_wave in mlp_tile.h), in
 // its round-4 form: the lane's chunks are two LDS base addresses + immediates (rows 16 apart share their swizzle),
 // the stores are buffer stores with a fixed lane offset, the row part in the scalar offset and the ragged last tile
@@ -325,14 +413,17 @@ __device__ __forceinline__ void save_tile_h_wave(const _Float16* xh, const _Floa
         const u32x2 om = {l8_of4(vl[j][0], vl[j][1]), l8_of4(vl[j][2], vl[j][3])};
         __builtin_amdgcn_raw_buffer_store_b128(vh[j], rs, voff, soff + it * RPI * 512, 2);      // streamed once: nt
         __builtin_amdgcn_raw_buffer_store_b64(om, rm, voffm, soff + it * RPI * 256, 2);
+        STORE_DATA_HOLD(vh[j]);                         // (common.h)
       } else {
         float x[8];
 #pragma unroll
         for (int k = 0; k < 4; ++k) join2(vh[j][k], vl[j][k], x[2 * k], x[2 * k + 1]);
-        const u32x4 o0 = {__float_as_uint(x[0] * sc[j]), __float_as_uint(x[1] * sc[j]), __float_as_uint(x[2] * sc[j]), __float_as_uint(x[3] * sc[j])};
-        const u32x4 o1 = {__float_as_uint(x[4] * sc[j]), __float_as_uint(x[5] * sc[j]), __float_as_uint(x[6] * sc[j]), __float_as_uint(x[7] * sc[j])};
+        u32x4 o0 = {__float_as_uint(x[0] * sc[j]), __float_as_uint(x[1] * sc[j]), __float_as_uint(x[2] * sc[j]), __float_as_uint(x[3] * sc[j])};
+        u32x4 o1 = {__float_as_uint(x[4] * sc[j]), __float_as_uint(x[5] * sc[j]), __float_as_uint(x[6] * sc[j]), __float_as_uint(x[7] * sc[j])};
         __builtin_amdgcn_raw_buffer_store_b128(o0, rs, voff, soff + it * RPI * 1024, 2);          // streamed once: nt
         __builtin_amdgcn_raw_buffer_store_b128(o1, rs, voff + 16, soff + it * RPI * 1024, 2);
+        STORE_DATA_HOLD(o1);                            // (common.h: the next chunk's join wrote o0[0] one slot behind)
+        STORE_DATA_PIN(o0);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -384,7 +384,10 @@ struct SaveRider16 {
       soff_p = soff0 + it * 2 * 512;
     }
   }
-  __device__ __forceinline__ void emit() { __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff_p, 2); }
+  __device__ __forceinline__ void emit() {
+    __builtin_amdgcn_raw_buffer_store_b128(v, rs, voff, soff_p, 2);
+    STORE_DATA_HOLD(v);                                 // (common.h: read() of the next chunk follows)
+  }
 };
 
 // ReLU sign bits of one layer: 4 x 32-bit words per lane.  The 64 packed dwords a lane produces
