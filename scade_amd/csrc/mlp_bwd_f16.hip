@@ -321,11 +321,6 @@ __device__ __forceinline__ void hw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
-// value of column c of a 24-bit row in LDS (h plane row, l8 plane row): h + l * 2^-11
-__device__ __forceinline__ float hw_col24(const unsigned char* h_row, const unsigned char* l_row, int c) {
-  return r24_value(*reinterpret_cast<const unsigned short*>(h_row + 2 * c), l_row[c]);
-}
-
 // RID: the job's rider as a COMPILE-TIME choice (0 none, WF_ALPHA the alpha head, WF_VIEWCOLS the view columns): as
 // run-time branches inside the stage loop the two rare riders cost EVERY 256-wide job its schedule (+6 ... +9 % on the
 // launch mix with the alpha head's dot products behind a wave-uniform flag)
@@ -369,26 +364,42 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[t][u][i] = 0.f;
 
-  // ---- LDS-DMA of stage st into slot sl: wave w moves point rows 2w, 2w+1 of both tiles - their two hi rows are
-  // 1 KiB (one instruction), their two mid rows 512 bytes (one instruction, lanes 0-31), the two 256-byte
-  // embedding rows likewise - and the rider scalars of those two points.  The same count in every stage, also
-  // past the chunk end (zeros, no traffic), so the vmcnt below is a compile-time constant.
+  // ---- LDS-DMA of stage st into slot sl.  The LDS image of an instruction is lane-linear (64 x 16 bytes), its SOURCE
+  // is free per lane - so the tiles land TILE-MAJOR, laid out for the transposing reads of compute():
+  //   h  tile [16 points][256 cols] fp16: byte (p >> 3) * 4096 + ((p >> 2) & 1) * 2048 + (c >> 5) * 256 + (p & 3) * 64
+  //      + (c & 31) * 2 - a 256-byte block is [4 points][32 columns], what one ds_read_b64_tr_b16 of a 32-lane pass
+  //      gathers (one LDS row: conflict-free); 32-column tiles 256 bytes apart, the point quads 2 KiB (immediates);
+  //   l8 tile [16 points][256 cols] e5m2: byte (p >> 3) * 2048 + (c >> 6) * 512 + (p & 7) * 64
+  //      + ((((c >> 5) & 1) ^ ((p & 7) >> 2)) * 32) + (c & 31) - [8 points][64 B] per pair of 32-column tiles, the two
+  //      tiles' halves swapped in points 4..7, so the 8 x 32 bytes one ds_read_b64_tr_b8 pass gathers cover the 16
+  //      16-byte slots of an LDS row once.
+  // Every quad of lanes still fetches 64 contiguous bytes of one row, every 128-byte line is consumed by one
+  // instruction.  Wave w moves point quad (w >> 1) x column half (w & 1) of both h tiles (1 KiB each) and, the l8
+  // tiles, waves 0-3 the dZ tile's and waves 4-7 the input tile's point half (w4 >> 1) x column half (w4 & 1) - and
+  // the rider scalars of two points.  The same count in every stage, also past the chunk end (zeros, no traffic),
+  // so the vmcnt below is a compile-time constant.
+  const int dma_h_voff = ((lane >> 2) & 3) * 512 + (4 * (wave & 1) + (lane >> 4)) * 64 + (lane & 3) * 16;
+  const int dma_h_lds = (wave >> 1) * 2048 + (wave & 1) * 1024;
+  const int dfj = (lane >> 2) & 7;
+  const int dma_l_voff = dfj * 256 + (2 * (wave & 1) + (lane >> 5)) * 64 + ((((lane >> 1) & 1) ^ (dfj >> 2)) * 32) + (lane & 1) * 16;
+  const int dma_l_lds = ((wave & 3) >> 1) * 2048 + (wave & 1) * 1024;
   auto issue = [&](int st, int sl) {
     unsigned char* slot = lds + sl * HW_SLOT;
-    const int grow = st * PT + 2 * wave;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr_t)(slot + HW_DZ_HI + 2 * wave * 512), 16, lane * 16, grow * 512, 0, 2);
-    // the l8 rows four at a time (1 KiB per instruction): waves 0-3 the dZ tile's, waves 4-7 the input tile's
-    const int w4 = wave & 3, grow4 = st * PT + 4 * w4;
+    const int grow = st * PT + 2 * wave;                      // (rider scalars: two points per wave)
+    const int growh = st * PT + 4 * (wave >> 1);              // h: this wave's point quad
+    const int w4 = wave & 3, grow8 = st * PT + 8 * (w4 >> 1); // l8: this wave's point half
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rah, (lds_ptr_t)(slot + HW_DZ_HI + dma_h_lds), 16, dma_h_voff, growh * 512, 0, 2);
     if (KW == 256) {
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 2 * wave * 512), 16, lane * 16, grow * 512, 0, 2);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + dma_h_lds), 16, dma_h_voff, growh * 512, 0, 2);
       if (wave < 4)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + dma_l_lds), 16, dma_l_voff, grow8 * 256, 0, 2);
       else
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbm, (lds_ptr_t)(slot + HW_IN_MID + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rbm, (lds_ptr_t)(slot + HW_IN_MID + dma_l_lds), 16, dma_l_voff, grow8 * 256, 0, 2);
     } else {
-      // (the fp32 embedding rows are 256 bytes too: waves 4-7 take them four at a time)
+      // (the fp32 embedding rows [16][64] stay row-major, four rows per instruction on waves 4-7)
+      const int grow4 = st * PT + 4 * w4;
       if (wave < 4)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(ram, (lds_ptr_t)(slot + HW_DZ_MID + dma_l_lds), 16, dma_l_voff, grow8 * 256, 0, 2);
       else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
     }
@@ -423,7 +434,11 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
       for (int q = 0; q < PT / 2; ++q) {
         const int p = ph * (PT / 2) + q;
-        const float x = hw_col24(slot + HW_DZ_HI + p * 512, slot + HW_DZ_MID + p * 256, col) * isv[p];   // the true dZ value
+        // (the tile-major images of issue())
+        const unsigned char* hp = slot + HW_DZ_HI + (p >> 3) * 4096 + ((p >> 2) & 1) * 2048 + (col >> 5) * 256 + (p & 3) * 64 + (col & 31) * 2;
+        const unsigned char* lp = slot + HW_DZ_MID + (p >> 3) * 2048 + (col >> 6) * 512 + (p & 7) * 64 +
+                                  ((((col >> 5) & 1) ^ ((p & 7) >> 2)) * 32) + (col & 31);
+        const float x = r24_value(*reinterpret_cast<const unsigned short*>(hp), *lp) * isv[p];   // the true dZ value
         vc0 = fmaf(x, vw[3 * q + 0], vc0); vc1 = fmaf(x, vw[3 * q + 1], vc1); vc2 = fmaf(x, vw[3 * q + 2], vc2);
       }
     }
@@ -433,13 +448,21 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   // waves of the first feature block, which cover the 256 input columns between them
   float aacc[4] = {0.f, 0.f, 0.f, 0.f}, dal_acc = 0.f;
 
-  // ---- fragments: lane (r, hh) reads its 8 points p = 8 hh + j; features 2r + t of dZ, NKT r + u of the input: per
-  // point one h dword + one l8 halfword (two values), or an h pair + an l8 dword (four).  An MFMA operand is the
-  // pair (point 2 j2, point 2 j2 + 1) of ONE column: one v_perm_b32 per pair and plane picks the column's half / byte
-  // out of the two points' words (the byte lands in the upper half of its fp16: widened on the way); the l pairs take
-  // their 2^-11 and - dZ - the points' S / s_p (powers of two, packed fp16 multiplies).  No conversion-class VALU
-  // work at all; the fp32 embedding rows of the KW = 64 jobs keep the split (v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16).
+  // ---- fragments: lane (r, hh) holds column r of a 32-column tile for its 8 points p = 8 hh + j, as the MFMA wants
+  // them - and gfx950's transposing LDS reads deliver exactly that from the tile-major images of issue(): one
+  // ds_read_b64_tr_b16 = four points of the h plane (two MFMA pairs, no VALU), one ds_read_b64_tr_b8 = eight points of
+  // the l8 plane (a byte lands in the upper half of its fp16 by one v_perm_b32 per pair).  MFMA row m of tile t is
+  // feature n0 + 32 t + m, column r of tile u is input k0 + 32 u + r.  The dZ pairs take the points' S / s_p (powers
+  // of two, packed fp16 multiplies); the 2^-11 of BOTH cross terms sits on the dZ side (ahs = ah * 2^-11 against the
+  // raw l pairs of the input, al * 2^-11 against its h pairs), so the input fragments need no arithmetic at all.
+  // Per stage and wave 18 LDS reads + 48 VALU operations beside the 24 MFMAs (the round-5 first form, row-major
+  // images read a dword per point and transposed by v_perm_b32: 32 + 80).  The fp32 embedding rows of the KW = 64 jobs
+  // keep the split (v_cvt_pk_f16_f32 + v_fma_mixlo/hi_f16).
   typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+  typedef short s16x4 __attribute__((ext_vector_type(4)));
+  typedef int i32x2 __attribute__((ext_vector_type(2)));
+  typedef s16x4 __attribute__((address_space(3))) * tr16_ptr;
+  typedef i32x2 __attribute__((address_space(3))) * tr8_ptr;
   auto split_pair = [](float x0, float x1, unsigned& h, unsigned& l) {
     asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(h) : "v"(x0), "v"(x1));
     asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel_hi:[1,0,0]" : "=v"(l) : "v"(h), "v"(x0));
@@ -447,10 +470,19 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   };
   auto pk_mul = [](unsigned a, half2v k) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(half2v, a) * k); };
   const half2v k_l = {(_Float16)LINV, (_Float16)LINV};
+  // the lane's gather addresses inside a slot (lane i of a 16-lane group supplies the address of row i >> 2 (i >> 1),
+  // 8-byte piece i & 3 (i & 1) of its group's 16 columns; it receives column i)
+  const int i16 = lane & 15, cbit = (lane >> 4) & 1;
+  const int la_h = hh * 4096 + (i16 >> 2) * 64 + cbit * 32 + (i16 & 3) * 8;
+  const int la_8 = hh * 2048 + (i16 >> 1) * 64 + cbit * 16 + (i16 & 1) * 8, sw8 = (i16 >> 3) * 32;
+  const int a_h = HW_DZ_HI + la_h + (n0 >> 5) * 256;                     // tile t: + 256 t; points 4..7: + 2048
+  const int a_8 = HW_DZ_MID + la_8 + (n0 >> 6) * 512;                    // tile t: + ((32 t) ^ sw8)
+  const int b_h = HW_IN_HI + la_h + (k0 >> 5) * 256;
+  const int b_8 = HW_IN_MID + la_8 + (k0 >> 6) * 512;                    // tile u: + 512 (u >> 1) + ((32 (u & 1)) ^ sw8)
   auto compute = [&](int sl) {
     if (!active) return;
     const unsigned char* slot = lds + sl * HW_SLOT;
-    // (S / s_p) of the lane's point pairs, and the same times 2^-11 for the l plane
+    // (S / s_p) of the lane's point pairs, and the same times 2^-11 for the cross terms
     half2v kp[4], kl[4];
     {
       const f32x4* isv = reinterpret_cast<const f32x4*>(slot + HW_SCAL + 256) + 2 * hh;
@@ -465,43 +497,43 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) kl[j2] = kp[j2] * k_l;
     }
-    unsigned ah[8], am[8];
-    u32x2 bh[8];
-    unsigned bm[8];
-    float be[8];
+    auto tr16 = [&](int off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr16_ptr)(slot + off))); };
+    auto tr8 = [&](int off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr8_b64_v2i32((tr8_ptr)(slot + off))); };
+    // the four fp16 pairs (value = byte << 8) of eight e5m2 bytes
+    auto widen = [](u32x2 v) {
+      return u32x4{__builtin_amdgcn_perm(0u, v[0], 0x010c000cu), __builtin_amdgcn_perm(0u, v[0], 0x030c020cu),
+                   __builtin_amdgcn_perm(0u, v[1], 0x010c000cu), __builtin_amdgcn_perm(0u, v[1], 0x030c020cu)};
+    };
+    u32x4 ahp[2], ahs[2], alp[2], bhp[NKT], blp[NKT];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const int p = 8 * hh + j;
-      ah[j] = *reinterpret_cast<const unsigned*>(slot + HW_DZ_HI + p * 512 + (n0 + 2 * r) * 2);
-      am[j] = *reinterpret_cast<const unsigned short*>(slot + HW_DZ_MID + p * 256 + n0 + 2 * r);
-      if (NKT == 4) {
-        bh[j] = *reinterpret_cast<const u32x2*>(slot + HW_IN_HI + p * 512 + (k0 + 4 * r) * 2);
-        bm[j] = *reinterpret_cast<const unsigned*>(slot + HW_IN_MID + p * 256 + k0 + 4 * r);
-      } else {
-        be[j] = reinterpret_cast<const float*>(slot + HW_IN_HI)[p * 64 + k0 + r];
+    for (int t = 0; t < 2; ++t) {
+      const u32x2 lo = tr16(a_h + 256 * t), hi = tr16(a_h + 256 * t + 2048);
+      const u32x4 l4 = widen(tr8(a_8 + ((32 * t) ^ sw8)));
+      const unsigned hv[4] = {lo[0], lo[1], hi[0], hi[1]};
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) {
+        const unsigned lw = l4[j2];
+        ahp[t][j2] = pk_mul(hv[j2], kp[j2]);
+        ahs[t][j2] = pk_mul(hv[j2], kl[j2]);
+        alp[t][j2] = pk_mul(lw, kl[j2]);
       }
     }
-    u32x4 ahp[2], alp[2], bhp[NKT], blp[NKT];
+    if (NKT == 4) {
 #pragma unroll
-    for (int j2 = 0; j2 < 4; ++j2) {
-      const int e = 2 * j2, o = 2 * j2 + 1;
-      ahp[0][j2] = pk_mul(__builtin_amdgcn_perm(ah[o], ah[e], 0x05040100u), kp[j2]);
-      ahp[1][j2] = pk_mul(__builtin_amdgcn_perm(ah[o], ah[e], 0x07060302u), kp[j2]);
-      alp[0][j2] = pk_mul(__builtin_amdgcn_perm(am[o], am[e], 0x040c000cu), kl[j2]);
-      alp[1][j2] = pk_mul(__builtin_amdgcn_perm(am[o], am[e], 0x050c010cu), kl[j2]);
-      if (NKT == 4) {
-        bhp[0][j2] = __builtin_amdgcn_perm(bh[o][0], bh[e][0], 0x05040100u);
-        bhp[NKT > 1 ? 1 : 0][j2] = __builtin_amdgcn_perm(bh[o][0], bh[e][0], 0x07060302u);
-        bhp[NKT > 2 ? 2 : 0][j2] = __builtin_amdgcn_perm(bh[o][1], bh[e][1], 0x05040100u);
-        bhp[NKT > 3 ? 3 : 0][j2] = __builtin_amdgcn_perm(bh[o][1], bh[e][1], 0x07060302u);
-        blp[0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x040c000cu), k_l);
-        blp[NKT > 1 ? 1 : 0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x050c010cu), k_l);
-        blp[NKT > 2 ? 2 : 0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x060c020cu), k_l);
-        blp[NKT > 3 ? 3 : 0][j2] = pk_mul(__builtin_amdgcn_perm(bm[o], bm[e], 0x070c030cu), k_l);
-      } else {
+      for (int u = 0; u < NKT; ++u) {
+        const u32x2 lo = tr16(b_h + 256 * u), hi = tr16(b_h + 256 * u + 2048);
+        bhp[u] = u32x4{lo[0], lo[1], hi[0], hi[1]};
+        blp[u] = widen(tr8(b_8 + 512 * (u >> 1) + ((32 * (u & 1)) ^ sw8)));        // raw l: its 2^-11 is in ahs
+      }
+    } else {
+      float be[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) be[j] = reinterpret_cast<const float*>(slot + HW_IN_HI)[(8 * hh + j) * 64 + k0 + r];
+#pragma unroll
+      for (int j2 = 0; j2 < 4; ++j2) {
         unsigned h, l;
-        split_pair(be[e], be[o], h, l);
-        bhp[0][j2] = h; blp[0][j2] = l;
+        split_pair(be[2 * j2], be[2 * j2 + 1], h, l);
+        bhp[0][j2] = h; blp[0][j2] = l;                                        // l' = x - h at its true scale
       }
     }
     if (bias_wave) {
@@ -533,6 +565,7 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
       if (r == 0 && (wave & 1) == 0) dal_acc += d0 + d1;   // (lanes 0 and 32 of the even waves: every point once)
       unsigned dh, dl;
       split_pair(d0 * S, d1 * S, dh, dl);
+      const unsigned dhs = pk_mul(dh, k_l);           // (the input's l pairs are raw: their 2^-11 rides here)
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         // (bhp / blp are indexed by a wave-uniform j2: selects, not a dynamic register index)
@@ -544,7 +577,7 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
         }
         aacc[u] = dot2(bhw, dh, aacc[u]);
         aacc[u] = dot2(bhw, dl, aacc[u]);
-        aacc[u] = dot2(blw, dh, aacc[u]);
+        aacc[u] = dot2(blw, dhs, aacc[u]);
       }
     }
 #pragma unroll
@@ -552,9 +585,10 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const half8 ah8 = __builtin_bit_cast(half8, ahp[t]), al8 = __builtin_bit_cast(half8, alp[t]);
+        const half8 as8 = __builtin_bit_cast(half8, NKT == 4 ? ahs[t] : ahp[t]);
         const half8 bh8 = __builtin_bit_cast(half8, bhp[u]), bl8 = __builtin_bit_cast(half8, blp[u]);
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah8, bh8, acc[t][u], 0, 0, 0);
-        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah8, bl8, acc[t][u], 0, 0, 0);
+        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(as8, bl8, acc[t][u], 0, 0, 0);
         acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al8, bh8, acc[t][u], 0, 0, 0);
       }
   };
@@ -575,29 +609,21 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land on the reduction scratch below
   hw_barrier();
 
-  // ---- write the partial (dZ scale removed): MFMA row m of tile t = feature 2m + t, column r of tile u =
-  // input NKT r + u
+  // ---- write the partial (dZ scale removed): MFMA row m of tile t = feature n0 + 32 t + m, column r of tile u =
+  // input k0 + 32 u + r (a row's 32 lanes store 128 contiguous bytes)
   const float invS = 1.0f / S;
   if (active) {
-    const bool vec_ok = NKT == 4 && (jb.ld & 3) == 0 && (jb.kcol0 & 3) == 0 && (jb.w_off & 3) == 0 &&
-                        (reinterpret_cast<unsigned long long>(out) & 15) == 0 && jb.kvalid == 256;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int i = 0; i < 16; ++i) {
         const int m = (i & 3) + 8 * (i >> 2) + 4 * hh;
-        const int n = n0 + 2 * m + t;
+        const int n = n0 + 32 * t + m;
         if (n < jb.n_rows) {
-          float* dst = out + jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k0 + NKT * r;
-          if (NKT == 4 && vec_ok) {
-            const f32x4 v = {acc[t][0][i] * invS, acc[t][NKT > 1 ? 1 : 0][i] * invS, acc[t][NKT > 2 ? 2 : 0][i] * invS,
-                             acc[t][NKT > 3 ? 3 : 0][i] * invS};
-            *reinterpret_cast<f32x4*>(dst) = v;
-          } else {
+          float* dst = out + jb.w_off + (size_t)n * jb.ld + jb.kcol0 + k0 + r;
 #pragma unroll
-            for (int u = 0; u < NKT; ++u)
-              if (k0 + NKT * r + u < jb.kvalid) dst[u] = acc[t][u][i] * invS;
-          }
+          for (int u = 0; u < NKT; ++u)
+            if (k0 + 32 * u + r < jb.kvalid) dst[32 * u] = acc[t][u][i] * invS;
         }
       }
   }
@@ -606,7 +632,7 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const float b = bacc[t] + __shfl_xor(bacc[t], 32, 64);
-      const int n = n0 + 2 * r + t;
+      const int n = n0 + 32 * t + r;
       if (hh == 0 && n < jb.n_rows) out[jb.b_off + n] = b * invS;
     }
   }
@@ -618,7 +644,7 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const float v = aacc[u] + __shfl_xor(aacc[u], 32, 64);
-      if (hh == 0) reda[(wave >> 1) * 256 + k0 + 4 * r + u] = v;
+      if (hh == 0) reda[(wave >> 1) * 256 + k0 + 32 * u + r] = v;
     }
     const float dsum = dal_acc + __shfl_xor(dal_acc, 32, 64);
     if ((wave & 1) == 0 && lane == 0) reda[4 * 256 + (wave >> 1)] = dsum;
