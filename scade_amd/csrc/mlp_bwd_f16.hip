@@ -289,7 +289,7 @@ constexpr int DGRAD_F16_LDS_BYTES = 2 * XPLANE * 2 + 128 * 4 + 16;   // + the fo
 // per-point scalars (d alpha, view direction) ride the ring as 4-byte LDS-DMA pieces.
 // ---------------------------------------------------------------------------
 constexpr int HW_PT = 16;                                 // points per ring slot = one k16 block
-constexpr int HW_D = 5;                                   // ring slots (4 and 6 measure the same)
+constexpr int HW_D = 6;                                   // ring slots: three PAIRS of stages (see the stage loop)
 // bytes of a slot: dZ h [16][256] fp16 | dZ l8 [16][256] e5m2 | input h | input l8 (KW = 64: the fp32 embedding
 // rows [16][64] instead) | d alpha [16] fp32 | view dirs [16][3] fp32 | 1 / s_p [16] fp32
 constexpr int HW_DZ_HI = 0, HW_DZ_MID = HW_PT * 512, HW_IN_HI = HW_PT * 768, HW_IN_MID = HW_PT * 1280;
@@ -321,6 +321,12 @@ __device__ __forceinline__ void hw_barrier() {
   __builtin_amdgcn_sched_barrier(0);
 }
 
+#ifdef HW_TRACE
+// -DHW_TRACE (variant build, SCADE_AB_FLAGS): per workgroup and wave of the LAST launch, sums over the ring stages of
+// {wait for the stage's data + barrier, DMA issue, compute, stages} on the 100 MHz wall clock (tools/probe_wgrad_f16_trace.py)
+__device__ unsigned long long hw_dbg[4096 * 8 * 4];
+#define HW_T() wall_clock64()
+#endif
 // RID: the job's rider as a COMPILE-TIME choice (0 none, WF_ALPHA the alpha head, WF_VIEWCOLS the view columns): as
 // run-time branches inside the stage loop the two rare riders cost EVERY 256-wide job its schedule (+6 ... +9 % on the
 // launch mix with the alpha head's dot products behind a wave-uniform flag)
@@ -329,7 +335,8 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
                                               int c0, int c1, float S, float* __restrict__ out) {
   constexpr int NKT = KW == 256 ? 4 : 1;
   constexpr int D = HW_D, PT = HW_PT;
-  constexpr int NI = (KW == 256 ? 3 : 2) + 3;     // LDS-DMA instructions per wave and stage
+  // LDS-DMA instructions per wave and stage: the tiles, 1 / s_p, and the rider scalars only in the job that has the rider
+  constexpr int NI = (KW == 256 ? 3 : 2) + 1 + (RID == WF_ALPHA ? 1 : 0) + (RID == WF_VIEWCOLS ? 1 : 0);
   typedef __attribute__((address_space(3))) void* lds_ptr_t;
   typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
   unsigned char* lds = reinterpret_cast<unsigned char*>(lds_f);
@@ -376,7 +383,8 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   // Every quad of lanes still fetches 64 contiguous bytes of one row, every 128-byte line is consumed by one
   // instruction.  Wave w moves point quad (w >> 1) x column half (w & 1) of both h tiles (1 KiB each) and, the l8
   // tiles, waves 0-3 the dZ tile's and waves 4-7 the input tile's point half (w4 >> 1) x column half (w4 & 1) - and
-  // the rider scalars of two points.  The same count in every stage, also past the chunk end (zeros, no traffic),
+  // the rider scalars of two points (1 / s_p in every job, d alpha / the view
+  // directions only in the job with that rider: RID is a template argument).  The same count in every stage, also past the chunk end (zeros, no traffic),
   // so the vmcnt below is a compile-time constant.
   const int dma_h_voff = ((lane >> 2) & 3) * 512 + (4 * (wave & 1) + (lane >> 4)) * 64 + (lane & 3) * 16;
   const int dma_h_lds = (wave >> 1) * 2048 + (wave & 1) * 1024;
@@ -403,11 +411,11 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
       else
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rbh, (lds_ptr_t)(slot + HW_IN_HI + 4 * w4 * 256), 16, lane * 16, grow4 * 256, 0, 2);
     }
-    if (lane < 2)
+    if (RID == WF_ALPHA && lane < 2)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rd, (lds_ptr_t)(slot + HW_SCAL + 4 * 2 * wave), 4, lane * 4, grow * 4, 0, 0);
     if (lane < 2)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(slot + HW_SCAL + 256 + 4 * 2 * wave), 4, lane * 4, grow * 4, 0, 0);
-    if (lane < 6)
+    if (RID == WF_VIEWCOLS && lane < 6)
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rv, (lds_ptr_t)(slot + HW_SCAL + 64 + 4 * 6 * wave), 4,
                                                (lane / 3) * 256 + (60 + lane % 3) * 4, grow * 256, 0, 0);
   };
@@ -593,19 +601,59 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
       }
   };
 
+  // ---- the ring runs in PAIRS of stages: one barrier per 32 points.  Pair pi's two slots have landed (each wave's
+  // vmcnt leaves its pieces of pair pi + 1 in flight) -> barrier -> both stages are contracted -> pair pi + 2 is issued
+  // into the slots of pair pi - 1, which every wave left behind at this pair's barrier.  Measured on the step's launch
+  // mix, same box: 16-point stages with a barrier each and the issue in front of the compute 544 us (ring depth 4 / 5 /
+  // 6 alike), the issue behind the compute 525-532 (an LDS-DMA instruction costs its wave 35-50 ns of issue - the
+  // back-pressure of a memory system that is kept full - and in front of the compute that sits on the path to every
+  // wave's first MFMA), pairs with the issue behind 515-517, in front 709, between the two stages 676.  Kernel stamps
+  // (-DHW_TRACE, tools/probe_wgrad_f16_trace.py): a SIMD's second wave (waves 4-7) finishes a stage ~450 ns behind
+  // its first - the MFMA pipe serves the older wave first (s_setprio on waves 4-7 swaps the roles, alternating it per
+  // stage evens them out; the pair takes 3.3 us either way) - and waves 0-3 spend that at the barrier.  Giving those four
+  // waves ALL the DMA issue (they have the slack) was built and is slower, 556-576 us: the stream a wave can keep in
+  // flight is bounded per wave, four issuers move 3.6 TB/s where eight move 5.
   const int ns = (npts + PT - 1) / PT;
+  const int np = (ns + 1) >> 1;                    // (an odd last stage's partner is all range-check zeros)
 #pragma unroll
-  for (int st = 0; st < D - 1; ++st) issue(st, st);
-  int sl = 0;
-  for (int st = 0; st < ns; ++st) {
-    // stage st: this wave's pieces have landed (D-2 younger stages stay in flight) ...
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 2) * NI) : "memory");
-    hw_barrier();                                 // ... and so have everybody's; the slot of stage st-1 is read out
-    issue(st + D - 1, sl == 0 ? D - 1 : sl - 1);
-    compute(sl);
-    riders_add(sl);
-    sl = sl + 1 == D ? 0 : sl + 1;
+  for (int st = 0; st < 4; ++st) issue(st, st);
+  int slp = 0;
+#ifdef HW_TRACE
+  unsigned long long tw = 0, ti = 0, tc = 0;
+#endif
+  for (int pi = 0; pi < np; ++pi) {
+#ifdef HW_TRACE
+    const unsigned long long t0 = HW_T();
+#endif
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+    hw_barrier();
+#ifdef HW_TRACE
+    const unsigned long long t1 = HW_T();
+#endif
+    compute(slp);
+    riders_add(slp);
+    compute(slp + 1);
+    riders_add(slp + 1);
+#ifdef HW_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t2 = HW_T();
+#endif
+    const int sn = slp >= 2 ? slp - 2 : slp + 4;
+    issue(2 * pi + 4, sn);
+    issue(2 * pi + 5, sn + 1);
+#ifdef HW_TRACE
+    __builtin_amdgcn_sched_barrier(0);
+    const unsigned long long t3 = HW_T();
+    tw += t1 - t0; tc += t2 - t1; ti += t3 - t2;
+#endif
+    slp = slp == 4 ? 0 : slp + 2;
   }
+#ifdef HW_TRACE
+  if (lane == 0) {
+    unsigned long long* d = hw_dbg + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + wave) * 4;
+    d[0] = tw; d[1] = ti; d[2] = tc; d[3] = (unsigned long long)np | ((unsigned long long)KW << 32);
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // nothing may land on the reduction scratch below
   hw_barrier();
 
@@ -759,3 +807,9 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
   hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
   return scade_check_launch("scade_mlp_bwd_f16(reduce)");
 }
+
+#ifdef HW_TRACE
+extern "C" int scade_debug_hw(unsigned long long* out) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(scade::hw_dbg), sizeof(unsigned long long) * 4096 * 8 * 4);
+}
+#endif
