@@ -11,6 +11,7 @@
 // the chain is linear in g_out[p] and the product only mixes features, never points, so the
 // scale factors out exactly and is removed when the fp32 rows are stored.
 #include "mlp_tile_f16.h"
+#include <type_traits>
 #include "mlp_wgrad.h"
 
 namespace scade {
@@ -488,8 +489,35 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   const int b_h = HW_IN_HI + la_h + (k0 >> 5) * 256;
   const int b_8 = HW_IN_MID + la_8 + (k0 >> 6) * 512;                    // tile u: + 512 (u >> 1) + ((32 (u & 1)) ^ sw8)
   auto compute = [&](int sl) {
-    if (!active) return;
     const unsigned char* slot = lds + sl * HW_SLOT;
+    auto tr16 = [&](int off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr16_ptr)(slot + off))); };
+    auto tr8 = [&](int off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr8_b64_v2i32((tr8_ptr)(slot + off))); };
+    // the four fp16 pairs (value = byte << 8) of eight e5m2 bytes
+    auto widen = [](u32x2 v) {
+      return u32x4{__builtin_amdgcn_perm(0u, v[0], 0x010c000cu), __builtin_amdgcn_perm(0u, v[0], 0x030c020cu),
+                   __builtin_amdgcn_perm(0u, v[1], 0x010c000cu), __builtin_amdgcn_perm(0u, v[1], 0x030c020cu)};
+    };
+    // every LDS read of the stage first (nothing in them depends on the points' factors): the factors' own read and
+    // arithmetic then run under the gathers' latency instead of in front of it
+    u32x2 ra_lo[2], ra_hi[2], ra_8[2], rb_lo[NKT], rb_hi[NKT], rb_8[NKT];
+    float be[8];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      ra_lo[t] = tr16(a_h + 256 * t);
+      ra_hi[t] = tr16(a_h + 256 * t + 2048);
+      ra_8[t] = tr8(a_8 + ((32 * t) ^ sw8));
+    }
+    if (NKT == 4) {
+#pragma unroll
+      for (int u = 0; u < NKT; ++u) {
+        rb_lo[u] = tr16(b_h + 256 * u);
+        rb_hi[u] = tr16(b_h + 256 * u + 2048);
+        rb_8[u] = tr8(b_8 + 512 * (u >> 1) + ((32 * (u & 1)) ^ sw8));
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) be[j] = reinterpret_cast<const float*>(slot + HW_IN_HI)[(8 * hh + j) * 64 + k0 + r];
+    }
     // (S / s_p) of the lane's point pairs, and the same times 2^-11 for the cross terms
     half2v kp[4], kl[4];
     {
@@ -505,19 +533,11 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) kl[j2] = kp[j2] * k_l;
     }
-    auto tr16 = [&](int off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((tr16_ptr)(slot + off))); };
-    auto tr8 = [&](int off) { return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr8_b64_v2i32((tr8_ptr)(slot + off))); };
-    // the four fp16 pairs (value = byte << 8) of eight e5m2 bytes
-    auto widen = [](u32x2 v) {
-      return u32x4{__builtin_amdgcn_perm(0u, v[0], 0x010c000cu), __builtin_amdgcn_perm(0u, v[0], 0x030c020cu),
-                   __builtin_amdgcn_perm(0u, v[1], 0x010c000cu), __builtin_amdgcn_perm(0u, v[1], 0x030c020cu)};
-    };
     u32x4 ahp[2], ahs[2], alp[2], bhp[NKT], blp[NKT];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      const u32x2 lo = tr16(a_h + 256 * t), hi = tr16(a_h + 256 * t + 2048);
-      const u32x4 l4 = widen(tr8(a_8 + ((32 * t) ^ sw8)));
-      const unsigned hv[4] = {lo[0], lo[1], hi[0], hi[1]};
+      const u32x4 l4 = widen(ra_8[t]);
+      const unsigned hv[4] = {ra_lo[t][0], ra_lo[t][1], ra_hi[t][0], ra_hi[t][1]};
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
         const unsigned lw = l4[j2];
@@ -529,14 +549,10 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
     if (NKT == 4) {
 #pragma unroll
       for (int u = 0; u < NKT; ++u) {
-        const u32x2 lo = tr16(b_h + 256 * u), hi = tr16(b_h + 256 * u + 2048);
-        bhp[u] = u32x4{lo[0], lo[1], hi[0], hi[1]};
-        blp[u] = widen(tr8(b_8 + 512 * (u >> 1) + ((32 * (u & 1)) ^ sw8)));        // raw l: its 2^-11 is in ahs
+        bhp[u] = u32x4{rb_lo[u][0], rb_lo[u][1], rb_hi[u][0], rb_hi[u][1]};
+        blp[u] = widen(rb_8[u]);                                               // raw l: its 2^-11 is in ahs
       }
     } else {
-      float be[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) be[j] = reinterpret_cast<const float*>(slot + HW_IN_HI)[(8 * hh + j) * 64 + k0 + r];
 #pragma unroll
       for (int j2 = 0; j2 < 4; ++j2) {
         unsigned h, l;
@@ -617,37 +633,42 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   const int np = (ns + 1) >> 1;                    // (an odd last stage's partner is all range-check zeros)
 #pragma unroll
   for (int st = 0; st < 4; ++st) issue(st, st);
-  int slp = 0;
 #ifdef HW_TRACE
   unsigned long long tw = 0, ti = 0, tc = 0;
 #endif
-  for (int pi = 0; pi < np; ++pi) {
+  // (the loop is written once per value of the wave-uniform `active`: with the test inside it, each stage's
+  // contraction was a basic block of its own and nothing of the second stage could be scheduled under the first)
+  auto ring = [&](auto ACT) {
+    int slp = 0;
+    for (int pi = 0; pi < np; ++pi) {
 #ifdef HW_TRACE
-    const unsigned long long t0 = HW_T();
+      const unsigned long long t0 = HW_T();
 #endif
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
-    hw_barrier();
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NI) : "memory");
+      hw_barrier();
 #ifdef HW_TRACE
-    const unsigned long long t1 = HW_T();
+      const unsigned long long t1 = HW_T();
 #endif
-    compute(slp);
-    riders_add(slp);
-    compute(slp + 1);
-    riders_add(slp + 1);
+      if (decltype(ACT)::value) compute(slp);
+      riders_add(slp);
+      if (decltype(ACT)::value) compute(slp + 1);
+      riders_add(slp + 1);
 #ifdef HW_TRACE
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long t2 = HW_T();
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t2 = HW_T();
 #endif
-    const int sn = slp >= 2 ? slp - 2 : slp + 4;
-    issue(2 * pi + 4, sn);
-    issue(2 * pi + 5, sn + 1);
+      const int sn = slp >= 2 ? slp - 2 : slp + 4;
+      issue(2 * pi + 4, sn);
+      issue(2 * pi + 5, sn + 1);
 #ifdef HW_TRACE
-    __builtin_amdgcn_sched_barrier(0);
-    const unsigned long long t3 = HW_T();
-    tw += t1 - t0; tc += t2 - t1; ti += t3 - t2;
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t3 = HW_T();
+      tw += t1 - t0; tc += t2 - t1; ti += t3 - t2;
 #endif
-    slp = slp == 4 ? 0 : slp + 2;
-  }
+      slp = slp == 4 ? 0 : slp + 2;
+    }
+  };
+  if (active) ring(std::true_type{}); else ring(std::false_type{});
 #ifdef HW_TRACE
   if (lane == 0) {
     unsigned long long* d = hw_dbg + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + wave) * 4;
