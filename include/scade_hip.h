@@ -65,6 +65,13 @@ int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* v
  * stand-alone pack entries write. */
 int scade_mlp_pack_step(int n_nets, const float* const* params, int format, void* const* packed_fwd,
                         void* const* packed_t, void* stream);
+/* The same for the split-precision ("f16x3") training kernels: per network the scade_mlp_pack blob (the dgrad's
+ * heads read the fp32 head weights from it), the scade_mlp_pack_f16 blob and the scade_mlp_pack_t_f16 blob - six
+ * stand-alone launches per step otherwise.  n_nets output pointers each, NULL entries are skipped; same bytes as
+ * the stand-alone entries write.  (Host-side mirror of what the reference does implicitly: its nn.Linear weights
+ * ARE the operands, model/run_nerf_helpers.py:136-153; here the MFMA kernels read re-ordered copies.) */
+int scade_mlp_pack_step_f16x3(int n_nets, const float* const* params, float* const* packed_exact,
+                              void* const* packed_f16, void* const* packed_t_f16, void* stream);
 
 /* Backward of scade_mlp_fwd w.r.t. the 24 parameter tensors (what autograd computes for
  * NeRF.forward in the reference).  packed_t = scade_mlp_pack_t(params) (transposed weight

@@ -26,6 +26,7 @@ SIGNATURES = {
     "scade_mlp_lds_bytes": (c_int, []),
     "scade_mlp_pack": (c_int, [_P, _P, _P]),
     "scade_mlp_pack_step": (c_int, [_I, _P, _I, _P, _P, _P]),
+    "scade_mlp_pack_step_f16x3": (c_int, [_I, _P, _P, _P, _P, _P]),
     "scade_mlp_fwd": (c_int, [_P, _I, _P, _P, _I, _P, _I, _I, _P, _P, _P]),
     "scade_mlp_acts_floats": (c_long, [c_long]),
     "scade_mlp_packed_t_floats": (c_long, []),

@@ -10,54 +10,18 @@
 // is scaled by its own power of two s_p = 2^(-4 - exponent(max|g_out[p]|, |d alpha_pre[p]|)):
 // the chain is linear in g_out[p] and the product only mixes features, never points, so the
 // scale factors out exactly and is removed when the fp32 rows are stored.
-#include "mlp_tile_f16.h"
+#include "mlp_pack.h"       // (mlp_tile_f16.h + the pack rows shared with scade_mlp_pack_step)
 #include <type_traits>
 #include "mlp_wgrad.h"
 
 namespace scade {
-
-// transposed two-plane pack: for dgrad index t (mlp_layout.h), layer l = dgrad_layer(t):
-//   WT16[((kt*NB16 + nb)*2 + plane)*64*8 + lane*8 + j] = split(W[nb*16 + 8*(lane>>5) + j][hcol0 + kt*32 + (lane&31)])
-constexpr long wt16_halves(int t) { return (long)256 * n_out(dgrad_layer(t)) * 2; }
-constexpr long off_wt16(int t) {
-  long o = 0;
-  for (int i = 0; i < t; ++i) o += wt16_halves(i);
-  return o;
-}
-constexpr long PACKED_T_F16_HALVES = off_wt16(NLAYER_DGRAD) + 2 * 64 * 8;
 
 struct PackTF16Args {
   const float* p[N_PARAM_TENSORS];
   _Float16* packed;
 };
 
-__global__ void mlp_pack_t_f16_kernel(PackTF16Args a) {
-  const int t = blockIdx.y;
-  const int l = dgrad_layer(t);
-  const int widx = l <= 7 ? 2 * l : (l == L_FEAT ? 18 : 16);
-  const float* __restrict__ Wsrc = a.p[widx];
-  const int N = n_out(l);
-  const int NB = N / 16;
-  const int ld = l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W);
-  const int hcol0 = l == 5 ? EMB : 0;
-  const long total = (long)256 * N;
-  const long off = off_wt16(t);
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-    const long blk = i >> 9;
-    const int nb = (int)(blk % NB), kt = (int)(blk / NB);
-    const int n = nb * 16 + 8 * (lane >> 5) + j;
-    const int k = kt * 32 + (lane & 31);
-    _Float16 h, lo;
-    split2(Wsrc[(size_t)n * ld + hcol0 + k], h, lo);
-    const long base = off + blk * 1024 + lane * 8 + j;
-    a.packed[base] = h;
-    a.packed[base + 512] = lo;
-  }
-  if (t == 0)
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < 2 * 64 * 8; i += gridDim.x * blockDim.x)
-      a.packed[off_wt16(NLAYER_DGRAD) + i] = (_Float16)0.f;
-}
+__global__ void mlp_pack_t_f16_kernel(PackTF16Args a) { pack_t_f16_row(a.p, a.packed, blockIdx.y, blockIdx.x, gridDim.x); }
 
 __global__ void zero_word_kernel(unsigned int* w) {
   if (threadIdx.x == 0) *w = 0u;

@@ -20,7 +20,7 @@
 //
 // Validity: |activation| and |weight| < 65504 (fp16 range).  Inference only (no saved
 // activations); training uses the exact fp32 kernels.
-#include "mlp_tile_f16.h"
+#include "mlp_pack.h"       // (mlp_tile_f16.h + the pack rows shared with scade_mlp_pack_step)
 
 namespace scade {
 
@@ -329,52 +329,7 @@ struct PackF16Args {
   void* packed;
 };
 
-__device__ __forceinline__ int kmap16(int l, int kp) {
-  // padded channel kp -> source column of layer l's weight, or -1 (zero)
-  if (l == 0) return kp < EMB ? kp : -1;
-  if (l == 5) return kp < 64 ? (kp < EMB ? kp : -1) : EMB + (kp - 64);
-  if (l == L_VIEWS) return kp < 16 ? (kp < 3 ? W + kp : -1) : kp - 16;
-  return kp;
-}
-
-__global__ void mlp_pack_f16_kernel(PackF16Args a) {
-  const int l = blockIdx.y;
-  _Float16* wpk = reinterpret_cast<_Float16*>(a.packed);
-  if (l < NLAYER_MFMA) {
-    const int widx = l < 8 ? 2 * l : (l == L_FEAT ? 18 : 16);
-    const float* __restrict__ Wsrc = a.p[widx];
-    const int KB = kb16(l);
-    const long total = wh_halves(l) / 2;              // elements per plane pair
-    const int kr = l == 0 ? EMB : (l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W));
-    const long off = off_wh(l);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
-      const long blk = i >> 9;                        // (nt*KB + kb)
-      const int kb = (int)(blk % KB), nt = (int)(blk / KB);
-      const int n = nt * 32 + (lane & 31);
-      const int src = kmap16(l, kb * 16 + 8 * (lane >> 5) + j);
-      const float w = src >= 0 ? Wsrc[(size_t)n * kr + src] : 0.f;
-      _Float16 h, lo;
-      split2(w, h, lo);
-      const long base = off + (blk * 2) * 512 + lane * 8 + j;
-      wpk[base] = h;
-      wpk[base + 512] = lo;
-    }
-  } else {
-    float* tail = reinterpret_cast<float*>(wpk + PACKED_F16_HALVES);
-    const int t0 = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
-    for (int i = t0; i < NLAYER_MFMA * 256; i += stride) {
-      const int ll = i >> 8, f = i & 255;
-      const int bidx = ll < 8 ? 2 * ll + 1 : (ll == L_FEAT ? 19 : 17);
-      tail[i] = (ll == L_VIEWS && f >= 128) ? 0.f : a.p[bidx][f];
-    }
-    for (int i = t0; i < 256; i += stride) tail[OFF_WA - OFF_BIAS + i] = a.p[20][i];
-    for (int i = t0; i < 4; i += stride) tail[OFF_BA - OFF_BIAS + i] = i == 0 ? a.p[21][0] : 0.f;
-    for (int i = t0; i < 384; i += stride) tail[OFF_WR - OFF_BIAS + i] = a.p[22][i];
-    for (int i = t0; i < 4; i += stride) tail[OFF_BR - OFF_BIAS + i] = i < 3 ? a.p[23][i] : 0.f;
-    for (int i = t0; i < 2 * 64 * 8; i += stride) wpk[off_wh(NLAYER_MFMA) + i] = (_Float16)0.f;
-  }
-}
+__global__ void mlp_pack_f16_kernel(PackF16Args a) { pack_f16_row(a.p, a.packed, blockIdx.y, blockIdx.x, gridDim.x); }
 
 }  // namespace scade
 

@@ -205,4 +205,86 @@ __device__ __forceinline__ void pack_t_lp_row(const float* const* p, void* packe
   }
 }
 
+// ---- split-precision ("f16x3") packs: two fp16 planes in fragment order (mlp_fwd_f16.hip / mlp_bwd_f16.hip) ----------
+__device__ __forceinline__ int kmap16(int l, int kp) {
+  // padded channel kp -> source column of layer l's weight, or -1 (zero)
+  if (l == 0) return kp < EMB ? kp : -1;
+  if (l == 5) return kp < 64 ? (kp < EMB ? kp : -1) : EMB + (kp - 64);
+  if (l == L_VIEWS) return kp < 16 ? (kp < 3 ? W + kp : -1) : kp - 16;
+  return kp;
+}
+// forward pack, row l: 0..9 MFMA layers, 10 = the fp32 tail (biases, heads) + the slack block
+__device__ __forceinline__ void pack_f16_row(const float* const* p, void* packed, int l, int bx, int nbx) {
+  _Float16* wpk = reinterpret_cast<_Float16*>(packed);
+  if (l < NLAYER_MFMA) {
+    const int widx = l < 8 ? 2 * l : (l == L_FEAT ? 18 : 16);
+    const float* __restrict__ Wsrc = p[widx];
+    const int KB = kb16(l);
+    const long total = wh_halves(l) / 2;              // elements per plane pair
+    const int kr = l == 0 ? EMB : (l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W));
+    const long off = off_wh(l);
+    for (long i = (long)bx * 256 + threadIdx.x; i < total; i += (long)nbx * 256) {
+      const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+      const long blk = i >> 9;                        // (nt*KB + kb)
+      const int kb = (int)(blk % KB), nt = (int)(blk / KB);
+      const int n = nt * 32 + (lane & 31);
+      const int src = kmap16(l, kb * 16 + 8 * (lane >> 5) + j);
+      const float w = src >= 0 ? Wsrc[(size_t)n * kr + src] : 0.f;
+      _Float16 h, lo;
+      split2(w, h, lo);
+      const long base = off + (blk * 2) * 512 + lane * 8 + j;
+      wpk[base] = h;
+      wpk[base + 512] = lo;
+    }
+  } else {
+    float* tail = reinterpret_cast<float*>(wpk + PACKED_F16_HALVES);
+    const int t0 = bx * 256 + threadIdx.x, stride = nbx * 256;
+    for (int i = t0; i < NLAYER_MFMA * 256; i += stride) {
+      const int ll = i >> 8, f = i & 255;
+      const int bidx = ll < 8 ? 2 * ll + 1 : (ll == L_FEAT ? 19 : 17);
+      tail[i] = (ll == L_VIEWS && f >= 128) ? 0.f : p[bidx][f];
+    }
+    for (int i = t0; i < 256; i += stride) tail[OFF_WA - OFF_BIAS + i] = p[20][i];
+    for (int i = t0; i < 4; i += stride) tail[OFF_BA - OFF_BIAS + i] = i == 0 ? p[21][0] : 0.f;
+    for (int i = t0; i < 384; i += stride) tail[OFF_WR - OFF_BIAS + i] = p[22][i];
+    for (int i = t0; i < 4; i += stride) tail[OFF_BR - OFF_BIAS + i] = i < 3 ? p[23][i] : 0.f;
+    for (int i = t0; i < 2 * 64 * 8; i += stride) wpk[off_wh(NLAYER_MFMA) + i] = (_Float16)0.f;
+  }
+}
+// transposed two-plane pack: for dgrad index t (mlp_layout.h), layer l = dgrad_layer(t):
+//   WT16[((kt*NB16 + nb)*2 + plane)*64*8 + lane*8 + j] = split(W[nb*16 + 8*(lane>>5) + j][hcol0 + kt*32 + (lane&31)])
+constexpr long wt16_halves(int t) { return (long)256 * n_out(dgrad_layer(t)) * 2; }
+constexpr long off_wt16(int t) {
+  long o = 0;
+  for (int i = 0; i < t; ++i) o += wt16_halves(i);
+  return o;
+}
+constexpr long PACKED_T_F16_HALVES = off_wt16(NLAYER_DGRAD) + 2 * 64 * 8;
+__device__ __forceinline__ void pack_t_f16_row(const float* const* p, void* packed_t, int t, int bx, int nbx) {
+  _Float16* packed = reinterpret_cast<_Float16*>(packed_t);
+  const int l = dgrad_layer(t);
+  const int widx = l <= 7 ? 2 * l : (l == L_FEAT ? 18 : 16);
+  const float* __restrict__ Wsrc = p[widx];
+  const int N = n_out(l);
+  const int NB = N / 16;
+  const int ld = l == 5 ? EMB + W : (l == L_VIEWS ? W + 3 : W);
+  const int hcol0 = l == 5 ? EMB : 0;
+  const long total = (long)256 * N;
+  const long off = off_wt16(t);
+  for (long i = (long)bx * 256 + threadIdx.x; i < total; i += (long)nbx * 256) {
+    const int j = (int)(i & 7), lane = (int)((i >> 3) & 63);
+    const long blk = i >> 9;
+    const int nb = (int)(blk % NB), kt = (int)(blk / NB);
+    const int n = nb * 16 + 8 * (lane >> 5) + j;
+    const int k = kt * 32 + (lane & 31);
+    _Float16 h, lo;
+    split2(Wsrc[(size_t)n * ld + hcol0 + k], h, lo);
+    const long base = off + blk * 1024 + lane * 8 + j;
+    packed[base] = h;
+    packed[base + 512] = lo;
+  }
+  if (t == 0)
+    for (int i = bx * 256 + threadIdx.x; i < 2 * 64 * 8; i += nbx * 256) packed[off_wt16(NLAYER_DGRAD) + i] = (_Float16)0.f;
+}
+
 }  // namespace scade

@@ -185,6 +185,53 @@ def mlp_pack_step(nets, fmt: str) -> None:
         net.adopt_packs(fmt, bf, bt, key)
 
 
+def mlp_pack_step_f16x3(nets) -> None:
+    """The same for the split-precision training kernels (scade_mlp_pack_step_f16x3): per network the exact forward
+    blob (the dgrad's heads read the fp32 head weights), the two-plane forward blob and the two-plane transposed blob
+    - six stand-alone launches per step otherwise.  The blobs land in NeRF.packed / packed_f16 / packed_t_f16's caches."""
+    lib = _lib.load()
+    plist, ex, fw, tr, adopt = [], [], [], [], []
+    for net in nets:
+        ps = net.ordered_params()
+        dev = ps[0].device
+        key = net.pack_key()
+        d = net.__dict__
+        stale = lambda blob, k: blob is None or k != key or blob.device != dev
+        need = (stale(d.get("_packed"), d.get("_packed_key")), stale(d.get("_packed_f16"), d.get("_packed_f16_key")),
+                stale(d.get("_packed_t_f16"), d.get("_packed_t_f16_key")))
+        if not any(need):
+            continue
+        ptrs = tuple(k[0] for k in key[1:])
+        if d.get("_pack_checked") != ptrs:
+            for p in ps:
+                check(p, "mlp_pack_step_f16x3")
+            d["_pack_checked"] = ptrs
+        if not all(p.is_contiguous() for p in ps):
+            raise ValueError("mlp_pack_step_f16x3: parameters must be contiguous")
+        be = torch.empty(int(lib.scade_mlp_packed_floats()), device=dev, dtype=torch.float32) if need[0] else None
+        bf = torch.empty(int(lib.scade_mlp_packed_f16_bytes()), device=dev, dtype=torch.uint8) if need[1] else None
+        bt = torch.empty(int(lib.scade_mlp_packed_t_f16_bytes()), device=dev, dtype=torch.uint8) if need[2] else None
+        plist += ptrs
+        ex.append(be)
+        fw.append(bf)
+        tr.append(bt)
+        adopt.append((net, be, bf, bt, key))
+    if not adopt:
+        return
+    vp = lambda ts: ctypes.cast((ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts]),
+                                ctypes.c_void_p)
+    call("scade_mlp_pack_step_f16x3", len(adopt), ctypes.cast((ctypes.c_void_p * len(plist))(*plist), ctypes.c_void_p),
+         vp(ex), vp(fw), vp(tr), stream())
+    for net, be, bf, bt, key in adopt:
+        d = net.__dict__
+        if be is not None:
+            d["_packed"], d["_packed_key"] = be, key
+        if bf is not None:
+            d["_packed_f16"], d["_packed_f16_key"] = bf, key
+        if bt is not None:
+            d["_packed_t_f16"], d["_packed_t_f16_key"] = bt, key
+
+
 def mlp_acts_alloc(P: int, device) -> Tensor:
     return torch.empty(int(_lib.load().scade_mlp_acts_floats(P)), device=device, dtype=torch.float32)
 

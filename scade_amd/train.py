@@ -157,6 +157,8 @@ class Trainer:
         if (prec == "f32" or prec in ops.LP_FORMATS) and self.fine.train_precision == prec \
                 and torch.is_grad_enabled():
             ops.mlp_pack_step([self.coarse, self.fine], "bf16" if prec == "bf16-s8" else prec)
+        elif prec in ("f16x3", "f16x3-dgrad") and self.fine.train_precision == prec and torch.is_grad_enabled():
+            ops.mlp_pack_step_f16x3([self.coarse, self.fine])
         share = batch_share(rays.shape[0], n_total) if self.sharded else 1.0
         if c["joint"] and self.sharded:
             # the LAST sampler (sample_pdf_joint_return_u, :728) draws ONE u[S] for the whole batch

@@ -833,6 +833,45 @@ def test_one_launch_pack_of_both_networks_writes_the_same_blobs(dev, fmt):
     assert torch.equal((fine._packed if fmt == "f32" else fine._packed_lp).view(torch.uint8), ref.view(torch.uint8))
 
 
+def test_one_launch_pack_f16x3_writes_the_same_blobs(dev):
+    """ops.mlp_pack_step_f16x3 (scade_mlp_pack_step_f16x3: the exact forward blob, the two-plane forward blob and the
+    two-plane transposed blob of both networks in ONE launch - six launches per split-precision train step otherwise)
+    against the stand-alone entries: byte-identical, adopted by the caches, re-done only for what went stale."""
+    from scade_amd import ops
+    from scade_amd.train import make_scade_nets
+    coarse, fine = make_scade_nets(dev, seed=23)
+    want = []
+    for net in (coarse, fine):
+        ps = net.ordered_params()
+        want.append((ops.mlp_pack(ps), ops.mlp_pack_f16(ps), ops.mlp_pack_t_f16(ps)))
+    # (the two-plane forward blob has padding bytes no pack writes: the bytes a pack DOES write are the ones two packs
+    # into differently pre-filled buffers agree on)
+    ps0 = coarse.ordered_params()
+    a = ops.mlp_pack_f16(ps0, torch.full_like(want[0][1], 0xAA))
+    b = ops.mlp_pack_f16(ps0, torch.full_like(want[0][1], 0x55))
+    written = a == b
+    assert float(written.float().mean()) > 0.99
+    ops.mlp_pack_step_f16x3([coarse, fine])
+    torch.cuda.synchronize()
+    for net, (we, wf, wt) in zip((coarse, fine), want):
+        assert torch.equal(net._packed.view(torch.uint8), we.view(torch.uint8)), "exact layout differs"
+        assert torch.equal(net._packed_f16[written], wf[written]), "two-plane forward layout differs"
+        assert torch.equal(net._packed_t_f16.view(torch.uint8), wt.view(torch.uint8)), "two-plane transposed layout differs"
+        assert net.packed().data_ptr() == net._packed.data_ptr()
+        assert net.packed_f16().data_ptr() == net._packed_f16.data_ptr()
+        assert net.packed_t_f16().data_ptr() == net._packed_t_f16.data_ptr()
+    keep = coarse._packed_f16
+    ops.mlp_pack_step_f16x3([coarse, fine])
+    assert coarse._packed_f16 is keep
+    with torch.no_grad():
+        fine.pts_linears[2].weight.mul_(1.5)
+    ops.mlp_pack_step_f16x3([coarse, fine])
+    assert coarse._packed_f16 is keep
+    ps = fine.ordered_params()
+    assert torch.equal(fine._packed_t_f16.view(torch.uint8), ops.mlp_pack_t_f16(ps).view(torch.uint8))
+    assert torch.equal(fine._packed_f16[written], ops.mlp_pack_f16(ps)[written])
+
+
 def test_pack_step_checks_parameters_again_when_their_storage_changes(dev):
     """ops.mlp_pack_step validates the 24 parameter tensors once per SET OF POINTERS (round 4: the checks were 60 us
     of every eager step); a parameter whose storage is replaced - here by one of another dtype, then by a
