@@ -183,6 +183,13 @@ int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f16, void* s
 int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* acts,
                       const float* g_out, int P, int wgrad_f16, float* workspace, float* grad_flat,
                       void* stream);
+/* The same for TWO network calls (the coarse + fine NeRF of a train step, run_scade_scannet.py:976 backward of
+ * both) in one launch sequence - one dgrad launch, one weight-gradient launch, one reduce: every pointer argument is
+ * a HOST array of two, workspace[i] sized by scade_mlp_bwd_workspace_floats(P[i]).  Same bits as two
+ * scade_mlp_bwd_f16 calls. */
+int scade_mlp_bwd_f16_2(const float* const* packed, const void* const* packed_t_f16, const float* const* acts,
+                        const float* const* g_out, const int* P, int wgrad_f16, float* const* workspace,
+                        float* const* grad_flat, void* stream);
 
 /* ---- positional encoding (Embedder.embed, helpers:142-172; get_embedder :174-189) */
 /* out[P, D*(1+2*multires)] = [x, sin(x*pi*2^0), cos(x*pi*2^0), ..., cos(x*pi*2^(L-1))] */

@@ -55,6 +55,7 @@ SIGNATURES = {
     "scade_mlp_packed_t_f16_bytes": (c_long, []),
     "scade_mlp_pack_t_f16": (c_int, [_P, _P, _P]),
     "scade_mlp_bwd_f16": (c_int, [_P, _P, _P, _P, _I, _I, _P, _P, _P]),
+    "scade_mlp_bwd_f16_2": (c_int, [_P, _P, _P, _P, _P, _I, _P, _P, _P]),
     "scade_embed": (c_int, [_P, _I, _I, _I, _P, _P]),
     "scade_ray_points": (c_int, [_P, _I, _P, _P, _I, _I, _I, _P, _P, _P]),
     "scade_ray_points_draw": (c_int, [_P, _I, _P, _I, _I, _I, ctypes.c_ulonglong, ctypes.c_ulonglong, _P, _I, _P, _P, _P, _P,

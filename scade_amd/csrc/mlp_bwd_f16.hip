@@ -23,8 +23,8 @@ struct PackTF16Args {
 
 __global__ void mlp_pack_t_f16_kernel(PackTF16Args a) { pack_t_f16_row(a.p, a.packed, blockIdx.y, blockIdx.x, gridDim.x); }
 
-__global__ void zero_word_kernel(unsigned int* w) {
-  if (threadIdx.x == 0) *w = 0u;
+__global__ void zero_word_kernel(unsigned int* w0, unsigned int* w1) {
+  if (threadIdx.x == 0) { *w0 = 0u; if (w1) *w1 = 0u; }
 }
 
 struct MlpDgradF16Args {
@@ -35,6 +35,12 @@ struct MlpDgradF16Args {
   float* dz;                 // dz_floats(P)
   unsigned int* gmax;        // launch-wide max of |g_out| (float bits; zeroed by zero_word_kernel before the launch)
   int P;
+};
+
+// one or two network calls in one launch (the coarse + fine NeRF of a train step): workgroups [0, tiles0) take n[0]
+struct MlpDgradF16Args2 {
+  MlpDgradF16Args n[2];
+  int tiles0;
 };
 
 template <bool MASK, bool ADD_ALPHA>
@@ -73,7 +79,10 @@ __device__ __forceinline__ void dgrad_store_h(const f32x16 (&acc0)[2][2], const 
 // R24: the dZ rows leave as 24-bit rows (mlp_tile_f16.h) and the saved views-layer rows (the ReLU mask of the heads)
 // are read as such - the split-precision weight gradient follows; false: fp32 rows for the exact weight gradient
 template <bool R24>
-__global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a) {
+__global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args2 aa) {
+  const bool second = (int)blockIdx.x >= aa.tiles0;           // wave-uniform
+  const MlpDgradF16Args& a = second ? aa.n[1] : aa.n[0];
+  const int bid = (int)blockIdx.x - (second ? aa.tiles0 : 0);
   extern __shared__ __attribute__((aligned(16))) _Float16 ldsh[];
   _Float16* gh = ldsh;
   _Float16* gl = ldsh + XPLANE;
@@ -83,13 +92,13 @@ __global__ __launch_bounds__(256, 2) void mlp_dgrad_f16_kernel(MlpDgradF16Args a
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int p0 = blockIdx.x * HM;
+  const int p0 = bid * HM;
   const int P = a.P;
   const float* __restrict__ pk = a.packed;
   const _Float16* __restrict__ pt_ = a.packedT;
   const float* __restrict__ acts = a.acts;
   float* __restrict__ dz = a.dz;
-  auto mask_of = [&](int layer) { return load_relu_words<2>(acts, P, layer, tid, blockIdx.x); };
+  auto mask_of = [&](int layer) { return load_relu_words<2>(acts, P, layer, tid, bid); };
 
   // ---- heads: d alpha_pre, per-point scale, dZ of the views layer ------------------------
   {
@@ -635,7 +644,7 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   if (active) ring(std::true_type{}); else ring(std::false_type{});
 #ifdef HW_TRACE
   if (lane == 0) {
-    unsigned long long* d = hw_dbg + ((size_t)((blockIdx.y * gridDim.x + blockIdx.x) & 4095) * 8 + wave) * 4;
+    unsigned long long* d = hw_dbg + ((size_t)(blockIdx.x & 4095) * 8 + wave) * 4;
     d[0] = tw; d[1] = ti; d[2] = tc; d[3] = (unsigned long long)np | ((unsigned long long)KW << 32);
   }
 #endif
@@ -700,13 +709,24 @@ __device__ __forceinline__ void wgrad_f16_job(const WgradArgs& a, const WgradJob
   }
 }
 
-__global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) {
+// one or two network calls per launch: a 1-D grid, the blocks of net[0] first (job-major, chunk fastest)
+struct WgradF16Args2 {
+  WgradF16Args n[2];
+  int gx[2];          // chunks per job of each network
+  int blocks0;        // gx[0] * n[0].w.njobs
+};
+__global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args2 faa) {
   extern __shared__ __attribute__((aligned(16))) float ldsw[];
+  const bool second = (int)blockIdx.x >= faa.blocks0;        // wave-uniform
+  const WgradF16Args& fa = second ? faa.n[1] : faa.n[0];
+  const int bl = (int)blockIdx.x - (second ? faa.blocks0 : 0);
+  const int gx = second ? faa.gx[1] : faa.gx[0];
+  const int by = bl / gx, bx = bl - by * gx;
   const WgradArgs& a = fa.w;
-  const WgradJob& jb = a.jobs[blockIdx.y];
-  const int c0 = blockIdx.x * a.chunk;
+  const WgradJob& jb = a.jobs[by];
+  const int c0 = bx * a.chunk;
   const int c1 = min(a.P, c0 + a.chunk);
-  float* out = a.partial + (size_t)blockIdx.x * N_PARAM_FLOATS;
+  float* out = a.partial + (size_t)bx * N_PARAM_FLOATS;
   // one power-of-two scale for dZ: max|g_out| * S in [2^7, 2^8)
   float S = 1.f;
   const float m = fa.gmax[0];
@@ -724,6 +744,30 @@ __global__ __launch_bounds__(512, 2) void mlp_wgrad_f16_kernel(WgradF16Args fa) 
   } else {
     wgrad_f16_job<64>(a, jb, ldsw, c0, c1, S, out);
   }
+}
+
+// the chunk partials of one or two network calls summed in one launch (blockIdx.y = network; the order of
+// wgrad_reduce4_kernel: same bits)
+struct Reduce4PairArgs {
+  const float* partial[2];
+  int nchunks[2];
+  float* grad[2];
+};
+__global__ void wgrad_reduce4_pair_kernel(Reduce4PairArgs a) {
+  const int net = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= N_PARAM_FLOATS / 4) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(a.partial[net]) + i;
+  const int nchunks = a.nchunks[net];
+  constexpr size_t ST = N_PARAM_FLOATS / 4;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
+  int c = 0;
+  for (; c + 4 <= nchunks; c += 4) {
+    s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
+    s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
+  }
+  for (; c < nchunks; ++c) s0 += p[(size_t)c * ST];
+  reinterpret_cast<f32x4*>(a.grad[net])[i] = (s0 + s1) + (s2 + s3);
 }
 
 }  // namespace scade
@@ -744,13 +788,11 @@ extern "C" int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f
   return scade_check_launch("scade_mlp_pack_t_f16");
 }
 
-extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* acts,
-                                 const float* g_out, int P, int wgrad_f16, float* workspace,
-                                 float* grad_flat, void* stream) {
-  SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd_f16: P must be positive");
-  SCADE_REQUIRE(packed && packed_t_f16 && acts && g_out && workspace && grad_flat, -1,
-                "scade_mlp_bwd_f16: null pointer");
-  hipStream_t s = (hipStream_t)stream;
+// n = 1 or 2 network calls: one zeroing launch, one dgrad launch, one weight-gradient launch, one reduce (the
+// exact-weight-gradient mode wgrad_f16 = 0 runs the exact kernel's own launches per network)
+static int launch_bwd_f16(int n, const float* const* packed, const void* const* packed_t_f16, const float* const* acts,
+                          const float* const* g_out, const int* P, int wgrad_f16, float* const* workspace,
+                          float* const* grad_flat, hipStream_t s) {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_f16_kernel<false>),
@@ -761,22 +803,36 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(attr_set);
   }
-  float* dz = workspace;
-  float* partial = workspace + dz_floats(P);
-  // workspace tail: [dz | partial | gmax]
-  const int nchunks = pick_chunks(P);
-  unsigned int* gmax = reinterpret_cast<unsigned int*>(partial + (size_t)nchunks * N_PARAM_FLOATS);
+  float* dz[2] = {nullptr, nullptr};
+  float* partial[2] = {nullptr, nullptr};
+  unsigned int* gmax[2] = {nullptr, nullptr};
+  int tiles[2] = {0, 0};
+  MlpDgradF16Args2 d{};
+  for (int i = 0; i < n; ++i) {
+    // workspace: [dz | partial | gmax]
+    dz[i] = workspace[i];
+    partial[i] = workspace[i] + dz_floats(P[i]);
+    gmax[i] = reinterpret_cast<unsigned int*>(partial[i] + (size_t)pick_chunks(P[i]) * N_PARAM_FLOATS);
+    tiles[i] = (P[i] + HM - 1) / HM;
+    d.n[i] = MlpDgradF16Args{packed[i], reinterpret_cast<const _Float16*>(packed_t_f16[i]), acts[i], g_out[i], dz[i],
+                             gmax[i], P[i]};
+  }
+  d.tiles0 = tiles[0];
   // a one-thread KERNEL, not hipMemsetAsync: inside a captured train step that is a memset node, and memset
   // nodes of back-to-back graph replays are not ordered against their neighbouring kernels on this ROCm (the
   // dgrad workgroups' atomicMax raced the reset: see lp_gmax_kernel in mlp_bwd_lp.hip)
-  hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(64), 0, s, gmax);
+  hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(64), 0, s, gmax[0], gmax[1]);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(zero)")) return e;
-  MlpDgradF16Args d{packed, reinterpret_cast<const _Float16*>(packed_t_f16), acts, g_out, dz, gmax, P};
   // wgrad_f16: the whole backward works on 24-bit saved rows (the forward was run with mode + 2); else on fp32 rows
-  if (wgrad_f16) hipLaunchKernelGGL(mlp_dgrad_f16_kernel<true>, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
-  else hipLaunchKernelGGL(mlp_dgrad_f16_kernel<false>, dim3((P + HM - 1) / HM), dim3(256), DGRAD_F16_LDS_BYTES, s, d);
+  const dim3 dgrid(tiles[0] + tiles[1]);
+  if (wgrad_f16) hipLaunchKernelGGL(mlp_dgrad_f16_kernel<true>, dgrid, dim3(256), DGRAD_F16_LDS_BYTES, s, d);
+  else hipLaunchKernelGGL(mlp_dgrad_f16_kernel<false>, dgrid, dim3(256), DGRAD_F16_LDS_BYTES, s, d);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(dgrad)")) return e;
-  if (!wgrad_f16) return scade_launch_wgrad(acts, dz, g_out, P, partial, grad_flat, s);
+  if (!wgrad_f16) {
+    for (int i = 0; i < n; ++i)
+      if (int e = scade_launch_wgrad(acts[i], dz[i], g_out[i], P[i], partial[i], grad_flat[i], s)) return e;
+    return 0;
+  }
   static unsigned long long wattr = 0;   // one bit per device ordinal
   if (scade_attr_needed(wattr)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_wgrad_f16_kernel),
@@ -784,13 +840,45 @@ extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, 
     SCADE_REQUIRE(e == hipSuccess, (int)e, "scade_mlp_bwd_f16: hipFuncSetAttribute: %s", hipGetErrorString(e));
     scade_attr_done(wattr);
   }
-  WgradF16Args fa{};
-  const int grid_x = build_wgrad_jobs(fa.w, acts, dz, g_out, partial, P, HW_PT);
-  fa.gmax = reinterpret_cast<const float*>(gmax);
-  hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(grid_x, fa.w.njobs), dim3(512), WGRAD_F16_LDS_BYTES, s, fa);
+  WgradF16Args2 fa{};
+  Reduce4PairArgs r{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    fa.gx[i] = build_wgrad_jobs(fa.n[i].w, acts[i], dz[i], g_out[i], partial[i], P[i], HW_PT);
+    fa.n[i].gmax = reinterpret_cast<const float*>(gmax[i]);
+    if (i == 0) fa.blocks0 = fa.gx[0] * fa.n[0].w.njobs;
+    blocks += fa.gx[i] * fa.n[i].w.njobs;
+    r.partial[i] = partial[i]; r.nchunks[i] = fa.gx[i]; r.grad[i] = grad_flat[i];
+  }
+  hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(blocks), dim3(512), WGRAD_F16_LDS_BYTES, s, fa);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(wgrad)")) return e;
-  hipLaunchKernelGGL(wgrad_reduce4_kernel, dim3(WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, partial, grid_x, grad_flat);
+  hipLaunchKernelGGL(wgrad_reduce4_pair_kernel, dim3(WGRAD_REDUCE_BLOCKS, n), dim3(256), 0, s, r);
   return scade_check_launch("scade_mlp_bwd_f16(reduce)");
+}
+
+extern "C" int scade_mlp_bwd_f16(const float* packed, const void* packed_t_f16, const float* acts,
+                                 const float* g_out, int P, int wgrad_f16, float* workspace,
+                                 float* grad_flat, void* stream) {
+  SCADE_REQUIRE(P > 0, -2, "scade_mlp_bwd_f16: P must be positive");
+  SCADE_REQUIRE(packed && packed_t_f16 && acts && g_out && workspace && grad_flat, -1,
+                "scade_mlp_bwd_f16: null pointer");
+  return launch_bwd_f16(1, &packed, &packed_t_f16, &acts, &g_out, &P, wgrad_f16, &workspace, &grad_flat,
+                        (hipStream_t)stream);
+}
+
+// the split-precision backward of TWO network calls (the coarse + fine NeRF of a train step) in one launch sequence:
+// every pointer argument is a host array of two; workspace[i] as scade_mlp_bwd_f16 wants it for P[i]
+extern "C" int scade_mlp_bwd_f16_2(const float* const* packed, const void* const* packed_t_f16, const float* const* acts,
+                                   const float* const* g_out, const int* P, int wgrad_f16, float* const* workspace,
+                                   float* const* grad_flat, void* stream) {
+  SCADE_REQUIRE(packed && packed_t_f16 && acts && g_out && P && workspace && grad_flat, -1,
+                "scade_mlp_bwd_f16_2: null pointer");
+  for (int i = 0; i < 2; ++i) {
+    SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd_f16_2: P[%d] must be positive", i);
+    SCADE_REQUIRE(packed[i] && packed_t_f16[i] && acts[i] && g_out[i] && workspace[i] && grad_flat[i], -1,
+                  "scade_mlp_bwd_f16_2: null pointer in entry %d", i);
+  }
+  return launch_bwd_f16(2, packed, packed_t_f16, acts, g_out, P, wgrad_f16, workspace, grad_flat, (hipStream_t)stream);
 }
 
 #ifdef HW_TRACE

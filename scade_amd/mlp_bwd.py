@@ -44,7 +44,7 @@ class DeferredBackward:
 
 def _pair_key(net):
     p = net.train_precision
-    return p if (p == "f32" or p in ops.LP_FORMATS) else None
+    return p if (p == "f32" or p == "f16x3" or p in ops.LP_FORMATS) else None
 
 
 def flush_deferred(items, after_net=None):
@@ -54,6 +54,18 @@ def flush_deferred(items, after_net=None):
             items = sorted(items, key=lambda it: it[2].numel())          # the shorter backward first
         (n0, a0, g0), (n1, a1, g1) = items
         prec = n0.train_precision
+        if prec == "f16x3":
+            if after_net is None:
+                # (the larger call first: its workgroups are the launch's body, the smaller one's fill the tail)
+                (n0, a0, g0), (n1, a1, g1) = sorted(items, key=lambda it: -it[2].numel())
+                ops.mlp_bwd_f16_2([n0.packed(), n1.packed()], [n0.packed_t_f16(), n1.packed_t_f16()], [a0, a1],
+                                  [g0, g1], [n0._grad_sink, n1._grad_sink])
+                return
+            # (a staged gradient exchange wants the first network's gradient early: one launch sequence per network)
+            for net, acts, g in items:
+                _backward_now(net, acts, g, net._grad_sink)
+                after_net(net)
+            return
         sinks = [n0._grad_sink, n1._grad_sink]
         hook = None if after_net is None else (lambda: after_net(n0))
         if prec == "f32":

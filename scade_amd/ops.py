@@ -296,6 +296,25 @@ def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tenso
     return grad
 
 
+def mlp_bwd_f16_2(packed, packed_t_f16, acts, g_out, outs) -> None:
+    """Split-precision backward (24-bit saved rows) of TWO network calls - the coarse + fine NeRF of a train step - as
+    one zeroing launch, one dgrad launch, one weight-gradient launch and one reduce (scade_mlp_bwd_f16_2).  Every
+    argument: a pair; ``outs`` = the two flat gradient buffers [589700], OVERWRITTEN.  Same bits as two
+    ``mlp_bwd_f16`` calls (same tiles, same chunks, same summation order)."""
+    g = [_c(check(t, "mlp_bwd_f16_2: g_out")).reshape(-1, 4) for t in g_out]
+    P = [t.shape[0] for t in g]
+    lib = _lib.load()
+    ws = [torch.empty(int(lib.scade_mlp_bwd_workspace_floats(P[i])), device=g[i].device, dtype=torch.float32)
+          for i in range(2)]
+    grads = [_grad_out(o, g[0].device) for o in outs]
+    Pa = (ctypes.c_int * 2)(*P)
+    t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
+    call("scade_mlp_bwd_f16_2", _host_ptrs(packed), _host_ptrs(packed_t_f16), _host_ptrs(acts), _host_ptrs(g),
+         ctypes.cast(Pa, ctypes.c_void_p), 1, _host_ptrs(ws), _host_ptrs(grads), stream())
+    if t0 is not None:
+        KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
+
+
 def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb: Optional[Tensor],
                 acts: Optional[Tensor] = None, rows24: bool = False) -> Tensor:
     """Split-precision forward: inp [P,60] (viewdirs None) or pts [N,S,3] + viewdirs [N,3] + bb [4].  ``rows24``

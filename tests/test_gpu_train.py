@@ -756,7 +756,8 @@ def test_fused_train_loss_device_image_index_is_checked(dev):
         assert float(scales.grad.abs().sum()) == 0.0 and float(shifts.grad.abs().sum()) == 0.0
 
 
-@pytest.mark.parametrize("prec,n_rays", [("f32", 96), ("f32", 160), ("bf16", 96), ("bf16", 260), ("f16", 96)])
+@pytest.mark.parametrize("prec,n_rays", [("f32", 96), ("f32", 160), ("bf16", 96), ("bf16", 260), ("f16", 96),
+                                         ("f16x3", 96), ("f16x3", 260)])
 def test_joint_backward_of_both_networks_equals_the_separate_launches(dev, prec, n_rays):
     """Trainer(joint_backward=True): the MLP backward of the coarse and the fine NeRF as ONE dgrad launch, ONE
     weight-gradient launch and ONE reduce (scade_mlp_bwd2 / scade_mlp_bwd_lp2, mlp_bwd.DeferredBackward).  Per
@@ -795,6 +796,9 @@ def test_joint_backward_of_both_networks_equals_the_separate_launches(dev, prec,
         (rel_l2(gj[:n], gs[:n]), rel_l2(gj[n:2 * n], gs[n:2 * n]))
     assert torch.equal(gj[2 * n:], gs[2 * n:])          # scale / shift rows: untouched by the change
     assert float(gs[:n].abs().max()) > 0 and float(gs[n:2 * n].abs().max()) > 0
+    if prec == "f16x3":
+        # scade_mlp_bwd_f16_2 keeps every network's own tiles, chunks and summation order: the same bits
+        assert torch.equal(gj, gs)
 
 
 @pytest.mark.parametrize("fmt", ["f32", "bf16", "f16"])
