@@ -167,6 +167,32 @@ def test_f16x3_training_many_chunks_and_zero_rows(dev):
         assert rel_l2(p.grad, po[k].grad) < 2e-5, k
 
 
+@pytest.mark.parametrize("P", [1, 15, 17, 33, 47, 65, 130, 1000])
+def test_f16x3_training_gradients_ragged_and_odd_stage_counts(dev, P):
+    """The split-precision backward at sizes that exercise its edges (round 5): a lone partial stage, an odd number of
+    16-point stages (the ring runs in pairs: the partner is range-check zeros), ragged 64-point dgrad tiles whose row
+    copies ride in the next layer's k-loop, tile-major LDS images cut by the descriptor's range check - against autograd
+    of the oracle at the bars of the large-P tests."""
+    from test_gpu_train import grad_close
+    params = O.nerf_init(6)
+    net = make_net(params, dev)
+    net.train_precision = "f16x3"
+    g = torch.Generator().manual_seed(100 + P)
+    pts = torch.rand(P, 3, generator=g) * 2 - 1
+    vd = torch.nn.functional.normalize(torch.randn(P, 3, generator=g), dim=-1)
+    x = torch.cat([O.embed(pts, 9), vd], -1)
+    G = torch.randn(P, 4, generator=g) * 1e-3
+    po = {k: v.clone().requires_grad_(True) for k, v in params.items()}
+    (O.nerf_forward(po, x) * G).sum().backward()
+    out = net(x.to(dev))
+    (out * G.to(dev)).sum().backward()
+    for k, p in net.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        # (per element against the tensor's scale: with a handful of points an element is a short signed sum)
+        grad_close(p.grad, po[k].grad, f"P={P} d/d{k}", rtol=2e-4, scale_atol=2e-4)
+        assert rel_l2(p.grad, po[k].grad) < 3e-5, (k, rel_l2(p.grad, po[k].grad))
+
+
 def test_f16x3_train_step_golden(dev):
     """Full train step in split precision.  The loss is held to the golden value.  The gradients
     are checked in two ways: (i) STRICT - against the exact fp32 backward kernels evaluated on the
