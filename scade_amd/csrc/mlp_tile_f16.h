@@ -138,6 +138,9 @@ __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc
   acc1[0][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t0l, VH, acc1[0][PX], 0, 0, 0);        \
   if (NT > 1)                                                                                  \
     acc1[NT - 1][PX] = __builtin_amdgcn_mfma_f32_32x32x16_f16(A.t1l, VH, acc1[NT - 1][PX], 0, 0, 0);
+  // the k-loop at raised priority (dropped again behind it): a SIMD's other wave is the other workgroup's, and when
+  // that one is in its VALU-bound epilogue this one's MFMAs should win the issue slot (forward -1.3 %, dgrad -0.8 %)
+  __builtin_amdgcn_s_setprio(1);
   half8 b0h, b0l, b1h, b1l;
   LOAD_B(0, 0, b0h, b0l)
   LOAD_B(0, 1, b1h, b1l)
@@ -209,6 +212,7 @@ __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc
 #undef KBLOCK_H
 #undef LOAD_B
 #undef MFMA6
+  __builtin_amdgcn_s_setprio(0);
 }
 template <int NT, int KBP, int KBH, bool PRE_VIEW>
 __device__ __forceinline__ void layer_gemm_h(f32x16 (&acc0)[NT][2], f32x16 (&acc1)[NT][2], AFrag& an,
