@@ -65,7 +65,12 @@ __device__ __forceinline__ void dgrad_store_h(const f32x16 (&acc0)[2][2], const 
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
           if (ADD_ALPHA) x = x + wa[i] * dal_scaled[row];
-          if (MASK) x = ((bits >> (p * 32 + (t * 4 + q) * 4 + i)) & 1ull) ? x : 0.f;
+          // (the mask as a sign-extended bit field ANDed onto the value: two operations, not and + compare + select)
+          if (MASK) {
+            const unsigned wd = (unsigned)(bits >> (p * 32));
+            const int m = __builtin_amdgcn_sbfe((int)wd, (t * 4 + q) * 4 + i, 1);
+            x = __uint_as_float(__float_as_uint(x) & (unsigned)m);
+          }
           xs[i] = x;
         }
         split4(xs, vh, vl);

@@ -59,7 +59,14 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
                                                             const float* __restrict__ bias_next,
                                                             int ntile0_next) {
   const int r = lane & 31, hh = lane >> 5;
-  unsigned long long bits = 0ull;
+  // ReLU + sign bits in THREE operations per value (round 5; two compares, two selects, half an OR and the wait states
+  // between compare and select before: the epilogue's arithmetic is 29 % of this kernel and the other workgroup's
+  // MFMAs do not run under it - knock-out): v_maximum3_f32(x, 0, 0) is gfx950's NaN-PROPAGATING
+  // maximum (torch.relu semantics), "positive" is then "the result's bits are not zero" (v_min_u32 against 1) and the
+  // bit is shifted in; value n = (t*4 + q)*4 + i of point tile p ends at bit 31 - n (15 - n with one n-tile): one
+  // v_bfrev_b32 per point tile restores the exact kernel's format (bit n).  (A NaN now sets its bit: it poisons the row
+  // either way.)
+  unsigned w[2] = {0u, 0u};
 #pragma unroll
   for (int p = 0; p < 2; ++p) {
 #pragma unroll
@@ -72,8 +79,12 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           float x = fmaf(acc1[t][p][4 * q + i], LINV, acc0[t][p][4 * q + i]);
-          if (RELU && x > 0.f) bits |= 1ull << (p * 32 + (t * 4 + q) * 4 + i);
-          if (RELU) x = x < 0.f ? 0.f : x;     // NaN-propagating relu (torch.relu semantics)
+          if (RELU) {
+            x = __builtin_elementwise_maximum(x, 0.0f);
+            unsigned b;
+            asm("v_min_u32 %0, 1, %1" : "=v"(b) : "v"(__float_as_uint(x)));
+            w[p] = (w[p] << 1) | b;
+          }
           xs[i] = x;
         }
         split4(xs, vh, vl);
@@ -87,7 +98,9 @@ __device__ __forceinline__ unsigned long long layer_store_h(const f32x16 (&acc0)
       else load_bias16_h<1>(cb, bias_next, ntile0_next, lane);
     }
   }
-  return bits;
+  constexpr int SH = NT == 1 ? 16 : 0;
+  return (unsigned long long)(__builtin_bitreverse32(w[0]) >> SH) |
+         ((unsigned long long)(__builtin_bitreverse32(w[1]) >> SH) << 32);
 }
 
 template <int MODE, int SAVE>
