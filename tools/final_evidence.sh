@@ -16,5 +16,5 @@ timeout 200 tools/timeline.sh bf16-s8_128 30 python $R/tools/probe_step.py bf16-
 # the driver's loop (graph-captured step + fused batch gather) against the eager loop, and the fused tail kernel
 (ITERS=300 timeout 300 python tools/probe_driver.py f32 bf16-s8 2>&1 | grep -v amdgpu.ids) > $O/driver_loop.txt
 (for sz in 128:20 1024:20 512:40 4096:40; do bash tools/kstats.sh tail_$sz python $R/tools/probe_tail_train.py $sz | grep -i tail_train; done) > $O/tail_train.txt 2>&1
-(SOAK_STEPS=6000 SOAK_PRECISIONS=f32,bf16,bf16-s8 timeout 300 python tools/soak_train.py 2>&1 | grep -v amdgpu.ids) > $O/soak.txt
+(SOAK_STEPS=6000 SOAK_PRECISIONS=f32,f16x3,bf16,bf16-s8 timeout 300 python tools/soak_train.py 2>&1 | grep -v amdgpu.ids) > $O/soak.txt
 tail -3 $O/gputests.txt; tail -c 600 $O/bench_final.log; ls $R/gpurun_out/prof_$TAG | head -40
