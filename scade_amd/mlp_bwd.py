@@ -61,7 +61,8 @@ def flush_deferred(items, after_net=None):
                 ops.mlp_bwd_f16_2([n0.packed(), n1.packed()], [n0.packed_t_f16(), n1.packed_t_f16()], [a0, a1],
                                   [g0, g1], [n0._grad_sink, n1._grad_sink])
                 return
-            # (a staged gradient exchange wants the first network's gradient early: one launch sequence per network)
+            # (a staged gradient exchange wants the first network's gradient early: one launch sequence per network,
+            # the shorter backward first - ``items`` was sorted above)
             for net, acts, g in items:
                 _backward_now(net, acts, g, net._grad_sink)
                 after_net(net)
