@@ -97,6 +97,15 @@ def build(force=False, verbose=True):
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.run(cmd, check=True)
+    # a > 64-bit store whose data registers the VALU writes in the next two issue slots reaches memory with the new
+    # value on this part, and the compiler's hazard recognizer does not cover every form (build_checks.py)
+    from . import build_checks
+    if os.path.exists(build_checks.OBJDUMP):
+        bad, _ = build_checks.check(LIB)
+        if bad:
+            os.remove(LIB)
+            raise RuntimeError("store-data hazard in the built kernels (common.h STORE_DATA_HOLD):\n" +
+                               "\n".join(f"  {k}: {st}  ->  +{ws}: {nx}" for k, st, nx, ws in bad))
     with open(LIB + ".sha256", "w") as fh:
         fh.write(_link_stamp())
     return LIB
