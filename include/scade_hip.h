@@ -112,10 +112,13 @@ int scade_mlp_bwd2_phases(const float* const* packed, const float* const* packed
  * accumulators (~2^-21 relative error per product; requires |activations|,|weights| < 65504).
  * packed_f16 = scade_mlp_pack_f16(params), scade_mlp_packed_f16_bytes() bytes.  Same modes,
  * arguments, output and (optional) training workspace as scade_mlp_fwd.  mode + 2 (with acts): the saved rows are
- * written in the 24-bit form scade_mlp_bwd_f16(wgrad_f16 = 1) reads - every fp32 value rounded to its upper 24 bits
- * (16 significant bits), bits 31..16 in a u16 plane [P][256] at the start of the row slot, bits 15..8 in a u8 plane
- * [P][256] P * 512 bytes on: 768 of the slot's 1024 bytes per point (the weight gradient streams these rows at the
- * memory system's rate).  Without + 2: fp32 rows, for scade_mlp_bwd_f16(wgrad_f16 = 0) / scade_mlp_bwd. */
+ * written in the 3-byte split form scade_mlp_bwd_f16(wgrad_f16 = 1) reads (mlp_tile_f16.h r24_store4 / l8_of4,
+ * mlp_wgrad.h R24): of the kernel's own split x ~= h + l * 2^-11, the fp16 h plane [P][256] at byte 0 of the row
+ * slot and the l plane rounded to one e5m2 byte per value, [P][256] at byte P * 512 - x is recovered as
+ * h + l8 * 2^-11 with a relative error of about 2^-14 (14 significant bits); 768 of the slot's 1024 bytes per point
+ * (the weight gradient streams these rows at the memory system's rate).  The dZ rows scade_mlp_bwd_f16 stores for
+ * its weight gradient use the same two planes in the per-point scaled domain, the factors 1 / s_p as fp32 [P] at
+ * byte P * 768 of slot 0.  Without + 2: fp32 rows, for scade_mlp_bwd_f16(wgrad_f16 = 0) / scade_mlp_bwd. */
 long scade_mlp_packed_f16_bytes(void);
 int scade_mlp_pack_f16(const float* const* params, void* packed_f16, void* stream);
 int scade_mlp_fwd_f16(const void* packed_f16, int mode, const float* in, const float* viewdirs,

@@ -20,6 +20,7 @@ SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_wgrad2.hip", "mlp_fwd_
            "mlp_bwd_lp.hip", "mlp_pack_step.hip", "ray_ops.hip", "train_loss.hip", "optim.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
+MIN_KERNELS_SCANNED = 100       # the library holds ~250 kernel instantiations; the hazard scan must have seen them
 # kernel experiments (same-box A/B): SCADE_AB_FLAGS="-DSOMETHING" SCADE_AB_OUT=tools/scratch/ab1 python -m
 # scade_amd.build builds a VARIANT library + objects under that directory; run with SCADE_LIB=<dir>/libscade_hip.so
 if os.environ.get("SCADE_AB_OUT"):
@@ -101,7 +102,13 @@ def build(force=False, verbose=True):
     # value on this part, and the compiler's hazard recognizer does not cover every form (build_checks.py)
     from . import build_checks
     if os.path.exists(build_checks.OBJDUMP):
-        bad, _ = build_checks.check(LIB)
+        bad, kernels = build_checks.check(LIB)
+        if kernels < MIN_KERNELS_SCANNED:
+            # (compressed offload bundles, another bundle layout or target triple: the scan would pass without having
+            # looked at anything)
+            os.remove(LIB)
+            raise RuntimeError(f"the store-data hazard scan found {kernels} gfx950 kernels in the built library "
+                               f"(expected > {MIN_KERNELS_SCANNED}): code objects not extracted, nothing was checked")
         if bad:
             os.remove(LIB)
             raise RuntimeError("store-data hazard in the built kernels (common.h STORE_DATA_HOLD):\n" +

@@ -75,9 +75,13 @@ def scan(asm, window):
                 ws += int(n.group(1)) + 1
                 continue
             if t.startswith("v_") and not t.startswith(("v_cmp", "v_mfma", "v_smfma")):
-                dst = t.split(None, 1)[1].split(",")[0]
-                if regs(dst) & d:
-                    bad.append((kernel, ln, t, ws))
+                parts = t.split(None, 1)
+                if len(parts) == 2:                     # (v_nop and friends: no operands, one wait state)
+                    ops_ = [o.strip() for o in parts[1].split(",")]
+                    # the destination is the first operand; v_swap_b32 / v_permlane*_swap write BOTH of theirs
+                    dsts = ops_[:2] if parts[0].startswith(("v_swap", "v_permlane16_swap", "v_permlane32_swap")) else ops_[:1]
+                    if any(regs(o) & d for o in dsts):
+                        bad.append((kernel, ln, t, ws))
             ws += 1
     return bad
 

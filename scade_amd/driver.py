@@ -55,7 +55,7 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
                 shifts_init=None, seed: int = 0, precision: str = "f32", eval_precision: Optional[str] = None,
                 test_chunk: int = 1024 * 16, no_reload: bool = False, log=print, pixel_sampler: str = "device",
                 i_img: int = 0, n_val_images: int = 8, graph: Optional[bool] = None, loop_warmup: int = 0,
-                **trainer_kw):
+                tail_losses: int = 0, **trainer_kw):
     """``data`` = the tuple of scene.load_scene_scannet / load_scene_processed.  Returns a dict with the
     trainer, the loss trace and (rank 0) the test metrics.  ``trainer_kw`` goes to ``Trainer`` (lrate,
     scaleshift_lr, space_carving_weight, is_joint, warm_start_nerf, freeze_ss, allreduce, ...).
@@ -74,7 +74,9 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
     backend is not RCCL; the joint loss over ranks, whose shared draw is a host-side broadcast).  ``False`` = the
     eager ``Trainer.step`` on a batch from ``get_ray_batch`` (same pixels, same draws, same arithmetic: a test holds
     the two loops' parameters equal).  ``loop_warmup``: iterations left out of ``ms_per_iteration`` (graph capture,
-    allocator warm-up, clock ramp) - the figure is then the steady-state rate."""
+    allocator warm-up, clock ramp) - the figure is then the steady-state rate.  ``tail_losses`` > 0: the loss of each
+    of the last ``tail_losses`` iterations is kept (one device copy per iteration, no host read) and their mean is
+    returned as ``tail_loss_mean``; those iterations are left out of ``ms_per_iteration``."""
     imgs, depths, valid, poses, Hh, Ww, intr, near, far, i_split, gt_d, gt_v, hyps = data[:13]
     if len(data) >= 15 and scales_init is None:
         scales_init, shifts_init = data[13], data[14]
@@ -138,8 +140,11 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
         gt = GraphedTrainer(tr, b - a, t_hyp.shape[1], n_total=N_rand, with_mask=masked)
         gather = ops.ResidentBatchGather(Hh, Ww, t_img, t_hyp, t_pose, t_intr, near, far, gt.rays, gt.tgt, gt.hyp,
                                          gt.mask, corner_px=20 if mask_corners else 0, edge_px=10 if mask_edges else 0,
-                                         scalar_dst=gt.img_i, tick_states=(tr.opt.state, tr.opt_ss.state))
+                                         scalar_dst=gt.img_i, tick_states=(tr.opt, tr.opt_ss))
     trace, t0, t_aux, i0 = [], time.time(), 0.0, start     # t_aux: validation renders + checkpoint writes, not loop time
+    tail_losses = max(0, min(int(tail_losses), num_iterations - start - loop_warmup - 1))
+    tail_buf = torch.zeros(max(1, tail_losses), device=dev)
+    i_tail, t_end = num_iterations - tail_losses, None     # the timed span ends behind iteration i_tail
     for i in range(start + 1, num_iterations + 1):
         if loop_warmup > 0 and i == start + 1 + loop_warmup:
             torch.cuda.synchronize()
@@ -162,6 +167,12 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
                 Hh, Ww, t_intr[img_i], t_pose[img_i], coords, near, far, image=t_img[img_i], hypotheses=t_hyp[img_i],
                 mask_corners=mask_corners, mask_edges=mask_edges)
             loss, aux = tr.step(rays, target_s, target_h, img_i=img_i, mask=mask, n_total=N_rand)
+        if tail_losses and i >= i_tail:
+            if i == i_tail:
+                torch.cuda.synchronize()
+                t_end = time.time()
+            else:
+                tail_buf[i - i_tail - 1].copy_(loss.detach().reshape(()))
         if i % i_print == 0 or i == num_iterations:
             lv = float(loss)
             trace.append((i, lv))
@@ -189,7 +200,8 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
             t_aux += time.time() - ta
 
     torch.cuda.synchronize()
-    loop_ms = (time.time() - t0 - t_aux) * 1e3 / max(1, num_iterations - i0)
+    i_last = i_tail if t_end is not None else num_iterations
+    loop_ms = ((t_end if t_end is not None else time.time()) - t0 - t_aux) * 1e3 / max(1, i_last - i0)
 
     # ---- test at the last iteration (:1071-1086): every test image, metrics, images on disk -------------
     kw = render_kwargs_test(tr, near, far, eval_precision)
@@ -199,7 +211,9 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
                                            chunk=test_chunk, shard_group=group)
     out = {"trainer": tr, "trace": trace, "test": res["mean"], "iterations": num_iterations,
            "ms_per_iteration": loop_ms, "val": val_trace, "graphed": bool(graph),
-           "iterations_timed": num_iterations - i0}
+           "iterations_timed": i_last - i0}
+    if tail_losses:
+        out["tail_loss_mean"], out["tail_losses"] = float(tail_buf[:tail_losses].mean()), tail_losses
     if rank == 0:
         args = SimpleNamespace(ckpt_dir=out_dir, expname=expname, scene_id=scene_id)
         scene.write_images_with_metrics(res["images"], res["mean_metrics"], far, args)

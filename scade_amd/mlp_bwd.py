@@ -118,6 +118,12 @@ def mlp_backward(net, acts, g_out):
     direct = sink is not None and getattr(net, "_sink_fresh", False)
     out = sink if direct else None
     q = DeferredBackward.active
+    if not direct and q is not None and any(it[0] is net for it in q.items):
+        # the queued FIRST backward of this network OVERWRITES the sink when the queue is flushed: a contribution
+        # added now would be lost (and a staged exchange would send the piece without it).  The SCADE step evaluates
+        # each network once; a caller that evaluates one twice must not defer.
+        raise RuntimeError("scade_amd: a second backward of a network whose first backward of the step is still "
+                           "queued (DeferredBackward / Trainer(joint_backward=True)); use joint_backward=False")
     if direct and q is not None:
         # joined with the other network's backward when the queue is flushed (DeferredBackward.__exit__)
         q.items.append((net, acts, g_out))

@@ -930,22 +930,43 @@ class ResidentBatchGather:
         self._fixed_c = (self.K, int(corner_px), int(edge_px), ptr(rays), ptr(target_s), ptr(target_h), ptr(mask),
                          None if scalar_dst is None else scalar_dst.data_ptr())
         self._ticks = {True: None, False: None}
+        self._pix_ok, self._tick_src, self._tick_ptrs = None, None, None
         if tick_states is not None and any(t is not None for t in tick_states):
-            t2 = (list(tick_states) + [None])[:2]
-            for t in t2:
-                if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() >= 16 and t.is_contiguous()):
-                    raise ValueError("ResidentBatchGather: tick_states are the float32[16] device states of FusedAdam")
-            p2 = [None if t is None else t.data_ptr() for t in t2]
-            self._tick_arrs = ((ctypes.c_void_p * 2)(*p2), (ctypes.c_void_p * 2)(p2[0], None))
-            self._ticks = {True: ctypes.cast(self._tick_arrs[0], ctypes.c_void_p),
-                           False: ctypes.cast(self._tick_arrs[1], ctypes.c_void_p)}
+            # entries: a FusedAdam (its ``.state`` is looked up at every call: use_device_state() / a reloaded state
+            # REPLACES that tensor) or the float32[16] state tensor itself
+            self._tick_src = (list(tick_states) + [None])[:2]
+            self._bind_ticks()
         self._fn = getattr(load(), "scade_gather_batch")
+
+    def _tick_tensors(self):
+        return [t if (t is None or torch.is_tensor(t)) else t.state for t in self._tick_src]
+
+    def _bind_ticks(self):
+        t2 = self._tick_tensors()
+        for t in t2:
+            if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.numel() >= 16 and t.is_contiguous()):
+                raise ValueError("ResidentBatchGather: tick_states are the float32[16] device states of FusedAdam")
+        p2 = [None if t is None else t.data_ptr() for t in t2]
+        self._tick_ptrs = tuple(p2)
+        self._tick_arrs = ((ctypes.c_void_p * 2)(*p2), (ctypes.c_void_p * 2)(p2[0], None))
+        self._ticks = {True: ctypes.cast(self._tick_arrs[0], ctypes.c_void_p),
+                       False: ctypes.cast(self._tick_arrs[1], ctypes.c_void_p)}
 
     def __call__(self, pix: Tensor, offset: int, view: int, tick_second: bool = True) -> None:
         if not 0 <= view < self.V:
             raise IndexError(f"ResidentBatchGather: view {view} outside [0, {self.V})")
         if pix.dtype != torch.int64 or offset < 0 or offset + self.N > pix.numel():
             raise ValueError("ResidentBatchGather: pix[offset : offset + N] must lie inside an int64 tensor")
+        key = (pix.data_ptr(), pix.numel())
+        if key != self._pix_ok:
+            # (once per new buffer - the loop hands over the same permutation for H * W / N steps: a host tensor or a
+            # strided view would reach the kernel as a wild device pointer)
+            if not pix.is_cuda or pix.device != self._keep[4].device or not pix.is_contiguous():
+                raise ValueError("ResidentBatchGather: pix must be a contiguous int64 tensor on the batch's device")
+            self._pix_ok = key
+        if self._tick_ptrs is not None and \
+                tuple(None if t is None else t.data_ptr() for t in self._tick_tensors()) != self._tick_ptrs:
+            self._bind_ticks()            # an optimizer's device state was replaced since the last call
         rc = self._fn(pix.data_ptr() + 8 * offset, *self._fixed_a, self._intr[0] + view * self._intr[1],
                       self._pose[0] + view * self._pose[1], *self._fixed_b, self._img[0] + view * self._img[1],
                       self._hyp[0] + view * self._hyp[1], *self._fixed_c, view, self._ticks[bool(tick_second)], stream())

@@ -122,6 +122,18 @@ def test_no_store_data_hazard_in_the_built_kernels():
 """
     bad = C.scan(listing, 2)
     assert [(b[2].split()[0], b[3]) for b in bad] == [("v_lshl_add_u32", 0), ("v_add_u32_e32", 1)], bad
+    # an operand-less VALU instruction is one wait state, not a crash; a swap writes BOTH of its operands
+    listing2 = """0000000000002000 <k2>:
+	buffer_store_dwordx4 v[4:7], v8, s[4:7], s30 offen nt
+	v_nop
+	v_swap_b32 v9, v5
+	buffer_store_dwordx4 v[4:7], v8, s[4:7], s30 offen nt
+	v_nop
+	v_nop
+	v_swap_b32 v9, v5
+"""
+    bad = C.scan(listing2, 2)
+    assert [(b[2].split()[0], b[3]) for b in bad] == [("v_swap_b32", 1)], bad
     bad, kernels = C.check(_lib.LIB_PATH, 2)
     assert kernels > 100
     assert not bad, bad

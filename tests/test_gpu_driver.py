@@ -145,6 +145,11 @@ def test_gather_batch_writes_what_get_ray_batch_returns(dev, masked):
         g(perm, off, V)
     with pytest.raises(ValueError):
         g(perm, Hh * Ww - N + 1, 0)
+    with pytest.raises(ValueError):                          # a host tensor / a strided view would be a wild device read
+        g(perm.cpu(), off, view)
+    with pytest.raises(ValueError):
+        g(torch.stack([perm, perm], -1)[:, 0], off, view)
+    assert float(st[0][0]) == 2.0, "a refused call launches nothing"
     # the validated one-shot form writes the same bits
     r2, t2, h2 = torch.zeros_like(rays), torch.zeros_like(tgt), torch.zeros_like(th)
     ops.gather_batch(pix.contiguous(), Hh, Ww, t_intr[view], t_pose[view], 0.1, 5.0, t_img[view], t_hyp[view], r2, t2, h2)

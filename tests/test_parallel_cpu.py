@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the ray-sharded train step (scade_amd/parallel.py) reproduces
+"""CPU, world_size 2 / 4 / 8, gloo: the ray-sharded train step (scade_amd/parallel.py) reproduces
 the single-process gradients.  The HIP kernels cannot run here, so the per-rank compute is
 the CPU oracle; what is under test is the host logic: sharding, loss normalisation, the
 flat gradient bucket and its all-reduce."""
@@ -138,15 +138,20 @@ def _worker(rank, world, port, out_dir, n_rays, pieces):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rays,pieces", [(16, False), (17, False), (17, True), (17, "staged"), (16, "staged_late")])
-def test_sharded_gradients_match_single_process(tmp_path, n_rays, pieces):
-    """8 + 8 and 9 + 8 rays: the summed share-weighted gradients are the single-process ones."""
-    world = 2
+@pytest.mark.parametrize("world,n_rays,pieces", [
+    (2, 16, False), (2, 17, False), (2, 17, True), (2, 17, "staged"), (2, 16, "staged_late"),
+    # the rank counts of BASELINE configs[3] / [4] (no box of the pool has more than one GPU: the logic above two
+    # ranks runs here) - uneven shards: 35 rays = 9 + 9 + 9 + 8, 43 rays = 6 + 6 + 6 + 5 + 5 + 5 + 5 + 5
+    (4, 35, False), (4, 35, "staged"), (8, 43, False), (8, 43, "staged"), (8, 40, "staged_late")])
+def test_sharded_gradients_match_single_process(tmp_path, world, n_rays, pieces):
+    """Even and uneven ray shards over 2 / 4 / 8 ranks: the summed share-weighted gradients are the single-process ones."""
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_rays, pieces), nprocs=world, join=True)
-    g0, l0, k0 = torch.load(os.path.join(tmp_path, "g0.pt"))
-    g1, l1, k1 = torch.load(os.path.join(tmp_path, "g1.pt"))
-    assert len({k0[0], k0[1], k1[0], k1[1]}) == 4, "in-kernel draw keys: distinct per rank AND per torch seed at first use"
-    assert torch.equal(g0, g1), "all ranks must hold identical reduced gradients"
+    outs = [torch.load(os.path.join(tmp_path, f"g{r}.pt")) for r in range(world)]
+    g0 = outs[0][0]
+    keys = {k for _, _, ks in outs for k in ks}
+    assert len(keys) == 2 * world, "in-kernel draw keys: distinct per rank AND per torch seed at first use"
+    for g, _, _ in outs[1:]:
+        assert torch.equal(g0, g), "all ranks must hold identical reduced gradients"
     rays, tgt, hyp, t_rand, u = _problem(n_rays)
     tensors, pc, pf, scale, shift = _params()
     want = _loss(pc, pf, scale, shift, rays, tgt, hyp, t_rand, u)
@@ -155,7 +160,29 @@ def test_sharded_gradients_match_single_process(tmp_path, n_rays, pieces):
     err = (g0 - ref).norm() / ref.norm()
     assert err < 1e-5, f"sharded vs single-process gradient rel-L2 {err:.3e}"
     assert float(ref[-2:].abs().min()) > 0, "scale / shift gradients ride in the same bucket"
-    assert abs(float(l0 + l1) - float(want)) < 1e-5 * abs(float(want)), "rank terms sum to the global loss"
+    assert abs(sum(float(l) for _, l, _ in outs) - float(want)) < 1e-5 * abs(float(want)), "rank terms sum to the global loss"
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_shards_of_a_1000_ray_batch(world):
+    """The slicing every rank applies to a global batch (rays, targets, hypothesis-major [K,N,1] depth hypotheses,
+    wild mask): the shards tile the batch, the hypothesis slices are the matching COLUMNS of every hypothesis row, and
+    the n_local / N_total shares sum to one - at 1000 rays (125 per rank at world 8) and at 1001 (uneven)."""
+    for n in (1000, 1001):
+        g = torch.Generator().manual_seed(n)
+        rays, tgt = torch.rand(n, 11, generator=g), torch.rand(n, 3, generator=g)
+        hyp, mask = torch.rand(40, n, 1, generator=g), (torch.rand(n, generator=g) > 0.5).float()
+        parts = [shard_batch(rays, tgt, hyp, r, world, mask=mask) for r in range(world)]
+        assert torch.equal(torch.cat([p[0] for p in parts], 0), rays)
+        assert torch.equal(torch.cat([p[1] for p in parts], 0), tgt)
+        assert torch.equal(torch.cat([p[2] for p in parts], 1), hyp), "dim 1 of [K,N,1] is the ray axis"
+        assert torch.equal(torch.cat([p[3] for p in parts], 0), mask)
+        sizes = [p[0].shape[0] for p in parts]
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1
+        if n == 1000 and world == 8:
+            assert sizes == [125] * 8
+        assert all(p[2].shape == (40, s, 1) for p, s in zip(parts, sizes))
+        assert abs(sum(s / n for s in sizes) - 1.0) < 1e-12
 
 
 def test_flat_segments_share_the_bucket():
@@ -221,7 +248,7 @@ class _JointShardedCpu(torch.autograd.Function):
 
 def _joint_problem():
     g = torch.Generator().manual_seed(11)
-    N, K, P = 17, 6, 12                                    # uneven shards: 9 + 8 rays
+    N, K, P = 17, 6, 12                                    # uneven shards: 9 + 8 rays (world 2) .. 3 + 2 x 7 (world 8)
     pred = (torch.rand(N, P, generator=g) * 4 + 0.5)
     hyp = torch.rand(K, N, 1, generator=g) * 4.9 + 0.1
     return pred, hyp
@@ -244,8 +271,8 @@ def _joint_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_joint_space_carving_exchange_matches_single_process(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_joint_space_carving_exchange_matches_single_process(tmp_path, world):
     mp.spawn(_joint_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     outs = [torch.load(os.path.join(tmp_path, f"j{r}.pt")) for r in range(world)]
     pred, hyp = _joint_problem()
@@ -261,7 +288,8 @@ def test_joint_space_carving_exchange_matches_single_process(tmp_path):
     gh = torch.cat([outs[r][2] for r in range(world)], 1)
     assert torch.allclose(gp, p.grad, rtol=1e-5, atol=1e-8)
     assert torch.allclose(gh, h.grad, rtol=1e-5, atol=1e-8)
-    assert torch.equal(outs[0][3], outs[1][3]), "sample_pdf_joint's u must be one draw for all ranks"
+    for r in range(1, world):
+        assert torch.equal(outs[0][3], outs[r][3]), "sample_pdf_joint's u must be one draw for all ranks"
 
 
 def _fake_render(rows):
@@ -269,13 +297,16 @@ def _fake_render(rows):
     return {"rgb_map": rows[:, :3] * 2.0, "depth_map": rows.sum(-1), "z_vals": rows[:, :4].repeat(1, 2)}
 
 
+_RENDER_RAYS = 17
+
+
 def _render_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rays = O.synthetic_rays(17, seed=9)                       # 17 rays over 2 ranks: shards of 9 and 8
-    a, b = shard_range(17, rank, world)
-    full = gather_rows(rays[a:b].contiguous(), 17)
+    rays = O.synthetic_rays(_RENDER_RAYS, seed=9)             # 17 rays: shards of 9 + 8 (world 2) .. 3 + 7 x 2 (world 8)
+    a, b = shard_range(_RENDER_RAYS, rank, world)
+    full = gather_rows(rays[a:b].contiguous(), _RENDER_RAYS)
     img = render_rays_sharded(rays, _fake_render)             # default keys: per-pixel maps only
     everything = render_rays_sharded(rays, _fake_render, keys=None)
     seed_rank_streams(5)
@@ -287,18 +318,19 @@ def _render_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_sharded_test_render_gathers_whole_image_on_every_rank():
+@pytest.mark.parametrize("world", [2, 8])
+def test_sharded_test_render_gathers_whole_image_on_every_rank(world):
     """the test render shards the H*W rays over the ranks and gathers the image."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_render_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_render_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     res = [q.get(timeout=120) for _ in procs]
     for p in procs:
         p.join(60)
-    rays = O.synthetic_rays(17, seed=9)
+    rays = O.synthetic_rays(_RENDER_RAYS, seed=9)
     want = _fake_render(rays)
     draws = {}
     for rank, full, img, everything, draw in res:
@@ -312,6 +344,6 @@ def test_sharded_test_render_gathers_whole_image_on_every_rank():
         assert sorted(everything) == ["depth_map", "rgb_map", "z_vals"]
         for k in everything:
             assert torch.equal(everything[k], want[k]), (rank, k)
-    assert not torch.equal(draws[0], draws[1]), "per-rank distinct jitter streams (SURVEY 8e)"
+    assert len({tuple(d.tolist()) for d in draws.values()}) == world, "per-rank distinct jitter streams (SURVEY 8e)"
     # one process (no group): the function is the identity wrapper
     assert torch.equal(render_rays_sharded(rays, _fake_render)["z_vals"], want["z_vals"])

@@ -76,9 +76,11 @@ if isinstance(dl, list):
     rows.append(("the training LOOP (`driver.train_scene`: view pick, pixel pick, fused batch gather into the captured step's inputs, "
                  "graph replay; 468 × 624, 18 views, K = 20; steady state, host clock)", "; ".join(cells), "`driver_loop`"))
 di = d.get("train_step_dropin")
-if isinstance(di, dict) and "ms_per_step" in di:
-    rows.append(("the drop-in operator path of INTEGRATION.md §2 (public operators + `loss.backward()` + `torch.optim.Adam` × 2, exact, eager)",
-                 f"{di['ms_per_step']:.3f} ms / step at {di['rays']} rays", "`train_step_dropin`"))
+di = [di] if isinstance(di, dict) else di
+if isinstance(di, list) and di and all(isinstance(e, dict) and "ms_per_step" in e for e in di):
+    rows.append(("the drop-in operator path of INTEGRATION.md §2 (public operators + `loss.backward()` + `torch.optim.Adam` × 2, eager)",
+                 "; ".join(f"{e['rays']} rays {e.get('precision', 'f32')}: {e['ms_per_step']:.3f} ms / step" for e in di),
+                 "`train_step_dropin`"))
 ce = d.get("strong_scaling_ceiling_8gpu")
 if isinstance(ce, dict) and ce:
     rows.append(("strong-scaling ceiling of a 1024-ray batch on 8 GPUs before any RCCL time = ms(1024-ray step) / ms(128-ray graphed shard)",
