@@ -398,6 +398,47 @@ int scade_adam_step2(float* const* params, const float* const* grads, float* con
                      const float* beta2, const float* eps, const int* step, const float* grad_scale,
                      float* const* state, int ticked, void* stream);
 
+/* ---- the end of a train step as ONE launch (round 6) -------------------------------------------------------------
+ * run_scade_scannet.py:985-997: loss.backward() ends in the weight gradient's sum over its partial rows, then
+ * optimizer.step() / optimizer_ss.step(), and the next iteration's forward needs the MFMA weight blobs re-packed from
+ * the updated parameters - three launches over the same 1.18 M floats (reduce, scade_adam_step2, scade_mlp_pack_step).
+ *
+ * scade_mlp_bwd2_deferred / scade_mlp_bwd_lp2_deferred / scade_mlp_bwd_f16_2_deferred = scade_mlp_bwd2 /
+ * scade_mlp_bwd_lp2 / scade_mlp_bwd_f16_2 (wgrad_f16 = 1) WITHOUT their reduce launch: the partial rows stay in the
+ * workspaces (which must stay alive until scade_step_finish has run) and *reduce_desc - 64 bytes of HOST memory,
+ * opaque: pointers and row counts of the two entries, in the order of the call - describes them.  For train steps
+ * whose gradient is not exchanged between ranks (with ranks: reduce -> all-reduce -> scade_step_finish without
+ * descriptor).  scade_mlp_bwd_lp2_deferred also takes gmax_pre (NULL, or per entry NULL / 256 floats whose maximum is
+ * the loss-scale maximum of that entry's EFFECTIVE output gradient - colour channels as they are, the density channel
+ * times sigmoid(10 alpha_pre) - when the caller's loss launch already produced it: the maxima launch is then
+ * skipped) and reduce_desc may be NULL there (then grad_flat is written as by scade_mlp_bwd_lp2). */
+typedef struct { unsigned char opaque[64]; } scade_reduce_desc;
+int scade_mlp_bwd2_deferred(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                            const float* const* g_out, const int* P, float* const* workspace, void* reduce_desc,
+                            void* stream);
+int scade_mlp_bwd_lp2_deferred(const void* const* packed_t_lp, int bf16, const void* const* acts,
+                               const float* const* g_out, const int* P, void* const* workspace,
+                               float* const* grad_flat, const float* const* gmax_pre, void* reduce_desc,
+                               void* stream);
+int scade_mlp_bwd_f16_2_deferred(const float* const* packed, const void* const* packed_t_f16,
+                                 const float* const* acts, const float* const* g_out, const int* P,
+                                 float* const* workspace, void* reduce_desc, void* stream);
+/* [sum of the partial rows reduce_desc describes -> grads[0]] -> Adam on both segments (arguments as scade_adam_step2;
+ * segment 0 = the n_nets networks' parameters, n_nets x 589,700 consecutive floats in scade_mlp_pack order; device
+ * states, when given, were ALREADY advanced for this step) -> the weight blobs of the next step re-packed from the
+ * updated parameters: pack_format -1 none, 0 exact (packed_exact = scade_mlp_pack layout, packed_t = scade_mlp_pack_t),
+ * 1 bf16 / 2 fp16 (packed_fwd = scade_mlp_pack_lp, packed_t = scade_mlp_pack_t_lp), 3 split precision (packed_exact,
+ * packed_fwd = scade_mlp_pack_f16, packed_t = scade_mlp_pack_t_f16); host arrays of n_nets device pointers, entries
+ * may be NULL (skipped).  net_params: n_nets x 24 parameter pointers (views of params[0]).  Same arithmetic, same
+ * summation order, same bits as the separate launches.  The two phases are separated by a grid-wide barrier inside
+ * the launch: sync = 8 bytes of device memory, zero when first used, owned by the caller, used by these launches only
+ * (a monotonic arrival counter: never reset, so a captured step holds no memset node). */
+int scade_step_finish(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
+                      const long* n, const float* lr, const float* beta1, const float* beta2, const float* eps,
+                      const int* step, const float* grad_scale, float* const* state, const void* reduce_desc,
+                      int n_nets, const float* const* net_params, int pack_format, float* const* packed_exact,
+                      void* const* packed_fwd, void* const* packed_t, unsigned long long* sync, void* stream);
+
 /* The fine tail, the train loss and the backward of both tails of a TRAIN step in one launch (+ the loss's
  * one-workgroup reduce): scade_ray_tail (fine form, run_scade_scannet.py:720-730) -> scade_train_loss_fb (:954,
  * :968-983) -> scade_ray_tail_bwd, and - raw0 != NULL - scade_composite_bwd of the coarse ray; same arithmetic, same

@@ -17,7 +17,7 @@ LIBDIR = os.path.join(HERE, "lib")
 OBJDIR = os.path.join(LIBDIR, "obj")
 LIB = os.path.join(LIBDIR, "libscade_hip.so")
 SOURCES = ["capi.hip", "mlp_fwd.hip", "mlp_bwd.hip", "mlp_wgrad2.hip", "mlp_fwd_f16.hip", "mlp_bwd_f16.hip", "mlp_fwd_lp.hip",
-           "mlp_bwd_lp.hip", "mlp_pack_step.hip", "ray_ops.hip", "train_loss.hip", "optim.hip"]
+           "mlp_bwd_lp.hip", "mlp_pack_step.hip", "step_finish.hip", "ray_ops.hip", "train_loss.hip", "optim.hip"]
 CFLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fPIC"]
 LDFLAGS = ["--offload-arch=gfx950", "-fPIC", "-shared"]
 MIN_KERNELS_SCANNED = 100       # the library holds ~250 kernel instantiations; the hazard scan must have seen them

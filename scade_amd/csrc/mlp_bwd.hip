@@ -18,6 +18,7 @@
 #include "mlp_tile.h"
 #include "mlp_pack.h"
 #include "mlp_wgrad.h"
+#include "mlp_reduce.h"
 
 namespace scade {
 
@@ -228,7 +229,7 @@ int pick_chunks_v2(int P);
 void wgrad2_joint_chunking(const int* P, int& chunk, int& gx0, int& gx1);
 }
 int scade_launch_wgrad2(const float* const* acts, const float* const* dz, const float* const* g_out, const int* P,
-                        float* const* partial, float* const* grad_flat, hipStream_t s);
+                        float* const* partial, float* const* grad_flat, hipStream_t s, scade::ReduceDesc* defer = nullptr);
 
 // chunk count of the exact weight-gradient kernel (mlp_wgrad2.hip)
 extern "C" int scade_mlp_bwd_chunks(int P) { return pick_chunks_v2(P); }
@@ -286,14 +287,14 @@ extern "C" int scade_mlp_bwd(const float* packed, const float* packed_t, const f
 // weight-gradient launch and ONE reduce: same arithmetic per network as two scade_mlp_bwd calls (bitwise - a
 // workgroup's work does not depend on its neighbours), but the joint grid fills whole rounds of two workgroups
 // per CU, which matters for the 128-ray shards of a strongly scaled batch, and three launches go.
-extern "C" int scade_mlp_bwd2_phases(const float* const* packed, const float* const* packed_t, const float* const* acts,
-                                     const float* const* g_out, const int* P, float* const* workspace,
-                                     float* const* grad_flat, int phases, void* stream) {
-  SCADE_REQUIRE(packed && packed_t && acts && g_out && P && workspace && grad_flat, -1, "scade_mlp_bwd2: null pointer");
+static int mlp_bwd2_impl(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                         const float* const* g_out, const int* P, float* const* workspace,
+                         float* const* grad_flat, int phases, ReduceDesc* defer, void* stream) {
+  SCADE_REQUIRE(packed && packed_t && acts && g_out && P && workspace && (grad_flat || defer), -1, "scade_mlp_bwd2: null pointer");
   SCADE_REQUIRE(phases > 0 && phases <= 7, -2, "scade_mlp_bwd2: phases is a mask of bits 0..2");
   for (int i = 0; i < 2; ++i) {
     SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd2: P[%d] must be positive", i);
-    SCADE_REQUIRE(packed[i] && packed_t[i] && acts[i] && g_out[i] && workspace[i] && grad_flat[i], -1,
+    SCADE_REQUIRE(packed[i] && packed_t[i] && acts[i] && g_out[i] && workspace[i] && (defer || grad_flat[i]), -1,
                   "scade_mlp_bwd2: null pointer in entry %d", i);
   }
   hipStream_t s = (hipStream_t)stream;
@@ -308,12 +309,29 @@ extern "C" int scade_mlp_bwd2_phases(const float* const* packed, const float* co
   }
   float* partial[2] = {workspace[0] + dz_floats(P[0]), workspace[1] + dz_floats(P[1])};
   const float* dz[2] = {workspace[0], workspace[1]};
-  if ((phases & 6) == 6) return scade_launch_wgrad2(acts, dz, g_out, P, partial, grad_flat, s);
+  if ((phases & 6) == 6) return scade_launch_wgrad2(acts, dz, g_out, P, partial, grad_flat, s, defer);
   // one network's weight gradient on its own (scade_mlp_bwd2_workspace_floats covers the separate launch too)
   for (int i = 0; i < 2; ++i)
     if (phases & (2 << i))
       if (int e = scade_launch_wgrad(acts[i], dz[i], g_out[i], P[i], partial[i], grad_flat[i], s)) return e;
   return 0;
+}
+
+extern "C" int scade_mlp_bwd2_phases(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                                     const float* const* g_out, const int* P, float* const* workspace,
+                                     float* const* grad_flat, int phases, void* stream) {
+  SCADE_REQUIRE(grad_flat, -1, "scade_mlp_bwd2: null pointer");
+  return mlp_bwd2_impl(packed, packed_t, acts, g_out, P, workspace, grad_flat, phases, nullptr, stream);
+}
+
+// scade_mlp_bwd2 WITHOUT its last launch: the weight gradient's partial rows stay in the workspaces and *reduce_desc
+// (64 bytes, host memory) describes them for scade_step_finish, which sums them inside the optimizer's launch - for
+// train steps whose gradient is not exchanged between ranks.  The workspaces must stay alive until that launch.
+extern "C" int scade_mlp_bwd2_deferred(const float* const* packed, const float* const* packed_t, const float* const* acts,
+                                       const float* const* g_out, const int* P, float* const* workspace,
+                                       void* reduce_desc, void* stream) {
+  SCADE_REQUIRE(reduce_desc, -1, "scade_mlp_bwd2_deferred: null descriptor");
+  return mlp_bwd2_impl(packed, packed_t, acts, g_out, P, workspace, nullptr, 7, reinterpret_cast<ReduceDesc*>(reduce_desc), stream);
 }
 
 extern "C" int scade_mlp_bwd2(const float* const* packed, const float* const* packed_t, const float* const* acts,

@@ -13,6 +13,7 @@
 #include "mlp_pack.h"       // (mlp_tile_f16.h + the pack rows shared with scade_mlp_pack_step)
 #include <type_traits>
 #include "mlp_wgrad.h"
+#include "mlp_reduce.h"
 
 namespace scade {
 
@@ -797,7 +798,7 @@ extern "C" int scade_mlp_pack_t_f16(const float* const* params, void* packed_t_f
 // exact-weight-gradient mode wgrad_f16 = 0 runs the exact kernel's own launches per network)
 static int launch_bwd_f16(int n, const float* const* packed, const void* const* packed_t_f16, const float* const* acts,
                           const float* const* g_out, const int* P, int wgrad_f16, float* const* workspace,
-                          float* const* grad_flat, hipStream_t s) {
+                          float* const* grad_flat, hipStream_t s, ReduceDesc* defer = nullptr) {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
   if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(mlp_dgrad_f16_kernel<false>),
@@ -853,10 +854,14 @@ static int launch_bwd_f16(int n, const float* const* packed, const void* const* 
     fa.n[i].gmax = reinterpret_cast<const float*>(gmax[i]);
     if (i == 0) fa.blocks0 = fa.gx[0] * fa.n[0].w.njobs;
     blocks += fa.gx[i] * fa.n[i].w.njobs;
-    r.partial[i] = partial[i]; r.nchunks[i] = fa.gx[i]; r.grad[i] = grad_flat[i];
+    r.partial[i] = partial[i]; r.nchunks[i] = fa.gx[i]; r.grad[i] = grad_flat ? grad_flat[i] : nullptr;
   }
   hipLaunchKernelGGL(mlp_wgrad_f16_kernel, dim3(blocks), dim3(512), WGRAD_F16_LDS_BYTES, s, fa);
   if (int e = scade_check_launch("scade_mlp_bwd_f16(wgrad)")) return e;
+  if (defer) {            // summed by scade_step_finish, inside the optimizer's launch
+    *defer = ReduceDesc{{partial[0], partial[1]}, {r.nchunks[0], r.nchunks[1]}, {}};
+    return 0;
+  }
   hipLaunchKernelGGL(wgrad_reduce4_pair_kernel, dim3(WGRAD_REDUCE_BLOCKS, n), dim3(256), 0, s, r);
   return scade_check_launch("scade_mlp_bwd_f16(reduce)");
 }
@@ -884,6 +889,21 @@ extern "C" int scade_mlp_bwd_f16_2(const float* const* packed, const void* const
                   "scade_mlp_bwd_f16_2: null pointer in entry %d", i);
   }
   return launch_bwd_f16(2, packed, packed_t_f16, acts, g_out, P, wgrad_f16, workspace, grad_flat, (hipStream_t)stream);
+}
+
+// scade_mlp_bwd_f16_2 (wgrad_f16 = 1) WITHOUT its reduce launch: see scade_mlp_bwd2_deferred
+extern "C" int scade_mlp_bwd_f16_2_deferred(const float* const* packed, const void* const* packed_t_f16,
+                                            const float* const* acts, const float* const* g_out, const int* P,
+                                            float* const* workspace, void* reduce_desc, void* stream) {
+  SCADE_REQUIRE(packed && packed_t_f16 && acts && g_out && P && workspace && reduce_desc, -1,
+                "scade_mlp_bwd_f16_2_deferred: null pointer");
+  for (int i = 0; i < 2; ++i) {
+    SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd_f16_2_deferred: P[%d] must be positive", i);
+    SCADE_REQUIRE(packed[i] && packed_t_f16[i] && acts[i] && g_out[i] && workspace[i], -1,
+                  "scade_mlp_bwd_f16_2_deferred: null pointer in entry %d", i);
+  }
+  return launch_bwd_f16(2, packed, packed_t_f16, acts, g_out, P, 1, workspace, nullptr, (hipStream_t)stream,
+                        reinterpret_cast<ReduceDesc*>(reduce_desc));
 }
 
 #ifdef HW_TRACE

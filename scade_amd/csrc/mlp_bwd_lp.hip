@@ -18,6 +18,7 @@
 #include "mlp_tile_lp.h"
 #include "mlp_pack.h"
 #include "mlp_wgrad.h"
+#include "mlp_reduce.h"
 
 namespace scade {
 
@@ -46,7 +47,21 @@ struct LpGmaxArgs {
   long n[2];              // floats
   float* slots[2];
   int blocks0;            // workgroups [0, blocks0) take g[0], the rest g[1]
+  const float* alpha_pre[2];   // [P] the forward's saved alpha_linear outputs (see below), or null
 };
+// What enters the dgrad chain through the density channel is NOT g_out[p][3] but d alpha_pre = g_out[p][3] *
+// sigmoid(10 alpha_pre[p]) (the backward of softplus(beta = 10), model/run_nerf_helpers.py:242) - and the two can be
+// ten decades apart: the last sample of a ray has delta = 1e10 (run_scade_scannet.py:515), so for a near-empty sample
+// d alpha / d sigma = delta exp(-sigma delta) ~ 1e10 while sigmoid(10 alpha_pre) ~ 1e-9; an importance sampler's
+// empty bin (den < 1e-5 -> 1, helpers:371) does the same.  Round 6 (tests/test_gpu_config5.py, the full-size bucket
+// comparison): ONE such entry (1.5e3 against a 99.99th percentile of 4e-5) set the launch-wide scale of a 1024-ray
+// step, every 8-bit dZ row of the fine network underflowed e5m2 and its weight gradient came out as exact zeros -
+// silently, on one batch in two at K = 40.  The maximum is therefore taken over the EFFECTIVE gradient: the colour
+// channels as they are and the density channel behind its sigmoid, evaluated as the dgrad heads evaluate it.
+__device__ __forceinline__ float lp_effective_g3(float g3, float alpha_pre) {
+  const float bx = alpha_pre * 10.f;
+  return bx > 20.f ? g3 : g3 / (1.f + expf(-bx));
+}
 __global__ __launch_bounds__(LP_GMAX_SLOTS) void lp_gmax_kernel(LpGmaxArgs a) {
   __shared__ float part[LP_GMAX_SLOTS / 64];
   const bool second = (int)blockIdx.x >= a.blocks0;                  // wave-uniform
@@ -57,8 +72,10 @@ __global__ __launch_bounds__(LP_GMAX_SLOTS) void lp_gmax_kernel(LpGmaxArgs a) {
   const int nb = second ? (int)gridDim.x - a.blocks0 : a.blocks0;
   float m = 0.f;
   const f32x4* g4 = reinterpret_cast<const f32x4*>(g);        // 16-byte loads (g_out is [P,4])
+  const float* __restrict__ ap = second ? a.alpha_pre[1] : a.alpha_pre[0];
   for (long i = (long)bx * blockDim.x + threadIdx.x; i < n / 4; i += (long)nb * blockDim.x) {
-    const f32x4 v = g4[i];
+    f32x4 v = g4[i];
+    if (ap) v[3] = lp_effective_g3(v[3], ap[i]);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float x = fabsf(v[j]);
@@ -1266,51 +1283,11 @@ extern "C" int scade_debug_wl(unsigned long long* out) {
 namespace scade {
 #endif
 
-// flat-gradient offsets of the parameter tensors as compile-time constants (param_offsets() of mlp_wgrad.h)
-struct LpParamOffsets { int v[N_PARAM_TENSORS + 1]; };
-constexpr LpParamOffsets lp_make_offsets() {
-  LpParamOffsets o{};
-  int at = 0, i = 0;
-  for (int l = 0; l < 8; ++l) {
-    const int k = l == 0 ? 57 : (l == 5 ? 313 : 256);
-    o.v[i++] = at; at += 256 * k;
-    o.v[i++] = at; at += 256;
-  }
-  o.v[i++] = at; at += 128 * 259;
-  o.v[i++] = at; at += 128;
-  o.v[i++] = at; at += 256 * 256;
-  o.v[i++] = at; at += 256;
-  o.v[i++] = at; at += 256;
-  o.v[i++] = at; at += 1;
-  o.v[i++] = at; at += 3 * 128;
-  o.v[i++] = at; at += 3;
-  o.v[i] = at;
-  return o;
-}
-constexpr LpParamOffsets LP_OFF = lp_make_offsets();
-static_assert(LP_OFF.v[N_PARAM_TENSORS] == N_PARAM_FLOATS, "parameter layout");
-
-// job (index into build_wgrad_lp_jobs' table) that writes flat-gradient element x.  The offsets are immediates
-// (an unrolled compare chain): indexed from the kernel arguments every step of the search was a dependent
-// memory load per lane, which doubled the reduce kernel's time.
-__host__ __device__ inline int lp_param_job(int x) {
-  int t = 0;
-#pragma unroll
-  for (int k = 1; k < N_PARAM_TENSORS; ++k) t += x >= LP_OFF.v[k] ? 1 : 0;
-  if (t < 16) {                                   // pts_linears[l]: weight (even t), bias (odd t)
-    const int l = t >> 1;
-    if (l == 0) return 9;                         // the embedding job of layer 0
-    if (t == 10 && (x - LP_OFF.v[10]) % 313 < 57) return 10;   // skip-connection columns: embedding job
-    return l - 1;
-  }
-  if (t == 16) return (x - LP_OFF.v[16]) % 259 < 256 ? 8 : 11;   // views_linears.0: hidden | view-direction columns
-  if (t == 17) return 8;
-  if (t <= 21) return 7;                          // feature_linear + the alpha head riding on its job
-  return 12;                                      // rgb head
-}
+// (mlp_reduce.h: LP_OFF, lp_param_job, reduce_rows4 - shared with scade_step_finish)
+static_assert(MAX_WGRAD_JOBS == REDUCE_MAX_JOBS, "the reduce descriptor holds one row count per job");
 
 // sum of the per-segment partial rows: element x of network n = sum over the rows [0, nseg[n][job(x)]) of
-// partial[n]; one float4 per thread (four scalar sums where a float4 straddles two jobs), four accumulators
+// partial[n]; one float4 per thread
 struct ReduceLpArgs {
   const float* partial[2];
   float* grad[2];
@@ -1321,49 +1298,9 @@ __global__ static void wgrad_lp_reduce_kernel(ReduceLpArgs r) {
   const bool second = blockIdx.x >= WGRAD_REDUCE_BLOCKS;
   const int i = (blockIdx.x - (second ? WGRAD_REDUCE_BLOCKS : 0)) * 256 + threadIdx.x;
   if (i >= N_PARAM_FLOATS / 4) return;
-  const float* part = second ? r.partial[1] : r.partial[0];
-  const unsigned char* nseg = second ? r.nseg[1] : r.nseg[0];
-  const int uni = second ? r.uniform[1] : r.uniform[0];
-  if (uni > 0) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
-    constexpr size_t ST = N_PARAM_FLOATS / 4;
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int c = 0;
-    for (; c + 4 <= uni; c += 4) {
-      s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
-      s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
-    }
-    for (; c < uni; ++c) s0 += p[(size_t)c * ST];
-    reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = (s0 + s1) + (s2 + s3);
-    return;
-  }
-  int job[4];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) job[q] = lp_param_job(4 * i + q);
-  f32x4 res;
-  if (job[0] == job[3]) {                          // (jobs own contiguous runs within a tensor row: ends equal = all equal)
-    const f32x4* p = reinterpret_cast<const f32x4*>(part) + i;
-    constexpr size_t ST = N_PARAM_FLOATS / 4;
-    const int n = nseg[job[0]];
-    f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0, s2 = s0, s3 = s0;
-    int c = 0;
-    for (; c + 4 <= n; c += 4) {
-      s0 += p[(size_t)c * ST]; s1 += p[(size_t)(c + 1) * ST];
-      s2 += p[(size_t)(c + 2) * ST]; s3 += p[(size_t)(c + 3) * ST];
-    }
-    for (; c < n; ++c) s0 += p[(size_t)c * ST];
-    res = (s0 + s1) + (s2 + s3);
-  } else {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const float* p = part + 4 * i + q;
-      const int n = nseg[job[q]];
-      float t = 0.f;
-      for (int c = 0; c < n; ++c) t += p[(size_t)c * N_PARAM_FLOATS];
-      res[q] = t;
-    }
-  }
-  reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] = res;
+  reinterpret_cast<f32x4*>(second ? r.grad[1] : r.grad[0])[i] =
+      reduce_rows4(second ? r.partial[1] : r.partial[0], second ? r.nseg[1] : r.nseg[0],
+                   second ? r.uniform[1] : r.uniform[0], i);
 }
 
 // fills the job table (13 jobs; identical for every network: offsets are slots)
@@ -1582,11 +1519,13 @@ static int lp_gmax_blocks(int P) {
   return (int)(want < LP_GMAX_SLOTS ? want : LP_GMAX_SLOTS);
 }
 // one launch for one network (P[1] = 0) or for both networks of a joint launch
-static int lp_launch_gmax(const float* const* g_out, const int* P, float* const* gmax, hipStream_t s) {
+static int lp_launch_gmax(const float* const* g_out, const int* P, float* const* gmax, const unsigned char* const* acts,
+                          hipStream_t s) {
   LpGmaxArgs a{};
   int blocks = 0;
   for (int i = 0; i < 2 && P[i] > 0; ++i) {
     a.g[i] = g_out[i]; a.n[i] = 4L * P[i]; a.slots[i] = gmax[i];
+    a.alpha_pre[i] = reinterpret_cast<const float*>(acts[i] + lp_acts_alpha_byte(P[i]));
     if (i == 0) a.blocks0 = lp_gmax_blocks(P[0]);
     blocks += lp_gmax_blocks(P[i]);
   }
@@ -1605,7 +1544,8 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
     const float* gs[2] = {g_out, nullptr};
     const int Pg[2] = {P, 0};
     float* gm[2] = {gmax, nullptr};
-    if (int e = lp_launch_gmax(gs, Pg, gm, s)) return e;
+    const unsigned char* ac[2] = {acts, nullptr};
+    if (int e = lp_launch_gmax(gs, Pg, gm, ac, s)) return e;
   }
   // same point tiling as the forward that wrote the sign words of this workspace
   const int npt = lp_pick_point_tiles(P);
@@ -1635,9 +1575,13 @@ static int launch_bwd_lp(const float* packed, const void* packed_t, const unsign
 // of network 0 / 1.  Bits 1 and 2 together = ONE balanced weight-gradient launch over both networks; one of them = that
 // network's own balanced launch (a sharded step starts the gradient exchange of the first network behind its reduce
 // and lets it run under the second network's weight gradient).
+// gmax_pre (nullable): per network the LP_GMAX_SLOTS maxima of |g_out| already computed by the caller's loss
+// launch (scade_ray_tail_train writes them) - the lp_gmax launch is skipped; defer (nullable): leave the partial
+// rows unreduced and describe them (scade_step_finish sums them inside the optimizer's launch).
 template <bool BF, bool S8>
 static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, const float* const* g_out,
-                          const int* P, void* const* wsv, float* const* grad_flat, int phases, hipStream_t s) {
+                          const int* P, void* const* wsv, float* const* grad_flat, int phases, hipStream_t s,
+                          const float* const* gmax_pre = nullptr, ReduceDesc* defer = nullptr) {
   if (int e = lp_bwd_set_attr<BF, S8>()) return e;
   const int npt = lp_pick_point_tiles(P[0]);
   SCADE_REQUIRE(lp_pick_point_tiles(P[1]) == npt, -3,
@@ -1652,14 +1596,16 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
     unsigned char* ws = reinterpret_cast<unsigned char*>(wsv[i]);
     const unsigned char* ac = reinterpret_cast<const unsigned char*>(acts[i]);
     partial[i] = reinterpret_cast<float*>(ws + lp_dz_bytes(P[i]));
-    float* gmax = partial[i] + (size_t)lp_ws_rows() * N_PARAM_FLOATS;
+    float* gmax = gmax_pre && gmax_pre[i] ? const_cast<float*>(gmax_pre[i])
+                                          : partial[i] + (size_t)lp_ws_rows() * N_PARAM_FLOATS;
     gmaxs[i] = gmax;
     d.n[i] = MlpDgradLpArgs{nullptr, packed_t[i], ac, g_out[i], ws, gmax, P[i]};
     w.net[i] = WgradLpNet{ac, ws, g_out[i], partial[i], gmax, P[i]};
   }
   if (phases & 1) {
-    if (!BF || S8) {                        // both networks' maxima in one launch
-      if (int e = lp_launch_gmax(g_out, P, gmaxs, s)) return e;
+    if ((!BF || S8) && !(gmax_pre && gmax_pre[0] && gmax_pre[1])) {      // both networks' maxima in one launch
+      const unsigned char* ac[2] = {reinterpret_cast<const unsigned char*>(acts[0]), reinterpret_cast<const unsigned char*>(acts[1])};
+      if (int e = lp_launch_gmax(g_out, P, gmaxs, ac, s)) return e;
     }
     d.tiles0 = (P[0] + 32 * npt - 1) / (32 * npt);
     d.tiles1 = (P[1] + 32 * npt - 1) / (32 * npt);
@@ -1676,6 +1622,12 @@ static int launch_bwd_lp2(const void* const* packed_t, const void* const* acts, 
     r.uniform[1] = w.plan.chunk > 0 ? w.plan.gx1 : 0;
     hipLaunchKernelGGL((mlp_wgrad_lp_kernel<BF, S8>), dim3(w.plan.nwg), dim3(512), WGRAD_LP_LDS_BYTES, s, w);
     if (int e = scade_check_launch("scade_mlp_bwd_lp2(wgrad)")) return e;
+    if (defer) {
+      *defer = ReduceDesc{{partial[0], partial[1]}, {r.uniform[0], r.uniform[1]}, {}};
+      for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < MAX_WGRAD_JOBS; ++j) defer->nseg[i][j] = r.nseg[i][j];
+      return 0;
+    }
     for (int i = 0; i < 2; ++i) { r.partial[i] = partial[i]; r.grad[i] = grad_flat[i]; }
     hipLaunchKernelGGL(wgrad_lp_reduce_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
     return scade_check_launch("scade_mlp_bwd_lp2(reduce)");
@@ -1748,6 +1700,29 @@ extern "C" int scade_mlp_bwd_lp2_phases(const void* const* packed_t_lp, int bf16
   if (bf16 == 2) return launch_bwd_lp2<true, true>(packed_t_lp, acts, g_out, P, workspace, grad_flat, phases, s);
   return bf16 ? launch_bwd_lp2<true, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, phases, s)
               : launch_bwd_lp2<false, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, phases, s);
+}
+
+// scade_mlp_bwd_lp2 for a train step that (a) has the loss-scale maxima of both networks' output gradients already
+// (gmax_pre[i]: LP_GMAX_SLOTS floats whose maximum is max|g_out[i]| over the finite entries, written by
+// scade_ray_tail_train; NULL array or entry: computed here as usual) and (b) does not exchange its gradient between
+// ranks (reduce_desc != NULL: no reduce launch, the partial rows are described for scade_step_finish; the workspaces
+// must stay alive until then).  With both NULL this is scade_mlp_bwd_lp2.
+extern "C" int scade_mlp_bwd_lp2_deferred(const void* const* packed_t_lp, int bf16, const void* const* acts,
+                                          const float* const* g_out, const int* P, void* const* workspace,
+                                          float* const* grad_flat, const float* const* gmax_pre, void* reduce_desc,
+                                          void* stream) {
+  SCADE_REQUIRE(packed_t_lp && acts && g_out && P && workspace && (grad_flat || reduce_desc), -1, "scade_mlp_bwd_lp2_deferred: null pointer");
+  for (int i = 0; i < 2; ++i) {
+    SCADE_REQUIRE(P[i] > 0, -2, "scade_mlp_bwd_lp2_deferred: P[%d] must be positive", i);
+    SCADE_REQUIRE(packed_t_lp[i] && acts[i] && g_out[i] && workspace[i] && (reduce_desc || grad_flat[i]), -1,
+                  "scade_mlp_bwd_lp2_deferred: null pointer in entry %d", i);
+  }
+  hipStream_t s = (hipStream_t)stream;
+  ReduceDesc* defer = reinterpret_cast<ReduceDesc*>(reduce_desc);
+  SCADE_REQUIRE(bf16 >= 0 && bf16 <= 2, -2, "scade_mlp_bwd_lp2_deferred: format 0 (fp16), 1 (bf16) or 2 (bf16, 8-bit saved rows)");
+  if (bf16 == 2) return launch_bwd_lp2<true, true>(packed_t_lp, acts, g_out, P, workspace, grad_flat, 7, s, gmax_pre, defer);
+  return bf16 ? launch_bwd_lp2<true, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, 7, s, gmax_pre, defer)
+              : launch_bwd_lp2<false, false>(packed_t_lp, acts, g_out, P, workspace, grad_flat, 7, s, gmax_pre, defer);
 }
 
 extern "C" int scade_mlp_bwd_lp2(const void* const* packed_t_lp, int bf16, const void* const* acts,

@@ -35,6 +35,7 @@
 // as were THREE workgroups per CU (168 VGPRs, no spill: +5 % time - a third wave per SIMD only adds contention
 // for a matrix pipe two already fill) and a ONE-ROUND variant of the second design (511 equal-cost resident workgroups: 3-7 % slower).
 #include "mlp_wgrad.h"
+#include "mlp_reduce.h"
 
 namespace scade {
 
@@ -508,7 +509,7 @@ int scade_launch_wgrad(const float* acts, const float* dz, const float* g_out, i
 
 // the same for TWO networks in one weight-gradient launch and one reduce launch (scade_mlp_bwd2)
 int scade_launch_wgrad2(const float* const* acts, const float* const* dz, const float* const* g_out, const int* P,
-                        float* const* partial, float* const* grad_flat, hipStream_t s) {
+                        float* const* partial, float* const* grad_flat, hipStream_t s, ReduceDesc* defer) {
   if (int e = wgrad2_set_attr()) return e;
   Wgrad2Args w{};
   build_wgrad2_jobs(w);
@@ -519,6 +520,10 @@ int scade_launch_wgrad2(const float* const* acts, const float* const* dz, const 
   w.chunk = chunk; w.gx0 = gx0;
   hipLaunchKernelGGL(mlp_wgrad2_kernel, dim3(gx0 + gx1, w.njobs), dim3(256), W2_LDS_BYTES, s, w);
   if (int e = scade_check_launch("scade_mlp_bwd2(wgrad)")) return e;
+  if (defer) {          // the partial rows are summed by scade_step_finish, inside the optimizer's launch
+    *defer = ReduceDesc{{partial[0], partial[1]}, {gx0, gx1}, {}};
+    return 0;
+  }
   Reduce2Args r{{partial[0], partial[1]}, {grad_flat[0], grad_flat[1]}, {gx0, gx1}};
   hipLaunchKernelGGL(wgrad2_reduce_pair_kernel, dim3(2 * WGRAD_REDUCE_BLOCKS), dim3(256), 0, s, r);
   return scade_check_launch("scade_mlp_bwd2(reduce)");

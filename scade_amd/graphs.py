@@ -92,10 +92,10 @@ class GraphedTrainer:
         if tr._unit_loss_ready:
             tr._unit_loss_ready = False
             tr.flat_ss.grad.zero_()
-        tr.backward(loss)
+        tr.backward(loss, defer_reduce=True)
         tr.bucket.end_backward()
         tr.reduce_grads()
-        adam_step_pair(tr.opt, tr.opt_ss if tr.scaleshift_active() else None, dev=True, ticked=True)
+        tr.finish(dev=True)
         # the three loss terms of the step (:968-983) as static tensors too: the loop's log line reads them
         self.terms = (aux["img_loss"], aux["carve"], aux["img_loss0"])
         return aux["loss_report"]
@@ -120,6 +120,12 @@ class GraphedTrainer:
             dst.copy_(src)
         tr.opt.steps, tr.opt_ss.steps = steps
         ops.PARAM_EPOCH += 1
+        if tr.fused_finish and tr.finish_fmt is not None:
+            # the captured step ends with the packs of the NEXT replay (Trainer.finish): bring the blobs up to date
+            # with the rolled-back parameters here, outside the capture, so that the body's own pack finds nothing to
+            # do (the blobs are re-packed in place: their addresses are what the captured kernels read)
+            (ops.mlp_pack_step_f16x3 if tr.finish_fmt == "f16x3" else
+             (lambda nets: ops.mlp_pack_step(nets, tr.finish_fmt)))([tr.coarse, tr.fine])
         self._captured = (tr.scaleshift_active(), tr.carving_active())
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
@@ -172,6 +178,8 @@ class GraphedTrainer:
         if with_ss:
             tr.opt_ss.steps += 1
         ops.PARAM_EPOCH += 1          # parameters changed behind the module caches' back
+        if tr.fused_finish and tr.finish_fmt is not None:
+            ops.mark_packs_fresh([tr.coarse, tr.fine], tr.finish_fmt)   # ... and the replay's last launch re-packed them
         return self.loss
 
 

@@ -21,12 +21,16 @@ class DeferredBackward:
     nothing downstream waits for them); everything is launched on the stream current at exit."""
     active = None
 
-    def __init__(self, after_net=None):
+    def __init__(self, after_net=None, defer_reduce=False):
         """``after_net(net)``: called when the gradient of the FIRST network of a joint launch (the one with fewer
         points: the coarse NeRF) is complete on the stream and the second one's weight gradient has not been launched
         yet - where a sharded step starts that network's share of the gradient exchange (Trainer(allreduce="staged"))."""
         self.items = []
         self.after_net = after_net
+        # ``defer_reduce``: a joint launch leaves its partial rows unsummed; ``self.reduce`` = (ops.ReduceDesc, (first
+        # network, second network) of the call) for ops.step_finish, or None when the flush took another route
+        self.defer_reduce = bool(defer_reduce) and after_net is None
+        self.reduce = None
 
     def __enter__(self):
         if DeferredBackward.active is not None:
@@ -38,7 +42,7 @@ class DeferredBackward:
         DeferredBackward.active = None
         items, self.items = self.items, []
         if et is None:
-            flush_deferred(items, self.after_net)
+            self.reduce = flush_deferred(items, self.after_net, self.defer_reduce)
         return False
 
 
@@ -47,7 +51,8 @@ def _pair_key(net):
     return p if (p == "f32" or p == "f16x3" or p in ops.LP_FORMATS) else None
 
 
-def flush_deferred(items, after_net=None):
+def flush_deferred(items, after_net=None, defer=False):
+    """-> (ops.ReduceDesc, (net of entry 0, net of entry 1)) when ``defer`` and the joint launch took it, else None"""
     if len(items) == 2 and _pair_key(items[0][0]) is not None and _pair_key(items[0][0]) == _pair_key(items[1][0]) \
             and items[0][0] is not items[1][0]:
         if after_net is not None:
@@ -58,9 +63,9 @@ def flush_deferred(items, after_net=None):
             if after_net is None:
                 # (the larger call first: its workgroups are the launch's body, the smaller one's fill the tail)
                 (n0, a0, g0), (n1, a1, g1) = sorted(items, key=lambda it: -it[2].numel())
-                ops.mlp_bwd_f16_2([n0.packed(), n1.packed()], [n0.packed_t_f16(), n1.packed_t_f16()], [a0, a1],
-                                  [g0, g1], [n0._grad_sink, n1._grad_sink])
-                return
+                desc = ops.mlp_bwd_f16_2([n0.packed(), n1.packed()], [n0.packed_t_f16(), n1.packed_t_f16()], [a0, a1],
+                                         [g0, g1], [n0._grad_sink, n1._grad_sink], defer=defer)
+                return (desc, (n0, n1)) if desc is not None else None
             # (a staged gradient exchange wants the first network's gradient early: one launch sequence per network,
             # the shorter backward first - ``items`` was sorted above)
             for net, acts, g in items:
@@ -70,23 +75,26 @@ def flush_deferred(items, after_net=None):
         sinks = [n0._grad_sink, n1._grad_sink]
         hook = None if after_net is None else (lambda: after_net(n0))
         if prec == "f32":
-            ops.mlp_bwd2([n0.packed(), n1.packed()], [n0.packed_t(), n1.packed_t()], [a0, a1], [g0, g1], sinks,
-                         after_first=hook)
+            desc = ops.mlp_bwd2([n0.packed(), n1.packed()], [n0.packed_t(), n1.packed_t()], [a0, a1], [g0, g1], sinks,
+                                after_first=hook, defer=defer and hook is None)
             if after_net is not None:
                 after_net(n1)
-            return
+            return (desc, (n0, n1)) if desc is not None else None
         code, bf16 = ops.LP_FORMATS[prec]
         P0, P1 = g0.numel() // 4, g1.numel() // 4
         if ops.lp_point_tiles(P0) == ops.lp_point_tiles(P1):
-            ops.mlp_bwd_lp2([n0.packed_t_lp(bf16), n1.packed_t_lp(bf16)], code, [a0, a1], [g0, g1], sinks,
-                            after_first=hook)
+            gm = [ops.GMAX_READY.pop(g.data_ptr(), None) for g in (g0, g1)]
+            gmax = gm if (hook is None and all(t is not None for t in gm)) else None
+            desc = ops.mlp_bwd_lp2([n0.packed_t_lp(bf16), n1.packed_t_lp(bf16)], code, [a0, a1], [g0, g1], sinks,
+                                   after_first=hook, defer=defer and hook is None, gmax=gmax)
             if after_net is not None:
                 after_net(n1)
-            return
+            return (desc, (n0, n1)) if desc is not None else None
     for net, acts, g in items:
         _backward_now(net, acts, g, net._grad_sink)
         if after_net is not None:
             after_net(net)
+    return None
 
 
 def _backward_now(net, acts, g_out, out):

@@ -165,12 +165,9 @@ def mlp_pack_step(nets, fmt: str) -> None:
         # the layout is NOT implied by the pointer (``w.data = w.data.t()`` keeps it): checked every time (~2 us)
         if not all(p.is_contiguous() for p in ps):
             raise ValueError("mlp_pack_step: parameters must be contiguous")
-        if code == 0:
-            bf = torch.empty(int(lib.scade_mlp_packed_floats()), device=dev, dtype=torch.float32) if need_f else None
-            bt = torch.empty(int(lib.scade_mlp_packed_t_floats()), device=dev, dtype=torch.float32) if need_t else None
-        else:
-            bf = torch.empty(int(lib.scade_mlp_packed_lp_bytes()), device=dev, dtype=torch.uint8) if need_f else None
-            bt = torch.empty(int(lib.scade_mlp_packed_t_lp_bytes()), device=dev, dtype=torch.uint8) if need_t else None
+        # a network's blobs are allocated once per format and re-packed IN PLACE ever after: their addresses are
+        # baked into captured steps (graphs.py), and step_finish() packs into them at the end of every step
+        bf, bt = _train_blobs(net, fmt, dev, need_f, need_t)
         plist += ptrs
         fwd.append(bf)
         tr.append(bt)
@@ -183,6 +180,144 @@ def mlp_pack_step(nets, fmt: str) -> None:
          vp(fwd), vp(tr), stream())
     for net, bf, bt, key in adopt:
         net.adopt_packs(fmt, bf, bt, key)
+
+
+def _blob(cur, numel, dtype, dev):
+    if cur is not None and cur.device == dev and cur.numel() == numel and cur.dtype == dtype:
+        return cur
+    return torch.empty(numel, device=dev, dtype=dtype)
+
+
+def _train_blobs(net, fmt, dev, need_f=True, need_t=True):
+    """(forward blob, transposed blob) of format "f32" | "bf16" | "f16" for ``net``: its existing tensors (to be
+    re-packed in place) or fresh ones."""
+    lib = _lib.load()
+    d = net.__dict__
+    if fmt == "f32":
+        bf = _blob(d.get("_packed"), int(lib.scade_mlp_packed_floats()), torch.float32, dev) if need_f else None
+        bt = _blob(d.get("_packed_t"), int(lib.scade_mlp_packed_t_floats()), torch.float32, dev) if need_t else None
+    else:
+        bf = _blob(d.get("_packed_lp"), int(lib.scade_mlp_packed_lp_bytes()), torch.uint8, dev) if need_f else None
+        bt = _blob(d.get("_packed_t_lp"), int(lib.scade_mlp_packed_t_lp_bytes()), torch.uint8, dev) if need_t else None
+    return bf, bt
+
+
+def _train_blobs_f16x3(net, dev, need=(True, True, True)):
+    lib = _lib.load()
+    d = net.__dict__
+    be = _blob(d.get("_packed"), int(lib.scade_mlp_packed_floats()), torch.float32, dev) if need[0] else None
+    bf = _blob(d.get("_packed_f16"), int(lib.scade_mlp_packed_f16_bytes()), torch.uint8, dev) if need[1] else None
+    bt = _blob(d.get("_packed_t_f16"), int(lib.scade_mlp_packed_t_f16_bytes()), torch.uint8, dev) if need[2] else None
+    return be, bf, bt
+
+
+def _adopt_f16x3(net, be, bf, bt, key):
+    d = net.__dict__
+    if be is not None:
+        d["_packed"], d["_packed_key"] = be, key
+    if bf is not None:
+        d["_packed_f16"], d["_packed_f16_key"] = bf, key
+    if bt is not None:
+        d["_packed_t_f16"], d["_packed_t_f16_key"] = bt, key
+
+
+# loss-scale maxima a step's loss launch produced for the output gradients it wrote: {g_out.data_ptr(): float32[256]
+# device tensor}, consumed (popped) by the joint 16-bit backward of the same step (mlp_bwd.flush_deferred)
+GMAX_READY = {}
+
+
+class ReduceDesc:
+    """What a deferred MLP backward leaves for ``step_finish``: the 64-byte descriptor scade_mlp_bwd*_deferred filled
+    (partial-row pointers and row counts of the two entries of the call) and the workspaces it points into."""
+
+    def __init__(self, keep):
+        self.buf = ctypes.create_string_buffer(64)
+        self.keep = keep
+
+    def swap(self):
+        """exchange the two entries (the descriptor is indexed by the network's position in the optimizer's segment)"""
+        b = self.buf.raw
+        self.buf.raw = b[8:16] + b[0:8] + b[20:24] + b[16:20] + b[40:56] + b[24:40] + b[56:64]
+        return self
+
+
+def step_finish(opt_a, opt_b, nets, fmt: Optional[str], sync: Tensor, lr_a=None, dev: bool = False,
+                reduce: Optional[ReduceDesc] = None) -> None:
+    """The end of a train step as ONE launch (scade_step_finish): [``reduce``: the sum of a deferred backward's
+    partial rows ->] ``opt_a.step(lr=lr_a)`` on the networks' segment and (``opt_b`` given) ``opt_b.step()`` on the
+    scale / shift segment -> the weight blobs of training format ``fmt`` ("f32" | "bf16" | "f16" | "f16x3"; None: no
+    pack) of ``nets`` re-packed in place from the updated parameters and marked fresh.  ``dev``: the optimizers' scalars
+    come from their device states, already advanced for this step.  ``sync``: int64[1] device tensor owned by the
+    caller (the launch's grid barrier)."""
+    opts = [opt_a] + ([opt_b] if opt_b is not None else [])
+    for o in opts:
+        o.steps += 1
+    two = lambda f, ct: (ct * 2)(*[f(o) for o in opts] + ([ct()] if len(opts) == 1 else []))
+    P = ctypes.c_void_p
+    pp = lambda f: ctypes.cast(two(lambda o: f(o).data_ptr(), ctypes.c_void_p), P)
+    n = two(lambda o: o.flat.numel, ctypes.c_long)
+    if opt_a.flat.numel != len(nets) * N_PARAM_FLOATS:
+        raise ValueError("step_finish: the first optimizer's segment must be the networks' parameters")
+    if dev:
+        scal = (None,) * 6 + (pp(lambda o: o.state),)
+    else:
+        scal = (ctypes.cast(two(lambda o: float(lr_a if (o is opt_a and lr_a is not None) else o.lr), ctypes.c_float), P),
+                ctypes.cast(two(lambda o: float(o.betas[0]), ctypes.c_float), P),
+                ctypes.cast(two(lambda o: float(o.betas[1]), ctypes.c_float), P),
+                ctypes.cast(two(lambda o: float(o.eps), ctypes.c_float), P),
+                ctypes.cast(two(lambda o: int(o.steps), ctypes.c_int), P),
+                ctypes.cast(two(lambda o: 1.0, ctypes.c_float), P), None)
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
+    code = {None: -1, "f32": 0, "bf16": 1, "f16": 2, "f16x3": 3}[fmt]
+    ex = fw = tr = plist = None
+    adopt = []
+    if code >= 0:
+        if sync.dtype != torch.int64 or not sync.is_cuda or sync.numel() < 1:
+            raise ValueError("step_finish: sync must be an int64 device tensor")
+        plist, exl, fwl, trl = [], [], [], []
+        for net in nets:
+            ps = net.ordered_params()
+            if not all(p.is_contiguous() for p in ps):
+                raise ValueError("step_finish: parameters must be contiguous")
+            d = ps[0].device
+            if code == 3:
+                be, bf, bt = _train_blobs_f16x3(net, d)
+            else:
+                bf, bt = _train_blobs(net, fmt, d)
+                be = None
+                if code == 0:
+                    be, bf = bf, None
+            plist += [p.data_ptr() for p in ps]
+            exl.append(be); fwl.append(bf); trl.append(bt)
+            adopt.append((net, be, bf, bt))
+        vp = lambda ts: ctypes.cast((ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts]), P)
+        ex, fw, tr = vp(exl), vp(fwl), vp(trl)
+        plist = ctypes.cast((ctypes.c_void_p * len(plist))(*plist), P)
+    call("scade_step_finish", pp(lambda o: o.flat.data), pp(lambda o: o.flat.grad), pp(lambda o: o.exp_avg),
+         pp(lambda o: o.exp_avg_sq), ctypes.cast(n, P), *scal, None if reduce is None else ctypes.cast(reduce.buf, P),
+         len(nets), plist, code, ex, fw, tr, None if code < 0 else sync.data_ptr(), stream())
+    for net, be, bf, bt in adopt:
+        key = net.pack_key()
+        if code == 3:
+            _adopt_f16x3(net, be, bf, bt, key)
+        elif code == 0:
+            net.adopt_packs("f32", be, bt, key)
+        else:
+            net.adopt_packs(fmt, bf, bt, key)
+
+
+def mark_packs_fresh(nets, fmt: str) -> None:
+    """Re-key the existing training blobs of ``nets`` to the parameters' current state: a graph replay whose captured
+    ``step_finish`` packed them leaves ``PARAM_EPOCH`` bumped behind it."""
+    for net in nets:
+        d, key = net.__dict__, net.pack_key()
+        if fmt == "f16x3":
+            _adopt_f16x3(net, d.get("_packed"), d.get("_packed_f16"), d.get("_packed_t_f16"), key)
+        elif fmt == "f32":
+            net.adopt_packs("f32", d.get("_packed"), d.get("_packed_t"), key)
+        else:
+            net.adopt_packs(fmt, d.get("_packed_lp"), d.get("_packed_t_lp"), key)
 
 
 def mlp_pack_step_f16x3(nets) -> None:
@@ -208,9 +343,7 @@ def mlp_pack_step_f16x3(nets) -> None:
             d["_pack_checked"] = ptrs
         if not all(p.is_contiguous() for p in ps):
             raise ValueError("mlp_pack_step_f16x3: parameters must be contiguous")
-        be = torch.empty(int(lib.scade_mlp_packed_floats()), device=dev, dtype=torch.float32) if need[0] else None
-        bf = torch.empty(int(lib.scade_mlp_packed_f16_bytes()), device=dev, dtype=torch.uint8) if need[1] else None
-        bt = torch.empty(int(lib.scade_mlp_packed_t_f16_bytes()), device=dev, dtype=torch.uint8) if need[2] else None
+        be, bf, bt = _train_blobs_f16x3(net, dev, need)
         plist += ptrs
         ex.append(be)
         fw.append(bf)
@@ -223,13 +356,7 @@ def mlp_pack_step_f16x3(nets) -> None:
     call("scade_mlp_pack_step_f16x3", len(adopt), ctypes.cast((ctypes.c_void_p * len(plist))(*plist), ctypes.c_void_p),
          vp(ex), vp(fw), vp(tr), stream())
     for net, be, bf, bt, key in adopt:
-        d = net.__dict__
-        if be is not None:
-            d["_packed"], d["_packed_key"] = be, key
-        if bf is not None:
-            d["_packed_f16"], d["_packed_f16_key"] = bf, key
-        if bt is not None:
-            d["_packed_t_f16"], d["_packed_t_f16_key"] = bt, key
+        _adopt_f16x3(net, be, bf, bt, key)
 
 
 def mlp_acts_alloc(P: int, device) -> Tensor:
@@ -296,11 +423,12 @@ def mlp_bwd_f16(packed: Tensor, packed_t_f16: Tensor, acts: Tensor, g_out: Tenso
     return grad
 
 
-def mlp_bwd_f16_2(packed, packed_t_f16, acts, g_out, outs) -> None:
+def mlp_bwd_f16_2(packed, packed_t_f16, acts, g_out, outs, defer: bool = False):
     """Split-precision backward (24-bit saved rows) of TWO network calls - the coarse + fine NeRF of a train step - as
     one zeroing launch, one dgrad launch, one weight-gradient launch and one reduce (scade_mlp_bwd_f16_2).  Every
     argument: a pair; ``outs`` = the two flat gradient buffers [589700], OVERWRITTEN.  Same bits as two
-    ``mlp_bwd_f16`` calls (same tiles, same chunks, same summation order)."""
+    ``mlp_bwd_f16`` calls (same tiles, same chunks, same summation order).  ``defer``: no reduce launch - the partial
+    rows stay in the workspaces and the returned ``ReduceDesc`` hands them to ``step_finish`` (``outs`` untouched)."""
     g = [_c(check(t, "mlp_bwd_f16_2: g_out")).reshape(-1, 4) for t in g_out]
     P = [t.shape[0] for t in g]
     lib = _lib.load()
@@ -309,10 +437,17 @@ def mlp_bwd_f16_2(packed, packed_t_f16, acts, g_out, outs) -> None:
     grads = [_grad_out(o, g[0].device) for o in outs]
     Pa = (ctypes.c_int * 2)(*P)
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
-    call("scade_mlp_bwd_f16_2", _host_ptrs(packed), _host_ptrs(packed_t_f16), _host_ptrs(acts), _host_ptrs(g),
-         ctypes.cast(Pa, ctypes.c_void_p), 1, _host_ptrs(ws), _host_ptrs(grads), stream())
+    desc = None
+    if defer:
+        desc = ReduceDesc(ws)
+        call("scade_mlp_bwd_f16_2_deferred", _host_ptrs(packed), _host_ptrs(packed_t_f16), _host_ptrs(acts), _host_ptrs(g),
+             ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), ctypes.cast(desc.buf, ctypes.c_void_p), stream())
+    else:
+        call("scade_mlp_bwd_f16_2", _host_ptrs(packed), _host_ptrs(packed_t_f16), _host_ptrs(acts), _host_ptrs(g),
+             ctypes.cast(Pa, ctypes.c_void_p), 1, _host_ptrs(ws), _host_ptrs(grads), stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
+    return desc
 
 
 def mlp_fwd_f16(packed_f16: Tensor, inp: Tensor, viewdirs: Optional[Tensor], bb: Optional[Tensor],
@@ -385,12 +520,13 @@ def _host_ptrs(ts):
     return ctypes.cast((ctypes.c_void_p * len(ts))(*[t.data_ptr() for t in ts]), ctypes.c_void_p)
 
 
-def mlp_bwd2(packed, packed_t, acts, g_out, outs, after_first=None) -> None:
+def mlp_bwd2(packed, packed_t, acts, g_out, outs, after_first=None, defer: bool = False):
     """Exact backward of TWO network calls (coarse + fine NeRF of a train step) as one dgrad launch, one
     weight-gradient launch and one reduce (scade_mlp_bwd2).  Every argument: a pair; ``outs`` = the two flat
     gradient buffers [589700], OVERWRITTEN.  ``after_first``: a callable run when the FIRST entry's gradient is
     complete on the stream (scade_mlp_bwd2_phases: joint dgrad, entry 0's weight gradient + reduce, callback, entry
-    1's) - a sharded step starts entry 0's gradient exchange there, under entry 1's weight gradient."""
+    1's) - a sharded step starts entry 0's gradient exchange there, under entry 1's weight gradient.  ``defer``: no
+    reduce launch - the returned ``ReduceDesc`` hands the partial rows to ``step_finish`` (``outs`` untouched)."""
     g = [_c(check(t, "mlp_bwd2: g_out")).reshape(-1, 4) for t in g_out]
     P = [t.shape[0] for t in g]
     lib = _lib.load()
@@ -401,7 +537,13 @@ def mlp_bwd2(packed, packed_t, acts, g_out, outs, after_first=None) -> None:
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
     args = (_host_ptrs(packed), _host_ptrs(packed_t), _host_ptrs(acts), _host_ptrs(g),
             ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads))
-    if after_first is None:
+    desc = None
+    if defer:
+        if after_first is not None:
+            raise ValueError("mlp_bwd2: a deferred reduce has no first-network hook")
+        desc = ReduceDesc(ws)
+        call("scade_mlp_bwd2_deferred", *args[:6], ctypes.cast(desc.buf, ctypes.c_void_p), stream())
+    elif after_first is None:
         call("scade_mlp_bwd2", *args, stream())
     else:
         call("scade_mlp_bwd2_phases", *args, 3, stream())
@@ -409,10 +551,12 @@ def mlp_bwd2(packed, packed_t, acts, g_out, outs, after_first=None) -> None:
         call("scade_mlp_bwd2_phases", *args, 4, stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
+    return desc
 
 
-def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs, after_first=None) -> None:
-    """16-bit backward of two network calls in one launch each (scade_mlp_bwd_lp2); see mlp_bwd2."""
+def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs, after_first=None, defer: bool = False, gmax=None):
+    """16-bit backward of two network calls in one launch each (scade_mlp_bwd_lp2); see mlp_bwd2.  ``gmax``: per entry
+    the 256 loss-scale maxima the step's loss launch already produced (``GMAX_READY``), or None."""
     g = [_c(check(t, "mlp_bwd_lp2: g_out")).reshape(-1, 4) for t in g_out]
     P = [t.shape[0] for t in g]
     lib = _lib.load()
@@ -423,7 +567,16 @@ def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs, after_first=None) ->
     t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
     args = (_host_ptrs(packed_t_lp), int(bf16), _host_ptrs(acts), _host_ptrs(g),
             ctypes.cast(Pa, ctypes.c_void_p), _host_ptrs(ws), _host_ptrs(grads))
-    if after_first is None:
+    desc = None
+    if defer or gmax is not None:
+        if after_first is not None:
+            raise ValueError("mlp_bwd_lp2: a deferred reduce / precomputed maxima have no first-network hook")
+        desc = ReduceDesc(ws) if defer else None
+        gm = None if gmax is None else ctypes.cast((ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in gmax]),
+                                                   ctypes.c_void_p)
+        call("scade_mlp_bwd_lp2_deferred", *args, gm, None if desc is None else ctypes.cast(desc.buf, ctypes.c_void_p),
+             stream())
+    elif after_first is None:
         call("scade_mlp_bwd_lp2", *args, stream())
     else:
         call("scade_mlp_bwd_lp2_phases", *args, 3, stream())
@@ -431,6 +584,7 @@ def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs, after_first=None) ->
         call("scade_mlp_bwd_lp2_phases", *args, 4, stream())
     if t0 is not None:
         KERNEL_TIMER.stop("mlp_bwd", t0, float(P[0] + P[1]) * 2 * MLP_FLOP_PER_POINT)
+    return desc
 
 
 def stage_inputs(pairs, scalar=None, tick=None) -> None:

@@ -114,6 +114,13 @@ class Trainer:
         # d loss / d loss = 1 (see _unit_grad; built here, never inside a graph capture).  Private and IMMUTABLE: the
         # one-launch loss forms bake the factor 1.0 in and recognise this tensor by address and version
         self._one = torch.ones((), device=dev)
+        # the end of the step as ONE launch (ops.step_finish: [partial-row sums ->] Adam -> next step's weight blobs);
+        # the sums ride along when no gradient exchange sits between backward and optimizer (finish_fmt: the packs'
+        # format; None = the split-precision dgrad-only mode, which keeps the separate launches)
+        self.finish_fmt = {"f32": "f32", "bf16": "bf16", "bf16-s8": "bf16", "f16": "f16", "f16x3": "f16x3"}.get(precision)
+        self.fused_finish = True
+        self._sync = torch.zeros(1, device=dev, dtype=torch.int64)
+        self._pending_reduce = None
         self.bucket.broadcast_params(0)
 
     def draw_key(self) -> int:
@@ -293,14 +300,25 @@ class Trainer:
         self.bucket.begin_step(zero_outside_sinks=not unit)
         self._unit_loss_ready = unit
 
-    def backward(self, loss):
-        """loss.backward() (:985) with the two networks' MLP backwards joined into one launch sequence."""
+    def backward(self, loss, defer_reduce=False):
+        """loss.backward() (:985) with the two networks' MLP backwards joined into one launch sequence.
+        ``defer_reduce`` (``step`` and the captured step pass True): where no gradient exchange follows, the joint
+        launch leaves its partial rows unsummed and ``finish()`` - which MUST then follow - sums them inside the
+        optimizer's launch; the bucket holds the step's gradient only after that.  False: the gradient is in the bucket
+        when this returns."""
+        self._pending_reduce = None
         if self.joint_backward:
             from .mlp_bwd import DeferredBackward
-            staged = self.allreduce == "staged" and (self.sharded or self.force_allreduce)
+            exchange = self.sharded or self.force_allreduce
+            staged = self.allreduce == "staged" and exchange
             self._staged_works, self._staged_done = [], []
-            with DeferredBackward(after_net=self._send_net_grads if staged else None):
+            defer = (defer_reduce and self.fused_finish and self.finish_fmt is not None and not exchange
+                     and len(self.bucket._sinks) == 2)
+            with DeferredBackward(after_net=self._send_net_grads if staged else None, defer_reduce=defer) as q:
                 loss.backward(self._unit_grad(loss))
+            if q.reduce is not None:
+                desc, (n0, _) = q.reduce
+                self._pending_reduce = desc.swap() if n0 is self.fine else desc
         else:
             loss.backward(self._unit_grad(loss))
 
@@ -312,11 +330,22 @@ class Trainer:
         if self._unit_loss_ready:        # the loss took another form (cached-quantile hypotheses): zero the rows now
             self._unit_loss_ready = False
             self.flat_ss.grad.zero_()
-        self.backward(loss)                                                                   # :985
+        self.backward(loss, defer_reduce=True)                                                # :985
         self.bucket.end_backward()
         self.reduce_grads()
         lr = staircase_lr(self.cfg["lrate"], self.cfg["rate"], self.cfg["step"], self.it + 1)  # :988-991
-        # optimizer.step() (:993) and, while i < freeze_ss, optimizer_ss.step() (:996-997): one launch
-        adam_step_pair(self.opt, self.opt_ss if self.scaleshift_active() else None, lr_a=lr)
+        self.finish(lr_a=lr)
         self.it += 1
         return aux["loss_report"], aux
+
+    def finish(self, lr_a=None, dev=False):
+        """optimizer.step() (:993) and, while i < freeze_ss, optimizer_ss.step() (:996-997) - with the sum of a deferred
+        backward's partial rows in front and the next step's weight blobs behind, as ONE launch (ops.step_finish)."""
+        opt_ss = self.opt_ss if self.scaleshift_active() else None
+        desc, self._pending_reduce = self._pending_reduce, None
+        if not (self.fused_finish and self.finish_fmt is not None):
+            if desc is not None:
+                raise RuntimeError("Trainer.finish: a deferred reduce needs the fused finish")
+            return adam_step_pair(self.opt, opt_ss, lr_a=lr_a, dev=dev, ticked=dev)
+        ops.step_finish(self.opt, opt_ss, [self.coarse, self.fine], self.finish_fmt, self._sync, lr_a=lr_a, dev=dev,
+                        reduce=desc)
