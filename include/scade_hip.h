@@ -398,10 +398,30 @@ int scade_adam_step2(float* const* params, const float* const* grads, float* con
                      const float* beta2, const float* eps, const int* step, const float* grad_scale,
                      float* const* state, int ticked, void* stream);
 
-/* ---- the end of a train step as ONE launch (round 6) -------------------------------------------------------------
+/* ---- the launch that OPENS a graph-captured step also runs its first per-ray kernel (round 6) -----------------------
+ * scade_stage_inputs / scade_gather_batch + scade_ray_points_draw (run_scade_scannet.py:638-657, :564-579) as ONE
+ * launch: extra workgroups of four waves = four rays compute z_vals [N,S], the coarse sample positions pts [N,S,3] and
+ * the step's sampler draws u_a / u_b [N,Si] (nullable) into the captured step's static buffers - from the SOURCE ray
+ * rows being staged (scade_stage_inputs_points: rays [N, ray_stride]) or from the ray rows they derive themselves from
+ * the pixel ids (scade_gather_batch_points).  ``step`` is the host's count of optimizer steps taken so far (what
+ * scade_ray_points_draw reads from the device state inside a captured step: these launches run outside it).  Same
+ * bits as the separate launches. */
+int scade_stage_inputs_points(const void* const* src, void* const* dst, const long* bytes, int n,
+                              long long* scalar_dst, long long scalar, float* const* tick_states, const float* rays,
+                              int ray_stride, const float* t_vals, int N, int S, int lindisp,
+                              unsigned long long seed, unsigned long long step, int Si, float* z_vals, float* pts,
+                              float* u_a, float* u_b, void* stream);
+int scade_gather_batch_points(const long long* pix, int N, int H, int W, const float* intrinsic, const float* c2w,
+                              int c2w_stride, float near, float far, const float* image, const float* hyps, int K,
+                              int corner_px, int edge_px, float* rays, float* target_s, float* target_h, float* mask,
+                              long long* scalar_dst, long long scalar, float* const* tick_states,
+                              const float* t_vals, int S, int lindisp, unsigned long long seed,
+                              unsigned long long step, int Si, float* z_vals, float* pts, float* u_a, float* u_b,
+                              void* stream);
+
+/* ---- the weight gradient's reduce inside the optimizer's launch (round 6) ----------------------------------------
  * run_scade_scannet.py:985-997: loss.backward() ends in the weight gradient's sum over its partial rows, then
- * optimizer.step() / optimizer_ss.step(), and the next iteration's forward needs the MFMA weight blobs re-packed from
- * the updated parameters - three launches over the same 1.18 M floats (reduce, scade_adam_step2, scade_mlp_pack_step).
+ * optimizer.step() / optimizer_ss.step() - two launches over the same 1.18 M floats (reduce, scade_adam_step2).
  *
  * scade_mlp_bwd2_deferred / scade_mlp_bwd_lp2_deferred / scade_mlp_bwd_f16_2_deferred = scade_mlp_bwd2 /
  * scade_mlp_bwd_lp2 / scade_mlp_bwd_f16_2 (wgrad_f16 = 1) WITHOUT their reduce launch: the partial rows stay in the
@@ -423,21 +443,16 @@ int scade_mlp_bwd_lp2_deferred(const void* const* packed_t_lp, int bf16, const v
 int scade_mlp_bwd_f16_2_deferred(const float* const* packed, const void* const* packed_t_f16,
                                  const float* const* acts, const float* const* g_out, const int* P,
                                  float* const* workspace, void* reduce_desc, void* stream);
-/* [sum of the partial rows reduce_desc describes -> grads[0]] -> Adam on both segments (arguments as scade_adam_step2;
- * segment 0 = the n_nets networks' parameters, n_nets x 589,700 consecutive floats in scade_mlp_pack order; device
- * states, when given, were ALREADY advanced for this step) -> the weight blobs of the next step re-packed from the
- * updated parameters: pack_format -1 none, 0 exact (packed_exact = scade_mlp_pack layout, packed_t = scade_mlp_pack_t),
- * 1 bf16 / 2 fp16 (packed_fwd = scade_mlp_pack_lp, packed_t = scade_mlp_pack_t_lp), 3 split precision (packed_exact,
- * packed_fwd = scade_mlp_pack_f16, packed_t = scade_mlp_pack_t_f16); host arrays of n_nets device pointers, entries
- * may be NULL (skipped).  net_params: n_nets x 24 parameter pointers (views of params[0]).  Same arithmetic, same
- * summation order, same bits as the separate launches.  The two phases are separated by a grid-wide barrier inside
- * the launch: sync = 8 bytes of device memory, zero when first used, owned by the caller, used by these launches only
- * (a monotonic arrival counter: never reset, so a captured step holds no memset node). */
+/* scade_adam_step2 with the weight gradient's last stage inside it: [sum of the partial rows reduce_desc describes ->
+ * grads[0]] -> Adam on both segments (arguments as scade_adam_step2; segment 0 = the n_nets networks' parameters,
+ * n_nets x 589,700 consecutive floats in scade_mlp_pack order; device states, when given, were ALREADY advanced for
+ * this step).  reduce_desc NULL: Adam only.  Same arithmetic, same summation order, same bits as the separate
+ * launches.  (The next step's weight packs as a second phase of this launch behind a grid-wide barrier were built
+ * and measured in round 6: 5 - 8 x slower than the separate launch on this 8-XCD part - step_finish.hip.) */
 int scade_step_finish(float* const* params, float* const* grads, float* const* exp_avg, float* const* exp_avg_sq,
                       const long* n, const float* lr, const float* beta1, const float* beta2, const float* eps,
                       const int* step, const float* grad_scale, float* const* state, const void* reduce_desc,
-                      int n_nets, const float* const* net_params, int pack_format, float* const* packed_exact,
-                      void* const* packed_fwd, void* const* packed_t, unsigned long long* sync, void* stream);
+                      int n_nets, void* stream);
 
 /* The fine tail, the train loss and the backward of both tails of a TRAIN step in one launch (+ the loss's
  * one-workgroup reduce): scade_ray_tail (fine form, run_scade_scannet.py:720-730) -> scade_train_loss_fb (:954,

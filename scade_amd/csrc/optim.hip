@@ -2,6 +2,7 @@
 // one allocation, scade_amd/parallel.py FlatParams).  Same update as torch.optim.Adam with
 // default flags (run_scade_scannet.py:469, :888): no weight decay, no amsgrad.
 #include "common.h"
+#include "ray_points_dev.h"
 
 namespace scade {
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -100,8 +101,19 @@ struct StageArgs {
   long long* scalar_dst;
   long long scalar;
   float* tick[2];        // device-resident optimizer scalars to advance (scade_adam_step_dev's layout), or null
+  // scade_stage_inputs_points: workgroups [points_block0, gridDim.x) are four waves = four rays of ray_points over
+  // the SOURCE ray rows (pts.rays): the step's first per-ray kernel rides in the launch that stages its inputs
+  RayPointsArgs pts;
+  int points_block0;
 };
 __global__ void stage_inputs_kernel(StageArgs a) {
+  if (a.points_block0 >= 0 && (int)blockIdx.x >= a.points_block0) {
+    const int ray = ((int)blockIdx.x - a.points_block0) * RAYS_PER_WG + (int)(threadIdx.x >> 6);
+    if (ray >= a.pts.N) return;
+    const float* r = a.pts.rays + (size_t)ray * a.pts.ray_stride;
+    ray_points_ray(a.pts, ray, lane_id(), r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
+    return;
+  }
   if (blockIdx.x == 0 && threadIdx.x == 0 && a.scalar_dst) *a.scalar_dst = a.scalar;
   if (blockIdx.x == 0 && threadIdx.x == 64 && a.tick[0]) adam_tick(a.tick[0]);
   if (blockIdx.x == 0 && threadIdx.x == 128 && a.tick[1]) adam_tick(a.tick[1]);
@@ -123,8 +135,9 @@ __global__ void stage_inputs_kernel(StageArgs a) {
 }
 }  // namespace scade
 
-extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, const long* bytes, int n,
-                                  long long* scalar_dst, long long scalar, float* const* tick_states, void* stream) {
+static int stage_inputs_impl(const void* const* src, void* const* dst, const long* bytes, int n,
+                             long long* scalar_dst, long long scalar, float* const* tick_states,
+                             const scade::RayPointsArgs* pts, void* stream) {
   SCADE_REQUIRE(n >= 0 && n <= scade::STAGE_MAX, -2, "scade_stage_inputs: 0..%d copies per launch", scade::STAGE_MAX);
   SCADE_REQUIRE(n == 0 || (src && dst && bytes), -1, "scade_stage_inputs: null pointer");
   scade::StageArgs a{};
@@ -146,9 +159,38 @@ extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, cons
   a.scalar_dst = scalar_dst;
   a.scalar = scalar;
   if (tick_states) { a.tick[0] = tick_states[0]; a.tick[1] = tick_states[1]; }
-  if (blocks == 0 && !scalar_dst && !a.tick[0] && !a.tick[1]) return 0;
-  hipLaunchKernelGGL(scade::stage_inputs_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, (hipStream_t)stream, a);
+  if (blocks == 0 && !scalar_dst && !a.tick[0] && !a.tick[1] && !pts) return 0;
+  if (blocks == 0) blocks = 1;
+  a.points_block0 = -1;
+  if (pts && pts->N > 0) {
+    a.pts = *pts;
+    a.points_block0 = blocks;
+    blocks += (pts->N + scade::RAYS_PER_WG - 1) / scade::RAYS_PER_WG;
+  }
+  hipLaunchKernelGGL(scade::stage_inputs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, a);
   return scade_check_launch("scade_stage_inputs");
+}
+
+extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, const long* bytes, int n,
+                                  long long* scalar_dst, long long scalar, float* const* tick_states, void* stream) {
+  return stage_inputs_impl(src, dst, bytes, n, scalar_dst, scalar, tick_states, nullptr, stream);
+}
+
+// scade_stage_inputs + scade_ray_points_draw (host step index) of the ray rows ``rays`` [N, ray_stride] - the rows being
+// staged, read at their source - as ONE launch; outputs as scade_ray_points_draw's.  Same bits as the two launches.
+extern "C" int scade_stage_inputs_points(const void* const* src, void* const* dst, const long* bytes, int n,
+                                         long long* scalar_dst, long long scalar, float* const* tick_states,
+                                         const float* rays, int ray_stride, const float* t_vals, int N, int S,
+                                         int lindisp, unsigned long long seed, unsigned long long step, int Si,
+                                         float* z_vals, float* pts, float* u_a, float* u_b, void* stream) {
+  SCADE_REQUIRE(N <= 0 || (rays && t_vals && z_vals), -1, "scade_stage_inputs_points: null pointer");
+  SCADE_REQUIRE(ray_stride >= 8 && S >= 1 && Si >= 0, -2, "scade_stage_inputs_points: ray_stride >= 8, S >= 1, Si >= 0 required");
+  SCADE_REQUIRE(Si > 0 || (!u_a && !u_b), -2, "scade_stage_inputs_points: sampler draws requested with Si = 0");
+  scade::RayPointsArgs p{};
+  p.rays = rays; p.t_vals = t_vals; p.z_vals = z_vals; p.pts = pts; p.N = N; p.S = S; p.ray_stride = ray_stride;
+  p.lindisp = lindisp; p.draw = 1; p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32); p.step = step;
+  p.u_a = u_a; p.u_b = u_b; p.Si = Si;
+  return stage_inputs_impl(src, dst, bytes, n, scalar_dst, scalar, tick_states, &p, stream);
 }
 
 static int adam_blocks(long n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }

@@ -15,12 +15,11 @@
 // (cumprod / cumsum) accumulated in fp64 and rounded per prefix, as ATen's CPU
 // cumsum/cumprod kernels do.
 #include "common.h"
+#include "ray_points_dev.h"
 #include "train_loss_dev.h"
 #include "mlp_layout.h"
 
 namespace scade {
-
-constexpr int RAYS_PER_WG = 4;
 
 // fp64 scans / reductions of a ray's samples: the DPP primitives of common.h (round 3; until then
 // __shfl_up(double) = two ds_bpermute per step)
@@ -31,105 +30,13 @@ __device__ __forceinline__ double wave_incl_sum_rev(double v) { return wave_incl
 __device__ __forceinline__ double wave_sum_d(double v) { return wave_sum_dpp_d(v); }
 
 // ---------------------------------------------------------------------------
-// ray_points: z_vals (+ stratified jitter) and sample positions
+// ray_points: z_vals (+ stratified jitter) and sample positions (ray_points_dev.h)
 // ---------------------------------------------------------------------------
-struct RayPointsArgs {
-  const float* rays;     // [N, ray_stride]: o(0..2) d(3..5) near(6) far(7)
-  const float* t_vals;   // [S] torch.linspace(0,1,S)
-  const float* t_rand;   // [N,S] or null
-  float* z_vals;         // [N,S]
-  float* pts;            // [N,S,3] or null
-  int N, S, ray_stride, lindisp;
-  // draw mode (scade_ray_points_draw): the step's uniform draws come from a counter-based generator inside
-  // this kernel instead of a tensor - the jitter is consumed in registers, the two samplers' draws are written
-  // out for the ray tails
-  int draw;                  // 0: t_rand as above
-  unsigned seed_lo, seed_hi; // Philox key
-  unsigned long long step;   // host step index ...
-  const float* step_dev;     // ... or the device-resident step count (FusedAdam.state[0], graph-captured steps)
-  float* u_a;                // [N,Si] draws of the coarse importance sampler (helpers:346-361), or null
-  float* u_b;                // [N,Si] draws of the depth-hypothesis sampler (helpers:395-410), or null
-  int Si;
-};
-
-// Philox4x32-10 (Salmon et al., SC'11; the generator family torch's device RNG uses): a pure function
-// (key, counter) -> 4 x 32 random bits, so every (step, ray, draw) has its value without any state to carry.
-__device__ __forceinline__ void philox4x32_10(unsigned (&c)[4], unsigned k0, unsigned k1) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned long long p0 = (unsigned long long)0xD2511F53u * c[0];
-    const unsigned long long p1 = (unsigned long long)0xCD9E8D57u * c[2];
-    const unsigned n0 = (unsigned)(p1 >> 32) ^ c[1] ^ k0, n2 = (unsigned)(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = (unsigned)p1; c[3] = (unsigned)p0; c[0] = n0; c[2] = n2;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-}
-// draw d of ray `ray` at step `step`: block d / 4 of the ray's stream, element d % 4; 24 random bits -> [0,1)
-// (the construction of torch.rand for float32)
-__device__ __forceinline__ void draw_block(unsigned seed_lo, unsigned seed_hi, unsigned long long step, int ray,
-                                           int block, float (&u)[4]) {
-  unsigned c[4] = {(unsigned)block, (unsigned)ray, (unsigned)step, (unsigned)(step >> 32)};
-  philox4x32_10(c, seed_lo, seed_hi);
-#pragma unroll
-  for (int i = 0; i < 4; ++i) u[i] = (float)(c[i] >> 8) * 5.9604644775390625e-8f;     // 2^-24
-}
-
 __global__ void ray_points_kernel(RayPointsArgs a) {
   const int ray = blockIdx.x * RAYS_PER_WG + (threadIdx.x >> 6);
   if (ray >= a.N) return;
-  const int lane = lane_id();
   const float* r = a.rays + (size_t)ray * a.ray_stride;
-  const float ox = r[0], oy = r[1], oz = r[2], dx = r[3], dy = r[4], dz = r[5];
-  const float near = r[6], far = r[7];
-  const int S = a.S;
-  auto zlin = [&](int i) {
-    const float t = a.t_vals[i];
-    const float om = 1.0f - t;
-    if (!a.lindisp) return near * om + far * t;                      // :642
-    return 1.0f / (1.0f / near * om + 1.0f / far * t);               // :645
-  };
-  // draw mode: the ray's stream is [jitter: S draws | sampler a: Si | sampler b: Si], every block of four
-  // padded up separately so that the arrays start on a block boundary
-  const unsigned long long step = a.draw ? (a.step_dev ? (unsigned long long)a.step_dev[0] : a.step) : 0ull;
-  const int jb = (S + 3) >> 2, sb = (a.Si + 3) >> 2;
-  if (a.draw) {
-    for (int which = 0; which < 2; ++which) {
-      float* dst = which ? a.u_b : a.u_a;
-      if (!dst) continue;
-      for (int b = lane; b < sb; b += 64) {
-        float u[4];
-        draw_block(a.seed_lo, a.seed_hi, step, ray, jb + which * sb + b, u);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (4 * b + j < a.Si) dst[(size_t)ray * a.Si + 4 * b + j] = u[j];
-      }
-    }
-  }
-  for (int i = lane; i < S; i += 64) {
-    float z = zlin(i);
-    if (a.t_rand || a.draw) {                                        // :564-579
-      float t;
-      if (a.draw) {
-        float u[4];
-        draw_block(a.seed_lo, a.seed_hi, step, ray, i >> 2, u);
-        t = u[i & 3];
-      } else {
-        t = a.t_rand[(size_t)ray * S + i];
-      }
-      const float zm = i > 0 ? zlin(i - 1) : z;
-      const float zp = i + 1 < S ? zlin(i + 1) : z;
-      const float lower = i > 0 ? 0.5f * (z + zm) : z;
-      const float upper = i + 1 < S ? 0.5f * (zp + z) : z;
-      z = lower + (upper - lower) * t;
-    }
-    a.z_vals[(size_t)ray * S + i] = z;
-    if (a.pts) {
-      float* p = a.pts + ((size_t)ray * S + i) * 3;                  // :657  o + d*z
-      p[0] = ox + dx * z;
-      p[1] = oy + dy * z;
-      p[2] = oz + dz * z;
-    }
-  }
+  ray_points_ray(a, ray, lane_id(), r[0], r[1], r[2], r[3], r[4], r[5], r[6], r[7]);
 }
 
 // ---------------------------------------------------------------------------
@@ -1799,15 +1706,36 @@ struct GatherBatchArgs {
   long long* scalar_dst;
   long long scalar;
   float* tick[2];
+  // scade_gather_batch_points: workgroups [points_block0, gridDim.x) are four waves = four rays of the step's first
+  // per-ray kernel (ray_points: z_vals, coarse sample positions, the step's uniform draws), each from the ray row it
+  // derives itself with gen_ray_item's arithmetic (nobody waits for the row another workgroup writes)
+  RayPointsArgs pts;
+  int points_block0;
 };
 __global__ void gather_batch_kernel(GatherBatchArgs b) {
   const GenRaysArgs& a = b.g;
+  if (b.points_block0 >= 0 && (int)blockIdx.x >= b.points_block0) {
+    const int n = ((int)blockIdx.x - b.points_block0) * RAYS_PER_WG + (int)(threadIdx.x >> 6);
+    if (n >= a.N) return;
+    const long long p = b.pix[n];
+    const int j = (int)(p / a.W), i = (int)(p - (long long)j * a.W);
+    const CamRT c = load_cam(a.intrinsic, a.c2w, a.c2w_stride);
+    const float d0 = (((float)i + 0.5f) - c.cx) / c.fx;                     // (gen_ray_item, helpers:296-298)
+    const float d1 = ((float)a.H - ((float)j + 0.5f) - c.cy) / c.fy;
+    const float d2 = -1.0f;
+    float d[3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = (d0 * c.R[r][0] + d1 * c.R[r][1]) + d2 * c.R[r][2];
+    ray_points_ray(b.pts, n, lane_id(), c.T[0], c.T[1], c.T[2], d[0], d[1], d[2], a.near, a.far);
+    return;
+  }
+  const int nblk = b.points_block0 >= 0 ? b.points_block0 : (int)gridDim.x;
   if (blockIdx.x == 0 && threadIdx.x == 0 && b.scalar_dst) *b.scalar_dst = b.scalar;
   if (blockIdx.x == 0 && threadIdx.x == 64 && b.tick[0]) adam_tick(b.tick[0]);
   if (blockIdx.x == 0 && threadIdx.x == 128 && b.tick[1]) adam_tick(b.tick[1]);
   const long items = (long)a.N * (1 + (a.hyps && a.target_h ? a.K : 0));
   const size_t plane = (size_t)a.H * a.W;
-  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < items; t += (long)gridDim.x * 256) {
+  for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < items; t += (long)nblk * 256) {
     if (t < a.N) {
       const int n = (int)t;
       const long long p = b.pix[n];
@@ -1838,11 +1766,11 @@ extern "C" int scade_gen_rays(const int* coords, int N, int H, int W, const floa
   return scade_check_launch("scade_gen_rays");
 }
 
-extern "C" int scade_gather_batch(const long long* pix, int N, int H, int W, const float* intrinsic,
-                                  const float* c2w, int c2w_stride, float near, float far, const float* image,
-                                  const float* hyps, int K, int corner_px, int edge_px, float* rays,
-                                  float* target_s, float* target_h, float* mask, long long* scalar_dst,
-                                  long long scalar, float* const* tick_states, void* stream) {
+static int gather_batch_impl(const long long* pix, int N, int H, int W, const float* intrinsic,
+                             const float* c2w, int c2w_stride, float near, float far, const float* image,
+                             const float* hyps, int K, int corner_px, int edge_px, float* rays,
+                             float* target_s, float* target_h, float* mask, long long* scalar_dst,
+                             long long scalar, float* const* tick_states, const scade::RayPointsArgs* pts, void* stream) {
   SCADE_REQUIRE(N >= 0 && H > 0 && W > 0 && K >= 0, -2, "scade_gather_batch: bad sizes");
   SCADE_REQUIRE(N == 0 || (pix && intrinsic && c2w && c2w_stride >= 4), -1, "scade_gather_batch: pix / intrinsic / c2w missing");
   SCADE_REQUIRE(!hyps == !target_h || K == 0, -1, "scade_gather_batch: hyps and target_h go together");
@@ -1858,6 +1786,41 @@ extern "C" int scade_gather_batch(const long long* pix, int N, int H, int W, con
   long grid = (items + 255) / 256;
   if (grid < 1) grid = 1;
   if (grid > 4096) grid = 4096;
+  b.points_block0 = -1;
+  if (pts && N > 0) {
+    b.pts = *pts;
+    b.points_block0 = (int)grid;
+    grid += (N + scade::RAYS_PER_WG - 1) / scade::RAYS_PER_WG;
+  }
   hipLaunchKernelGGL(scade::gather_batch_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, b);
   return scade_check_launch("scade_gather_batch");
+}
+
+extern "C" int scade_gather_batch(const long long* pix, int N, int H, int W, const float* intrinsic,
+                                  const float* c2w, int c2w_stride, float near, float far, const float* image,
+                                  const float* hyps, int K, int corner_px, int edge_px, float* rays,
+                                  float* target_s, float* target_h, float* mask, long long* scalar_dst,
+                                  long long scalar, float* const* tick_states, void* stream) {
+  return gather_batch_impl(pix, N, H, W, intrinsic, c2w, c2w_stride, near, far, image, hyps, K, corner_px, edge_px, rays,
+                           target_s, target_h, mask, scalar_dst, scalar, tick_states, nullptr, stream);
+}
+
+// scade_gather_batch + scade_ray_points_draw of the gathered rays (host step index: this launch runs OUTSIDE the
+// captured step, every iteration) as ONE launch: z_vals [N,S], pts [N,S,3], u_a / u_b [N,Si] (nullable) are the
+// captured step's static coarse-sample buffers.  Same bits as the two launches.
+extern "C" int scade_gather_batch_points(const long long* pix, int N, int H, int W, const float* intrinsic,
+                                         const float* c2w, int c2w_stride, float near, float far, const float* image,
+                                         const float* hyps, int K, int corner_px, int edge_px, float* rays,
+                                         float* target_s, float* target_h, float* mask, long long* scalar_dst,
+                                         long long scalar, float* const* tick_states, const float* t_vals, int S,
+                                         int lindisp, unsigned long long seed, unsigned long long step, int Si,
+                                         float* z_vals, float* pts, float* u_a, float* u_b, void* stream) {
+  SCADE_REQUIRE(t_vals && z_vals && S >= 1 && Si >= 0, -2, "scade_gather_batch_points: t_vals, z_vals, S >= 1, Si >= 0 required");
+  SCADE_REQUIRE(Si > 0 || (!u_a && !u_b), -2, "scade_gather_batch_points: sampler draws requested with Si = 0");
+  scade::RayPointsArgs a{};
+  a.t_vals = t_vals; a.z_vals = z_vals; a.pts = pts; a.N = N; a.S = S; a.lindisp = lindisp;
+  a.draw = 1; a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.step = step;
+  a.u_a = u_a; a.u_b = u_b; a.Si = Si;
+  return gather_batch_impl(pix, N, H, W, intrinsic, c2w, c2w_stride, near, far, image, hyps, K, corner_px, edge_px, rays,
+                           target_s, target_h, mask, scalar_dst, scalar, tick_states, &a, stream);
 }

@@ -69,11 +69,22 @@ class GraphedTrainer:
         # step index, and a second GraphedTrainer on it does not apply the offset twice.
         self._resume_offset = tr.it - tr.opt.steps
         self._step_dev = tr.opt.state[13:14]
+        # in-kernel draws: the coarse samples of a step (z_vals, positions, both samplers' draws) are computed by the
+        # launch that opens it (ops.stage_inputs / ops.ResidentBatchGather ``points=``), not by a launch of the
+        # captured step: one launch less per iteration, same kernel body, same bits.  ``coarse_pre = None`` (set it
+        # before the first step) keeps scade_ray_points_draw inside the graph.
+        self.coarse_pre = None
+        if self.draws is None and not c["joint"]:
+            self.coarse_pre = ops.CoarsePoints(n_rays, c["Ns"], c["Ni"], c["lindisp"], dev, key=self._points_key,
+                                               step=lambda: tr.opt.steps)
         self.graph = None
         self.loss = None
         self.terms = None
         self._captured = None     # (scale/shift update in the graph?, carving term in the graph?)
         self._key = None          # Philox key baked into the captured launches (None: draws are injected)
+
+    def _points_key(self):
+        return (self.tr.draw_key() + self._resume_offset * 0x2545F4914F6CDD1D) & (2 ** 64 - 1)
 
     def _body(self):
         tr = self.tr
@@ -81,6 +92,9 @@ class GraphedTrainer:
         kw = {}
         if self.draws is not None:
             kw = dict(t_rand=self.draws[0], u_coarse=self.draws[1], cached_u=self.draws[2])
+        elif self.coarse_pre is not None:
+            self._key = tr.draw_key()          # (not baked into the graph any more; kept for the re-capture rule)
+            kw = dict(_coarse_pre=self.coarse_pre)
         else:
             # the Philox key is a kernel ARGUMENT of the captured launches: recorded, and step() re-captures when
             # Trainer.reseed_draws() / a new torch seed changed it (eager and graphed steps stay on one stream)
@@ -120,12 +134,6 @@ class GraphedTrainer:
             dst.copy_(src)
         tr.opt.steps, tr.opt_ss.steps = steps
         ops.PARAM_EPOCH += 1
-        if tr.fused_finish and tr.finish_fmt is not None:
-            # the captured step ends with the packs of the NEXT replay (Trainer.finish): bring the blobs up to date
-            # with the rolled-back parameters here, outside the capture, so that the body's own pack finds nothing to
-            # do (the blobs are re-packed in place: their addresses are what the captured kernels read)
-            (ops.mlp_pack_step_f16x3 if tr.finish_fmt == "f16x3" else
-             (lambda nets: ops.mlp_pack_step(nets, tr.finish_fmt)))([tr.coarse, tr.fine])
         self._captured = (tr.scaleshift_active(), tr.carving_active())
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
@@ -153,7 +161,8 @@ class GraphedTrainer:
         if self.draws is not None:
             pairs += [(t_rand, self.draws[0]), (u_coarse, self.draws[1]), (cached_u, self.draws[2])]
         # ... and the optimizers' device-resident step scalars advance in the same launch (no tick launch in the graph)
-        ops.stage_inputs(pairs, scalar, tick=self.tick_states())
+        ops.stage_inputs(pairs, scalar, tick=self.tick_states(), points=self.coarse_pre,
+                         rays=rays if self.coarse_pre is not None else None)
         return self.step_staged()
 
     def tick_states(self):
@@ -178,8 +187,6 @@ class GraphedTrainer:
         if with_ss:
             tr.opt_ss.steps += 1
         ops.PARAM_EPOCH += 1          # parameters changed behind the module caches' back
-        if tr.fused_finish and tr.finish_fmt is not None:
-            ops.mark_packs_fresh([tr.coarse, tr.fine], tr.finish_fmt)   # ... and the replay's last launch re-packed them
         return self.loss
 
 

@@ -241,14 +241,11 @@ class ReduceDesc:
         return self
 
 
-def step_finish(opt_a, opt_b, nets, fmt: Optional[str], sync: Tensor, lr_a=None, dev: bool = False,
-                reduce: Optional[ReduceDesc] = None) -> None:
-    """The end of a train step as ONE launch (scade_step_finish): [``reduce``: the sum of a deferred backward's
-    partial rows ->] ``opt_a.step(lr=lr_a)`` on the networks' segment and (``opt_b`` given) ``opt_b.step()`` on the
-    scale / shift segment -> the weight blobs of training format ``fmt`` ("f32" | "bf16" | "f16" | "f16x3"; None: no
-    pack) of ``nets`` re-packed in place from the updated parameters and marked fresh.  ``dev``: the optimizers' scalars
-    come from their device states, already advanced for this step.  ``sync``: int64[1] device tensor owned by the
-    caller (the launch's grid barrier)."""
+def step_finish(opt_a, opt_b, n_nets: int, lr_a=None, dev: bool = False, reduce: Optional[ReduceDesc] = None) -> None:
+    """``optim.adam_step_pair`` with the weight gradient's reduce inside the launch (scade_step_finish): [``reduce``: the
+    sum of a deferred backward's partial rows, written to the bucket on the way ->] ``opt_a.step(lr=lr_a)`` on the
+    ``n_nets`` networks' segment and (``opt_b`` given) ``opt_b.step()`` on the scale / shift segment.  ``dev``: the
+    optimizers' scalars come from their device states, already advanced for this step."""
     opts = [opt_a] + ([opt_b] if opt_b is not None else [])
     for o in opts:
         o.steps += 1
@@ -256,7 +253,7 @@ def step_finish(opt_a, opt_b, nets, fmt: Optional[str], sync: Tensor, lr_a=None,
     P = ctypes.c_void_p
     pp = lambda f: ctypes.cast(two(lambda o: f(o).data_ptr(), ctypes.c_void_p), P)
     n = two(lambda o: o.flat.numel, ctypes.c_long)
-    if opt_a.flat.numel != len(nets) * N_PARAM_FLOATS:
+    if opt_a.flat.numel != n_nets * N_PARAM_FLOATS:
         raise ValueError("step_finish: the first optimizer's segment must be the networks' parameters")
     if dev:
         scal = (None,) * 6 + (pp(lambda o: o.state),)
@@ -267,57 +264,11 @@ def step_finish(opt_a, opt_b, nets, fmt: Optional[str], sync: Tensor, lr_a=None,
                 ctypes.cast(two(lambda o: float(o.eps), ctypes.c_float), P),
                 ctypes.cast(two(lambda o: int(o.steps), ctypes.c_int), P),
                 ctypes.cast(two(lambda o: 1.0, ctypes.c_float), P), None)
-    global PARAM_EPOCH
-    PARAM_EPOCH += 1
-    code = {None: -1, "f32": 0, "bf16": 1, "f16": 2, "f16x3": 3}[fmt]
-    ex = fw = tr = plist = None
-    adopt = []
-    if code >= 0:
-        if sync.dtype != torch.int64 or not sync.is_cuda or sync.numel() < 1:
-            raise ValueError("step_finish: sync must be an int64 device tensor")
-        plist, exl, fwl, trl = [], [], [], []
-        for net in nets:
-            ps = net.ordered_params()
-            if not all(p.is_contiguous() for p in ps):
-                raise ValueError("step_finish: parameters must be contiguous")
-            d = ps[0].device
-            if code == 3:
-                be, bf, bt = _train_blobs_f16x3(net, d)
-            else:
-                bf, bt = _train_blobs(net, fmt, d)
-                be = None
-                if code == 0:
-                    be, bf = bf, None
-            plist += [p.data_ptr() for p in ps]
-            exl.append(be); fwl.append(bf); trl.append(bt)
-            adopt.append((net, be, bf, bt))
-        vp = lambda ts: ctypes.cast((ctypes.c_void_p * len(ts))(*[None if t is None else t.data_ptr() for t in ts]), P)
-        ex, fw, tr = vp(exl), vp(fwl), vp(trl)
-        plist = ctypes.cast((ctypes.c_void_p * len(plist))(*plist), P)
     call("scade_step_finish", pp(lambda o: o.flat.data), pp(lambda o: o.flat.grad), pp(lambda o: o.exp_avg),
          pp(lambda o: o.exp_avg_sq), ctypes.cast(n, P), *scal, None if reduce is None else ctypes.cast(reduce.buf, P),
-         len(nets), plist, code, ex, fw, tr, None if code < 0 else sync.data_ptr(), stream())
-    for net, be, bf, bt in adopt:
-        key = net.pack_key()
-        if code == 3:
-            _adopt_f16x3(net, be, bf, bt, key)
-        elif code == 0:
-            net.adopt_packs("f32", be, bt, key)
-        else:
-            net.adopt_packs(fmt, bf, bt, key)
-
-
-def mark_packs_fresh(nets, fmt: str) -> None:
-    """Re-key the existing training blobs of ``nets`` to the parameters' current state: a graph replay whose captured
-    ``step_finish`` packed them leaves ``PARAM_EPOCH`` bumped behind it."""
-    for net in nets:
-        d, key = net.__dict__, net.pack_key()
-        if fmt == "f16x3":
-            _adopt_f16x3(net, d.get("_packed"), d.get("_packed_f16"), d.get("_packed_t_f16"), key)
-        elif fmt == "f32":
-            net.adopt_packs("f32", d.get("_packed"), d.get("_packed_t"), key)
-        else:
-            net.adopt_packs(fmt, d.get("_packed_lp"), d.get("_packed_t_lp"), key)
+         n_nets, stream())
+    global PARAM_EPOCH
+    PARAM_EPOCH += 1
 
 
 def mlp_pack_step_f16x3(nets) -> None:
@@ -587,11 +538,32 @@ def mlp_bwd_lp2(packed_t_lp, bf16: bool, acts, g_out, outs, after_first=None, de
     return desc
 
 
-def stage_inputs(pairs, scalar=None, tick=None) -> None:
+class CoarsePoints:
+    """The static coarse-sample buffers of a graph-captured step and what the launch in front of it needs to fill them
+    (scade_stage_inputs_points / scade_gather_batch_points = ray_points_draw inside that launch): ``z`` [N,S], ``pts``
+    [N,S,3], ``u_a`` / ``u_b`` [N,Si] (None: that sampler's draws are injected); ``key()`` -> the Philox key, ``step()``
+    -> the host's count of optimizer steps taken (the step index the captured kernel would read from the device)."""
+
+    def __init__(self, n_rays, n_samples, n_importance, lindisp, device, key, step, want_a=True, want_b=True):
+        self.N, self.S, self.Si, self.lindisp = int(n_rays), int(n_samples), int(n_importance), bool(lindisp)
+        self.z = torch.empty(n_rays, n_samples, device=device, dtype=torch.float32)
+        self.pts = torch.empty(n_rays, n_samples, 3, device=device, dtype=torch.float32)
+        self.u_a = torch.empty(n_rays, n_importance, device=device, dtype=torch.float32) if want_a else None
+        self.u_b = torch.empty(n_rays, n_importance, device=device, dtype=torch.float32) if want_b else None
+        self.t_vals = linspace01(n_samples, device)
+        self.key, self.step = key, step
+
+    def tail_args(self):
+        return (ptr(self.t_vals), self.S, int(self.lindisp), int(self.key()) & (2 ** 64 - 1), int(self.step()), self.Si,
+                ptr(self.z), ptr(self.pts), ptr(self.u_a), ptr(self.u_b))
+
+
+def stage_inputs(pairs, scalar=None, tick=None, points=None, rays=None) -> None:
     """``dst.copy_(src)`` for up to eight (src, dst) pairs - and ``scalar = (int64 tensor, value)``: one 8-byte
     store; ``tick = [state, state | None]``: the device-resident scalars of up to two fused optimizers advanced by
     one step - in ONE launch (scade_stage_inputs): the prologue of a graph-captured step.  Pairs that the
-    kernel does not take as they are (other dtype / shape / layout / device) fall back to ``copy_``."""
+    kernel does not take as they are (other dtype / shape / layout / device) fall back to ``copy_``.  ``points`` +
+    ``rays``: see CoarsePoints."""
     src_p, dst_p, nbytes = [], [], []
     for src, dst in pairs:
         if src.data_ptr() == dst.data_ptr() and src.shape == dst.shape:
@@ -613,10 +585,20 @@ def stage_inputs(pairs, scalar=None, tick=None) -> None:
                 raise ValueError("stage_inputs: tick entries are the float32[16] device states of FusedAdam")
         t2 = (list(tick) + [None])[:2]
         ticks = ctypes.cast((ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in t2]), ctypes.c_void_p)
-    if not src_p and sd is None and ticks is None:
+    if not src_p and sd is None and ticks is None and points is None:
         return
     n = len(src_p)
     vp = lambda v: ctypes.cast((ctypes.c_void_p * max(n, 1))(*v), ctypes.c_void_p)
+    if points is not None:
+        # ``points`` (a CoarsePoints) + ``rays`` (the SOURCE ray rows of this step): ray_points_draw rides in the launch
+        rr, stride = _rows(rays, "stage_inputs: rays")
+        if rr.shape[0] != points.N or rr.shape[1] < 8:
+            raise ValueError("stage_inputs: rays must be the step's [N, >= 8] ray rows")
+        t = points.tail_args()
+        call("scade_stage_inputs_points", vp(src_p), vp(dst_p),
+             ctypes.cast((ctypes.c_long * max(n, 1))(*nbytes), ctypes.c_void_p), n, sd, sv, ticks, ptr(rr), stride, t[0],
+             points.N, *t[1:], stream())
+        return
     call("scade_stage_inputs", vp(src_p), vp(dst_p), ctypes.cast((ctypes.c_long * max(n, 1))(*nbytes), ctypes.c_void_p), n,
          sd, sv, ticks, stream())
 
@@ -1058,7 +1040,7 @@ class ResidentBatchGather:
     scale / shift optimizer after its freeze point)."""
 
     def __init__(self, H, W, images, hyps, poses, intrinsics, near, far, rays, target_s, target_h, mask=None,
-                 corner_px=0, edge_px=0, scalar_dst=None, tick_states=None):
+                 corner_px=0, edge_px=0, scalar_dst=None, tick_states=None, points=None):
         V = images.shape[0]
         for t, what in ((images, "images"), (hyps, "hyps"), (poses, "poses"), (intrinsics, "intrinsics")):
             check(t, "ResidentBatchGather: " + what)
@@ -1090,7 +1072,11 @@ class ResidentBatchGather:
             # REPLACES that tensor) or the float32[16] state tensor itself
             self._tick_src = (list(tick_states) + [None])[:2]
             self._bind_ticks()
-        self._fn = getattr(load(), "scade_gather_batch")
+        # ``points`` (a CoarsePoints of this batch size): the captured step's coarse samples are computed in this launch
+        if points is not None and points.N != self.N:
+            raise ValueError("ResidentBatchGather: the coarse-sample buffers are for another batch size")
+        self._points = points
+        self._fn = getattr(load(), "scade_gather_batch_points" if points is not None else "scade_gather_batch")
 
     def _tick_tensors(self):
         return [t if (t is None or torch.is_tensor(t)) else t.state for t in self._tick_src]
@@ -1123,7 +1109,8 @@ class ResidentBatchGather:
             self._bind_ticks()            # an optimizer's device state was replaced since the last call
         rc = self._fn(pix.data_ptr() + 8 * offset, *self._fixed_a, self._intr[0] + view * self._intr[1],
                       self._pose[0] + view * self._pose[1], *self._fixed_b, self._img[0] + view * self._img[1],
-                      self._hyp[0] + view * self._hyp[1], *self._fixed_c, view, self._ticks[bool(tick_second)], stream())
+                      self._hyp[0] + view * self._hyp[1], *self._fixed_c, view, self._ticks[bool(tick_second)],
+                      *(() if self._points is None else self._points.tail_args()), stream())
         if rc != 0:
             raise RuntimeError(f"scade_gather_batch failed (code {rc}): {last_error()}")
 

@@ -159,7 +159,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
                 precomputed_z_samples=None, embedded_cam=None, retraw=False, lindisp=False,
                 perturb=0., N_importance=0, network_fine=None, raw_noise_std=0., verbose=False,
                 pytest=False, is_joint=False, cached_u=None, t_rand=None, u_coarse=None,
-                coarse_stream=None, fuse_tails=True, draws=None, _stop_before_fine_tail=False):
+                coarse_stream=None, fuse_tails=True, draws=None, _stop_before_fine_tail=False, _coarse_pre=None):
     """run_scade_scannet.py:581-751 (live branch ``N_importance > 0``).
 
     Extra keyword-only knobs beyond the reference signature: ``t_rand`` [N,N_samples]
@@ -177,7 +177,9 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     step, ray and draw index) instead of by torch.rand launches.
     ``_stop_before_fine_tail`` (Trainer only): return after the fine MLP with ``raw`` / ``raw0`` / ``u`` and
     ``'_fine_tail_pending': True`` - the caller runs the fine tail, the loss and both tails' backward as ONE launch
-    (ops.FineTailLossFn); ignored (a complete result is returned) when that launch cannot take the case."""
+    (ops.FineTailLossFn); ignored (a complete result is returned) when that launch cannot take the case.
+    ``_coarse_pre`` (GraphedTrainer only; an ``ops.CoarsePoints``): the coarse samples - z_vals, positions, the samplers'
+    draws - were already computed by the launch in front of the captured step (same kernel body, same bits)."""
     if N_importance <= 0:
         raise NotImplementedError(
             "render_rays: N_importance == 0 is dead code in the reference (raises UnboundLocalError "
@@ -198,7 +200,7 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
     det = (perturb == 0.)
 
     # ---- coarse: z (+jitter) and points in one launch (:638-657) -------------
-    in_kernel = perturb > 0. and t_rand is None and draws is not None and not pytest
+    in_kernel = perturb > 0. and t_rand is None and (draws is not None or _coarse_pre is not None) and not pytest
     if in_kernel:
         pass                                     # jitter drawn by scade_ray_points_draw (coarse_stage)
     elif perturb > 0.:
@@ -217,7 +219,11 @@ def render_rays(ray_batch, use_viewdirs, network_fn, network_query_fn, N_samples
 
     def coarse_stage():
         nonlocal u_coarse, cached_u
-        if in_kernel:
+        if in_kernel and _coarse_pre is not None:
+            z, p, ua, ub = _coarse_pre.z, _coarse_pre.pts, _coarse_pre.u_a, _coarse_pre.u_b
+            u_coarse = ua if u_coarse is None else u_coarse
+            cached_u = ub if (cached_u is None and not is_joint) else cached_u
+        elif in_kernel:
             # the two samplers' draws that were not injected come out of the same launch (the last sampler's
             # stay with the host when is_joint shares ONE row among all rays, helpers:498-513)
             z, p, ua, ub = ops.ray_points_draw(rays, N_samples, lindisp, draws, N_importance,

@@ -114,12 +114,9 @@ class Trainer:
         # d loss / d loss = 1 (see _unit_grad; built here, never inside a graph capture).  Private and IMMUTABLE: the
         # one-launch loss forms bake the factor 1.0 in and recognise this tensor by address and version
         self._one = torch.ones((), device=dev)
-        # the end of the step as ONE launch (ops.step_finish: [partial-row sums ->] Adam -> next step's weight blobs);
-        # the sums ride along when no gradient exchange sits between backward and optimizer (finish_fmt: the packs'
-        # format; None = the split-precision dgrad-only mode, which keeps the separate launches)
-        self.finish_fmt = {"f32": "f32", "bf16": "bf16", "bf16-s8": "bf16", "f16": "f16", "f16x3": "f16x3"}.get(precision)
-        self.fused_finish = True
-        self._sync = torch.zeros(1, device=dev, dtype=torch.int64)
+        # the weight gradient's reduce rides in the optimizer's launch (ops.step_finish) when no gradient exchange sits
+        # between backward and optimizer; ``fused_finish = False`` keeps the separate launches (same bits: a test)
+        self.fused_finish = precision in ("f32", "bf16", "bf16-s8", "f16", "f16x3")
         self._pending_reduce = None
         self.bucket.broadcast_params(0)
 
@@ -171,7 +168,7 @@ class Trainer:
             # the LAST sampler (sample_pdf_joint_return_u, :728) draws ONE u[S] for the whole batch
             # (helpers:498-513): rank 0's draw.  The coarse importance sampler stays per ray (:705).
             render_kw.setdefault("cached_u", shared_uniform((c["Ni"],), rays.device))
-        if not any(k in render_kw for k in ("t_rand", "u_coarse", "pytest", "draws")):
+        if not any(k in render_kw for k in ("t_rand", "u_coarse", "pytest", "draws", "_coarse_pre")):
             # the step's uniform draws (stratified jitter :564-579, the sample_pdf draws helpers:346-361,
             # :395-410) are made inside the step's first kernel: no generator launch, no jitter tensor.
             # Injected draws (parity tests, the reference's pytest=True streams) take precedence.
@@ -312,8 +309,7 @@ class Trainer:
             exchange = self.sharded or self.force_allreduce
             staged = self.allreduce == "staged" and exchange
             self._staged_works, self._staged_done = [], []
-            defer = (defer_reduce and self.fused_finish and self.finish_fmt is not None and not exchange
-                     and len(self.bucket._sinks) == 2)
+            defer = defer_reduce and self.fused_finish and not exchange and len(self.bucket._sinks) == 2
             with DeferredBackward(after_net=self._send_net_grads if staged else None, defer_reduce=defer) as q:
                 loss.backward(self._unit_grad(loss))
             if q.reduce is not None:
@@ -339,13 +335,10 @@ class Trainer:
         return aux["loss_report"], aux
 
     def finish(self, lr_a=None, dev=False):
-        """optimizer.step() (:993) and, while i < freeze_ss, optimizer_ss.step() (:996-997) - with the sum of a deferred
-        backward's partial rows in front and the next step's weight blobs behind, as ONE launch (ops.step_finish)."""
+        """optimizer.step() (:993) and, while i < freeze_ss, optimizer_ss.step() (:996-997) as one launch - with the
+        sum of a deferred backward's partial rows in front (ops.step_finish)."""
         opt_ss = self.opt_ss if self.scaleshift_active() else None
         desc, self._pending_reduce = self._pending_reduce, None
-        if not (self.fused_finish and self.finish_fmt is not None):
-            if desc is not None:
-                raise RuntimeError("Trainer.finish: a deferred reduce needs the fused finish")
+        if desc is None:
             return adam_step_pair(self.opt, opt_ss, lr_a=lr_a, dev=dev, ticked=dev)
-        ops.step_finish(self.opt, opt_ss, [self.coarse, self.fine], self.finish_fmt, self._sync, lr_a=lr_a, dev=dev,
-                        reduce=desc)
+        ops.step_finish(self.opt, opt_ss, 2, lr_a=lr_a, dev=dev, reduce=desc)
