@@ -1046,6 +1046,7 @@ def test_one_launch_step_finish_equals_the_separate_launches(dev, precision, n_r
     parameters, gradient bucket and both moments after each of four steps, bit for bit.  The sizes cover the
     small-launch (chunk, job) grids and, for the 16-bit formats above 100k points, the balanced plan's per-job row
     counts."""
+    from scade_amd import ops
     from scade_amd.train import Trainer, make_scade_nets
     K = 12
     rays = O.synthetic_rays(n_rays, seed=41).to(dev)
@@ -1075,7 +1076,10 @@ def test_one_launch_step_finish_equals_the_separate_launches(dev, precision, n_r
             torch.cuda.synchronize()
             snaps.append((float(loss), tr.bucket.data.clone(), tr.bucket.grad.clone(), tr.opt.exp_avg.clone(),
                           tr.opt.exp_avg_sq.clone(), tr.opt_ss.exp_avg.clone()))
-        assert used == (len(draws) if fused else 0), "the deferred reduce was (not) taken"
+        # (the 16-bit pair launch needs both networks' forwards on one point tiling: 260 rays straddles the switch and
+        # runs the two backwards one by one, reduce included - the fused finish is then Adam alone)
+        pair = precision not in ops.LP_FORMATS or ops.lp_point_tiles(n_rays * 64) == ops.lp_point_tiles(n_rays * 192)
+        assert used == (len(draws) if fused and pair else 0), "the deferred reduce was (not) taken"
         runs[fused] = snaps
     for i, (a, b) in enumerate(zip(runs[False], runs[True])):
         assert a[0] == b[0], (i, a[0], b[0])
