@@ -398,6 +398,22 @@ int scade_adam_step2(float* const* params, const float* const* grads, float* con
                      const float* beta2, const float* eps, const int* step, const float* grad_scale,
                      float* const* state, int ticked, void* stream);
 
+/* scade_ray_tail_train that also leaves the loss-scale maxima of the two output gradients it writes, for the 16-bit
+ * MLP backward of the same step (scade_mlp_bwd_lp2_deferred's gmax_pre: its own maxima launch is then skipped).
+ * gmax_ws: [2 N] floats of workspace (per-ray maxima, reduced by the loss's one-workgroup reduce); gmax_fine /
+ * gmax_coarse: [256] floats each - slot 0 = the maximum over the finite entries of the EFFECTIVE gradient of g_raw /
+ * g_raw0 (colour channels as they are, the density channel times 1 - exp(-10 sigma) = the softplus' derivative
+ * sigmoid(10 alpha_pre), model/run_nerf_helpers.py:242), the rest zero.  Needs the coarse ray; no raw noise. */
+int scade_ray_tail_train_gmax(const float* raw, const float* z_vals, const float* rays, int ray_stride, int N, int S,
+                              const float* u, int u_stride, int Si, float* rgb_map, float* disp_map, float* acc_map,
+                              float* weights, float* depth_map, float* samples, float* z_std, const float* rgb0,
+                              const float* target, const float* hyp, const float* scales, const float* shifts,
+                              const long long* img_i_dev, int img_i, const float* mask, int mse_masked, int carve_on,
+                              float carve_weight, float threshold, float out_scale, int K, float* workspace,
+                              float* loss4, float* g_scales, float* g_shifts, int n_ss, float* g_raw,
+                              const float* raw0, const float* z0, int S0, float* g_raw0, float* gmax_ws,
+                              float* gmax_fine, float* gmax_coarse, void* stream);
+
 /* ---- the launch that OPENS a graph-captured step also runs its first per-ray kernel (round 6) -----------------------
  * scade_stage_inputs / scade_gather_batch + scade_ray_points_draw (run_scade_scannet.py:638-657, :564-579) as ONE
  * launch: extra workgroups of four waves = four rays compute z_vals [N,S], the coarse sample positions pts [N,S,3] and

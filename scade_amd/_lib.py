@@ -91,6 +91,9 @@ SIGNATURES = {
     "scade_adam_step_dev": (c_int, [_P, _P, _P, _P, c_long, _P, _P]),
     "scade_adam_step2": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P]),
     "scade_mse_bwd": (c_int, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    "scade_ray_tail_train_gmax": (c_int, [_P, _P, _P, _I, _I, _I, _P, _I, _I, _P, _P, _P, _P, _P, _P, _P,
+                                          _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, c_float, c_float, c_float, _I, _P, _P, _P, _P, _I,
+                                          _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "scade_stage_inputs_points": (c_int, [_P, _P, _P, _I, _P, ctypes.c_longlong, _P, _P, _I, _P, _I, _I, _I,
                                           ctypes.c_ulonglong, ctypes.c_ulonglong, _I, _P, _P, _P, _P, _P]),
     "scade_gather_batch_points": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P, _P,

@@ -146,7 +146,8 @@ __global__ void composite_fwd_kernel(CompositeArgs a) {
 template <int NC>
 __device__ __forceinline__ void composite_bwd_ray(const CompositeArgs& a, int ray, int lane, const SampleState (&st)[NC],
                                                   double sd, double sa, const float* gw_inner,
-                                                  bool reg_g = false, float rg_r = 0.f, float rg_g = 0.f, float rg_b = 0.f) {
+                                                  bool reg_g = false, float rg_r = 0.f, float rg_g = 0.f, float rg_b = 0.f,
+                                                  float* gmax_lane = nullptr) {
   const int S = a.S;
   const float depth = (float)sd, acc = (float)sa;
   // (reg_g: the colour gradient is handed over in registers - the fused tail + loss kernel below)
@@ -196,6 +197,20 @@ __device__ __forceinline__ void composite_bwd_ray(const CompositeArgs& a, int ra
       g[2] = gb * s.w * s.sb * (1.0f - s.sb);
       g[3] = gsig;
       gout[i] = g;
+      if (gmax_lane) {
+        // max over the finite entries of what ENTERS the MLP's backward: the colour channels as they are, the
+        // density channel behind the softplus' derivative sigmoid(10 alpha_pre) = 1 - exp(-10 sigma) (the 16-bit
+        // backward's loss scale is taken from it: mlp_bwd_lp.hip lp_effective_g3 - a raw d / d sigma of 1e3 beside
+        // 1e-5 everywhere else is what the last sample's delta = 1e10 produces for a near-empty sample)
+        const float e3 = gsig * -expm1f(-10.0f * s.sigpos);
+        float m = *gmax_lane;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float x = fabsf(q < 3 ? g[q] : e3);
+          if (x < 3.0e38f) m = fmaxf(m, x);
+        }
+        *gmax_lane = m;
+      }
     }
   }
 }
@@ -699,6 +714,7 @@ struct TailTrainArgs {
   TrainLossArgs l;         // rgb / pred / g_rgb / g_pred unused (registers, LDS); g_rgb0 optional
   float* g_raw;            // [N,S,4] fine
   CompositeArgs c0;        // coarse ray: raw, z, rays_d, noise, g_raw (S0 <= 64), or raw = null
+  float* gmax_ray;         // [2][N] per-ray maxima of the effective d loss / d raw (fine | coarse), or null
 };
 template <int NC, int WAVES>
 __device__ __forceinline__ void ray_tail_train_body(TailTrainArgs a) {
@@ -792,14 +808,26 @@ __device__ __forceinline__ void ray_tail_train_body(TailTrainArgs a) {
     CompositeArgs cb = a.t.c;
     cb.g_rgb = nullptr; cb.g_disp = nullptr; cb.g_acc = nullptr; cb.g_w = nullptr; cb.g_depth = nullptr;
     cb.g_raw = a.g_raw;
-    composite_bwd_ray<NC>(cb, ray, lane, st, sd, sa, gwi, true, g_r, g_g, g_b);
+    float gm = 0.f;
+    composite_bwd_ray<NC>(cb, ray, lane, st, sd, sa, gwi, true, g_r, g_g, g_b, a.gmax_ray ? &gm : nullptr);
+    if (a.gmax_ray) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gm = fmaxf(gm, __shfl_xor(gm, o, 64));
+      if (lane == 0) a.gmax_ray[ray] = gm;
+    }
     if (WAVES == 1 && a.c0.raw) {
       // ---- backward of the coarse ray's compositing (composite_bwd_kernel<1>) ----
       const float g0_r = tl_bcast(gx, 3), g0_g = tl_bcast(gx, 4), g0_b = tl_bcast(gx, 5);
       SampleState s0[1];
       double r0, g0, b0, d0, a0;
       composite_ray<1>(a.c0, ray, lane, s0, r0, g0, b0, d0, a0);
-      composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b);
+      float gm0 = 0.f;
+      composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b, a.gmax_ray ? &gm0 : nullptr);
+      if (a.gmax_ray) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm0 = fmaxf(gm0, __shfl_xor(gm0, o, 64));
+        if (lane == 0) a.gmax_ray[a.t.c.N + ray] = gm0;
+      }
     }
   } else if (role == 1) {
     // ---- backward of the coarse ray's compositing (composite_bwd_kernel<1>); its colour gradient is the loss's
@@ -812,7 +840,13 @@ __device__ __forceinline__ void ray_tail_train_body(TailTrainArgs a) {
       SampleState s0[1];
       double r0, g0, b0, d0, a0;
       composite_ray<1>(a.c0, ray, lane, s0, r0, g0, b0, d0, a0);
-      composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b);
+      float gm0 = 0.f;
+      composite_bwd_ray<1>(a.c0, ray, lane, s0, d0, a0, nullptr, true, g0_r, g0_g, g0_b, a.gmax_ray ? &gm0 : nullptr);
+      if (a.gmax_ray) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gm0 = fmaxf(gm0, __shfl_xor(gm0, o, 64));
+        if (lane == 0) a.gmax_ray[a.t.c.N + ray] = gm0;
+      }
     }
     __syncthreads();
     // ---- the ray's loss terms (train_loss_fb_kernel's forward) ----
@@ -1355,7 +1389,7 @@ __global__ __launch_bounds__(256) void ray_tail_train_split(TailTrainArgs a) { r
 template <int NC>
 __global__ __launch_bounds__(256) void ray_tail_train_seq(TailTrainArgs a) { ray_tail_train_body<NC, 1>(a); }
 }  // namespace scade
-extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+static int ray_tail_train_impl(const float* raw, const float* z_vals, const float* rays, int ray_stride,
                                     const float* noise, int N, int S, const float* u, int u_stride, int Si,
                                     float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
                                     float* samples, float* z_std,
@@ -1364,8 +1398,10 @@ extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const
                                     int mse_masked, int carve_on, float carve_weight, float threshold, float out_scale,
                                     int K, float* workspace, float* loss4, float* g_scales, float* g_shifts, int n_ss,
                                     float* g_raw, const float* raw0, const float* z0, const float* noise0, int S0,
-                                    float* g_raw0, void* stream) {
+                                    float* g_raw0, float* gmax_ws, float* gmax_fine, float* gmax_coarse, void* stream) {
   SCADE_REQUIRE(N > 0, -2, "scade_ray_tail_train: empty batch");
+  SCADE_REQUIRE(!gmax_ws || (gmax_fine && gmax_coarse && raw0 && !noise && !noise0), -2,
+                "scade_ray_tail_train_gmax: the maxima need both rays, both slot arrays and no raw noise");
   SCADE_REQUIRE(raw && z_vals && rays && u && rgb_map && disp_map && acc_map && weights && depth_map && g_raw, -1,
                 "scade_ray_tail_train: null pointer");
   SCADE_REQUIRE(rgb0 && target && workspace && loss4, -1, "scade_ray_tail_train: null pointer (loss)");
@@ -1388,6 +1424,7 @@ extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const
   a.l.carve_weight = carve_weight; a.l.threshold = threshold; a.l.out_scale = out_scale; a.l.N = N; a.l.P = Si; a.l.K = K;
   a.l.partial = workspace; a.l.loss = loss4; a.l.g_scales = g_scales; a.l.g_shifts = g_shifts;
   a.g_raw = g_raw;
+  a.gmax_ray = gmax_ws;
   if (raw0) {
     a.c0.raw = raw0; a.c0.z = z0; a.c0.rays_d = rays + 3; a.c0.noise = noise0; a.c0.d_stride = ray_stride;
     a.c0.g_raw = g_raw0; a.c0.N = N; a.c0.S = S0;
@@ -1401,7 +1438,45 @@ extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const
     DISPATCH_NC(ray_tail_train_seq, S, dim3(grid_rays(N)), dim3(256), RAYS_PER_WG * row, s, a);
   }
   if (int e = scade_check_launch("scade_ray_tail_train")) return e;
-  return scade_launch_train_loss_fb_reduce(a.l, n_ss, s);
+  return scade_launch_train_loss_fb_reduce(a.l, n_ss, s, gmax_ws, gmax_fine, gmax_coarse);
+}
+
+extern "C" int scade_ray_tail_train(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                                    const float* noise, int N, int S, const float* u, int u_stride, int Si,
+                                    float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
+                                    float* samples, float* z_std,
+                                    const float* rgb0, const float* target, const float* hyp, const float* scales,
+                                    const float* shifts, const long long* img_i_dev, int img_i, const float* mask,
+                                    int mse_masked, int carve_on, float carve_weight, float threshold, float out_scale,
+                                    int K, float* workspace, float* loss4, float* g_scales, float* g_shifts, int n_ss,
+                                    float* g_raw, const float* raw0, const float* z0, const float* noise0, int S0,
+                                    float* g_raw0, void* stream) {
+  return ray_tail_train_impl(raw, z_vals, rays, ray_stride, noise, N, S, u, u_stride, Si, rgb_map, disp_map, acc_map, weights,
+                             depth_map, samples, z_std, rgb0, target, hyp, scales, shifts, img_i_dev, img_i, mask, mse_masked,
+                             carve_on, carve_weight, threshold, out_scale, K, workspace, loss4, g_scales, g_shifts, n_ss, g_raw,
+                             raw0, z0, noise0, S0, g_raw0, nullptr, nullptr, nullptr, stream);
+}
+
+// scade_ray_tail_train that also leaves the loss-scale maxima of the two output gradients it writes, for the 16-bit MLP
+// backward of the same step (scade_mlp_bwd_lp2_deferred's gmax_pre: its own maxima launch is then skipped): gmax_ws
+// [2 N] floats of workspace (per-ray maxima), gmax_fine / gmax_coarse [256] floats each = the slots the backward reads
+// (slot 0 = the maximum over the finite entries of the EFFECTIVE gradient - colour channels as they are, the density
+// channel times 1 - exp(-10 sigma) = sigmoid(10 alpha_pre) - the rest zero).  Needs the coarse ray and no raw noise.
+extern "C" int scade_ray_tail_train_gmax(const float* raw, const float* z_vals, const float* rays, int ray_stride,
+                                         int N, int S, const float* u, int u_stride, int Si,
+                                         float* rgb_map, float* disp_map, float* acc_map, float* weights, float* depth_map,
+                                         float* samples, float* z_std,
+                                         const float* rgb0, const float* target, const float* hyp, const float* scales,
+                                         const float* shifts, const long long* img_i_dev, int img_i, const float* mask,
+                                         int mse_masked, int carve_on, float carve_weight, float threshold, float out_scale,
+                                         int K, float* workspace, float* loss4, float* g_scales, float* g_shifts, int n_ss,
+                                         float* g_raw, const float* raw0, const float* z0, int S0, float* g_raw0,
+                                         float* gmax_ws, float* gmax_fine, float* gmax_coarse, void* stream) {
+  SCADE_REQUIRE(gmax_ws && gmax_fine && gmax_coarse, -1, "scade_ray_tail_train_gmax: null pointer");
+  return ray_tail_train_impl(raw, z_vals, rays, ray_stride, nullptr, N, S, u, u_stride, Si, rgb_map, disp_map, acc_map, weights,
+                             depth_map, samples, z_std, rgb0, target, hyp, scales, shifts, img_i_dev, img_i, mask, mse_masked,
+                             carve_on, carve_weight, threshold, out_scale, K, workspace, loss4, g_scales, g_shifts, n_ss, g_raw,
+                             raw0, z0, nullptr, S0, g_raw0, gmax_ws, gmax_fine, gmax_coarse, stream);
 }
 
 extern "C" long scade_carve_workspace_floats(int N, int P, int K, int is_joint) {

@@ -64,8 +64,25 @@ __global__ void train_loss_fb_kernel(TrainLossArgs a) {
 }
 // its one-workgroup reduce: the loss terms, and the scale / shift gradient rows - WRITTEN for all n_ss images
 // (zero except the batch's image: the caller needs no zero fill of those rows), or accumulated when n_ss = 0
-__global__ __launch_bounds__(1024) void train_loss_fb_reduce_kernel(TrainLossArgs a, int n_ss) {
+struct TlGmaxArgs { const float* ray; float* slots[2]; };
+__global__ __launch_bounds__(1024) void train_loss_fb_reduce_kernel(TrainLossArgs a, int n_ss, TlGmaxArgs gm) {
   __shared__ double red[5][16];
+  if (gm.ray) {       // the loss-scale maxima of the step's two output gradients ride in this launch (no lp_gmax launch)
+    __shared__ float gred[2][16];
+    float m0 = 0.f, m1 = 0.f;
+    for (int i = threadIdx.x; i < a.N; i += 1024) { m0 = fmaxf(m0, gm.ray[i]); m1 = fmaxf(m1, gm.ray[a.N + i]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { m0 = fmaxf(m0, __shfl_xor(m0, o, 64)); m1 = fmaxf(m1, __shfl_xor(m1, o, 64)); }
+    if ((threadIdx.x & 63) == 0) { gred[0][threadIdx.x >> 6] = m0; gred[1][threadIdx.x >> 6] = m1; }
+    __syncthreads();
+    if (threadIdx.x < 512) {
+      const int net = threadIdx.x >> 8, slot = threadIdx.x & 255;
+      float m = 0.f;
+      if (slot == 0)
+        for (int w = 0; w < 16; ++w) m = fmaxf(m, gred[net][w]);
+      gm.slots[net][slot] = m;
+    }
+  }
   double s[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
   const f32x4* p0 = reinterpret_cast<const f32x4*>(a.partial);
   const f32x4* p1 = p0 + a.N;
@@ -135,8 +152,10 @@ __global__ __launch_bounds__(1024) void train_loss_ss_reduce_kernel(TrainLossArg
 
 using namespace scade;
 
-int scade_launch_train_loss_fb_reduce(const scade::TrainLossArgs& a, int n_ss, hipStream_t s) {
-  hipLaunchKernelGGL(train_loss_fb_reduce_kernel, dim3(1), dim3(1024), 0, s, a, n_ss);
+int scade_launch_train_loss_fb_reduce(const scade::TrainLossArgs& a, int n_ss, hipStream_t s, const float* gmax_ray,
+                                      float* gmax_a, float* gmax_b) {
+  const TlGmaxArgs gm{gmax_ray, {gmax_a, gmax_b}};
+  hipLaunchKernelGGL(train_loss_fb_reduce_kernel, dim3(1), dim3(1024), 0, s, a, n_ss, gm);
   return scade_check_launch("scade_train_loss_fb");
 }
 

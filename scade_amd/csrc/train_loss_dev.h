@@ -214,4 +214,7 @@ __device__ __forceinline__ float tl_bwd_ray(const TrainLossArgs& a, int ray, int
 }  // namespace scade
 
 // launches the one-workgroup reduce of scade_train_loss_fb's partials (train_loss.hip)
-int scade_launch_train_loss_fb_reduce(const scade::TrainLossArgs& a, int n_ss, hipStream_t s);
+// gmax_ray [2][N] (nullable): per-ray maxima of the two output gradients the caller's kernel wrote - reduced into the
+// 256 loss-scale slots the 16-bit MLP backward reads (slot 0 = the maximum, the rest zero)
+int scade_launch_train_loss_fb_reduce(const scade::TrainLossArgs& a, int n_ss, hipStream_t s,
+                                      const float* gmax_ray = nullptr, float* gmax_a = nullptr, float* gmax_b = nullptr);

@@ -1395,7 +1395,7 @@ class FineTailLossFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, raw, z_vals, rays, u, n_samples, raw0, z0, rgb0, target, hyp, scales, shifts, img_i, mask,
-                mse_masked, carve_on, carve_weight, threshold, out_scale, unit):
+                mse_masked, carve_on, carve_weight, threshold, out_scale, unit, want_gmax=False):
         for t, w in ((raw, "raw"), (z_vals, "z_vals"), (raw0, "raw0"), (z0, "z_vals0"), (rgb0, "rgb0"),
                      (target, "target"), (hyp, "hypotheses")):
             check(t, "ray_tail_train: " + w)
@@ -1435,12 +1435,26 @@ class FineTailLossFn(torch.autograd.Function):
         ws, loss4 = f(8 * N), f(4)
         g_raw, g_raw0 = f(N, S, 4), f(N, S0, 4)
         t0 = KERNEL_TIMER.start() if KERNEL_TIMER is not None else None
-        call("scade_ray_tail_train", ptr(raw_c), ptr(z_c), ptr(rays_c), rstride, None, N, S, ptr(u_c), ustride,
-             n_samples, ptr(rgb), ptr(disp), ptr(acc), ptr(w), ptr(depth), ptr(samples), ptr(std),
-             ptr(rgb0_c), ptr(tgt_c), ptr(hyp_c), ptr(sc), ptr(sh), ptr(idx_t), idx, ptr(mask_c),
-             int(bool(mse_masked)), int(bool(carve_on)), float(carve_weight), float(threshold), float(out_scale),
-             K, ptr(ws), ptr(loss4), ptr(gs), ptr(gh), sc.numel(), ptr(g_raw), ptr(raw0_c), ptr(z0_c), None, S0,
-             ptr(g_raw0), stream())
+        GMAX_READY.clear()
+        if want_gmax:
+            # the loss-scale maxima of g_raw / g_raw0 come out of this launch's reduce: the joint 16-bit backward of
+            # the step (mlp_bwd.flush_deferred) finds them by the gradients' addresses and skips its own maxima launch
+            gws, gm = f(2 * N), f(2, 256)
+            call("scade_ray_tail_train_gmax", ptr(raw_c), ptr(z_c), ptr(rays_c), rstride, N, S, ptr(u_c), ustride,
+                 n_samples, ptr(rgb), ptr(disp), ptr(acc), ptr(w), ptr(depth), ptr(samples), ptr(std),
+                 ptr(rgb0_c), ptr(tgt_c), ptr(hyp_c), ptr(sc), ptr(sh), ptr(idx_t), idx, ptr(mask_c),
+                 int(bool(mse_masked)), int(bool(carve_on)), float(carve_weight), float(threshold), float(out_scale),
+                 K, ptr(ws), ptr(loss4), ptr(gs), ptr(gh), sc.numel(), ptr(g_raw), ptr(raw0_c), ptr(z0_c), S0,
+                 ptr(g_raw0), ptr(gws), ptr(gm[0]), ptr(gm[1]), stream())
+            GMAX_READY[g_raw.data_ptr()] = gm[0]
+            GMAX_READY[g_raw0.data_ptr()] = gm[1]
+        else:
+            call("scade_ray_tail_train", ptr(raw_c), ptr(z_c), ptr(rays_c), rstride, None, N, S, ptr(u_c), ustride,
+                 n_samples, ptr(rgb), ptr(disp), ptr(acc), ptr(w), ptr(depth), ptr(samples), ptr(std),
+                 ptr(rgb0_c), ptr(tgt_c), ptr(hyp_c), ptr(sc), ptr(sh), ptr(idx_t), idx, ptr(mask_c),
+                 int(bool(mse_masked)), int(bool(carve_on)), float(carve_weight), float(threshold), float(out_scale),
+                 K, ptr(ws), ptr(loss4), ptr(gs), ptr(gh), sc.numel(), ptr(g_raw), ptr(raw0_c), ptr(z0_c), None, S0,
+                 ptr(g_raw0), stream())
         if t0 is not None:
             KERNEL_TIMER.stop("ray_tail_train", t0, 0.0)
         ctx.save_for_backward(g_raw, g_raw0)
@@ -1457,7 +1471,7 @@ class FineTailLossFn(torch.autograd.Function):
                                "(Trainer.backward does)")
         g_raw, g_raw0 = ctx.saved_tensors
         need = ctx.needs_input_grad
-        return (g_raw if need[0] else None, None, None, None, None, g_raw0 if need[5] else None) + (None,) * 14
+        return (g_raw if need[0] else None, None, None, None, None, g_raw0 if need[5] else None) + (None,) * 15
 
 
 class MseFn(torch.autograd.Function):

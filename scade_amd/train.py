@@ -118,6 +118,9 @@ class Trainer:
         # between backward and optimizer; ``fused_finish = False`` keeps the separate launches (same bits: a test)
         self.fused_finish = precision in ("f32", "bf16", "bf16-s8", "f16", "f16x3")
         self._pending_reduce = None
+        # the loss-scale maxima of the 16-bit backward come out of the fine tail + loss launch (no lp_gmax launch);
+        # False: the backward computes them itself (tests compare the two)
+        self.tail_gmax = True
         self.bucket.broadcast_params(0)
 
     def draw_key(self) -> int:
@@ -189,7 +192,9 @@ class Trainer:
             loss, comps, rgb, disp, acc, w, depth, pred, std = ops.FineTailLossFn.apply(
                 raw, ret["z_vals"], rays, u, c["Ni"], raw0, ret["z_vals0"], ret["rgb0"].detach(), target_s, target_hyp,
                 self.depth_scales, self.depth_shifts, img_i, mask, c["mask_mode"] == "wild", self.carving_active(),
-                c["w"], c["thr"], share, self._one)
+                c["w"], c["thr"], share, self._one,
+                # (the formats whose saved dZ rows carry a launch-wide loss scale, when the joint backward will run)
+                prec in ("bf16-s8", "f16") and self.joint_backward and self.tail_gmax)
             if u.dim() == 1 or u.stride(0) == 0:
                 u = u.expand(rays.shape[0], c["Ni"])
             ret.update(rgb_map=rgb, disp_map=disp, acc_map=acc, depth_map=depth, weights=w, pred_hyp=pred, u=u, z_std=std)

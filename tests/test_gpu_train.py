@@ -1086,3 +1086,30 @@ def test_one_launch_step_finish_equals_the_separate_launches(dev, precision, n_r
         for j, what in enumerate(("parameters", "gradient bucket", "exp_avg", "exp_avg_sq", "exp_avg (scale / shift)"), 1):
             assert torch.equal(a[j], b[j]), f"step {i}: {what} differ"
     assert float(runs[True][-1][2].abs().max()) > 0 and runs[True][0][0] != runs[True][-1][0]
+
+
+@pytest.mark.parametrize("precision", ["bf16-s8", "f16"])
+def test_loss_scale_maxima_from_the_tail_launch_equal_the_backwards_own(dev, precision):
+    """The 16-bit backward's loss-scale maxima computed by the fine tail + loss launch (scade_ray_tail_train_gmax: per-ray
+    maxima of the effective d loss / d raw, reduced by the loss's reduce - no lp_gmax launch) against the backward's
+    own maxima launch: the same gradient bucket.  (The two evaluate sigmoid(10 alpha_pre) from sigma and from
+    alpha_pre: the maxima may differ in the last bits, the power-of-two scale only if they straddle a binade.)"""
+    from scade_amd.train import Trainer, make_scade_nets
+    n_rays, K = 160, 12
+    rays = O.synthetic_rays(n_rays, seed=51).to(dev)
+    g = torch.Generator().manual_seed(52)
+    tgt = torch.rand(n_rays, 3, generator=g).to(dev)
+    hyp = (torch.rand(K, n_rays, 1, generator=g) * 4.9 + 0.1).to(dev)
+    d = dict(t_rand=torch.rand(n_rays, 64, generator=g).to(dev), u_coarse=torch.rand(n_rays, 128, generator=g).to(dev),
+             cached_u=torch.rand(n_rays, 128, generator=g).to(dev))
+    res = []
+    for tail in (False, True):
+        coarse, fine = make_scade_nets(dev, seed=14)
+        tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=1, precision=precision)
+        tr.tail_gmax = tail
+        loss, _ = tr.step(rays, tgt, hyp, **d)
+        torch.cuda.synchronize()
+        res.append((float(loss), tr.bucket.grad.clone()))
+    assert res[0][0] == res[1][0]
+    assert torch.equal(res[0][1], res[1][1]), rel_l2(res[0][1], res[1][1])
+    assert float(res[1][1].abs().max()) > 0
