@@ -414,25 +414,37 @@ int scade_ray_tail_train_gmax(const float* raw, const float* z_vals, const float
                               const float* raw0, const float* z0, int S0, float* g_raw0, float* gmax_ws,
                               float* gmax_fine, float* gmax_coarse, void* stream);
 
-/* ---- the launch that OPENS a graph-captured step also runs its first per-ray kernel (round 6) -----------------------
- * scade_stage_inputs / scade_gather_batch + scade_ray_points_draw (run_scade_scannet.py:638-657, :564-579) as ONE
- * launch: extra workgroups of four waves = four rays compute z_vals [N,S], the coarse sample positions pts [N,S,3] and
- * the step's sampler draws u_a / u_b [N,Si] (nullable) into the captured step's static buffers - from the SOURCE ray
- * rows being staged (scade_stage_inputs_points: rays [N, ray_stride]) or from the ray rows they derive themselves from
- * the pixel ids (scade_gather_batch_points).  ``step`` is the host's count of optimizer steps taken so far (what
- * scade_ray_points_draw reads from the device state inside a captured step: these launches run outside it).  Same
- * bits as the separate launches. */
+/* ---- the launch that OPENS a graph-captured step also runs its first per-ray kernel and its weight packs (round 6) --
+ * scade_stage_inputs / scade_gather_batch + scade_ray_points_draw (run_scade_scannet.py:638-657, :564-579) +
+ * scade_mlp_pack_step / scade_mlp_pack_step_f16x3 as ONE launch, so that the captured step starts at its first MLP
+ * launch:
+ *  - extra workgroups of four waves = four rays compute z_vals [N,S], the coarse sample positions pts [N,S,3] and the
+ *    step's sampler draws u_a / u_b [N,Si] (nullable) into the captured step's static buffers - from the SOURCE ray
+ *    rows being staged (scade_stage_inputs_points: rays [N, ray_stride]; N = 0: no points) or from the ray rows they
+ *    derive themselves from the pixel ids (scade_gather_batch_points).  ``step`` is the host's count of optimizer steps
+ *    taken so far (what scade_ray_points_draw reads from the device state inside a captured step: these launches run
+ *    outside it);
+ *  - further workgroups re-pack the networks' weight blobs IN PLACE from the parameters the previous step's optimizer
+ *    launch left: pack_format -1 none, 0 exact (packed_exact = scade_mlp_pack layout, packed_t = scade_mlp_pack_t),
+ *    1 bf16 / 2 fp16 (packed_fwd = scade_mlp_pack_lp, packed_t = scade_mlp_pack_t_lp), 3 split precision
+ *    (packed_exact, packed_fwd = scade_mlp_pack_f16, packed_t = scade_mlp_pack_t_f16); host arrays of n_nets device
+ *    pointers, entries may be NULL (skipped); net_params: n_nets x 24 parameter pointers.
+ * Same bits as the separate launches. */
 int scade_stage_inputs_points(const void* const* src, void* const* dst, const long* bytes, int n,
                               long long* scalar_dst, long long scalar, float* const* tick_states, const float* rays,
                               int ray_stride, const float* t_vals, int N, int S, int lindisp,
                               unsigned long long seed, unsigned long long step, int Si, float* z_vals, float* pts,
-                              float* u_a, float* u_b, void* stream);
+                              float* u_a, float* u_b, int pack_format, int n_nets, const float* const* net_params,
+                              float* const* packed_exact, void* const* packed_fwd, void* const* packed_t,
+                              void* stream);
 int scade_gather_batch_points(const long long* pix, int N, int H, int W, const float* intrinsic, const float* c2w,
                               int c2w_stride, float near, float far, const float* image, const float* hyps, int K,
                               int corner_px, int edge_px, float* rays, float* target_s, float* target_h, float* mask,
                               long long* scalar_dst, long long scalar, float* const* tick_states,
                               const float* t_vals, int S, int lindisp, unsigned long long seed,
                               unsigned long long step, int Si, float* z_vals, float* pts, float* u_a, float* u_b,
+                              int pack_format, int n_nets, const float* const* net_params,
+                              float* const* packed_exact, void* const* packed_fwd, void* const* packed_t,
                               void* stream);
 
 /* ---- the weight gradient's reduce inside the optimizer's launch (round 6) ----------------------------------------

@@ -95,10 +95,11 @@ SIGNATURES = {
                                           _P, _P, _P, _P, _P, _P, _I, _P, _I, _I, c_float, c_float, c_float, _I, _P, _P, _P, _P, _I,
                                           _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "scade_stage_inputs_points": (c_int, [_P, _P, _P, _I, _P, ctypes.c_longlong, _P, _P, _I, _P, _I, _I, _I,
-                                          ctypes.c_ulonglong, ctypes.c_ulonglong, _I, _P, _P, _P, _P, _P]),
+                                          ctypes.c_ulonglong, ctypes.c_ulonglong, _I, _P, _P, _P, _P,
+                                          _I, _I, _P, _P, _P, _P, _P]),
     "scade_gather_batch_points": (c_int, [_P, _I, _I, _I, _P, _P, _I, c_float, c_float, _P, _P, _I, _I, _I, _P, _P, _P, _P,
                                           _P, ctypes.c_longlong, _P, _P, _I, _I, ctypes.c_ulonglong, ctypes.c_ulonglong,
-                                          _I, _P, _P, _P, _P, _P]),
+                                          _I, _P, _P, _P, _P, _I, _I, _P, _P, _P, _P, _P]),
     "scade_mlp_bwd2_deferred": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     "scade_mlp_bwd_lp2_deferred": (c_int, [_P, _I, _P, _P, _P, _P, _P, _P, _P, _P]),
     "scade_mlp_bwd_f16_2_deferred": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),

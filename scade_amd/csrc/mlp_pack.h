@@ -287,4 +287,58 @@ __device__ __forceinline__ void pack_t_f16_row(const float* const* p, void* pack
     for (int i = bx * 256 + threadIdx.x; i < 2 * 64 * 8; i += nbx * 256) packed[off_wt16(NLAYER_DGRAD) + i] = (_Float16)0.f;
 }
 
+// ---- the weight packs of a train step as numbered work items -------------------------------------------------------
+// One item = one (network, row, block) of the per-step pack (mlp_pack_step.hip runs them as its grid); the launches that
+// OPEN a graph-captured step (scade_stage_inputs_points / scade_gather_batch_points) run them as extra workgroups, so
+// the captured step itself starts at the first MLP launch.  fmt: 0 exact (exact + tr = scade_mlp_pack / _pack_t
+// layouts), 1 bf16, 2 fp16 (fwd + tr = scade_mlp_pack_lp / _pack_t_lp), 3 split precision (exact, fwd = _pack_f16,
+// tr = _pack_t_f16); blob entries may be null (skipped).
+struct PackItemsArgs {
+  const float* p[2][N_PARAM_TENSORS];
+  float* exact[2];
+  void* fwd[2];
+  void* tr[2];
+  int n_nets, fmt;
+};
+__host__ __device__ constexpr int pack_item_rows(int fmt) {
+  return fmt == 3 ? 2 * PACK_FWD_ROWS + PACK_T_ROWS : PACK_FWD_ROWS + PACK_T_ROWS;
+}
+__host__ __device__ constexpr int pack_item_count(int n_nets, int fmt) { return n_nets * pack_item_rows(fmt) * PACK_BLOCKS; }
+__device__ __forceinline__ void pack_item(const PackItemsArgs& a, int item) {      // (item is workgroup-uniform)
+  const int bx = item % PACK_BLOCKS, rw = item / PACK_BLOCKS;
+  const int rows = pack_item_rows(a.fmt);
+  const int net = rw / rows, row = rw % rows;
+  const float* const* p = a.p[net];
+  if (a.fmt == 3) {
+    if (row < PACK_FWD_ROWS) { if (a.exact[net]) pack_fwd_row(p, a.exact[net], row, bx, PACK_BLOCKS); }
+    else if (row < 2 * PACK_FWD_ROWS) { if (a.fwd[net]) pack_f16_row(p, a.fwd[net], row - PACK_FWD_ROWS, bx, PACK_BLOCKS); }
+    else if (a.tr[net]) pack_t_f16_row(p, a.tr[net], row - 2 * PACK_FWD_ROWS, bx, PACK_BLOCKS);
+  } else if (row < PACK_FWD_ROWS) {
+    if (a.fmt == 0) { if (a.exact[net]) pack_fwd_row(p, a.exact[net], row, bx, PACK_BLOCKS); }
+    else if (a.fwd[net]) { if (a.fmt == 1) pack_lp_row<true>(p, a.fwd[net], row, bx, PACK_BLOCKS); else pack_lp_row<false>(p, a.fwd[net], row, bx, PACK_BLOCKS); }
+  } else if (a.tr[net]) {
+    if (a.fmt == 0) pack_t_row(p, reinterpret_cast<float*>(a.tr[net]), row - PACK_FWD_ROWS, bx, PACK_BLOCKS);
+    else if (a.fmt == 1) pack_t_lp_row<true>(p, a.tr[net], row - PACK_FWD_ROWS, bx, PACK_BLOCKS);
+    else pack_t_lp_row<false>(p, a.tr[net], row - PACK_FWD_ROWS, bx, PACK_BLOCKS);
+  }
+}
+// host side: the arguments of a C entry -> PackItemsArgs (pack_format < 0: none; returns false on a missing pointer)
+inline bool pack_items_fill(PackItemsArgs& a, int pack_format, int n_nets, const float* const* net_params,
+                            float* const* packed_exact, void* const* packed_fwd, void* const* packed_t) {
+  a = PackItemsArgs{};
+  a.fmt = pack_format; a.n_nets = pack_format < 0 ? 0 : n_nets;
+  if (pack_format < 0) return true;
+  if (!net_params || n_nets < 1 || n_nets > 2 || pack_format > 3) return false;
+  for (int k = 0; k < n_nets; ++k) {
+    for (int i = 0; i < N_PARAM_TENSORS; ++i) {
+      if (!net_params[k * N_PARAM_TENSORS + i]) return false;
+      a.p[k][i] = net_params[k * N_PARAM_TENSORS + i];
+    }
+    a.exact[k] = packed_exact ? packed_exact[k] : nullptr;
+    a.fwd[k] = packed_fwd ? packed_fwd[k] : nullptr;
+    a.tr[k] = packed_t ? packed_t[k] : nullptr;
+  }
+  return true;
+}
+
 }  // namespace scade

@@ -3,6 +3,7 @@
 // default flags (run_scade_scannet.py:469, :888): no weight decay, no amsgrad.
 #include "common.h"
 #include "ray_points_dev.h"
+#include "mlp_pack.h"
 
 namespace scade {
 __global__ void adam_step_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -105,8 +106,16 @@ struct StageArgs {
   // the SOURCE ray rows (pts.rays): the step's first per-ray kernel rides in the launch that stages its inputs
   RayPointsArgs pts;
   int points_block0;
+  // ... and workgroups [pack_block0, points_block0 or gridDim.x) the step's weight packs (mlp_pack.h pack_item)
+  PackItemsArgs pack;
+  int pack_block0;
 };
 __global__ void stage_inputs_kernel(StageArgs a) {
+  if (a.pack_block0 >= 0 && (int)blockIdx.x >= a.pack_block0 &&
+      (a.points_block0 < 0 || (int)blockIdx.x < a.points_block0)) {
+    pack_item(a.pack, (int)blockIdx.x - a.pack_block0);
+    return;
+  }
   if (a.points_block0 >= 0 && (int)blockIdx.x >= a.points_block0) {
     const int ray = ((int)blockIdx.x - a.points_block0) * RAYS_PER_WG + (int)(threadIdx.x >> 6);
     if (ray >= a.pts.N) return;
@@ -137,7 +146,7 @@ __global__ void stage_inputs_kernel(StageArgs a) {
 
 static int stage_inputs_impl(const void* const* src, void* const* dst, const long* bytes, int n,
                              long long* scalar_dst, long long scalar, float* const* tick_states,
-                             const scade::RayPointsArgs* pts, void* stream) {
+                             const scade::RayPointsArgs* pts, const scade::PackItemsArgs* pack, void* stream) {
   SCADE_REQUIRE(n >= 0 && n <= scade::STAGE_MAX, -2, "scade_stage_inputs: 0..%d copies per launch", scade::STAGE_MAX);
   SCADE_REQUIRE(n == 0 || (src && dst && bytes), -1, "scade_stage_inputs: null pointer");
   scade::StageArgs a{};
@@ -159,9 +168,15 @@ static int stage_inputs_impl(const void* const* src, void* const* dst, const lon
   a.scalar_dst = scalar_dst;
   a.scalar = scalar;
   if (tick_states) { a.tick[0] = tick_states[0]; a.tick[1] = tick_states[1]; }
-  if (blocks == 0 && !scalar_dst && !a.tick[0] && !a.tick[1] && !pts) return 0;
+  if (blocks == 0 && !scalar_dst && !a.tick[0] && !a.tick[1] && !pts && !(pack && pack->n_nets > 0)) return 0;
   if (blocks == 0) blocks = 1;
   a.points_block0 = -1;
+  a.pack_block0 = -1;
+  if (pack && pack->n_nets > 0) {
+    a.pack = *pack;
+    a.pack_block0 = blocks;
+    blocks += scade::pack_item_count(pack->n_nets, pack->fmt);
+  }
   if (pts && pts->N > 0) {
     a.pts = *pts;
     a.points_block0 = blocks;
@@ -173,7 +188,7 @@ static int stage_inputs_impl(const void* const* src, void* const* dst, const lon
 
 extern "C" int scade_stage_inputs(const void* const* src, void* const* dst, const long* bytes, int n,
                                   long long* scalar_dst, long long scalar, float* const* tick_states, void* stream) {
-  return stage_inputs_impl(src, dst, bytes, n, scalar_dst, scalar, tick_states, nullptr, stream);
+  return stage_inputs_impl(src, dst, bytes, n, scalar_dst, scalar, tick_states, nullptr, nullptr, stream);
 }
 
 // scade_stage_inputs + scade_ray_points_draw (host step index) of the ray rows ``rays`` [N, ray_stride] - the rows being
@@ -182,7 +197,13 @@ extern "C" int scade_stage_inputs_points(const void* const* src, void* const* ds
                                          long long* scalar_dst, long long scalar, float* const* tick_states,
                                          const float* rays, int ray_stride, const float* t_vals, int N, int S,
                                          int lindisp, unsigned long long seed, unsigned long long step, int Si,
-                                         float* z_vals, float* pts, float* u_a, float* u_b, void* stream) {
+                                         float* z_vals, float* pts, float* u_a, float* u_b, int pack_format, int n_nets,
+                                         const float* const* net_params, float* const* packed_exact,
+                                         void* const* packed_fwd, void* const* packed_t, void* stream) {
+  scade::PackItemsArgs pk;
+  SCADE_REQUIRE(scade::pack_items_fill(pk, pack_format, n_nets, net_params, packed_exact, packed_fwd, packed_t), -1,
+                "scade_stage_inputs_points: pack arguments (format 0..3, one or two networks, 24 parameter pointers each)");
+  if (N <= 0) return stage_inputs_impl(src, dst, bytes, n, scalar_dst, scalar, tick_states, nullptr, &pk, stream);
   SCADE_REQUIRE(N <= 0 || (rays && t_vals && z_vals), -1, "scade_stage_inputs_points: null pointer");
   SCADE_REQUIRE(ray_stride >= 8 && S >= 1 && Si >= 0, -2, "scade_stage_inputs_points: ray_stride >= 8, S >= 1, Si >= 0 required");
   SCADE_REQUIRE(Si > 0 || (!u_a && !u_b), -2, "scade_stage_inputs_points: sampler draws requested with Si = 0");
@@ -190,7 +211,7 @@ extern "C" int scade_stage_inputs_points(const void* const* src, void* const* ds
   p.rays = rays; p.t_vals = t_vals; p.z_vals = z_vals; p.pts = pts; p.N = N; p.S = S; p.ray_stride = ray_stride;
   p.lindisp = lindisp; p.draw = 1; p.seed_lo = (unsigned)seed; p.seed_hi = (unsigned)(seed >> 32); p.step = step;
   p.u_a = u_a; p.u_b = u_b; p.Si = Si;
-  return stage_inputs_impl(src, dst, bytes, n, scalar_dst, scalar, tick_states, &p, stream);
+  return stage_inputs_impl(src, dst, bytes, n, scalar_dst, scalar, tick_states, &p, &pk, stream);
 }
 
 static int adam_blocks(long n) { return (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048); }

@@ -18,6 +18,7 @@
 #include "ray_points_dev.h"
 #include "train_loss_dev.h"
 #include "mlp_layout.h"
+#include "mlp_pack.h"
 
 namespace scade {
 
@@ -1786,9 +1787,17 @@ struct GatherBatchArgs {
   // derives itself with gen_ray_item's arithmetic (nobody waits for the row another workgroup writes)
   RayPointsArgs pts;
   int points_block0;
+  // ... and workgroups [pack_block0, points_block0 or gridDim.x) the step's weight packs (mlp_pack.h pack_item)
+  PackItemsArgs pack;
+  int pack_block0;
 };
 __global__ void gather_batch_kernel(GatherBatchArgs b) {
   const GenRaysArgs& a = b.g;
+  if (b.pack_block0 >= 0 && (int)blockIdx.x >= b.pack_block0 &&
+      (b.points_block0 < 0 || (int)blockIdx.x < b.points_block0)) {
+    pack_item(b.pack, (int)blockIdx.x - b.pack_block0);
+    return;
+  }
   if (b.points_block0 >= 0 && (int)blockIdx.x >= b.points_block0) {
     const int n = ((int)blockIdx.x - b.points_block0) * RAYS_PER_WG + (int)(threadIdx.x >> 6);
     if (n >= a.N) return;
@@ -1804,7 +1813,7 @@ __global__ void gather_batch_kernel(GatherBatchArgs b) {
     ray_points_ray(b.pts, n, lane_id(), c.T[0], c.T[1], c.T[2], d[0], d[1], d[2], a.near, a.far);
     return;
   }
-  const int nblk = b.points_block0 >= 0 ? b.points_block0 : (int)gridDim.x;
+  const int nblk = b.pack_block0 >= 0 ? b.pack_block0 : (b.points_block0 >= 0 ? b.points_block0 : (int)gridDim.x);
   if (blockIdx.x == 0 && threadIdx.x == 0 && b.scalar_dst) *b.scalar_dst = b.scalar;
   if (blockIdx.x == 0 && threadIdx.x == 64 && b.tick[0]) adam_tick(b.tick[0]);
   if (blockIdx.x == 0 && threadIdx.x == 128 && b.tick[1]) adam_tick(b.tick[1]);
@@ -1845,7 +1854,8 @@ static int gather_batch_impl(const long long* pix, int N, int H, int W, const fl
                              const float* c2w, int c2w_stride, float near, float far, const float* image,
                              const float* hyps, int K, int corner_px, int edge_px, float* rays,
                              float* target_s, float* target_h, float* mask, long long* scalar_dst,
-                             long long scalar, float* const* tick_states, const scade::RayPointsArgs* pts, void* stream) {
+                             long long scalar, float* const* tick_states, const scade::RayPointsArgs* pts,
+                             const scade::PackItemsArgs* pack, void* stream) {
   SCADE_REQUIRE(N >= 0 && H > 0 && W > 0 && K >= 0, -2, "scade_gather_batch: bad sizes");
   SCADE_REQUIRE(N == 0 || (pix && intrinsic && c2w && c2w_stride >= 4), -1, "scade_gather_batch: pix / intrinsic / c2w missing");
   SCADE_REQUIRE(!hyps == !target_h || K == 0, -1, "scade_gather_batch: hyps and target_h go together");
@@ -1862,6 +1872,12 @@ static int gather_batch_impl(const long long* pix, int N, int H, int W, const fl
   if (grid < 1) grid = 1;
   if (grid > 4096) grid = 4096;
   b.points_block0 = -1;
+  b.pack_block0 = -1;
+  if (pack && pack->n_nets > 0) {
+    b.pack = *pack;
+    b.pack_block0 = (int)grid;
+    grid += scade::pack_item_count(pack->n_nets, pack->fmt);
+  }
   if (pts && N > 0) {
     b.pts = *pts;
     b.points_block0 = (int)grid;
@@ -1877,7 +1893,7 @@ extern "C" int scade_gather_batch(const long long* pix, int N, int H, int W, con
                                   float* target_s, float* target_h, float* mask, long long* scalar_dst,
                                   long long scalar, float* const* tick_states, void* stream) {
   return gather_batch_impl(pix, N, H, W, intrinsic, c2w, c2w_stride, near, far, image, hyps, K, corner_px, edge_px, rays,
-                           target_s, target_h, mask, scalar_dst, scalar, tick_states, nullptr, stream);
+                           target_s, target_h, mask, scalar_dst, scalar, tick_states, nullptr, nullptr, stream);
 }
 
 // scade_gather_batch + scade_ray_points_draw of the gathered rays (host step index: this launch runs OUTSIDE the
@@ -1889,7 +1905,12 @@ extern "C" int scade_gather_batch_points(const long long* pix, int N, int H, int
                                          float* target_s, float* target_h, float* mask, long long* scalar_dst,
                                          long long scalar, float* const* tick_states, const float* t_vals, int S,
                                          int lindisp, unsigned long long seed, unsigned long long step, int Si,
-                                         float* z_vals, float* pts, float* u_a, float* u_b, void* stream) {
+                                         float* z_vals, float* pts, float* u_a, float* u_b, int pack_format, int n_nets,
+                                         const float* const* net_params, float* const* packed_exact,
+                                         void* const* packed_fwd, void* const* packed_t, void* stream) {
+  scade::PackItemsArgs pk;
+  SCADE_REQUIRE(scade::pack_items_fill(pk, pack_format, n_nets, net_params, packed_exact, packed_fwd, packed_t), -1,
+                "scade_gather_batch_points: pack arguments (format 0..3, one or two networks, 24 parameter pointers each)");
   SCADE_REQUIRE(t_vals && z_vals && S >= 1 && Si >= 0, -2, "scade_gather_batch_points: t_vals, z_vals, S >= 1, Si >= 0 required");
   SCADE_REQUIRE(Si > 0 || (!u_a && !u_b), -2, "scade_gather_batch_points: sampler draws requested with Si = 0");
   scade::RayPointsArgs a{};
@@ -1897,5 +1918,5 @@ extern "C" int scade_gather_batch_points(const long long* pix, int N, int H, int
   a.draw = 1; a.seed_lo = (unsigned)seed; a.seed_hi = (unsigned)(seed >> 32); a.step = step;
   a.u_a = u_a; a.u_b = u_b; a.Si = Si;
   return gather_batch_impl(pix, N, H, W, intrinsic, c2w, c2w_stride, near, far, image, hyps, K, corner_px, edge_px, rays,
-                           target_s, target_h, mask, scalar_dst, scalar, tick_states, &a, stream);
+                           target_s, target_h, mask, scalar_dst, scalar, tick_states, &a, &pk, stream);
 }

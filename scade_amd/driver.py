@@ -140,7 +140,11 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
         gt = GraphedTrainer(tr, b - a, t_hyp.shape[1], n_total=N_rand, with_mask=masked)
         gather = ops.ResidentBatchGather(Hh, Ww, t_img, t_hyp, t_pose, t_intr, near, far, gt.rays, gt.tgt, gt.hyp,
                                          gt.mask, corner_px=20 if mask_corners else 0, edge_px=10 if mask_edges else 0,
-                                         scalar_dst=gt.img_i, tick_states=(tr.opt, tr.opt_ss), points=gt.coarse_pre)
+                                         scalar_dst=gt.img_i, tick_states=(tr.opt, tr.opt_ss), points=gt.coarse_pre,
+                                         packs=gt.packs if gt.coarse_pre is not None else None)
+        if gt.packs is not None and gt.coarse_pre is not None:
+            gt.opening_packs = True       # (this loop's opening launch is the gather: it packs)
+            gt.packs.prepare()            # the blobs exist before the first gather launch re-packs them
     trace, t0, t_aux, i0 = [], time.time(), 0.0, start     # t_aux: validation renders + checkpoint writes, not loop time
     tail_losses = max(0, min(int(tail_losses), num_iterations - start - loop_warmup - 1))
     tail_buf = torch.zeros(max(1, tail_losses), device=dev)

@@ -73,6 +73,16 @@ class GraphedTrainer:
         # launch that opens it (ops.stage_inputs / ops.ResidentBatchGather ``points=``), not by a launch of the
         # captured step: one launch less per iteration, same kernel body, same bits.  ``coarse_pre = None`` (set it
         # before the first step) keeps scade_ray_points_draw inside the graph.
+        # ... and so are the step's weight packs (ops.StepPacks: re-packed in place from what the previous replay's
+        # optimizer launch left); ``packs = None`` keeps scade_mlp_pack_step inside the graph
+        fmt = {"f32": "f32", "bf16": "bf16", "bf16-s8": "bf16", "f16": "f16", "f16x3": "f16x3"}.get(tr.coarse.train_precision)
+        self.packs = ops.StepPacks([tr.coarse, tr.fine], fmt) if (fmt and tr.fine.train_precision == tr.coarse.train_precision) else None
+        # does the launch in front of every replay pack?  ``step()`` does; a caller that drives ``step_staged()`` with its
+        # own opening launch sets this when that launch packs (driver.train_scene: ResidentBatchGather(packs=...)) - a
+        # replay of a graph captured WITHOUT its own pack behind an opening launch that does not pack would run on the
+        # previous step's blobs, so the flag is part of what a capture is valid for
+        self.opening_packs = False
+        self._cap_packs = None
         self.coarse_pre = None
         if self.draws is None and not c["joint"]:
             self.coarse_pre = ops.CoarsePoints(n_rays, c["Ns"], c["Ni"], c["lindisp"], dev, key=self._points_key,
@@ -134,6 +144,12 @@ class GraphedTrainer:
             dst.copy_(src)
         tr.opt.steps, tr.opt_ss.steps = steps
         ops.PARAM_EPOCH += 1
+        self._cap_packs = self.packs is not None and self.opening_packs
+        if self._cap_packs:
+            # the blobs from the rolled-back parameters, outside the capture, marked fresh: the captured body's own pack
+            # finds nothing to do and the graph starts at the first MLP launch; every replay's blobs come from the launch
+            # in front of it (``packs=`` of ops.stage_inputs / ops.ResidentBatchGather)
+            self.packs.prepare()
         self._captured = (tr.scaleshift_active(), tr.carving_active())
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph, capture_error_mode=_capture_mode()):
@@ -161,8 +177,11 @@ class GraphedTrainer:
         if self.draws is not None:
             pairs += [(t_rand, self.draws[0]), (u_coarse, self.draws[1]), (cached_u, self.draws[2])]
         # ... and the optimizers' device-resident step scalars advance in the same launch (no tick launch in the graph)
+        self.opening_packs = self.packs is not None
+        if self.packs is not None and self.graph is None:
+            self.packs.prepare()          # (the blobs must exist before the first opening launch re-packs them)
         ops.stage_inputs(pairs, scalar, tick=self.tick_states(), points=self.coarse_pre,
-                         rays=rays if self.coarse_pre is not None else None)
+                         rays=rays if self.coarse_pre is not None else None, packs=self.packs)
         return self.step_staged()
 
     def tick_states(self):
@@ -178,6 +197,7 @@ class GraphedTrainer:
         tr = self.tr
         with_ss = tr.scaleshift_active()
         if self.graph is None or (with_ss, tr.carving_active()) != self._captured or \
+                self._cap_packs != (self.packs is not None and self.opening_packs) or \
                 (self._key is not None and self._key != tr.draw_key()):
             self._capture()      # first step, the warm-start (:973) / scale-shift freeze point (:996) was crossed, or
             #                      the draws were re-seeded (the key is baked into the captured launches)

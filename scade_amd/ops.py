@@ -558,7 +558,42 @@ class CoarsePoints:
                 ptr(self.z), ptr(self.pts), ptr(self.u_a), ptr(self.u_b))
 
 
-def stage_inputs(pairs, scalar=None, tick=None, points=None, rays=None) -> None:
+class StepPacks:
+    """The weight packs of a graph-captured step done by the launch in front of it (``stage_inputs`` / ``ResidentBatchGather``
+    ``packs=``): the training blobs of format ``fmt`` ("f32" | "bf16" | "f16" | "f16x3") of ``nets`` are re-packed IN
+    PLACE from the current parameters.  ``prepare()`` allocates missing blobs, packs them once and marks them fresh
+    (call it right before a capture: the captured body's own pack then finds nothing to do)."""
+
+    def __init__(self, nets, fmt: str):
+        self.nets, self.fmt = list(nets), fmt
+        self.code = {"f32": 0, "bf16": 1, "f16": 2, "f16x3": 3}[fmt]
+
+    def prepare(self):
+        (mlp_pack_step_f16x3 if self.fmt == "f16x3" else (lambda nets: mlp_pack_step(nets, self.fmt)))(self.nets)
+
+    def tail_args(self):
+        plist, ex, fw, tr = [], [], [], []
+        for net in self.nets:
+            d = net.__dict__
+            plist += [p.data_ptr() for p in net.ordered_params()]
+            if self.code == 3:
+                be, bf, bt = d.get("_packed"), d.get("_packed_f16"), d.get("_packed_t_f16")
+            elif self.code == 0:
+                be, bf, bt = d.get("_packed"), None, d.get("_packed_t")
+            else:
+                be, bf, bt = None, d.get("_packed_lp"), d.get("_packed_t_lp")
+            if (be is None and bf is None) or bt is None:
+                raise RuntimeError("StepPacks: the networks' training blobs do not exist yet (prepare() first)")
+            ex.append(be); fw.append(bf); tr.append(bt)
+        P = ctypes.c_void_p
+        vp = lambda ts: ctypes.cast((P * len(ts))(*[None if t is None else t.data_ptr() for t in ts]), P)
+        return (self.code, len(self.nets), ctypes.cast((P * len(plist))(*plist), P), vp(ex), vp(fw), vp(tr))
+
+
+_NO_PACK = (-1, 0, None, None, None, None)
+
+
+def stage_inputs(pairs, scalar=None, tick=None, points=None, rays=None, packs=None) -> None:
     """``dst.copy_(src)`` for up to eight (src, dst) pairs - and ``scalar = (int64 tensor, value)``: one 8-byte
     store; ``tick = [state, state | None]``: the device-resident scalars of up to two fused optimizers advanced by
     one step - in ONE launch (scade_stage_inputs): the prologue of a graph-captured step.  Pairs that the
@@ -585,19 +620,24 @@ def stage_inputs(pairs, scalar=None, tick=None, points=None, rays=None) -> None:
                 raise ValueError("stage_inputs: tick entries are the float32[16] device states of FusedAdam")
         t2 = (list(tick) + [None])[:2]
         ticks = ctypes.cast((ctypes.c_void_p * 2)(*[None if t is None else t.data_ptr() for t in t2]), ctypes.c_void_p)
-    if not src_p and sd is None and ticks is None and points is None:
+    if not src_p and sd is None and ticks is None and points is None and packs is None:
         return
     n = len(src_p)
     vp = lambda v: ctypes.cast((ctypes.c_void_p * max(n, 1))(*v), ctypes.c_void_p)
-    if points is not None:
-        # ``points`` (a CoarsePoints) + ``rays`` (the SOURCE ray rows of this step): ray_points_draw rides in the launch
-        rr, stride = _rows(rays, "stage_inputs: rays")
-        if rr.shape[0] != points.N or rr.shape[1] < 8:
-            raise ValueError("stage_inputs: rays must be the step's [N, >= 8] ray rows")
-        t = points.tail_args()
+    if points is not None or packs is not None:
+        # ``points`` (a CoarsePoints) + ``rays`` (the SOURCE ray rows of this step): ray_points_draw rides in the launch;
+        # ``packs`` (a StepPacks): so do the step's weight packs
+        pk = _NO_PACK if packs is None else packs.tail_args()
+        if points is not None:
+            rr, stride = _rows(rays, "stage_inputs: rays")
+            if rr.shape[0] != points.N or rr.shape[1] < 8:
+                raise ValueError("stage_inputs: rays must be the step's [N, >= 8] ray rows")
+            t = points.tail_args()
+            pa = (ptr(rr), stride, t[0], points.N) + tuple(t[1:])
+        else:
+            pa = (None, 8, None, 0, 1, 0, 0, 0, 0, None, None, None, None)
         call("scade_stage_inputs_points", vp(src_p), vp(dst_p),
-             ctypes.cast((ctypes.c_long * max(n, 1))(*nbytes), ctypes.c_void_p), n, sd, sv, ticks, ptr(rr), stride, t[0],
-             points.N, *t[1:], stream())
+             ctypes.cast((ctypes.c_long * max(n, 1))(*nbytes), ctypes.c_void_p), n, sd, sv, ticks, *pa, *pk, stream())
         return
     call("scade_stage_inputs", vp(src_p), vp(dst_p), ctypes.cast((ctypes.c_long * max(n, 1))(*nbytes), ctypes.c_void_p), n,
          sd, sv, ticks, stream())
@@ -1040,7 +1080,7 @@ class ResidentBatchGather:
     scale / shift optimizer after its freeze point)."""
 
     def __init__(self, H, W, images, hyps, poses, intrinsics, near, far, rays, target_s, target_h, mask=None,
-                 corner_px=0, edge_px=0, scalar_dst=None, tick_states=None, points=None):
+                 corner_px=0, edge_px=0, scalar_dst=None, tick_states=None, points=None, packs=None):
         V = images.shape[0]
         for t, what in ((images, "images"), (hyps, "hyps"), (poses, "poses"), (intrinsics, "intrinsics")):
             check(t, "ResidentBatchGather: " + what)
@@ -1075,7 +1115,9 @@ class ResidentBatchGather:
         # ``points`` (a CoarsePoints of this batch size): the captured step's coarse samples are computed in this launch
         if points is not None and points.N != self.N:
             raise ValueError("ResidentBatchGather: the coarse-sample buffers are for another batch size")
-        self._points = points
+        if packs is not None and points is None:
+            raise ValueError("ResidentBatchGather: packs ride with the coarse points (points=)")
+        self._points, self._packs = points, packs
         self._fn = getattr(load(), "scade_gather_batch_points" if points is not None else "scade_gather_batch")
 
     def _tick_tensors(self):
@@ -1110,7 +1152,8 @@ class ResidentBatchGather:
         rc = self._fn(pix.data_ptr() + 8 * offset, *self._fixed_a, self._intr[0] + view * self._intr[1],
                       self._pose[0] + view * self._pose[1], *self._fixed_b, self._img[0] + view * self._img[1],
                       self._hyp[0] + view * self._hyp[1], *self._fixed_c, view, self._ticks[bool(tick_second)],
-                      *(() if self._points is None else self._points.tail_args()), stream())
+                      *(() if self._points is None else
+                        self._points.tail_args() + (_NO_PACK if self._packs is None else self._packs.tail_args())), stream())
         if rc != 0:
             raise RuntimeError(f"scade_gather_batch failed (code {rc}): {last_error()}")
 

@@ -198,3 +198,58 @@ def test_graphed_driver_crosses_the_freeze_point_and_resumes(dev, tmp_path):
     r2 = driver.train_scene(data, str(tmp_path / "ck"), "t", "mem", num_iterations=12, **kw)
     assert r2["trainer"].it == 12 and torch.equal(r2["trainer"].depth_scales, ss8), "frozen rows restored and left alone"
     assert np.isfinite(r2["trace"][-1][1])
+
+
+@pytest.mark.parametrize("fmt", ["f32", "bf16", "f16x3"])
+def test_opening_launch_computes_the_coarse_samples_and_the_weight_packs(dev, fmt):
+    """scade_gather_batch_points / scade_stage_inputs_points (round 6: the launch in front of a captured step also runs
+    ray_points_draw on the batch and re-packs the networks' weight blobs in place) against the separate launches -
+    scade_gather_batch / scade_stage_inputs, scade_ray_points_draw with the host's step index, scade_mlp_pack_step /
+    _f16x3: every buffer bit for bit."""
+    from scade_amd import ops
+    from scade_amd.train import make_scade_nets
+    data = _memory_scene()
+    imgs, poses, Hh, Ww, intr, hyps = data[0], data[3], data[4], data[5], data[6], data[12]
+    V, K, N, S, Si = hyps.shape[0], hyps.shape[1], 100, 64, 128
+    t_img = torch.as_tensor(imgs[:V], device=dev).contiguous()
+    t_hyp = torch.as_tensor(hyps, device=dev).contiguous()
+    t_pose = torch.as_tensor(poses[:V], device=dev).contiguous()
+    t_intr = torch.as_tensor(intr[:V], device=dev).contiguous()
+    perm = torch.randperm(Hh * Ww, device=dev, generator=torch.Generator(device=dev).manual_seed(6))
+    coarse, fine = make_scade_nets(dev, seed=21)
+    prec = {"f32": "f32", "bf16": "bf16", "f16x3": "f16x3"}[fmt]
+    coarse.train_precision = fine.train_precision = prec
+    blob_names = {"f32": ("_packed", "_packed_t"), "bf16": ("_packed_lp", "_packed_t_lp"),
+                  "f16x3": ("_packed", "_packed_f16", "_packed_t_f16")}[fmt]
+    packs = ops.StepPacks([coarse, fine], fmt)
+    packs.prepare()
+    want_blobs = [getattr(n, b).clone() for n in (coarse, fine) for b in blob_names]
+    key, step = 0x1234_5678_9ABC_DEF1, 37
+    pts = ops.CoarsePoints(N, S, Si, False, dev, key=lambda: key, step=lambda: step)
+    rays, tgt, th = torch.zeros(N, 11, device=dev), torch.zeros(N, 3, device=dev), torch.zeros(K, N, 1, device=dev)
+    g = ops.ResidentBatchGather(Hh, Ww, t_img, t_hyp, t_pose, t_intr, 0.1, 5.0, rays, tgt, th, points=pts, packs=packs)
+    for n in (coarse, fine):                                  # poison the blobs: the launch must rewrite every byte it owns
+        for b in blob_names:
+            getattr(n, b).fill_(7)
+    off, view = 11, 1
+    g(perm, off, view)
+    r2, t2, h2 = torch.zeros_like(rays), torch.zeros_like(tgt), torch.zeros_like(th)
+    ops.gather_batch(perm[off:off + N].contiguous(), Hh, Ww, t_intr[view], t_pose[view], 0.1, 5.0, t_img[view], t_hyp[view],
+                     r2, t2, h2)
+    assert torch.equal(rays, r2) and torch.equal(tgt, t2) and torch.equal(th, h2)
+    z, p, ua, ub = ops.ray_points_draw(r2, S, False, ops.Draws(key, step), Si)
+    assert torch.equal(pts.z, z) and torch.equal(pts.pts, p) and torch.equal(pts.u_a, ua) and torch.equal(pts.u_b, ub)
+    got_blobs = [getattr(n, b) for n in (coarse, fine) for b in blob_names]
+    for a, b in zip(got_blobs, want_blobs):
+        assert torch.equal(a, b), "a weight blob differs from scade_mlp_pack_step's"
+    # the staging form: the same coarse samples from the SOURCE rows, the same packs
+    for n in (coarse, fine):
+        for b in blob_names:
+            getattr(n, b).fill_(9)
+    pts.z.zero_(); pts.pts.zero_(); pts.u_a.zero_(); pts.u_b.zero_()
+    dst = torch.zeros_like(r2)
+    ops.stage_inputs([(r2, dst)], points=pts, rays=r2, packs=packs)
+    assert torch.equal(dst, r2)
+    assert torch.equal(pts.z, z) and torch.equal(pts.pts, p) and torch.equal(pts.u_a, ua) and torch.equal(pts.u_b, ub)
+    for a, b in zip([getattr(n, b) for n in (coarse, fine) for b in blob_names], want_blobs):
+        assert torch.equal(a, b)
