@@ -223,6 +223,11 @@ def test_opening_launch_computes_the_coarse_samples_and_the_weight_packs(dev, fm
                   "f16x3": ("_packed", "_packed_f16", "_packed_t_f16")}[fmt]
     packs = ops.StepPacks([coarse, fine], fmt)
     packs.prepare()
+    for n in (coarse, fine):                                  # (bytes no pack owns - slack - are 7 on both sides)
+        for b in blob_names:
+            getattr(n, b).fill_(7)
+    ops.PARAM_EPOCH += 1
+    packs.prepare()                                           # the separate launch, in place
     want_blobs = [getattr(n, b).clone() for n in (coarse, fine) for b in blob_names]
     key, step = 0x1234_5678_9ABC_DEF1, 37
     pts = ops.CoarsePoints(N, S, Si, False, dev, key=lambda: key, step=lambda: step)
@@ -245,7 +250,7 @@ def test_opening_launch_computes_the_coarse_samples_and_the_weight_packs(dev, fm
     # the staging form: the same coarse samples from the SOURCE rows, the same packs
     for n in (coarse, fine):
         for b in blob_names:
-            getattr(n, b).fill_(9)
+            getattr(n, b).fill_(7)
     pts.z.zero_(); pts.pts.zero_(); pts.u_a.zero_(); pts.u_b.zero_()
     dst = torch.zeros_like(r2)
     ops.stage_inputs([(r2, dst)], points=pts, rays=r2, packs=packs)

@@ -1,5 +1,5 @@
 #!/bin/bash
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06i; mkdir -p $O
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r06j; mkdir -p $O
 cd $R
 (timeout 1500 python -m pytest tests -m gpu -q 2>&1 | tail -40) > $O/gputests.txt
 timeout 400 python bench.py --no-cpu-baseline --no-image --no-rayops > $O/bench_quick.json 2> $O/bench_quick.err
