@@ -101,16 +101,8 @@ __device__ unsigned long long fwd_sect[4 * 16];        // [kernel x wg]: wave 0'
 #else
 #define FS_STAMP(I)
 #endif
-// NW: wavefronts per workgroup.  4 (the throughput shape): a wave owns TWO n-tiles = 64 output features.  8 (round 6;
-// PT = 1 only): a wave owns ONE n-tile, so a 32-point workgroup puts two waves on every SIMD - for launches that give a CU
-// at most two such workgroups (the coarse pass of a 128-ray shard: 8,192 points = ONE 32-point workgroup per CU, i.e.
-// one wave per SIMD issuing its dependent MFMA chain alone).  Same arithmetic per output element (the k order of a
-// dot product does not depend on who owns the n-tile): same bits.
-template <int MODE, bool SAVE, int PT, int NW = 4>
-__global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
-  static_assert(NW == 4 || (NW == 8 && PT == 1), "eight waves: the 32-point tile only");
-  constexpr int NT = 8 / NW;           // n-tiles of 32 features per wave in the 256-wide layers
-  constexpr int NTHR = NW * 64;
+template <int MODE, bool SAVE, int PT>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   constexpr int TM = tile_pts(PT);     // points of this workgroup (shadows the 64-point default)
   extern __shared__ __attribute__((aligned(16))) float lds[];
   float* hbuf = lds;
@@ -130,7 +122,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     // the view direction and meet zero weights in layers 0/5.
     const int nvalid = min(TM, P - p0);
     const f32x4* src = reinterpret_cast<const f32x4*>(a.in + (size_t)p0 * 60);
-    for (int i = tid; i < TM * 15; i += NTHR) {
+    for (int i = tid; i < TM * 15; i += 256) {
       const int row = i / 15;
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (row < nvalid) v = src[i];
@@ -175,7 +167,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
   __syncthreads();
   if (SAVE) {   // emb rows [64]: gamma(57) | 0 0 0 | view(3) | 0   (coalesced 256-B rows, 16-byte chunks)
     float* eo = a.acts + acts_emb_off(P);
-    for (int i = tid; i < TM * 16; i += NTHR) {
+    for (int i = tid; i < TM * 16; i += 256) {
       const int row = i >> 4, c4 = i & 15;
       const int pt = p0 + row;
       if (pt < P) {
@@ -194,15 +186,12 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     }
   }
 
-  f32x16 acc[NT][PT];
-  f32x4 an[2], bias[NT][4];
-  const int nt0 = wave * NT;
-  // the views layer has four n-tiles: one per wave of the first four (eight waves: the others idle through it and must
-  // not prefetch past the blob)
-  const int wv_views = NW == 4 ? wave : min(wave, 3);
+  f32x16 acc[2][PT];
+  f32x4 an[2], bias[2][4];
+  const int nt0 = wave * 2;
   // weight base of this wave for MFMA layer L (views layer: one n-tile per wave)
 #define WBASE(L) (reinterpret_cast<const f32x4*>(pk + off_w(L)) + \
-                  ((L) == L_VIEWS ? wv_views : nt0) * kb_total(L) * 64)
+                  ((L) == L_VIEWS ? wave : nt0) * kb_total(L) * 64)
 
   // -DFWD_TRACE (a variant build: SCADE_AB_FLAGS, scade_amd/build.py; tools/probe_fwd_trace.py): core-clock stamps of
   // two workgroups of the launch's third round at the phase boundaries of layers 1..4 -
@@ -217,21 +206,18 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 #define PTS_LAYER(L, LNEXT, KBP, PRE)                                                              \
   {                                                                                                \
     FT_STAMP(L, 0)                                                                                 \
-    layer_gemm<NT, KBP, kb_h(L), EMB_STRIDE, PT>(acc, an, WBASE(L), WBASE(LNEXT), kb_total(LNEXT), \
-                                                 PRE, hbuf, lane, bias);                           \
+    layer_gemm<2, KBP, kb_h(L), EMB_STRIDE, PT>(acc, an, WBASE(L), WBASE(LNEXT), kb_total(LNEXT),  \
+                                                PRE, hbuf, lane, bias);                            \
     /* the NEXT layer's bias: its registers are free since the accumulators took this layer's, and an */ \
     /* epilogue, a copy and two barriers hide the fetch */                                         \
-    load_bias<NT>(bias, pk + off_b(LNEXT), nt0, lane);                                             \
+    load_bias<2>(bias, pk + off_b(LNEXT), nt0, lane);                                              \
     FT_STAMP(L, 1)                                                                                 \
     __syncthreads();                                                                               \
     FT_STAMP(L, 2)                                                                                 \
-    const unsigned long long bits_ = layer_store<NT, true, PT>(acc, nt0, hbuf, lane);              \
+    const unsigned long long bits_ = layer_store<2, true, PT>(acc, nt0, hbuf, lane);               \
     FT_STAMP(L, 3)                                                                                 \
-    if (SAVE) {                                                                                    \
-      if constexpr (NW == 4) store_relu_words<PT>(a.acts, P, L, tid, bits_);                       \
-      else store_relu_half_words(a.acts, P, L, wave, lane, (unsigned)bits_);                       \
-    }                                                                                              \
-    if (SAVE) save_tile_wave<32 * NT, PT>(hbuf, a.acts + acts_slot_off(P, L), p0, P, 32 * NT * wave, lane); \
+    if (SAVE) store_relu_words<PT>(a.acts, P, L, tid, bits_);                                      \
+    if (SAVE) save_tile_wave<64, PT>(hbuf, a.acts + acts_slot_off(P, L), p0, P, 64 * wave, lane);    \
     FT_STAMP(L, 4)                                                                                 \
     __syncthreads();                                                                               \
     FT_STAMP(L, 5)                                                                                 \
@@ -239,8 +225,8 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 
   FS_STAMP(1)
   an[0] = WBASE(0)[lane];
-  an[1] = WBASE(0)[(NT - 1) * kb_total(0) * 64 + lane];
-  load_bias<NT>(bias, pk + off_b(0), nt0, lane);
+  an[1] = WBASE(0)[kb_total(0) * 64 + lane];
+  load_bias<2>(bias, pk + off_b(0), nt0, lane);
   PTS_LAYER(0, 1, 8, ebuf)
   FS_STAMP(2)
   PTS_LAYER(1, 2, 0, ebuf)
@@ -260,7 +246,7 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
     const int pt = min(p0 + row, P - 1);
     float v = 0.f;
     if (c < 3) v = MODE == 0 ? a.in[(size_t)pt * 60 + 57 + c] : a.viewdirs[(size_t)(pt / a.S) * a.vd_stride + c];
-    if ((PT == 2 && NW == 4) || row < TM) {
+    if (PT == 2 || row < TM) {
       ebuf[row * VIEW_PAD + c] = canon_nonfinite(v);
       ebuf[row * VIEW_PAD + 4 + c] = 0.f;
     }
@@ -297,26 +283,23 @@ __global__ __launch_bounds__(NW * 64, 2) void mlp_fwd_kernel(MlpFwdArgs a) {
 
   FS_STAMP(10)
   // ---------------- feature_linear: 256 -> 256, no activation ----------------
-  layer_gemm<NT, 0, 32, EMB_STRIDE, PT>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane, bias);
+  layer_gemm<2, 0, 32, EMB_STRIDE, PT>(acc, an, WBASE(L_FEAT), WBASE(L_VIEWS), 0, ebuf, hbuf, lane, bias);
   f32x4 biasv[1][4];
-  load_bias<1>(biasv, pk + off_b(L_VIEWS), wv_views, lane);
+  load_bias<1>(biasv, pk + off_b(L_VIEWS), wave, lane);
   __syncthreads();
-  layer_store<NT, false, PT>(acc, nt0, hbuf, lane);
-  if (SAVE) save_tile_wave<32 * NT, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 32 * NT * wave, lane);
+  layer_store<2, false, PT>(acc, nt0, hbuf, lane);
+  if (SAVE) save_tile_wave<64, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_FEAT), p0, P, 64 * wave, lane);
   __syncthreads();
 
   FS_STAMP(11)
   // ---------------- views_linears[0]: [view pad | feature] -> 128, ReLU ------
   {
     f32x16 accv[1][PT];
-    const bool views_wave = NW == 4 || wave < 4;      // (wave-uniform)
     // (an[1] is unused by the one-tile views layer; the trailing prefetch re-reads block 0)
-    if (views_wave) layer_gemm<1, 1, 32, VIEW_PAD, PT>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane, biasv);
+    layer_gemm<1, 1, 32, VIEW_PAD, PT>(accv, an, WBASE(L_VIEWS), WBASE(L_VIEWS), 0, ebuf, hbuf, lane, biasv);
     __syncthreads();
-    if (views_wave) {
-      layer_store<1, true, PT>(accv, wave, hbuf, lane);
-      if (SAVE) save_tile_wave<32, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, lane);
-    }
+    layer_store<1, true, PT>(accv, wave, hbuf, lane);
+    if (SAVE) save_tile_wave<32, PT>(hbuf, a.acts + acts_slot_off(P, SLOT_VIEWS_H), p0, P, 32 * wave, lane);
     __syncthreads();
   }
 
@@ -392,10 +375,10 @@ extern "C" int scade_mlp_pack(const float* const* params, float* packed, void* s
   return scade_check_launch("scade_mlp_pack");
 }
 
-template <int MODE, bool SAVE, int PT, int NW = 4>
+template <int MODE, bool SAVE, int PT>
 static int launch_fwd_pt(const MlpFwdArgs& a, hipStream_t s) {
   static unsigned long long attr_set = 0;   // one bit per device ordinal
-  auto kern = mlp_fwd_kernel<MODE, SAVE, PT, NW>;
+  auto kern = mlp_fwd_kernel<MODE, SAVE, PT>;
   if (scade_attr_needed(attr_set)) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, mlp_lds_bytes(PT));
@@ -403,14 +386,12 @@ static int launch_fwd_pt(const MlpFwdArgs& a, hipStream_t s) {
     scade_attr_done(attr_set);
   }
   const int grid = (a.P + tile_pts(PT) - 1) / tile_pts(PT);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(NW * 64), mlp_lds_bytes(PT), s, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), mlp_lds_bytes(PT), s, a);
   return scade_check_launch("scade_mlp_fwd");
 }
 template <int MODE, bool SAVE>
 static int launch_fwd(const MlpFwdArgs& a, hipStream_t s) {
-  if (pick_point_tiles(a.P) != 1) return launch_fwd_pt<MODE, SAVE, 2>(a, s);
-  // at most two 32-point workgroups per CU: eight waves each (two per SIMD), else four
-  return (a.P + 31) / 32 <= 2L * device_cus() ? launch_fwd_pt<MODE, SAVE, 1, 8>(a, s) : launch_fwd_pt<MODE, SAVE, 1>(a, s);
+  return pick_point_tiles(a.P) == 1 ? launch_fwd_pt<MODE, SAVE, 1>(a, s) : launch_fwd_pt<MODE, SAVE, 2>(a, s);
 }
 
 extern "C" int scade_mlp_fwd(const float* packed, int mode, const float* in, const float* viewdirs,

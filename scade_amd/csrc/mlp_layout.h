@@ -112,14 +112,6 @@ __device__ __forceinline__ void store_relu_words(float* acts, long P, int layer,
   w[0] = (unsigned)bits;
   if (PT > 1) w[256] = (unsigned)(bits >> 32);
 }
-// the eight-wave forward (one n-tile per wave): wave w8 holds the 16 bits of n-tile t = w8 & 1 of the four-wave thread
-// (w8 >> 1, lane) - the low / high half of that thread's word of the 32-point tile blockIdx.x
-__device__ __forceinline__ void store_relu_half_words(float* acts, long P, int layer, int wave8, int lane, unsigned bits16) {
-  unsigned short* w = reinterpret_cast<unsigned short*>(
-      reinterpret_cast<unsigned*>(acts + acts_mask_off(P)) +
-      ((size_t)layer * relu_word_tiles(P) + (size_t)blockIdx.x) * 256 + (wave8 >> 1) * 64 + lane);
-  w[wave8 & 1] = (unsigned short)bits16;
-}
 // ``blk``: index of the workgroup among those of ITS network (a launch may cover two networks)
 template <int PT>
 __device__ __forceinline__ unsigned long long load_relu_words(const float* acts, long P, int layer, int tid, int blk) {
