@@ -30,7 +30,7 @@ typedef __bf16 V8 __attribute__((ext_vector_type(8)));
 constexpr int NLAY = 8;
 constexpr long LAYER_ELEMS = 8L * 16 * 64 * 8;          // 65536 bf16 = 128 KiB
 
-struct Args { const __bf16* w; float* out; int tiles; };
+struct Args { const __bf16* w; float* out; int tiles; unsigned long long* trace; };   // trace: [64 workgroups][8 waves][4]
 
 __device__ __forceinline__ void pin(f32x16 (&acc)[2][4]) {
 #pragma unroll
@@ -56,14 +56,24 @@ __global__ __launch_bounds__(NW * 64) void k_l2(Args a) {
   A.s[0].t0 = wl(0)[lane]; A.s[0].t1 = wl(0)[16 * 64 + lane];
   A.s[1].t0 = wl(0)[64 + lane]; A.s[1].t1 = wl(0)[16 * 64 + 64 + lane];
   A.s[2].t0 = wl(0)[128 + lane]; A.s[2].t1 = wl(0)[16 * 64 + 128 + lane];
+  unsigned long long tk = 0, tb = 0;        // core clocks inside the k-loops / at the two layer barriers
   for (int tile = 0; tile < a.tiles; ++tile) {
 #pragma unroll 1
     for (int l = 0; l < NLAY; ++l) {
+      const unsigned long long t0 = __builtin_amdgcn_s_memtime();
       layer_gemm_lp<true, 2, 0, 16, false, 0, 4, 4>(acc, A, wl(l), wl(l + 1), 16, xw, xw, lane, nullptr);
+      __builtin_amdgcn_sched_barrier(0);
+      const unsigned long long t1 = __builtin_amdgcn_s_memtime();
       LP_SYNC();
       pin(acc);
       LP_SYNC();
+      const unsigned long long t2 = __builtin_amdgcn_s_memtime();
+      tk += t1 - t0; tb += t2 - t1;
     }
+  }
+  if (a.trace && blockIdx.x < 64 && lane == 0) {
+    unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 4;
+    o[0] = tk; o[1] = tb; o[2] = 0; o[3] = (unsigned long long)a.tiles * NLAY;
   }
   if (acc[0][0][0] == 12345.678f) a.out[0] = acc[1][3][5];
 }
@@ -183,6 +193,7 @@ __global__ __launch_bounds__(512) void k_lds2(Args a) {
   f32x16 acc[2][4];
   const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   V8 a0, a1, n0, n1;
+  unsigned long long tw = 0, tc = 0, tb = 0;   // core clocks: waiting for the slot (vmcnt + barrier) | issue + reads + MFMAs | layer barriers
   if (PAIR) {
     issue(0); issue(1);
   } else {
@@ -214,8 +225,11 @@ __global__ __launch_bounds__(512) void k_lds2(Args a) {
           }
         } else {
           // blocks <= g + 1 landed everywhere; block g - 1's slot is free (its fragments were read an iteration ago)
+          const unsigned long long s0 = __builtin_amdgcn_s_memtime();
           asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
           lds_barrier();
+          const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+          tw += s1 - s0; tc -= s1;
           issue(g + 3);
           read_a(g + 1, n0, n1);
         }
@@ -237,15 +251,22 @@ __global__ __launch_bounds__(512) void k_lds2(Args a) {
         acc[1][3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1, b3, acc[1][3], 0, 0, 0);
         LOAD_B(kn, 3, b3)
         __builtin_amdgcn_sched_barrier(0);
+        if (!PAIR) tc += __builtin_amdgcn_s_memtime();
         if (!PAIR || (kb & 1) == 0) { a0 = n0; a1 = n1; }
       }
 #undef LOAD_B
+      const unsigned long long e0 = __builtin_amdgcn_s_memtime();
       LP_SYNC();
       pin(acc);
       LP_SYNC();
+      tb += __builtin_amdgcn_s_memtime() - e0;
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (!PAIR && a.trace && blockIdx.x < 64 && lane == 0) {
+    unsigned long long* o = a.trace + ((size_t)blockIdx.x * 8 + wave) * 4;
+    o[0] = tc; o[1] = tb; o[2] = tw; o[3] = (unsigned long long)a.tiles * NLAY;
+  }
   if (acc[0][0][0] == 12345.678f) a.out[0] = acc[1][3][5];
 }
 
@@ -269,6 +290,20 @@ int main(int argc, char** argv) {
     for (long i = 0; i < NLAY * LAYER_ELEMS; ++i) h[i] = (unsigned short)(0x3c00 + (i * 2654435761u >> 26));   // bf16 ~ 0.0078 .. 0.0081
     CK(hipMemcpy(w, h, NLAY * LAYER_ELEMS * 2, hipMemcpyHostToDevice)); free(h);
   }
+  unsigned long long* trace; CK(hipMalloc(&trace, 64 * 8 * 4 * 8)); CK(hipMemset(trace, 0, 64 * 8 * 4 * 8));
+  auto print_trace = [&](const char* what, int waves) {
+    unsigned long long h[64 * 8 * 4];
+    CK(hipMemcpy(h, trace, sizeof(h), hipMemcpyDeviceToHost));
+    double k = 0, b = 0, w = 0, n = 0; int cnt = 0;
+    for (int g = 0; g < 64; ++g) for (int wv = 0; wv < waves; ++wv) {
+      const unsigned long long* o = h + (g * 8 + wv) * 4;
+      if (!o[3]) continue;
+      k += (double)o[0] / o[3]; b += (double)o[1] / o[3]; w += (double)o[2] / o[3]; n += 1; ++cnt;
+    }
+    if (cnt) printf("   %s: core clocks per layer of one wave (mean of %d waves): in the k-loop %.0f (its own MFMAs: 4096, its SIMD partner's: 4096)"
+                    ", of which waiting for the slot %.0f; at the two layer barriers %.0f\n", what, cnt, (k + w) / n, w / n, b / n);
+    CK(hipMemset(trace, 0, sizeof(h)));
+  };
   const int tiles = 12;                                   // 256-point tiles per CU (mode 0: per workgroup of 128 points)
   const double flop_cu = 2.0 * 256 * 256 * 256 * NLAY * tiles;   // per CU
   auto report = [&](const char* name, double ms) {
@@ -276,18 +311,20 @@ int main(int argc, char** argv) {
     printf("%-78s %8.1f us  %7.1f TFLOP/s  %.3f of 2.5 PF  %6.2f us per 256-point tile-layer\n", name, ms * 1e3, tfl, tfl / 2500.0,
            ms * 1e3 / (NLAY * tiles));
   };
-  Args a{w, o, tiles};
+  Args a{w, o, tiles, trace};
   if (only < 0 || only == 0) {
     const int ldsb = 128 * W * 2 + 16384;                 // 80 KiB: two workgroups per CU, as the real kernels
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2<4>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     report("mode 0: 2 x 4 waves per CU, 128-point tiles, A per wave from L2 (real layer_gemm_lp)",
            time_ms([&] { hipLaunchKernelGGL(k_l2<4>, dim3(2 * cus), dim3(256), ldsb, 0, a); }, 10));
+    print_trace("mode 0", 4);
   }
   if (only < 0 || only == 1) {
     const int ldsb = 256 * W * 2 + 32768;
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_l2<8>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     report("mode 1: 1 x 8 waves per CU, 256-point tile, A per wave from L2, wave pairs in lock-step",
            time_ms([&] { hipLaunchKernelGGL(k_l2<8>, dim3(cus), dim3(512), ldsb, 0, a); }, 10));
+    print_trace("mode 1", 8);
   }
   if (only < 0 || only == 2) {
     const int ldsb = 256 * W * 2 + 4 * 8192;
@@ -306,6 +343,7 @@ int main(int argc, char** argv) {
     CK(hipFuncSetAttribute(reinterpret_cast<const void*>(k_lds2<false>), hipFuncAttributeMaxDynamicSharedMemorySize, ldsb));
     report("mode 4: 4-slot ring, A fragments read from LDS one k-block ahead, one barrier per k-block",
            time_ms([&] { hipLaunchKernelGGL(k_lds2<false>, dim3(cus), dim3(512), ldsb, 0, a); }, 10));
+    print_trace("mode 4", 8);
   }
   if (only < 0 || only == 5) {
     const int ldsb = 256 * W * 2 + 4 * 8192;
