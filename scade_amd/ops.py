@@ -838,6 +838,10 @@ def sample_pdf_fwd(bins: Tensor, weights: Optional[Tensor], u: Tensor, n_samples
     N = bins.shape[0]
     M = bins.shape[1] - (1 if bins_are_mids else 0)
     wstride = 0
+    if M < 2:
+        # (the reference fails here too: its cdf of zero weights is empty - zeros_like(cdf[..., :1]) of an empty cdf,
+        # helpers:342-343 - and the gather of helpers:373 raises)
+        raise ValueError(f"sample_pdf: {M} bin edge(s): at least two are needed (N_samples >= 3 coarse samples per ray)")
     if weights is not None:
         weights, wstride = _rows(weights, "sample_pdf: weights")
         if tuple(weights.shape) != (N, M - 1):

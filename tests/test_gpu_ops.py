@@ -571,3 +571,13 @@ def test_stage_inputs_copies_every_pair_and_the_scalar_in_one_launch(dev):
     ops.stage_inputs([(dsts[0], dsts[0])])
     ops.stage_inputs([], scalar=(idx, 7))
     assert int(idx) == 7
+
+
+def test_sample_pdf_without_a_weight_is_refused_like_the_reference(dev):
+    """One bin edge / zero weights (N_samples = 2 coarse samples): the reference's cdf comes out empty (helpers:342-343)
+    and its gather raises (:373); the operator says why instead of handing the C ABI an empty tensor."""
+    bins, w, u = torch.rand(4, 1, device=dev), torch.zeros(4, 0, device=dev), torch.rand(4, 8, device=dev)
+    with pytest.raises(ValueError, match="at least two"):
+        S.sample_pdf_return_u(bins, w, 8, load_u=u)
+    with pytest.raises((RuntimeError, IndexError)):
+        O.sample_pdf(bins.cpu(), w.cpu(), u.cpu())
