@@ -40,3 +40,19 @@ def test_random_exact_configuration_vs_oracle_autograd(dev, seed):
     assert grad_rel < 1e-3 or (nudged > 0 and after < 1e-5), (c, grad_rel, nudged, after)
     if seed in (5, 356):
         assert nudged > 0 and after < 1e-5, (grad_rel, nudged, after)
+
+
+@pytest.mark.parametrize("seed", [3, 4, 8, 11, 14, 19, 25, 370])
+def test_random_render_configuration_vs_oracle_chunked_graphed_and_fast(dev, seed):
+    """tools/fuzz_render.py: the exact render of a random configuration against the oracle (coarse stage element-wise,
+    the rest by PSNR / norm - seed 370, where one ray of 222 carries the depth norm, by its distance to an fp64
+    evaluation), chunked and graph-replayed renders bit for bit, the fast inference precision against the exact one.
+    The 800-configuration run is profiles/r06_fuzz_render.json."""
+    import fuzz_render as F
+    c, g = F.config(seed)
+    row = F.one(c, g, dev, True)
+    assert "rgb_psnr" in row, "a configuration the oracle finishes in seconds"
+    assert row["ok"], row
+    assert row["z_vals0_bitwise"] and row["coarse_elementwise_excess"] <= 0
+    if seed == 370:
+        assert "vs_fp64" in row
