@@ -70,6 +70,8 @@ __device__ __forceinline__ unsigned tile_rows_left(int p0, int P) {
 
 // ---- wave-level primitives -------------------------------------------------
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// minimum that PROPAGATES NaN like torch.min (v_minimum3_f32; fminf / v_min_f32 return the other operand)
+__device__ __forceinline__ float min_nan(float a, float b) { return __builtin_elementwise_minimum(a, b); }
 
 template <typename T>
 __device__ __forceinline__ T wave_sum(T v) {

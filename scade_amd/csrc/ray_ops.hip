@@ -94,7 +94,7 @@ __device__ __forceinline__ void composite_ray(const CompositeArgs& a, int ray, i
       const float alpha = 1.0f - expf(-sp * dist);                   // :512
       const float x = (1.0f - alpha) + 1e-10f;                       // :520
       xd = (double)x;
-      s.alpha = alpha; s.dist = dist; s.sigpos = sig > 0.f ? sp : -1.f; s.z = zi;
+      s.alpha = alpha; s.dist = dist; s.sigpos = sig <= 0.f ? -1.f : sp; s.z = zi;      // (NaN stays NaN: threshold_backward)
       s.sr = 1.0f / (1.0f + expf(-rv[0]));                           // :543 sigmoid
       s.sg = 1.0f / (1.0f + expf(-rv[1]));
       s.sb = 1.0f / (1.0f + expf(-rv[2]));
@@ -191,7 +191,7 @@ __device__ __forceinline__ void composite_bwd_ray(const CompositeArgs& a, int ra
       const float x = (1.0f - s.alpha) + 1e-10f;
       const float galpha = G * s.T - (float)(after / (double)x);
       // alpha = 1 - exp(-relu(sig)*dist)
-      const float gsig = s.sigpos >= 0.f ? galpha * s.dist * expf(-s.sigpos * s.dist) : 0.f;
+      const float gsig = s.sigpos < 0.f ? 0.f : galpha * s.dist * expf(-s.sigpos * s.dist);
       f32x4 g;
       g[0] = gr * s.w * s.sr * (1.0f - s.sr);
       g[1] = gg * s.w * s.sg * (1.0f - s.sg);
@@ -921,7 +921,7 @@ __global__ void carve_fwd_kernel(CarveArgs a) {
       const float p = a.pred[(size_t)ray * a.P + s];
       float best = INFINITY;
       for (int k = 0; k < a.K; ++k)
-        best = fminf(best, carve_dist(p, lane_bcast(hreg, k), m, hm, a.threshold));
+        best = min_nan(best, carve_dist(p, lane_bcast(hreg, k), m, hm, a.threshold));
       acc += (double)best;
     }
   } else {
@@ -929,7 +929,7 @@ __global__ void carve_fwd_kernel(CarveArgs a) {
       const float p = a.pred[(size_t)ray * a.P + s];
       float best = INFINITY;
       for (int k = 0; k < a.K; ++k)
-        best = fminf(best, carve_dist(p, a.hyp[(size_t)k * a.N + ray], m, hm, a.threshold));
+        best = min_nan(best, carve_dist(p, a.hyp[(size_t)k * a.N + ray], m, hm, a.threshold));
       acc += (double)best;
     }
   }
@@ -1063,7 +1063,7 @@ __global__ void carve_knp_fwd_kernel(CarveArgs a) {
     const float p = a.pred[(size_t)ray * a.P + s];
     const float* h = a.hyp + (size_t)ray * a.P + s;
     float best = INFINITY;
-    for (int k = 0; k < a.K; ++k) best = fminf(best, carve_dist(p, h[k * kstride], m, hm, a.threshold));
+    for (int k = 0; k < a.K; ++k) best = min_nan(best, carve_dist(p, h[k * kstride], m, hm, a.threshold));
     acc += (double)best;
   }
   acc = wave_sum_d(acc);

@@ -94,7 +94,7 @@ __device__ __forceinline__ void tl_fwd_ray(const TrainLossArgs& a, int ray, int 
       for (int s = lane; s < a.P; s += 64) {
         const float p = pred_row[s];
         float best = INFINITY;
-        for (int k = 0; k < a.K; ++k) best = fminf(best, tl_dist(p, tl_bcast(hreg, k), m, hm, a.threshold));
+        for (int k = 0; k < a.K; ++k) best = min_nan(best, tl_dist(p, tl_bcast(hreg, k), m, hm, a.threshold));
         acc += (double)best;
       }
     } else {
@@ -104,13 +104,13 @@ __device__ __forceinline__ void tl_fwd_ray(const TrainLossArgs& a, int ray, int 
         for (int k = 0; k < a.K; ++k) {
           float h = a.hyp[(size_t)k * a.N + ray] * sc;
           h = h + sh;
-          best = fminf(best, tl_dist(p, h, m, hm, a.threshold));
+          best = min_nan(best, tl_dist(p, h, m, hm, a.threshold));
         }
         acc += (double)best;
       }
     }
     carve_ray = (float)(tl_wave_sum_d(acc) / (double)a.P);             // helpers:125 mean over samples
-    if (im < 0) carve_ray = __builtin_nanf("");     // device image index out of range (fminf drops the NaN distances)
+    if (im < 0) carve_ray = __builtin_nanf("");     // device image index out of range
   }
   if (lane == 0) {
     f32x4 o = {(float)sq_f, (float)sq_c, carve_ray, 0.f};

@@ -581,3 +581,64 @@ def test_sample_pdf_without_a_weight_is_refused_like_the_reference(dev):
         S.sample_pdf_return_u(bins, w, 8, load_u=u)
     with pytest.raises((RuntimeError, IndexError)):
         O.sample_pdf(bins.cpu(), w.cpu(), u.cpu())
+
+
+@pytest.mark.parametrize("special", [float("nan"), float("inf"), -float("inf"), 0.0, 1e-45, 1e38, -1e38])
+def test_special_values_leave_the_same_nan_and_inf_patterns_as_the_oracle(dev, special):
+    """A NaN / Inf / denormal / huge entry of the network output, of a sampler weight, of a depth hypothesis or of a
+    colour lands where torch leaves it: the positions of NaN, +Inf and -Inf of every forward output agree with the oracle's
+    (F.relu and torch.min PROPAGATE NaN - v_min_f32 / fminf would return the other operand), and so does the compositing
+    gradient (threshold_backward passes a NaN through).  Gradients of the space-carving loss w.r.t. NON-FINITE inputs are
+    not compared: torch's norm backward turns inf / inf into NaN there, the kernels return the sign."""
+    g = torch.Generator().manual_seed(5)
+    N, Sn = 12, 70
+
+    def same_pattern(a, b, what):
+        a, b = a.detach().cpu(), b.detach()
+        assert torch.equal(torch.isnan(a), torch.isnan(b)), f"{what}: NaN positions"
+        assert torch.equal(torch.isposinf(a), torch.isposinf(b)) and torch.equal(torch.isneginf(a), torch.isneginf(b)), f"{what}: Inf positions"
+        fin = torch.isfinite(b)
+        if bool(fin.any()):
+            assert_close(a[fin], b[fin], rtol=2e-4, atol=1e-5 * float(b[fin].abs().max()) + 1e-9, what=what)
+
+    raw = torch.randn(N, Sn, 4, generator=g)
+    z = torch.sort(torch.rand(N, Sn, generator=g) * 4 + 0.1, -1)[0]
+    d = torch.randn(N, 3, generator=g)
+    for ch in range(4):
+        raw[ch, 5 + ch, ch] = special
+    raw[8, Sn - 1, 3] = special
+    ro = raw.clone().requires_grad_(True)
+    wo = O.raw2outputs(ro, z, d)
+    sum(t.sum() for t in wo).backward()
+    rg = raw.to(dev).requires_grad_(True)
+    got = S.raw2outputs(rg, z.to(dev), d.to(dev))
+    sum(t.sum() for t in got).backward()
+    for a, b, n in zip(got, wo, ["rgb", "disp", "acc", "w", "depth"]):
+        same_pattern(a, b, f"composite {n}")
+    same_pattern(rg.grad, ro.grad, "composite gradient")
+    # sampler
+    M = Sn - 1
+    bins = torch.sort(torch.rand(N, M, generator=g) * 4 + 0.1, -1)[0]
+    w = torch.rand(N, M - 1, generator=g)
+    w[2, 7] = special
+    w[5, 0] = special
+    u = torch.rand(N, 33, generator=g)
+    so = O.sample_pdf(bins, w, u)
+    sg, _ = S.sample_pdf_return_u(bins.to(dev), w.to(dev), 33, load_u=u.to(dev))
+    same_pattern(sg, so, "sampler")
+    # space carving and the photometric term
+    pred = torch.rand(N, 20, generator=g) * 5
+    hyp = torch.rand(7, N, 1, generator=g) * 4.9 + 0.1
+    pred[1, 3] = special
+    hyp[2, 4, 0] = special
+    same_pattern(S.compute_space_carving_loss(pred.to(dev), hyp.to(dev)).reshape(1),
+                 O.compute_space_carving_loss(pred, hyp).reshape(1), "carve loss")
+    x, y = torch.rand(N, 3, generator=g), torch.rand(N, 3, generator=g)
+    x[0, 1] = special
+    xo = x.clone().requires_grad_(True)
+    O.img2mse(xo, y).backward()
+    xg = x.to(dev).requires_grad_(True)
+    mg = S.img2mse(xg, y.to(dev))
+    mg.backward()
+    same_pattern(mg.reshape(1), O.img2mse(x, y).reshape(1), "mse")
+    same_pattern(xg.grad, xo.grad, "mse gradient")
