@@ -642,3 +642,32 @@ def test_special_values_leave_the_same_nan_and_inf_patterns_as_the_oracle(dev, s
     mg.backward()
     same_pattern(mg.reshape(1), O.img2mse(x, y).reshape(1), "mse")
     same_pattern(xg.grad, xo.grad, "mse gradient")
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_space_carving_variants_random_shapes_forward_and_backward(dev, seed):
+    """Every variant of the space-carving loss (per-ray / joint minimum, mask, threshold, hypotheses per ray [K,N,1] or
+    per sample [K,N,P]) at random ragged shapes - hypothesis counts on both sides of the 64-lane wave, one ray, one
+    sample, one hypothesis - forward and backward against the oracle and its autograd."""
+    g = torch.Generator().manual_seed(300 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for it in range(6):
+        N, P, K = ri(1, 90), ri(1, 210), ri(1, 80)
+        if it == 0:
+            N, P, K = 1, 1, 1
+        pred = torch.rand(N, P, generator=g) * 5
+        for per_sample in (False, True):
+            hyp = torch.rand(K, N, P if per_sample else 1, generator=g) * 4.9 + 0.1
+            mask = (torch.rand(N, generator=g) > 0.3).float()
+            for kw in (dict(), dict(is_joint=True), dict(mask=mask), dict(threshold=0.3), dict(is_joint=True, mask=mask, threshold=0.3)):
+                po, ho = pred.clone().requires_grad_(True), hyp.clone().requires_grad_(True)
+                lo = O.compute_space_carving_loss(po, ho, **kw)
+                lo.backward()
+                pg, hg = pred.to(dev).requires_grad_(True), hyp.to(dev).requires_grad_(True)
+                kd = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in kw.items()}
+                lg = S.compute_space_carving_loss(pg, hg, **kd)
+                lg.backward()
+                tag = f"N={N} P={P} K={K} per_sample={per_sample} {sorted(kw)}"
+                assert_close(lg, lo.detach(), rtol=1e-5, atol=1e-7, what="carve " + tag)
+                assert_close(pg.grad, po.grad, rtol=1e-5, atol=1e-9, what="carve d/d pred " + tag)
+                assert_close(hg.grad, ho.grad, rtol=1e-5, atol=1e-9, what="carve d/d hyp " + tag)
