@@ -92,13 +92,21 @@ __device__ __forceinline__ bool lp_nonfinite(float v) { return !(fabsf(v) <= 3.4
 // -DFL_TRACE (variant build; tools/probe_dgrad_trace.py --fwd): core-clock stamps of sixteen consecutive workgroups of a
 // 1536-tile launch's third round at the phase boundaries of the format-code-2 training forward
 #ifdef FL_TRACE
+#ifndef FL_NPT      // which launch is stamped: -DFL_NPT=2 -DFL_GRID=128 -DFL_FIRST=0 = the coarse pass of a 128-ray shard
+#define FL_NPT 4
+#define FL_GRID 1536
+#define FL_FIRST 1100
+#endif
+#ifndef FL_SAVE     // 2: the format-code-2 training forward; 0: the inference forward (TRACE_RENDER=1)
+#define FL_SAVE 2
+#endif
 __device__ unsigned long long fl_trace[16 * 4 * 48];
 #define FL_STAMP(I)                                                                                        \
-  if (SAVE == 2 && NPT == 4 && gridDim.x == 1536 && blockIdx.x >= 1100 && blockIdx.x < 1116 && lane == 0)  \
-    fl_trace[((blockIdx.x - 1100) * 4 + wave) * 48 + (I)] = clock64();
+  if (SAVE == FL_SAVE && NPT == FL_NPT && gridDim.x == FL_GRID && blockIdx.x >= FL_FIRST && blockIdx.x < FL_FIRST + 16 && lane == 0)  \
+    fl_trace[((blockIdx.x - FL_FIRST) * 4 + wave) * 48 + (I)] = clock64();
 #define FL_STAMP_RT(I)                                                                                     \
-  if (SAVE == 2 && NPT == 4 && gridDim.x == 1536 && blockIdx.x >= 1100 && blockIdx.x < 1116 && lane == 0)  \
-    fl_trace[((blockIdx.x - 1100) * 4 + wave) * 48 + (I)] = wall_clock64();
+  if (SAVE == FL_SAVE && NPT == FL_NPT && gridDim.x == FL_GRID && blockIdx.x >= FL_FIRST && blockIdx.x < FL_FIRST + 16 && lane == 0)  \
+    fl_trace[((blockIdx.x - FL_FIRST) * 4 + wave) * 48 + (I)] = wall_clock64();
 #else
 #define FL_STAMP(I)
 #define FL_STAMP_RT(I)

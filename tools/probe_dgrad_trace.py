@@ -19,7 +19,7 @@ from scade_amd.synthetic import synthetic_rays
 from scade_amd.train import Trainer, make_scade_nets
 
 dev = torch.device("cuda:0")
-N, K = 1024, 20
+N, K = int(os.environ.get("TRACE_RAYS", "1024")), 20
 coarse, fine = make_scade_nets(dev, seed=0)
 tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), precision="bf16-s8")
 rays = synthetic_rays(N, seed=1).to(dev)
@@ -30,6 +30,12 @@ import time
 nsteps = int(os.environ.get("TRACE_STEPS", "10"))
 for _ in range(nsteps):
     tr.step(rays, tgt, hyp)
+if os.environ.get("TRACE_RENDER"):                     # the inference forward (-DFL_SAVE=0 variants)
+    import scade_amd as S
+    coarse.inference_precision = fine.inference_precision = "bf16"
+    with torch.no_grad():
+        for _ in range(5):
+            S.render_rays(rays, True, coarse, tr.query, 64, N_importance=128, network_fine=fine, perturb=0.)
 torch.cuda.synchronize()
 if os.environ.get("TRACE_IDLE"):                       # clocks after an idle gap: one step from a cold start
     time.sleep(float(os.environ["TRACE_IDLE"]))
