@@ -139,7 +139,8 @@ def train_scene(data, out_dir: str, expname: str = "scade", scene_id: str = "sce
         masked = bool(mask_corners or mask_edges)
         gt = GraphedTrainer(tr, b - a, t_hyp.shape[1], n_total=N_rand, with_mask=masked)
         gather = ops.ResidentBatchGather(Hh, Ww, t_img, t_hyp, t_pose, t_intr, near, far, gt.rays, gt.tgt, gt.hyp,
-                                         gt.mask, corner_px=20 if mask_corners else 0, edge_px=10 if mask_edges else 0,
+                                         gt.mask, corner_px=20 if mask_corners else 0,
+                                         edge_px=10 if (mask_edges and not mask_corners) else 0,      # (an elif: run_scade_wild.py:818)
                                          scalar_dst=gt.img_i, tick_states=(tr.opt, tr.opt_ss), points=gt.coarse_pre,
                                          packs=gt.packs if gt.coarse_pre is not None else None)
         if gt.packs is not None and gt.coarse_pre is not None:
@@ -287,6 +288,7 @@ def main(argv=None):
     p.add_argument("--freeze_ss", type=int, default=400000)
     p.add_argument("--is_joint", action="store_true")
     p.add_argument("--mask_corners", action="store_true")
+    p.add_argument("--mask_edges", action="store_true", help="10-px border mask of run_scade_wild.py (:1220; off by default there too)")
     p.add_argument("--precision", default="f32", choices=["f32", "f16x3", "bf16", "bf16-s8", "f16"])
     p.add_argument("--eval_precision", default=None, choices=[None, "f32", "f16x3", "bf16", "f16"])
     p.add_argument("--no_reload", action="store_true")
@@ -304,7 +306,7 @@ def main(argv=None):
         test_scene(data, a.ckpt_dir, a.expname, a.scene_id, a.task, a.eval_precision)
         return
     train_scene(data, a.ckpt_dir, a.expname, a.scene_id, a.num_iterations, a.N_rand, a.i_weights, a.i_print,
-                mask_corners=a.mask_corners, mask_edges=wild, wild=wild, precision=a.precision,
+                mask_corners=a.mask_corners, mask_edges=a.mask_edges, wild=wild, precision=a.precision,
                 eval_precision=a.eval_precision, no_reload=a.no_reload, i_img=a.i_img, lrate=a.lrate,
                 scaleshift_lr=a.scaleshift_lr if a.scaleshift_lr is not None else (1e-5 if wild else 1e-7),
                 space_carving_weight=a.space_carving_weight, warm_start_nerf=a.warm_start_nerf,

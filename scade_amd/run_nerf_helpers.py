@@ -371,8 +371,9 @@ def get_ray_batch(H, W, intrinsic, c2w, coords, near, far, image=None, hypothese
       image [H,W,3]; hypotheses [K,H,W] or [K,H,W,1]
     -> rays [N,11], target_s [N,3] | None, target_h [K,N,1] | None, mask [N] | None"""
     hy = None if hypotheses is None else hypotheses.reshape(hypotheses.shape[0], H, W)
+    # (the corner mask wins when both are asked for: the edge mask is an ``elif``, run_scade_wild.py:805,818)
     out = ops.gen_rays(H, W, intrinsic, c2w, coords=_coords_rc(coords), near=near, far=far, image=image,
-                       hyps=hy, corner_px=20 if mask_corners else 0, edge_px=10 if mask_edges else 0,
+                       hyps=hy, corner_px=20 if mask_corners else 0, edge_px=10 if (mask_edges and not mask_corners) else 0,
                        want_rows=True, want_mask=bool(mask_corners or mask_edges))
     th = None if out["target_h"] is None else out["target_h"].unsqueeze(-1)
     return out["rays"], out["target_s"], th, out["mask"]

@@ -671,3 +671,45 @@ def test_space_carving_variants_random_shapes_forward_and_backward(dev, seed):
                 assert_close(lg, lo.detach(), rtol=1e-5, atol=1e-7, what="carve " + tag)
                 assert_close(pg.grad, po.grad, rtol=1e-5, atol=1e-9, what="carve d/d pred " + tag)
                 assert_close(hg.grad, ho.grad, rtol=1e-5, atol=1e-9, what="carve d/d hyp " + tag)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2, 3])
+def test_ray_batch_random_cameras_and_masks_vs_oracle(dev, seed):
+    """get_rays / get_ray_batch for random image sizes (down to images SMALLER than the 20 px corner and 10 px edge bands),
+    intrinsics, poses and pixel selections that include the four corner pixels - against the oracle's get_rays / ray_rows
+    and the mask construction of run_scade_wild.py:805-831 (corners first; edges only when corners are off)."""
+    g = torch.Generator().manual_seed(400 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    for it in range(6):
+        Hh, Ww, K = ri(2, 90), ri(2, 120), ri(1, 9)
+        if it == 0:
+            Hh, Ww = 15, 33                                   # bands wider than the image
+        intr = torch.tensor([300.0 + 400 * float(torch.rand(1, generator=g)), 300.0 + 400 * float(torch.rand(1, generator=g)),
+                             Ww / 2 + float(torch.randn(1, generator=g)), Hh / 2 + float(torch.randn(1, generator=g))])
+        q, _ = torch.linalg.qr(torch.randn(3, 3, generator=g))
+        c2w = torch.cat([q, torch.randn(3, 1, generator=g)], -1).contiguous()
+        n = ri(1, 200)
+        sel = torch.stack([torch.randint(0, Hh, (n,), generator=g), torch.randint(0, Ww, (n,), generator=g)], -1)
+        sel[:min(n, 4)] = torch.tensor([[0, 0], [0, Ww - 1], [Hh - 1, 0], [Hh - 1, Ww - 1]])[:min(n, 4)]
+        image = torch.rand(Hh, Ww, 3, generator=g)
+        hyps = torch.rand(K, Hh, Ww, generator=g) * 4.9 + 0.1
+        ro, rd = O.get_rays(Hh, Ww, intr, c2w, coords=sel.float())
+        want_rows = O.ray_rows(ro, rd, 0.2, 4.5)
+        for corners, edges in ((False, False), (True, False), (False, True), (True, True)):
+            rays, ts, th, mask = S.get_ray_batch(Hh, Ww, intr.to(dev), c2w.to(dev), sel.to(dev), 0.2, 4.5, image=image.to(dev),
+                                                hypotheses=hyps.to(dev), mask_corners=corners, mask_edges=edges)
+            assert_close(rays, want_rows, rtol=2e-6, atol=1e-6, what=f"rows {Hh}x{Ww}")
+            assert torch.equal(ts.cpu(), image[sel[:, 0], sel[:, 1]])
+            assert torch.equal(th.cpu()[..., 0], hyps[:, sel[:, 0], sel[:, 1]])
+            if not (corners or edges):
+                assert mask is None
+                continue
+            m = torch.ones(Hh, Ww)
+            if corners:                                       # (:805-816)
+                m[:20, :20] = 0; m[:20, -20:] = 0; m[-20:, :20] = 0; m[-20:, -20:] = 0
+            else:                                             # (:818-829, an elif)
+                m[:10, :] = 0; m[-10:, :] = 0; m[:, -10:] = 0; m[:, :10] = 0
+            assert torch.equal(mask.cpu(), m[sel[:, 0], sel[:, 1]]), (Hh, Ww, corners, edges)
+        full = ops.gen_rays(Hh, Ww, intr.to(dev), c2w.to(dev), near=0.2, far=4.5)["rays"]
+        fo, fd = O.get_rays(Hh, Ww, intr, c2w)
+        assert_close(full, O.ray_rows(fo, fd, 0.2, 4.5), rtol=2e-6, atol=1e-6, what="full image rows")
