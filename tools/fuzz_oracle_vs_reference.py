@@ -4,7 +4,8 @@ nothing of it travels - the summary written by --out is counts and shapes).  too
 bit on fixed shapes; this walks random ones: compositing with and without density noise, the inverse-cdf sampler (det /
 given draws / numpy streams / joint), every variant of the space-carving loss with both hypothesis layouts and both
 norms, the stratified jitter, ray generation, the training-batch assembly of BOTH scripts with their mask flags, and
-render_rays (deterministic and jittered, lindisp, sample counts) with the three-term loss and its gradients.
+render_rays (deterministic and jittered, lindisp, sample counts) with the three-term loss and its gradients; and the
+GPU-free pieces of the host mirror: the learning-rate staircase, checkpoints in both directions.
 
   python tools/fuzz_oracle_vs_reference.py --seeds 40 [--out profiles/rNN_oracle_vs_reference.json]
 """
@@ -207,6 +208,54 @@ def render(seed):
             same(go, gr, tag + " d/d " + k, "render_rays gradients")
 
 
+def host_mirror():
+    """the pieces of the host-side mirror that run without a GPU, against the reference's own: the learning-rate staircase
+    and checkpoints in both directions (ours into the reference's DataParallel-wrapped modules, a reference one into ours)"""
+    import random
+    import tempfile
+    from train_utils.hyperparameter_update import get_learning_rate
+    from scade_amd import scene
+    from scade_amd.parallel import staircase_lr
+    from scade_amd.run_nerf_helpers import NeRF
+    random.seed(0)
+    c = COUNT.setdefault("learning-rate staircase", [0, 0])
+    for _ in range(20000):
+        lr0 = random.choice([5e-4, 1e-3, 1e-7, random.random() * 1e-2])
+        rate = random.choice([0.1, 0.5, 0.9, random.random()])
+        step = random.choice([1, 4, 400000, 250000, random.randint(1, 10 ** 6)])
+        it = random.randint(1, 2 * 10 ** 6)
+        c[0] += 1
+        c[1] += get_learning_rate(lr0, it, step, rate, staircase=True) != staircase_lr(lr0, rate, step, it)
+    mk = lambda: NeRF(D=8, W=256, input_ch=57, output_ch=5, skips=[4], input_ch_views=3, input_ch_cam=0, use_viewdirs=True)
+    ours_c, ours_f = mk(), mk()
+    d = tempfile.mkdtemp()
+    os.makedirs(os.path.join(d, "exp"))
+    scene.save_checkpoint(os.path.join(d, "exp", "001000.tar"), 1000, ours_c, ours_f, torch.zeros(3, 1), torch.ones(3, 1))
+    ck = torch.load(os.path.join(d, "exp", "001000.tar"), weights_only=False)
+    ref_c = torch.nn.DataParallel(MG.ref_nerf(O.nerf_init(1)))       # (create_nerf wraps both networks: :422, :431)
+    ref_f = torch.nn.DataParallel(MG.ref_nerf(O.nerf_init(2)))
+    ref_c.load_state_dict(ck["network_fn_state_dict"])
+    ref_f.load_state_dict(ck["network_fine_state_dict"])
+    for (k, a), b in zip(ref_c.module.state_dict().items(), ours_c.state_dict().values()):
+        same(a, b, "ours -> reference " + k, "checkpoint interop")
+    c = COUNT["checkpoint interop"]
+    c[0] += 1
+    c[1] += sorted(ck) != ["depth_scales", "depth_shifts", "global_step", "network_fine_state_dict", "network_fn_state_dict",
+                           "optimizer_state_dict"]
+    ref_c, ref_f = torch.nn.DataParallel(MG.ref_nerf(O.nerf_init(3))), torch.nn.DataParallel(MG.ref_nerf(O.nerf_init(4)))
+    torch.save({"global_step": 7000, "network_fn_state_dict": ref_c.state_dict(), "network_fine_state_dict": ref_f.state_dict(),
+                "optimizer_state_dict": {}, "depth_shifts": torch.zeros(3, 1), "depth_scales": torch.ones(3, 1)},
+               os.path.join(d, "exp", "007000.tar"))
+    ck = scene.load_checkpoint(d, "exp")
+    ours_c.load_reference_state_dict(ck["network_fn_state_dict"])
+    ours_f.load_reference_state_dict(ck["network_fine_state_dict"])
+    for net, ref in ((ours_c, ref_c), (ours_f, ref_f)):
+        for (k, a), b in zip(ref.module.state_dict().items(), net.state_dict().values()):
+            same(b, a, "reference -> ours " + k, "checkpoint interop")
+    c[0] += 1
+    c[1] += ck["global_step"] != 7000
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seeds", type=int, default=40)
@@ -218,6 +267,7 @@ def main():
         one(s)
     for s in range(a.render_seeds):
         render(s)
+    host_mirror()
     bad = sum(v[1] for v in COUNT.values())
     for k, (n, b) in COUNT.items():
         print(f"{k:24s} {n:6d} comparisons, {b} mismatches")
