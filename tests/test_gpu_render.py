@@ -383,3 +383,41 @@ def test_graphed_render_matches_eager_and_follows_weight_updates(dev):
         want = S.render_rays(rays_b, True, coarse, query, 64, N_importance=128, network_fine=fine, perturb=0.)
     got = gr(rays_b)
     assert torch.equal(got["rgb_map"], want["rgb_map"])
+
+
+def test_render_plumbing_golden(dev):
+    """render() around render_rays (run_scade_scannet.py:80-155) against the reference's own outputs on an 18 x 40 image
+    (tests/golden/f9_render_image.npz): the full image through a chunk length that does not divide it, the 5.33:9 centre
+    crop, a given [2,N,3] ray batch, and c2w_staticcam (one camera's view directions on another camera's rays) - shapes,
+    the split into (rgb, disp, acc, extras), and values (coarse outputs element-wise; the rest by PSNR / norm as in
+    check_ret: everything behind the resampling is ill-conditioned)."""
+    from test_oracle_golden import check_digest
+    g = load_golden("f9_render_image")
+    pc, pf = O.nerf_init(int(g["seed_coarse"])), O.nerf_init(int(g["seed_fine"]))
+    check_digest(pc, g, "digest_coarse")
+    check_digest(pf, g, "digest_fine")
+    coarse, fine, query = build(dev, pc, pf, g["bb_center"], g["bb_scale"])
+    Hh, Ww = int(g["H"]), int(g["W"])
+    intr, c2w, c2w_b = g["intrinsic"].to(dev), g["c2w"].to(dev), g["c2w_b"].to(dev)
+    kw = dict(near=0.1, far=5.0, use_viewdirs=True, network_fn=coarse, network_query_fn=query, N_samples=16,
+              N_importance=24, network_fine=fine, perturb=0.0)
+    with torch.no_grad():
+        cases = {"full": S.render(Hh, Ww, intr, chunk=37, c2w=c2w, **kw),
+                 "crop": S.render(Hh, Ww, intr, chunk=64, c2w=c2w, with_5_9=True, **kw),
+                 "batch": S.render(Hh, Ww, intr, chunk=20, rays=g["batch"].to(dev), **kw),
+                 "static": S.render(Hh, Ww, intr, chunk=128, c2w=c2w, c2w_staticcam=c2w_b, **kw)}
+    for name, out in cases.items():
+        assert len(out) == 4 and isinstance(out[3], dict), name
+        rgb, disp, acc, extras = out
+        assert len(extras) == int(g[f"{name}/n_extras"]), (name, sorted(extras))
+        assert not ({"rgb_map", "disp_map", "acc_map"} & set(extras)), name
+        for got, key in ((rgb, "rgb"), (disp, "disp"), (acc, "acc"), (extras["depth_map"], "depth_map"),
+                         (extras["rgb0"], "rgb0"), (extras["z_vals"], "z_vals"), (extras["pred_hyp"], "pred_hyp")):
+            want = g[f"{name}/{key}"]
+            assert tuple(got.shape) == tuple(want.shape), (name, key, tuple(got.shape), tuple(want.shape))
+        assert_close(extras["rgb0"], g[f"{name}/rgb0"], rtol=1e-4, atol=1e-6, what=f"{name} rgb0")
+        psnr = -10 * torch.log10(torch.mean((rgb.cpu() - g[f"{name}/rgb"]) ** 2) + 1e-30)
+        assert psnr > 70, (name, float(psnr))
+        assert rel_l2(extras["depth_map"], g[f"{name}/depth_map"]) < 1e-3 and rel_l2(extras["z_vals"], g[f"{name}/z_vals"]) < 5e-4, name
+        assert rel_l2(torch.nan_to_num(disp), torch.nan_to_num(g[f"{name}/disp"])) < 1e-3 and rel_l2(acc, g[f"{name}/acc"]) < 1e-3, name
+    assert tuple(cases["crop"][0].shape) == (18, 10, 3) and tuple(cases["batch"][0].shape) == (53, 3)

@@ -169,3 +169,24 @@ def test_rays():
     sel = g["sel"]
     rows = O.ray_rows(ro[sel[:, 0], sel[:, 1]], rd[sel[:, 0], sel[:, 1]], float(g["near"]), float(g["far"]))
     assert_close(rows, g["rows"], what="rows", **TIGHT)
+
+
+def test_render_image_plumbing_fixture():
+    """f9 (the reference's render() on an 18 x 40 image): the oracle's render_rays on the ray rows of the fixture's given
+    batch and of its full image reproduces the reference's maps."""
+    g = load_golden("f9_render_image")
+    pc, pf = O.nerf_init(int(g["seed_coarse"])), O.nerf_init(int(g["seed_fine"]))
+    check_digest(pc, g, "digest_coarse")
+    check_digest(pf, g, "digest_fine")
+    with torch.no_grad():
+        rows = O.ray_rows(g["batch"][0], g["batch"][1], 0.1, 5.0)
+        r = O.render_rays(rows, pc, pf, g["bb_center"], g["bb_scale"], n_samples=16, n_importance=24)
+        ro, rd = O.get_rays(int(g["H"]), int(g["W"]), g["intrinsic"], g["c2w"])
+        full = O.render_rays(O.ray_rows(ro.expand(rd.shape), rd, 0.1, 5.0), pc, pf, g["bb_center"], g["bb_scale"], n_samples=16,
+                             n_importance=24)
+    for k, key in (("rgb_map", "rgb"), ("depth_map", "depth_map"), ("rgb0", "rgb0"), ("z_vals", "z_vals"), ("pred_hyp", "pred_hyp")):
+        # (norm-wise: the reference ran its chunks of 20 / 37 rays through the BLAS one by one, the oracle all rays at once -
+        # other blockings of the same sums, 4e-6 on a colour)
+        for got, want in ((r[k], g[f"batch/{key}"]), (full[k].reshape(g[f"full/{key}"].shape), g[f"full/{key}"])):
+            e = float((got.double() - want.double()).norm() / want.double().norm())
+            assert e < 1e-4, (k, e)

@@ -441,7 +441,55 @@ def f8_rays():
          rows=rows, image=image, hyps=hyps, target_s=target_s, target_h=target_h, near=near, far=far)
 
 
+# ---------------------------------------------------------------- F9 render(): the plumbing around render_rays
+def f9_render_image():
+    """render() of the reference (run_scade_scannet.py:80-155) on an 18 x 40 image, 16 + 24 samples: full image through a
+    chunk length that does not divide it, the 5.33:9 centre crop, a given ray batch, and c2w_staticcam (view directions
+    of one camera on the rays of another)."""
+    Hh, Ww = 18, 40
+    seed_c, seed_f = 21, 22
+    pc, pf = O.nerf_init(seed_c), O.nerf_init(seed_f)
+    coarse, fine = ref_nerf(pc), ref_nerf(pf)
+    embed_fn, _ = H.get_embedder(9, 0)
+    embeddirs_fn, _ = H.get_embedder(0, 0)
+    bb_center, bb_scale = torch.tensor([0.05, -0.02, 0.1]), torch.tensor(0.2)
+
+    def query(pts, vd, cam, fn):
+        return R.run_network(pts, vd, cam, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn,
+                             bb_center=bb_center, bb_scale=bb_scale, netchunk=1024 * 64)
+
+    intrinsic = torch.tensor([35.0, 36.5, 19.6, 9.3])
+    ang = torch.tensor(-0.4)
+    c2w = torch.tensor([[torch.cos(ang), 0.0, torch.sin(ang), 0.2], [0.05, 0.995, 0.03, -0.1],
+                        [-torch.sin(ang), 0.01, torch.cos(ang), 0.7]])
+    c2w_b = torch.tensor([[1.0, 0.0, 0.0, -0.3], [0.0, 1.0, 0.0, 0.2], [0.0, 0.0, 1.0, 0.4]])
+    kw = dict(near=0.1, far=5.0, use_viewdirs=True, network_fn=coarse, network_query_fn=query, N_samples=16,
+              N_importance=24, network_fine=fine, perturb=0.0, embedded_cam=torch.tensor(()))
+    arrs = dict(H=Hh, W=Ww, intrinsic=intrinsic, c2w=c2w, c2w_b=c2w_b, bb_center=bb_center, bb_scale=bb_scale,
+                seed_coarse=seed_c, seed_fine=seed_f)
+    torch.manual_seed(3)
+    ro, rd = H.get_rays(Hh, Ww, intrinsic, c2w)
+    sel = torch.randperm(Hh * Ww)[:53]
+    batch = torch.stack([ro.reshape(-1, 3)[sel], rd.reshape(-1, 3)[sel]], 0)
+    arrs["batch"] = batch
+    with torch.no_grad():
+        cases = {"full": R.render(Hh, Ww, intrinsic, chunk=37, c2w=c2w, **kw),
+                 "crop": R.render(Hh, Ww, intrinsic, chunk=64, c2w=c2w, with_5_9=True, **kw),
+                 "batch": R.render(Hh, Ww, intrinsic, chunk=20, rays=batch, **kw),
+                 "static": R.render(Hh, Ww, intrinsic, chunk=128, c2w=c2w, c2w_staticcam=c2w_b, **kw)}
+    for name, (rgb, disp, acc, extras) in cases.items():
+        arrs[f"{name}/rgb"], arrs[f"{name}/disp"], arrs[f"{name}/acc"] = rgb, disp, acc
+        for k in ("depth_map", "rgb0", "z_vals", "pred_hyp"):
+            arrs[f"{name}/{k}"] = extras[k]
+        arrs[f"{name}/n_extras"] = len(extras)
+    for tag, p in (("coarse", pc), ("fine", pf)):
+        for k, v in weight_digest(p).items():
+            arrs[f"digest_{tag}/{k}"] = v
+    save("f9_render_image", **arrs)
+
+
 if __name__ == "__main__":
+    f9_render_image()
     f8_rays()
     f1_embed()
     f2_mlp()
