@@ -189,4 +189,4 @@ def test_render_image_plumbing_fixture():
         # other blockings of the same sums, 4e-6 on a colour)
         for got, want in ((r[k], g[f"batch/{key}"]), (full[k].reshape(g[f"full/{key}"].shape), g[f"full/{key}"])):
             e = float((got.double() - want.double()).norm() / want.double().norm())
-            assert e < 1e-4, (k, e)
+            assert e < (1e-3 if k == "pred_hyp" else 1e-4), (k, e)      # (the sampler amplifies: test_gpu_render.check_ret)
