@@ -236,7 +236,7 @@ def render_images_with_metrics(images, depths, valid_depths, poses, Hh, Ww, intr
     all-gathered, so each rank computes the same metrics from the same whole images."""
     idx = list(range(images.shape[0])) if indices is None else list(indices)
     if count is not None:
-        idx = idx[:count]
+        idx = [int(i) for i in np.random.choice(idx, size=count, replace=False)]      # "take random images" (:312-314)
     far = float(render_kwargs_test.get("far", 1.0))
     out = {"psnr": [], "img_loss": [], "psnr0": [], "depth_rmse": [], "rgbs": [], "depths": []}
     res = {k: [] for k in ("rgbs", "target_rgbs", "depths", "target_depths", "target_valid_depths", "rgbs0", "depths0")}
