@@ -713,3 +713,35 @@ def test_ray_batch_random_cameras_and_masks_vs_oracle(dev, seed):
         full = ops.gen_rays(Hh, Ww, intr.to(dev), c2w.to(dev), near=0.2, far=4.5)["rays"]
         fo, fd = O.get_rays(Hh, Ww, intr, c2w)
         assert_close(full, O.ray_rows(fo, fd, 0.2, 4.5), rtol=2e-6, atol=1e-6, what="full image rows")
+
+
+def test_small_exports_raw2depth_batchify_get_ray_dirs_embedder(dev):
+    """The exported names no other test calls: raw2depth (run_scade_scannet.py:524-528) against the oracle's weights,
+    batchify (:39-46) chunk by chunk, get_ray_dirs (helpers:285-299) against the oracle's ray directions, get_embedder's
+    identity form (i = -1) and widths, DenseLayer's initialisation (xavier with the activation's gain, zero bias)."""
+    g = torch.Generator().manual_seed(77)
+    raw, z, d = torch.randn(9, 70, 4, generator=g), torch.sort(torch.rand(9, 70, generator=g) * 4 + 0.1, -1)[0], torch.randn(9, 3, generator=g)
+    depth, std = S.raw2depth(raw.to(dev), z.to(dev), d.to(dev))
+    w = O.compute_weights(raw, z, d)
+    wd = torch.sum(w * z, -1)
+    assert_close(depth, wd, rtol=1e-5, atol=1e-6, what="raw2depth depth")
+    assert_close(std, (((z - wd.unsqueeze(-1)).pow(2) * w).sum(-1)).sqrt(), rtol=1e-4, atol=1e-5, what="raw2depth std")
+    x = torch.randn(23, 5, generator=g).to(dev)
+    fn = lambda t: t * 2 + 1
+    assert torch.equal(S.batchify(fn, 4)(x), fn(x)) and S.batchify(fn, None) is fn
+    Hh, Ww = 7, 11
+    intr = torch.tensor([20.0, 21.0, 5.3, 3.1])
+    c2w = torch.tensor([[0.8, 0.0, 0.6, 0.1], [0.0, 1.0, 0.0, 0.2], [-0.6, 0.0, 0.8, 0.3], [0.0, 0.0, 0.0, 1.0]])
+    _, rd = O.get_rays(Hh, Ww, intr, c2w)
+    assert_close(S.get_ray_dirs(Hh, Ww, intr.to(dev), c2w.to(dev)), rd, rtol=2e-6, atol=1e-7, what="get_ray_dirs")
+    sel = torch.tensor([[0, 0], [6, 10], [3, 4]])
+    assert_close(S.get_ray_dirs(Hh, Ww, intr.to(dev), c2w.to(dev), coords=sel.float().to(dev)), rd[sel[:, 0], sel[:, 1]],
+                 rtol=2e-6, atol=1e-7, what="get_ray_dirs coords")
+    ident, dim = S.get_embedder(9, -1)
+    assert dim == 3 and torch.equal(ident(x), x)
+    assert S.get_embedder(9, 0)[1] == 57 and S.get_embedder(0, 0)[1] == 3 and S.get_embedder(4, 0)[1] == 27
+    torch.manual_seed(5)
+    lin, rel = S.DenseLayer(256, 256, activation="linear"), S.DenseLayer(256, 256, activation="relu")
+    assert float(lin.bias.detach().abs().max()) == 0.0 and float(rel.bias.detach().abs().max()) == 0.0
+    bound = lambda gain: gain * (6.0 / 512) ** 0.5          # xavier_uniform: gain * sqrt(6 / (fan_in + fan_out))
+    assert float(lin.weight.detach().abs().max()) <= bound(1.0) < float(rel.weight.detach().abs().max()) <= bound(2.0 ** 0.5)
