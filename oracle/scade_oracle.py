@@ -13,7 +13,7 @@ reference from ``/root/reference`` (survey container only), asserts this
 module equals it on every fixture, and writes the fixtures under
 ``tests/golden/``.  The reference ships no tests / golden vectors of its own
 (SURVEY.md section 4), so those fixtures are the pin; ``tools/fuzz_oracle_vs_reference.py``
-repeats the bit-for-bit comparison at random shapes and flags (15,100 comparisons,
+repeats the bit-for-bit comparison at random shapes and flags (15,400 comparisons,
 ``profiles/r06_oracle_vs_reference.json``).  (The checkers under ``tools/`` - the
 golden generator, the randomized differential runs the GPU tests take slices of -
 use this module the way the tests do: as the checker, never as the thing measured.)

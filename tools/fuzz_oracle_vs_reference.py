@@ -208,6 +208,35 @@ def render(seed):
             same(go, gr, tag + " d/d " + k, "render_rays gradients")
 
 
+def render_joint(seed):
+    """render_rays(is_joint=True, perturb=1) on torch's own random stream: the jitter [N,S], the coarse sampler's draws
+    [N,Si], then ONE row [Si] shared by all rays for the depth-hypothesis sampler (helpers:498-503) - the oracle gets the
+    same three draws handed in"""
+    g = torch.Generator().manual_seed(8000 + seed)
+    ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
+    N, ns, ni = ri(1, 10), ri(3, 50), ri(1, 60)
+    pc, pf = O.nerf_init(300 + seed), O.nerf_init(400 + seed)
+    coarse, fine = MG.ref_nerf(pc), MG.ref_nerf(pf)
+    embed_fn, _ = H.get_embedder(9, 0)
+    embeddirs_fn, _ = H.get_embedder(0, 0)
+    bbc, bbs = torch.zeros(3), torch.tensor(0.2)
+
+    def query(pts, vd, cam, fn):
+        return R.run_network(pts, vd, cam, fn, embed_fn=embed_fn, embeddirs_fn=embeddirs_fn, bb_center=bbc, bb_scale=bbs,
+                             netchunk=1024 * 64)
+    rays = O.synthetic_rays(N, seed=500 + seed)
+    with torch.no_grad():
+        torch.manual_seed(seed)
+        ret = R.render_rays(rays, True, coarse, query, ns, embedded_cam=torch.tensor(()), N_importance=ni, network_fine=fine,
+                            perturb=1.0, is_joint=True)
+        torch.manual_seed(seed)
+        t_rand, uc, uj = torch.rand(N, ns), torch.rand(N, ni), torch.rand(ni)
+        ro = O.render_rays(rays, pc, pf, bbc, bbs, n_samples=ns, n_importance=ni, t_rand=t_rand, u_coarse=uc,
+                           u_fine=uj.unsqueeze(0).repeat(N, 1))
+    for k in ret:
+        same(ro[k], ret[k], f"N={N} ns={ns} ni={ni} .{k}", "render_rays is_joint")
+
+
 def host_mirror():
     """the pieces of the host-side mirror that run without a GPU, against the reference's own: the learning-rate staircase
     and checkpoints in both directions (ours into the reference's DataParallel-wrapped modules, a reference one into ours)"""
@@ -267,6 +296,7 @@ def main():
         one(s)
     for s in range(a.render_seeds):
         render(s)
+        render_joint(s)
     host_mirror()
     bad = sum(v[1] for v in COUNT.values())
     for k, (n, b) in COUNT.items():

@@ -41,6 +41,9 @@ def config(seed):
     # does ops.sample_pdf_fwd)
     if ri(0, 3) == 0:                                     # the reference's own counts, ragged ray counts
         c["Ns"], c["Ni"] = 64, 128
+    # --is_joint (one draw row shared by all rays in the depth-hypothesis sampler, joint minimum in the carving loss):
+    # from a generator of its own, so that the configurations and batches of the recorded seeds stay what they were
+    c["is_joint"] = bool(int(torch.randint(0, 4, (1,), generator=torch.Generator().manual_seed(70000 + seed))) == 0)
     return c, g
 
 
@@ -60,7 +63,7 @@ def make(c, dev, plain):
     torch.manual_seed(100 + c["seed"])
     tr = Trainer(coarse, fine, torch.zeros(3), torch.tensor(0.2), n_images=c["n_images"], precision=c["precision"],
                  N_samples=c["Ns"], N_importance=c["Ni"], mask_mode=c["mask_mode"], lindisp=c["lindisp"],
-                 space_carving_threshold=c["threshold"], scaleshift_lr=1e-3,
+                 space_carving_threshold=c["threshold"], scaleshift_lr=1e-3, is_joint=c.get("is_joint", False),
                  joint_backward=False if plain else None)
     if plain:
         tr.fused_tail_loss = False
@@ -71,10 +74,17 @@ def make(c, dev, plain):
 
 def run(c, bs, dev, mode):
     tr = make(c, dev, plain=(mode == "B"))
-    gt = GraphedTrainer(tr, c["N"], c["K"], with_mask=c["mask"]) if mode == "G" else None
+    # is_joint: the shared row of the last sampler is a host-side torch.rand (helpers:498-503), which a graph capture
+    # replaces by its own stream - so those configurations get their draws handed in, the same ones in every mode
+    inject = bool(c.get("is_joint"))
+    gt = GraphedTrainer(tr, c["N"], c["K"], with_mask=c["mask"], inject_draws=inject) if mode == "G" else None
+    gd = torch.Generator().manual_seed(90000 + c["seed"])
     losses, g1 = [], None
     for rays, tgt, hyp, m, im in bs:
         kw = dict(img_i=im)
+        if inject:
+            kw.update(t_rand=torch.rand(c["N"], c["Ns"], generator=gd).to(dev), u_coarse=torch.rand(c["N"], c["Ni"], generator=gd).to(dev),
+                      cached_u=torch.rand(1, c["Ni"], generator=gd).repeat(c["N"], 1).to(dev))
         if m is not None:
             kw["mask"] = m
         l = gt.step(rays, tgt, hyp, **kw) if gt else tr.step(rays, tgt, hyp, **kw)[0]
@@ -98,7 +108,7 @@ def oracle_grad(c, b0, draws, params_c, params_f, dt):
                           n_importance=c["Ni"], t_rand=t_rand, u_coarse=uc, u_fine=uf, lindisp=c["lindisp"])
         mk = None if m is None else m.cpu().to(dt)
         th, tg = hyp.cpu().to(dt), tgt.cpu().to(dt)        # scales = 1, shifts = 0 at the first step
-        carve = O.compute_space_carving_loss(w["pred_hyp"], th, mask=mk, threshold=c["threshold"])
+        carve = O.compute_space_carving_loss(w["pred_hyp"], th, mask=mk, threshold=c["threshold"], is_joint=c.get("is_joint", False))
         if c["mask_mode"] == "wild" and mk is not None:
             mse = lambda x: torch.mean((x - tg) ** 2 * mk[:, None])
         else:
@@ -153,6 +163,8 @@ def oracle_check(c, bs, dev):
     -> (loss rel. error, gradient rel-L2, units nudged, gradient rel-L2 after the nudge | None)"""
     g = torch.Generator().manual_seed(31 + c["seed"])
     draws = tuple(torch.rand(c["N"], n, generator=g) for n in (c["Ns"], c["Ni"], c["Ni"]))
+    if c.get("is_joint"):                                  # (helpers:498-503: ONE row for the whole batch)
+        draws = draws[:2] + (draws[2][:1].repeat(c["N"], 1),)
     rays, tgt, hyp, m, im = bs[0]
     kw = dict(img_i=im, t_rand=draws[0].to(dev), u_coarse=draws[1].to(dev), cached_u=draws[2].to(dev))
     if m is not None:
