@@ -23,6 +23,8 @@ MAPS = ["rgb_map", "depth_map", "acc_map"]
 FAST_PSNR = {"f16x3": 70.0, "f16": 30.0, "bf16": 30.0}
 ALWAYS_FP64 = False
 
+MAX_RAYS = 700             # --max-rays: larger batches (the 128-point tiles, several rounds of workgroups) without the oracle leg
+
 
 def rel_l2(a, b):
     a, b = torch.nan_to_num(a.double().reshape(-1).cpu()), torch.nan_to_num(b.double().reshape(-1).cpu())
@@ -36,7 +38,7 @@ def psnr(a, b):
 def config(seed):
     g = torch.Generator().manual_seed(11000 + seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
-    c = dict(seed=seed, N=ri(1, 700), Ns=ri(3, 130), Ni=ri(1, 200), lindisp=bool(ri(0, 3) == 0), jitter=bool(ri(0, 1)),
+    c = dict(seed=seed, N=ri(1, MAX_RAYS), Ns=ri(3, 130), Ni=ri(1, 200), lindisp=bool(ri(0, 3) == 0), jitter=bool(ri(0, 1)),
              fast=["f16x3", "f16", "bf16"][ri(0, 2)])
     if ri(0, 3) == 0:
         c["Ns"], c["Ni"] = 64, 128
@@ -151,9 +153,11 @@ def main():
     ap.add_argument("--first", type=int, default=0)
     ap.add_argument("--no-oracle", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--max-rays", type=int, default=700)
     ap.add_argument("--fp64", action="store_true", help="evaluate the oracle in fp64 for every row (statistics)")
     ap.add_argument("--only-lindisp", action="store_true")
     a = ap.parse_args()
+    globals()["MAX_RAYS"] = a.max_rays
     global ALWAYS_FP64
     ALWAYS_FP64 = a.fp64
     dev = torch.device("cuda", 0)

@@ -26,6 +26,8 @@ PRECISIONS = ["f32", "f32", "bf16-s8", "f16x3", "bf16", "f16"]
 LOSS_VS_FP64 = {}      # seed -> [kernels, torch fp32] distance of the loss to its fp64 evaluation (rows over the 2e-4 bar)
 PARAM_BAR = {"f32": 1e-4, "f16x3": 2e-3, "bf16": 5e-2, "bf16-s8": 5e-2, "f16": 5e-2}
 
+MAX_RAYS = 300             # --max-rays: larger batches (the 128-point tiles, several rounds of workgroups) without the oracle leg
+
 
 def rel_l2(a, b):
     a, b = a.double().reshape(-1), b.double().reshape(-1)
@@ -35,7 +37,7 @@ def rel_l2(a, b):
 def config(seed):
     g = torch.Generator().manual_seed(7000 + seed)
     ri = lambda lo, hi: int(torch.randint(lo, hi + 1, (1,), generator=g))
-    c = dict(seed=seed, N=ri(1, 300), Ns=ri(3, 130), Ni=ri(1, 200), K=ri(1, 45), n_images=ri(1, 4),
+    c = dict(seed=seed, N=ri(1, MAX_RAYS), Ns=ri(3, 130), Ni=ri(1, 200), K=ri(1, 45), n_images=ri(1, 4),
              mask_mode=["scannet", "wild"][ri(0, 1)], mask=bool(ri(0, 1)), lindisp=bool(ri(0, 3) == 0),
              threshold=[0.0, 0.0, 0.05][ri(0, 2)], precision=PRECISIONS[ri(0, len(PRECISIONS) - 1)])
     # (N_samples = 2 leaves the coarse sampler without a weight: the reference raises there, helpers:343,373, and so
@@ -216,7 +218,9 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--oracle", action="store_true")
     ap.add_argument("--out", default=None)
+    ap.add_argument("--max-rays", type=int, default=300)
     a = ap.parse_args()
+    globals()["MAX_RAYS"] = a.max_rays
     dev = torch.device("cuda", 0)
     bad, rows, t0 = [], [], time.time()
     for seed in range(a.first, a.first + a.seeds):
